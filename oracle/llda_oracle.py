@@ -2,28 +2,194 @@
 
 This file is a numpy restatement of the reference algorithm.  It is the *checker*: only
 ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
-The product path (``lda_thesis_amd``) never imports anything under ``oracle/`` and raises if the
-HIP extension is missing.
+The product (``lda_thesis_amd``) never imports anything under ``oracle/`` and raises if the HIP
+library is missing.
 
 Parity status: PINNED.  ``oracle/gen_golden.py`` imports the unmodified reference from
-``/root/reference`` (gensim stubbed, see ``oracle/refshim.py``), runs its own
+``/root/reference`` (gensim stubbed by ``oracle/refshim.py``), runs the reference's own
 ``training_iteration`` in the three modes below and commits the outputs under ``tests/golden/``;
-``tests/test_oracle_golden.py`` checks this file against those vectors bit for bit.
+``tests/test_oracle_golden.py`` checks this file (and the C restatement ``llda_oracle.c``) against
+those vectors bit for bit.
 
 Reference lines restated here (all in /root/reference):
   * sweep body           LabeledLDA.py:101-125  ==  CascadeLDA.py:397-421 (SubLDA)
   * count initialisation LabeledLDA.py:80-92, CascadeLDA.py:373-385 (with the phantom-column quirk)
   * read-outs            LabeledLDA.py:231-239 (get_phi/get_theta), :256-265 (perplexity),
                          CascadeLDA.py:394-395 (get_ph)
+  * np.sum               numpy 2.2.6 pairwise_sum (third party, not vendored): restated in
+                         ``pairwise_sum`` and checked against np.sum in tests/test_oracle_units.py
 
 Three execution modes of the same per-site body:
   O1  sequential, numpy's own legacy stream (np.random.multinomial) -- the reference verbatim.
-  O2  sequential, keyed draw  (``draw_keyed`` fed by a Philox uniform keyed on sweep/doc/site).
+  O2  sequential, keyed draw  (``KeyedDraw``: Philox uniform keyed on sweep/doc/site).
   O3  per-document snapshot, keyed draw: every document reads the sweep-start n_k_v / n_zk plus its
       own changes; integer deltas are summed afterwards.  This is the semantics the HIP kernel
       implements; it is independent of document order and of the number of GPUs.
+
+The keyed categorical draw (``draw_keyed``) is OURS to define (the reference takes whatever
+``multinom_draw`` is bound to, LabeledLDA.py:4,119).  Its summation order is the "group layout"
+below, chosen so that numpy's pairwise sum and the prefix scan are both lane-local on a wavefront.
 """
+import hashlib
+
 import numpy as np
+
+# ----------------------------------------------------------------------------------------------
+# Group layout of the K topics  (mirrors numpy's pairwise_sum blocking; see DESIGN.md section 3)
+# ----------------------------------------------------------------------------------------------
+PW_BLOCK = 128     # numpy PW_BLOCKSIZE
+MAX_K = 1024       # 8 leaves x 128
+
+
+def pairwise_leaves(n, start=0):
+    """Leaves (start, length<=128) of numpy's pairwise_sum recursion, left to right."""
+    if n <= PW_BLOCK:
+        return [(start, n)]
+    n2 = n // 2
+    n2 -= n2 % 8
+    return pairwise_leaves(n2, start) + pairwise_leaves(n - n2, start + n2)
+
+
+def _tree(n, first_leaf=0):
+    """Recursion tree over leaf indices: int (a leaf) or (left, right)."""
+    if n <= PW_BLOCK:
+        return first_leaf, 1
+    n2 = n // 2
+    n2 -= n2 % 8
+    l, nl = _tree(n2, first_leaf)
+    r, nr = _tree(n - n2, first_leaf + nl)
+    return (l, r), nl + nr
+
+
+class Layout(object):
+    """Topic k  <->  (lane g, slot s) of a G-lane group.
+
+    leaf p = numpy pairwise leaf containing k, rel = k - start_p, chain j = rel & 7, row = rel >> 3
+      lane g = 8*p + j,  slot s = row,  storage position pos = g*T + s   (pos is the device index)
+    P = leaves rounded up to a power of two, G = 8*P lanes, T = slots per lane (rounded up to a
+    multiple of 4 when > 2), KP = G*T padded row length.  A leaf of n topics has R = n//8 full rows
+    (slots 0..R-1, summed by the 8 chains) and n%8 tail topics in slot R of lanes j < n%8
+    (added sequentially after the chains are combined) -- only the last leaf can have a tail.
+    """
+
+    def __init__(self, K):
+        if K < 1 or K > MAX_K:
+            raise ValueError("K must be in 1..%d" % MAX_K)
+        self.K = K
+        self.leaves = pairwise_leaves(K)
+        m = len(self.leaves)
+        P = 1
+        while P < m:
+            P *= 2
+        self.m, self.P, self.G = m, P, 8 * P
+        t_used = max((n + 7) // 8 for _, n in self.leaves)
+        T = t_used
+        if T > 2:
+            T = (T + 3) // 4 * 4
+        self.T_used, self.T = t_used, T
+        self.KP = self.G * T
+        self.rows = [n // 8 for _, n in self.leaves]        # R_p
+        self.tails = [n % 8 for _, n in self.leaves]        # only the last may be non-zero
+        self.tree, _ = _tree(K)
+        self.slot_topic = np.full(self.KP, -1, dtype=np.int32)
+        self.topic_slot = np.zeros(K, dtype=np.int32)
+        for p, (st, n) in enumerate(self.leaves):
+            for rel in range(n):
+                pos = (8 * p + (rel & 7)) * T + (rel >> 3)
+                self.slot_topic[pos] = st + rel
+                self.topic_slot[st + rel] = pos
+
+    def grid(self, vec):
+        """length-K vector -> (G, T) array in group layout, zeros in the padding."""
+        out = np.zeros(self.KP, dtype=np.asarray(vec).dtype)
+        out[self.topic_slot] = vec
+        return out.reshape(self.G, self.T)
+
+    def combine_rounds(self):
+        """Butterfly schedule for the leaf totals: list of rounds, each a length-P array giving the
+        partner part of every part (itself = idle).  x_p <- x_p + x_partner reproduces the
+        recursion tree because fp addition is commutative."""
+        rounds = []
+
+        def depth(t):
+            return 0 if isinstance(t, int) else 1 + max(depth(t[0]), depth(t[1]))
+
+        def members(t):
+            return [t] if isinstance(t, int) else members(t[0]) + members(t[1])
+
+        def visit(t):
+            if isinstance(t, int):
+                return
+            visit(t[0])
+            visit(t[1])
+            d = depth(t) - 1
+            while len(rounds) <= d:
+                rounds.append(np.arange(self.P, dtype=np.int32))
+            lm, rm = members(t[0]), members(t[1])
+            for a in lm:
+                rounds[d][a] = rm[0]
+            for b in rm:
+                rounds[d][b] = lm[0]
+
+        visit(self.tree)
+        return rounds
+
+
+_LAYOUTS = {}
+
+
+def layout(K):
+    if K not in _LAYOUTS:
+        _LAYOUTS[K] = Layout(K)
+    return _LAYOUTS[K]
+
+
+def pairwise_sum(a):
+    """np.sum of a contiguous float64 vector, restated (numpy/_core/src/umath/loops_utils.h.src)."""
+    a = np.asarray(a, dtype=np.float64)
+    n = a.shape[0]
+    if n < 8:
+        res = 0.0
+        for i in range(n):
+            res = res + a[i]
+        return res
+    if n <= PW_BLOCK:
+        r = [a[j] for j in range(8)]
+        i = 8
+        while i < n - (n % 8):
+            for j in range(8):
+                r[j] = r[j] + a[i + j]
+            i += 8
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        while i < n:
+            res = res + a[i]
+            i += 1
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return pairwise_sum(a[:n2]) + pairwise_sum(a[n2:])
+
+
+def group_sum(lay, w):
+    """The same sum evaluated the way the wavefront does it: per-lane chains over the slots, xor
+    butterfly over the 8 chains of a leaf, sequential tail, butterfly over the leaves."""
+    g = lay.grid(np.asarray(w, dtype=np.float64))
+    part = np.zeros(lay.P, dtype=np.float64)
+    for p in range(lay.m):
+        R, t = lay.rows[p], lay.tails[p]
+        acc = np.zeros(8, dtype=np.float64)
+        for s in range(R):
+            acc = acc + g[8 * p:8 * p + 8, s]
+        for sh in (1, 2, 4):
+            acc = acc + acc[np.arange(8) ^ sh]
+        res = acc[0]
+        for j in range(t):
+            res = res + g[8 * p + j, R]
+        part[p] = res
+    for partner in lay.combine_rounds():
+        part = np.where(partner == np.arange(lay.P), part, part + part[partner])
+    return part[0]
+
 
 # ----------------------------------------------------------------------------------------------
 # Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11)
@@ -45,7 +211,7 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
     k0 = int(k0) & 0xFFFFFFFF
     k1 = int(k1) & 0xFFFFFFFF
-    for r in range(10):
+    for _ in range(10):
         p0 = _M0 * c0
         p1 = _M1 * c2
         hi0, lo0 = p0 >> _S32, p0 & _MASK
@@ -70,62 +236,42 @@ def keyed_uniform(seed, sweep, stream, doc, site):
 
 
 # ----------------------------------------------------------------------------------------------
-# The keyed categorical draw.  Its association order is the one the wavefront uses.
+# The keyed categorical draw
 # ----------------------------------------------------------------------------------------------
-def elems_per_lane(K):
-    """E = topics held by each of the 64 lanes: the smallest power of two with 64*E >= K."""
-    if K < 1 or K > 1024:
-        raise ValueError("K must be in 1..1024")
-    e = 1
-    while 64 * e < K:
-        e *= 2
-    return e
-
-
-def wave_scan(t):
-    """Inclusive scan of 64 float64 values in the order of the CDNA DPP scan:
-    row_shr:1,2,4,8 inside each 16-lane row, then row_bcast:15 (rows 1,3), then row_bcast:31 (rows 2,3)."""
-    x = np.array(t, dtype=np.float64)
-    lane = np.arange(64)
-    for sh in (1, 2, 4, 8):
-        y = x.copy()
-        m = (lane % 16) >= sh
-        y[m] = x[lane[m] - sh] + x[m]
-        x = y
-    x[16:32] = x[15] + x[16:32]
-    x[48:64] = x[47] + x[48:64]
-    x[32:64] = x[31] + x[32:64]
-    return x
-
-
-def draw_keyed(prob, u):
+def draw_keyed(prob, u, lay=None):
     """Topic chosen for the normalised probability vector ``prob`` (length K) and uniform ``u``.
 
-    lane l holds topics l*E .. l*E+E-1.  q = sequential inclusive prefix inside the lane,
-    X = wave_scan(lane totals), c[k] = X[l-1] + q (X[-1] := 0), t = u * X[63];
-    z = the first k with prob[k] > 0 and c[k] > t, or the last k with prob[k] > 0 if there is none.
+    In group layout: q[g][s] = sequential inclusive prefix over the slots of lane g;
+    X = Hillis-Steele inclusive scan of the lane totals q[g][T-1] over the G lanes
+    (for d = 1,2,4,..: x[g] <- x[g-d] + x[g] where g >= d);  t = u * X[G-1];
+    t_g = t - X[g-1]  (X[-1] := 0);  the draw is the first (g, s) in lane-major order with
+    prob > 0 and q[g][s] > t_g, or the last position with prob > 0 if there is none.
     """
     prob = np.asarray(prob, dtype=np.float64)
-    K = prob.shape[0]
-    E = elems_per_lane(K)
-    p = np.zeros(64 * E, dtype=np.float64)
-    p[:K] = prob
-    p = p.reshape(64, E)
+    if lay is None:
+        lay = layout(prob.shape[0])
+    p = lay.grid(prob)
     q = p.copy()
-    for s in range(1, E):
+    for s in range(1, lay.T):
         q[:, s] = q[:, s - 1] + p[:, s]
-    X = wave_scan(q[:, E - 1])
-    O = np.concatenate(([0.0], X[:-1]))
-    c = O[:, None] + q
-    t = u * X[63]
+    x = q[:, lay.T - 1].copy()
+    d = 1
+    while d < lay.G:
+        y = x.copy()
+        y[d:] = x[:-d] + x[d:]
+        x = y
+        d *= 2
+    t = u * x[lay.G - 1]
+    off = np.concatenate(([0.0], x[:-1]))
+    tg = t - off
     pos = p > 0.0
-    flag = (pos & (c > t)).ravel()
+    flag = (pos & (q > tg[:, None])).ravel()
     if flag.any():
-        return int(np.argmax(flag))
+        return int(lay.slot_topic[int(np.argmax(flag))])
     pos = pos.ravel()
     if not pos.any():
         raise FloatingPointError("draw_keyed: no positive probability")
-    return int(pos.shape[0] - 1 - np.argmax(pos[::-1]))
+    return int(lay.slot_topic[pos.shape[0] - 1 - int(np.argmax(pos[::-1]))])
 
 
 class KeyedDraw(object):
@@ -294,44 +440,26 @@ def get_ph(st):
 
 
 # ----------------------------------------------------------------------------------------------
-# Conversions between reference-shaped state and the flat device layout
+# Flat (CSR) views used by the C restatement and by the tests that feed the device
 # ----------------------------------------------------------------------------------------------
-def to_device_layout(st):
-    """-> dict of flat arrays in the layout include/llda_hip.h documents."""
-    K, V, D = st.K, st.V, st.D
-    E = elems_per_lane(K)
-    KP = 64 * E
+def to_flat(st):
+    """-> dict(doc_off int64[D+1], word int32[S], freq int32[S], z int64[S], labs uint8[D,K])."""
     lens = np.array([len(d) for d in st.docs], dtype=np.int64)
-    doc_off = np.zeros(D + 1, dtype=np.int64)
+    doc_off = np.zeros(st.D + 1, dtype=np.int64)
     np.cumsum(lens, out=doc_off[1:])
     word = np.array([v for d in st.docs for v in d], dtype=np.int32)
     freq = np.array([f for d in st.freqs for f in d], dtype=np.int32)
-    z = st.flat_z().astype(np.int32)
-    n_dk = np.zeros((D, KP), dtype=np.int32)
-    n_dk[:, :K] = st.n_d_k
-    n_kw = np.zeros((V, KP), dtype=np.int32)
-    n_kw[:, :K] = st.n_k_v.T
-    n_k = np.zeros(KP, dtype=np.int32)
-    n_k[:K] = st.n_zk
-    lab_bits = pack_label_bits(st.labs, KP)
-    return dict(doc_off=doc_off, word=word, freq=freq, z=z, n_dk=n_dk, n_kw=n_kw, n_k=n_k,
-                lab_bits=lab_bits, K=K, V=V, D=D, KP=KP, E=E)
-
-
-def pack_label_bits(labs, KP):
-    """(D,K) 0/1 -> (D, KP/32) uint32, bit (k % 32) of word k // 32 set iff labs[d,k] != 0."""
-    labs = np.asarray(labs)
-    D, K = labs.shape
-    bits = np.zeros((D, KP), dtype=np.uint8)
-    bits[:, :K] = labs != 0
-    bits = bits.reshape(D, KP // 32, 32).astype(np.uint32)
-    return (bits << np.arange(32, dtype=np.uint32)).sum(axis=2, dtype=np.uint64).astype(np.uint32)
+    return dict(doc_off=doc_off, word=word, freq=freq, z=st.flat_z().astype(np.int64),
+                labs=(st.labs != 0).astype(np.uint8))
 
 
 def digest(n_k_v, n_d_k, n_zk, z_flat):
     """SHA-256 over the four integer arrays as little-endian int64 (reference dtypes)."""
-    import hashlib
     h = hashlib.sha256()
     for a in (n_k_v, n_d_k, n_zk, z_flat):
         h.update(np.ascontiguousarray(a, dtype="<i8").tobytes())
     return h.hexdigest()
+
+
+def state_digest(st):
+    return digest(st.n_k_v, st.n_d_k, st.n_zk, st.flat_z())
