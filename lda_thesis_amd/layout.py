@@ -1,0 +1,153 @@
+"""Group layout: how the K topics of one document are spread over the lanes of a wavefront.
+
+The reference normalises the K topic scores with ``np.sum`` (/root/reference/LabeledLDA.py:117,
+CascadeLDA.py:413).  numpy adds a contiguous float64 vector *pairwise*: blocks ("leaves") of at
+most 128 elements are reduced by 8 interleaved accumulators (element i goes to accumulator i & 7),
+the accumulators are combined as ((0+1)+(2+3))+((4+5)+(6+7)), a tail of n % 8 elements is added
+sequentially, and leaves are combined by a binary recursion that splits n at n/2 rounded down to a
+multiple of 8.  Bit-exact parity with the reference therefore fixes the association order of the
+sum.  The layout below makes that order lane-local on a 64-wide wavefront:
+
+    leaf p (start_p, n_p), rel = k - start_p, chain j = rel & 7, row = rel >> 3
+    lane g = 8*p + j     slot s = row     device position pos = g*T + s
+
+so that one accumulator chain is one lane walking its T slots, the 8 accumulators of a leaf are 8
+neighbouring lanes (xor butterfly 1,2,4), and leaves are 8-lane groups combined by a short
+butterfly schedule.  A document occupies G = 8 * P lanes (P = number of leaves rounded up to a
+power of two), i.e. 64/G documents share a wavefront.  All per-topic device arrays (rows of n_kw,
+rows of n_dk, n_k, label masks) are stored in ``pos`` order with row length KP = G*T, so a lane's T
+slots are one contiguous, 16-byte aligned run.
+"""
+import numpy as np
+
+PW_BLOCK = 128          # numpy's pairwise-sum block size
+MAX_K = 1024            # 8 leaves x 128 topics = 64 lanes x 16 slots
+MAX_ROUNDS = 4          # depth of the leaf-combine schedule handed to the kernel
+
+
+def _leaves(n, start=0):
+    if n <= PW_BLOCK:
+        return [(start, n)]
+    n2 = n // 2
+    n2 -= n2 % 8
+    return _leaves(n2, start) + _leaves(n - n2, start + n2)
+
+
+def _tree(n, first=0):
+    """numpy's recursion over leaf indices: an int (leaf) or a pair (left, right)."""
+    if n <= PW_BLOCK:
+        return first, 1
+    n2 = n // 2
+    n2 -= n2 % 8
+    left, nl = _tree(n2, first)
+    right, nr = _tree(n - n2, first + nl)
+    return (left, right), nl + nr
+
+
+def _depth(t):
+    return 0 if isinstance(t, int) else 1 + max(_depth(t[0]), _depth(t[1]))
+
+
+def _members(t):
+    return [t] if isinstance(t, int) else _members(t[0]) + _members(t[1])
+
+
+class GroupLayout(object):
+    """Layout of K topics.  Attributes: K, leaves, P, G (lanes per document), T (slots per lane),
+    KP (padded row length), tail (n % 8 of the last leaf), tail_row, topic_pos[K] (topic -> device
+    position), pos_topic[KP] (device position -> topic, -1 in the padding), rounds (leaf-combine
+    schedule: ``n_rounds`` arrays of 8 partner-leaf ids, identity where a leaf idles)."""
+
+    def __init__(self, K):
+        K = int(K)
+        if K < 1 or K > MAX_K:
+            raise ValueError("K must be in 1..%d, got %d" % (MAX_K, K))
+        self.K = K
+        self.leaves = _leaves(K)
+        m = len(self.leaves)
+        if m > 8:
+            # happens only for some K in 969..1023: numpy's recursion yields 9 leaves there
+            raise ValueError("K=%d splits into %d pairwise leaves; at most 8 (64 lanes) supported"
+                             % (K, m))
+        P = 1
+        while P < m:
+            P *= 2
+        self.m, self.P, self.G = m, P, 8 * P
+        t_used = max((n + 7) // 8 for _, n in self.leaves)
+        T = t_used
+        if T > 2:
+            T = (T + 3) // 4 * 4
+        self.T_used, self.T = t_used, T
+        self.KP = self.G * T
+        self.rows = [n // 8 for _, n in self.leaves]
+        self.tail = self.leaves[-1][1] % 8
+        self.tail_row = self.leaves[-1][1] // 8
+        for _, n in self.leaves[:-1]:
+            assert n % 8 == 0
+        self.topic_pos = np.zeros(K, dtype=np.int32)
+        self.pos_topic = np.full(self.KP, -1, dtype=np.int32)
+        for p, (st, n) in enumerate(self.leaves):
+            for rel in range(n):
+                pos = (8 * p + (rel & 7)) * T + (rel >> 3)
+                self.topic_pos[st + rel] = pos
+                self.pos_topic[pos] = st + rel
+        self.leaf_start = np.zeros(8, dtype=np.int32)
+        self.leaf_rows = np.zeros(8, dtype=np.int32)
+        for p, (st, n) in enumerate(self.leaves):
+            self.leaf_start[p] = st
+            self.leaf_rows[p] = n // 8
+        self.rounds = self._schedule()
+        self.n_rounds = len(self.rounds)
+        if self.n_rounds > MAX_ROUNDS:
+            raise ValueError("leaf-combine schedule deeper than %d" % MAX_ROUNDS)
+
+    def _schedule(self):
+        tree, _ = _tree(self.K)
+        rounds = []
+
+        def visit(t):
+            if isinstance(t, int):
+                return
+            visit(t[0])
+            visit(t[1])
+            d = _depth(t) - 1
+            while len(rounds) <= d:
+                rounds.append(np.arange(8, dtype=np.int32))
+            lm, rm = _members(t[0]), _members(t[1])
+            for a in lm:
+                rounds[d][a] = rm[0]
+            for b in rm:
+                rounds[d][b] = lm[0]
+
+        visit(tree)
+        return rounds
+
+    # ---- conversions between reference order (K) and device order (KP) ----
+    def to_device(self, arr, dtype=None):
+        """(..., K) array in topic order -> (..., KP) array in device order (zeros in the padding)."""
+        arr = np.asarray(arr)
+        out = np.zeros(arr.shape[:-1] + (self.KP,), dtype=dtype or arr.dtype)
+        out[..., self.topic_pos] = arr
+        return out
+
+    def from_device(self, arr):
+        """(..., KP) array in device order -> (..., K) array in topic order."""
+        return np.asarray(arr)[..., self.topic_pos]
+
+    def lane_masks(self, labs):
+        """(D, K) 0/1 label matrix -> (D, G) uint16: bit s of [d, g] = label of the topic at slot s
+        of lane g (0 in the padding)."""
+        dev = self.to_device((np.asarray(labs) != 0).astype(np.uint16))
+        dev = dev.reshape(dev.shape[0], self.G, self.T)
+        weights = (1 << np.arange(self.T, dtype=np.uint32)).astype(np.uint16)
+        return (dev * weights).sum(axis=2).astype(np.uint16)
+
+
+_CACHE = {}
+
+
+def group_layout(K):
+    K = int(K)
+    if K not in _CACHE:
+        _CACHE[K] = GroupLayout(K)
+    return _CACHE[K]

@@ -1,0 +1,306 @@
+"""Golden-vector generator  --  TEST INFRASTRUCTURE, runs ONLY in the build container.
+
+Imports the UNMODIFIED reference from /root/reference (gensim stubbed by oracle/refshim.py), runs
+its own ``LabeledLDA.training_iteration`` / ``SubLDA.training_iteration`` and writes inputs and
+expected outputs to tests/golden/*.npz.  Nothing of the reference's source is copied: the fixtures
+hold integer/float arrays only.
+
+Three modes per fixture:
+  O1  np.random.seed(s); m.training_iteration()                       (reference verbatim)
+  O2  <module>.multinom_draw = KeyedDraw;  m.training_iteration()     (sequential, keyed draw)
+  O3  per-document snapshot: the reference's training_iteration is called on a one-document view
+      that shares n_k_v / n_zk; the sweep-start snapshot is restored after every document and the
+      integer deltas are applied at the end of the sweep.  This is the semantics of the HIP kernel.
+
+Usage:  python oracle/gen_golden.py [tiny] [sublda] [abstracts] [abstracts200]
+"""
+import copy
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import llda_oracle as orc          # noqa: E402
+import refshim                     # noqa: E402
+from lda_thesis_amd.text import Dictionary  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REF_L, REF_C = refshim.import_reference()
+
+
+# ------------------------------------------------------------------------------------------
+def snapshot_arrays(m):
+    return dict(n_k_v=m.n_k_v.astype(np.int32), n_d_k=m.n_d_k.astype(np.int32),
+                n_zk=m.n_zk.astype(np.int32),
+                z=np.concatenate([np.asarray(z, dtype=np.int32) for z in m.z_dn]))
+
+
+def model_digest(m):
+    return orc.digest(m.n_k_v, m.n_d_k, m.n_zk, np.concatenate([np.asarray(z) for z in m.z_dn]))
+
+
+def set_draw(module, draw):
+    module.multinom_draw = draw
+
+
+def run_o1(module, m, seed, sweeps):
+    set_draw(module, np.random.multinomial)
+    np.random.seed(seed)
+    out = []
+    for _ in range(sweeps):
+        m.training_iteration()
+        out.append(snapshot_arrays(m))
+    return out
+
+
+def run_o2(module, m, seed, sweeps, stream=0):
+    draw = orc.KeyedDraw(seed, stream)
+    set_draw(module, draw)
+    out = []
+    for s in range(sweeps):
+        draw.sweep = s
+        draw.plan = iter([(d, n) for d in range(m.D) for n in range(len(m.docs[d]))])
+        m.training_iteration()
+        out.append(snapshot_arrays(m))
+    set_draw(module, np.random.multinomial)
+    return out
+
+
+def o3_sweep(module, cls, m, draw, sweep, order=None, doc_base=0):
+    """One per-document-snapshot sweep using the reference's own training_iteration on views."""
+    draw.sweep = sweep
+    draw.plan = None
+    set_draw(module, draw)
+    delta_kv = np.zeros_like(m.n_k_v)
+    delta_zk = np.zeros_like(m.n_zk)
+    order = range(m.D) if order is None else order
+    for d in order:
+        view = object.__new__(cls)
+        view.docs = [m.docs[d]]
+        view.freqs = [m.freqs[d]]
+        view.z_dn = [m.z_dn[d]]
+        view.labs = m.labs[d:d + 1]
+        view.n_d_k = m.n_d_k[d:d + 1]
+        view.alpha, view.beta, view.V = m.alpha, m.beta, m.V
+        view.n_k_v, view.n_zk = m.n_k_v, m.n_zk
+        ids = list(m.docs[d])
+        save_kv = m.n_k_v[:, ids].copy()
+        save_zk = m.n_zk.copy()
+        draw.doc = d + doc_base
+        draw.site = 0
+        cls.training_iteration(view)                # UNMODIFIED reference code
+        delta_kv[:, ids] += m.n_k_v[:, ids] - save_kv
+        delta_zk += m.n_zk - save_zk
+        m.n_k_v[:, ids] = save_kv
+        m.n_zk[:] = save_zk
+    m.n_k_v += delta_kv
+    m.n_zk += delta_zk
+    set_draw(module, np.random.multinomial)
+
+
+def run_o3(module, cls, m, seed, sweeps, stream=0, orders=None):
+    draw = orc.KeyedDraw(seed, stream)
+    out = []
+    for s in range(sweeps):
+        o3_sweep(module, cls, m, draw, s, None if orders is None else orders[s])
+        out.append(snapshot_arrays(m))
+    return out
+
+
+def csr_of(m):
+    lens = np.array([len(d) for d in m.docs], dtype=np.int64)
+    doc_off = np.zeros(m.D + 1, dtype=np.int64)
+    np.cumsum(lens, out=doc_off[1:])
+    word = np.array([v for d in m.docs for v in d], dtype=np.int32)
+    freq = np.array([f for d in m.freqs for f in d], dtype=np.int32)
+    return doc_off, word, freq
+
+
+def pack(prefix, states, out):
+    for s, st in enumerate(states):
+        for k, v in st.items():
+            out["%s_s%d_%s" % (prefix, s + 1, k)] = v
+
+
+# ------------------------------------------------------------------------------------------
+def synth_corpus(rng, D, V, n_labels, max_labs, len_lo, len_hi):
+    vocab = ["w%04d" % i for i in range(V)]
+    pz = 1.0 / np.arange(1, V + 1)
+    pz /= pz.sum()
+    docs, labs = [], []
+    labelset = ["L%03d" % i for i in range(n_labels)]
+    for d in range(D):
+        n = int(rng.integers(len_lo, len_hi + 1))
+        docs.append([vocab[i] for i in rng.choice(V, size=n, p=pz)])
+        nl = int(rng.integers(0, max_labs + 1)) if n_labels else 0
+        labs.append([labelset[i] for i in rng.choice(n_labels, size=min(nl, n_labels), replace=False)]
+                    if nl else [])
+    return docs, labs, labelset
+
+
+TINY = [
+    # name        D    V   labels max_labs  lens      alpha beta  sweeps
+    ("k05",      40,  60,    4,   3,      (3, 25),   0.1, 0.01, 3),    # K<8: sequential np.sum
+    ("k12",      60, 120,   11,   4,      (5, 40),   0.1, 0.01, 3),    # one row + tail
+    ("k20dense", 50, 100,   19,  19,      (5, 40),   0.5, 0.1,  3),    # Cascade-root sized
+    ("k40",      60, 150,   39,   6,      (5, 50),   0.1, 0.01, 3),
+    ("k128",     40, 200,  127,  30,      (10, 60),  0.1, 0.01, 2),    # exactly one full leaf
+    ("k130",     40, 200,  129,  30,      (10, 60),  0.1, 0.01, 2),    # two leaves, tail 2
+    ("k200",     30, 150,  199,  40,      (10, 60),  0.001, 0.001, 2),
+    ("k392",     30, 150,  391,   7,      (10, 60),  0.1, 0.01, 2),    # abstracts-shaped, 4 leaves
+    ("k512",     24, 150,  511, 200,      (10, 60),  0.1, 0.01, 2),    # 4 full leaves
+    ("k777",     16, 120,  776, 300,      (10, 50),  0.1, 0.01, 2),    # unbalanced tree
+]
+
+
+def gen_tiny():
+    for (name, D, V, nl, ml, (lo, hi), alpha, beta, sweeps) in TINY:
+        rng = np.random.default_rng(sum(map(ord, name)))
+        docs, labs, labelset = synth_corpus(rng, D, V, nl, ml, lo, hi)
+        dicti = Dictionary(docs)
+        np.random.seed(1000 + len(name))
+        m0 = REF_L.LabeledLDA(docs, labs, list(labelset), dicti, alpha, beta)
+        out = dict(K=m0.K, V=m0.V, D=m0.D, alpha=alpha, beta=beta, seed=12345, sweeps=sweeps,
+                   labs=(m0.labs != 0).astype(np.uint8))
+        out["doc_off"], out["word"], out["freq"] = csr_of(m0)
+        for k, v in snapshot_arrays(m0).items():
+            out["init_" + k] = v
+        pack("o1", run_o1(REF_L, copy.deepcopy(m0), 777, sweeps), out)
+        pack("o2", run_o2(REF_L, copy.deepcopy(m0), 12345, sweeps), out)
+        m3 = copy.deepcopy(m0)
+        o3 = run_o3(REF_L, REF_L.LabeledLDA, m3, 12345, sweeps)
+        pack("o3", o3, out)
+        # order / shard independence of O3, asserted at generation time
+        perm = [np.random.default_rng(5).permutation(m0.D) for _ in range(sweeps)]
+        m3b = copy.deepcopy(m0)
+        run_o3(REF_L, REF_L.LabeledLDA, m3b, 12345, sweeps, orders=perm)
+        assert model_digest(m3b) == model_digest(m3), name
+        out["o3_digest"] = np.array(model_digest(m3))
+        out["o3_phi"] = m3.get_phi()
+        out["o3_theta"] = m3.get_theta()
+        out["o3_perplexity"] = np.float64(m3.perplexity())
+        np.savez_compressed(os.path.join(GOLDEN, "tiny_%s.npz" % name), **out)
+        print("tiny_%s: K=%d V=%d D=%d sites=%d digest=%s" % (name, m0.K, m0.V, m0.D,
+                                                             out["doc_off"][-1], model_digest(m3)[:16]))
+
+
+def gen_sublda():
+    """SubLDA with the phantom-column initialisation quirk (CascadeLDA.py:382-385)."""
+    rng = np.random.default_rng(99)
+    docs, labs, labelset = synth_corpus(rng, 50, 80, 7, 3, 5, 40)
+    dicti = Dictionary(docs)
+    doc_tups = [dicti.doc2bow(x) for x in docs]
+    alpha, beta, sweeps = 0.1, 0.01, 3
+    np.random.seed(4242)
+    m0 = REF_C.SubLDA(doc_tups, labs, list(labelset), dicti, alpha=alpha, beta=beta)
+    assert m0.n_k_v.sum() != m0.n_zk.sum()          # the quirk is present
+    out = dict(K=m0.K, V=m0.V, D=m0.D, alpha=alpha, beta=beta, seed=777, stream=5, sweeps=sweeps,
+               labs=(m0.labs != 0).astype(np.uint8))
+    out["doc_off"], out["word"], out["freq"] = csr_of(m0)
+    for k, v in snapshot_arrays(m0).items():
+        out["init_" + k] = v
+    pack("o1", run_o1(REF_C, copy.deepcopy(m0), 31337, sweeps), out)
+    pack("o2", run_o2(REF_C, copy.deepcopy(m0), 777, sweeps, stream=5), out)
+    m3 = copy.deepcopy(m0)
+    pack("o3", run_o3(REF_C, REF_C.SubLDA, m3, 777, sweeps, stream=5), out)
+    out["o3_ph"] = m3.get_ph()
+    np.savez_compressed(os.path.join(GOLDEN, "sublda.npz"), **out)
+    print("sublda: K=%d V=%d D=%d phantom=%d" % (m0.K, m0.V, m0.D, m0.n_k_v.sum() - m0.n_zk.sum()))
+
+
+# ------------------------------------------------------------------------------------------
+ABSTRACTS_CSV = os.path.join(refshim.REFERENCE_DIR, "abstracts_data.csv")
+
+
+def build_abstracts():
+    """config 1/2 of BASELINE.json: reference split_data + prune_dict(l=0,u=1) + LabeledLDA."""
+    np.random.seed(2024)
+    train, test = REF_L.split_data(ABSTRACTS_CSV, d=3)
+    a, b, c = train
+    dicti = REF_L.prune_dict(a, lower=0, upper=1)
+    np.random.seed(7)
+    t0 = time.time()
+    m = REF_L.LabeledLDA(a, b, c, dicti, 0.1, 0.01)
+    print("abstracts: D=%d K=%d V=%d init %.1fs" % (m.D, m.K, m.V, time.time() - t0))
+    return m, train, test, dicti
+
+
+def gen_abstracts(sweeps=(1, 2, 4)):
+    m, train, test, dicti = build_abstracts()
+    out = dict(K=m.K, V=m.V, D=m.D, alpha=0.1, beta=0.01, seed=42)
+    out["doc_off"], out["word"], out["freq"] = csr_of(m)
+    out["word"] = out["word"].astype(np.uint16 if m.V < 65536 else np.int32)
+    out["freq"] = out["freq"].astype(np.uint8 if max(out["freq"]) < 256 else np.int32)
+    lab_rows, lab_cols = np.nonzero(m.labs)
+    lab_off = np.zeros(m.D + 1, dtype=np.int64)
+    np.cumsum(np.bincount(lab_rows, minlength=m.D), out=lab_off[1:])
+    out["lab_off"], out["lab_idx"] = lab_off, lab_cols.astype(np.int16)
+    out["z_init"] = np.concatenate(m.z_dn).astype(np.int16)
+    out["labelset"] = np.array(list(m.labelmap.keys()))
+    # held-out split as CSR over the same dictionary (for the test-time path)
+    tdocs = [dicti.doc2bow(x) for x in test[0]]
+    toff = np.zeros(len(tdocs) + 1, dtype=np.int64)
+    np.cumsum([len(t) for t in tdocs], out=toff[1:])
+    out["test_doc_off"] = toff
+    out["test_word"] = np.array([v for t in tdocs for v, _ in t], dtype=np.uint16)
+    out["test_freq"] = np.array([f for t in tdocs for _, f in t], dtype=np.uint8)
+    tl_off = [0]
+    tl_idx = []
+    for lab in test[1]:
+        ids = sorted(m.labelmap[x] for x in lab if x in m.labelmap)
+        tl_idx += ids
+        tl_off.append(len(tl_idx))
+    out["test_lab_off"] = np.array(tl_off, dtype=np.int64)
+    out["test_lab_idx"] = np.array(tl_idx, dtype=np.int16)
+    draw = orc.KeyedDraw(42, 0)
+    digests, nzk, perp = {}, {}, {}
+    t0 = time.time()
+    for s in range(max(sweeps)):
+        o3_sweep(REF_L, REF_L.LabeledLDA, m, draw, s)
+        if (s + 1) in sweeps:
+            digests[s + 1] = model_digest(m)
+            nzk[s + 1] = m.n_zk.astype(np.int32)
+            print("  sweep %d digest %s  (%.0fs)" % (s + 1, digests[s + 1][:16], time.time() - t0))
+    for s in sweeps:
+        out["o3_digest_s%d" % s] = np.array(digests[s])
+        out["o3_n_zk_s%d" % s] = nzk[s]
+    out["o3_perplexity_s%d" % max(sweeps)] = np.float64(m.perplexity())
+    out["o3_z_s%d" % max(sweeps)] = np.concatenate(m.z_dn).astype(np.int16)
+    np.savez_compressed(os.path.join(GOLDEN, "abstracts_d3.npz"), **out)
+    return m
+
+
+def gen_abstracts200():
+    """200 sweeps of O3 through the reference (about 20-30 minutes); digests at 50/100/200."""
+    m, _, _, _ = build_abstracts()
+    draw = orc.KeyedDraw(42, 0)
+    out = {}
+    t0 = time.time()
+    for s in range(200):
+        o3_sweep(REF_L, REF_L.LabeledLDA, m, draw, s)
+        if (s + 1) in (1, 2, 4, 50, 100, 200):
+            out["o3_digest_s%d" % (s + 1)] = np.array(model_digest(m))
+            out["o3_n_zk_s%d" % (s + 1)] = m.n_zk.astype(np.int32)
+            print("  sweep %d %s (%.0fs)" % (s + 1, model_digest(m)[:16], time.time() - t0), flush=True)
+    out["o3_perplexity_s200"] = np.float64(m.perplexity())
+    out["o3_z_s200"] = np.concatenate(m.z_dn).astype(np.int16)
+    np.savez_compressed(os.path.join(GOLDEN, "abstracts_d3_s200.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLDEN, exist_ok=True)
+    what = sys.argv[1:] or ["tiny", "sublda"]
+    if "tiny" in what:
+        gen_tiny()
+    if "sublda" in what:
+        gen_sublda()
+    if "abstracts" in what:
+        gen_abstracts()
+    if "abstracts200" in what:
+        gen_abstracts200()

@@ -78,6 +78,8 @@ class Layout(object):
         self.K = K
         self.leaves = pairwise_leaves(K)
         m = len(self.leaves)
+        if m > 8:
+            raise ValueError("K=%d splits into %d pairwise leaves; at most 8 supported" % (K, m))
         P = 1
         while P < m:
             P *= 2
@@ -225,13 +227,18 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 def keyed_uniform(seed, sweep, stream, doc, site):
     """53-bit uniform in [0,1) for (seed; sweep, stream, doc, site).
 
-    counter = (site, doc, stream, sweep), key = (seed & 0xffffffff, seed >> 32);
-    u = ((r0 >> 5) * 2**26 + (r1 >> 6)) / 2**53   (all operations exact in float64).
+    One Philox block serves two consecutive sites of a document:
+    counter = (site >> 1, doc, stream, sweep), key = (seed & 0xffffffff, seed >> 32);
+    (a, b) = (r0, r1) for an even site, (r2, r3) for an odd site;
+    u = ((a >> 5) * 2**26 + (b >> 6)) / 2**53   (all operations exact in float64).
     """
     seed = int(seed)
-    r0, r1, _, _ = philox4x32_10(site, doc, stream, sweep, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    a = (r0 >> np.uint64(5)).astype(np.float64)
-    b = (r1 >> np.uint64(6)).astype(np.float64)
+    site = np.asarray(site, dtype=np.uint64)
+    r0, r1, r2, r3 = philox4x32_10(site >> np.uint64(1), doc, stream, sweep,
+                                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    odd = (site & np.uint64(1)).astype(bool)
+    a = (np.where(odd, r2, r0) >> np.uint64(5)).astype(np.float64)
+    b = (np.where(odd, r3, r1) >> np.uint64(6)).astype(np.float64)
     return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0)
 
 
@@ -276,8 +283,9 @@ def draw_keyed(prob, u, lay=None):
 
 class KeyedDraw(object):
     """Callable with numpy.random.multinomial's call shape: draw(1, prob) -> one-hot int array.
-    Injected into the reference as ``LabeledLDA.multinom_draw`` by gen_golden.py; the driver sets
-    ``.sweep``, ``.doc`` (global id) and ``.site`` before each call chain (site auto-increments)."""
+    Injected into the reference as the module global ``multinom_draw`` by gen_golden.py.  The
+    driver sets ``.sweep`` and either ``.doc``/``.site`` (site auto-increments) or a ``.plan``
+    iterator yielding (global_doc, site) in visit order."""
 
     def __init__(self, seed, stream=0):
         self.seed = seed
@@ -285,10 +293,15 @@ class KeyedDraw(object):
         self.sweep = 0
         self.doc = 0
         self.site = 0
+        self.plan = None
+        self.calls = 0
 
     def __call__(self, n, prob):
+        if self.plan is not None:
+            self.doc, self.site = next(self.plan)
         u = float(keyed_uniform(self.seed, self.sweep, self.stream, self.doc, self.site))
         self.site += 1
+        self.calls += 1
         z = draw_keyed(prob, u)
         out = np.zeros(len(prob), dtype=np.int64)
         out[z] = 1

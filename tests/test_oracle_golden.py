@@ -1,0 +1,83 @@
+"""The oracle (numpy restatement + C restatement) against vectors produced by the UNMODIFIED
+reference (oracle/gen_golden.py): bit-exact integer state after every sweep, in all three modes."""
+import numpy as np
+import pytest
+
+import llda_oracle as orc
+from conftest import golden_names, load_golden
+from helpers import assert_state_equal, c_state, oracle_state
+
+TINY = golden_names("tiny_")
+ALL = TINY + ["sublda"]
+
+
+def test_fixtures_present():
+    assert len(TINY) >= 8
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_numpy_oracle_native_stream_o1(name):
+    """O1: reference verbatim, numpy's own legacy MT19937 stream."""
+    g = load_golden(name)
+    st = oracle_state(g)
+    np.random.seed(777 if name != "sublda" else 31337)
+    for s in range(int(g["sweeps"])):
+        orc.sweep_sequential(st, None)
+        assert_state_equal(g, "o1_s%d" % (s + 1), st.n_k_v, st.n_d_k, st.n_zk, st.flat_z(), name)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_numpy_oracle_keyed_sequential_o2(name):
+    g = load_golden(name)
+    st = oracle_state(g)
+    draw = orc.KeyedDraw(int(g["seed"]), int(g["stream"]) if "stream" in g else 0)
+    for s in range(int(g["sweeps"])):
+        draw.sweep = s
+        orc.sweep_sequential(st, draw)
+        assert_state_equal(g, "o2_s%d" % (s + 1), st.n_k_v, st.n_d_k, st.n_zk, st.flat_z(), name)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_numpy_oracle_snapshot_o3(name):
+    g = load_golden(name)
+    st = oracle_state(g)
+    draw = orc.KeyedDraw(int(g["seed"]), int(g["stream"]) if "stream" in g else 0)
+    rng = np.random.default_rng(3)
+    for s in range(int(g["sweeps"])):
+        draw.sweep = s
+        orc.sweep_snapshot(st, draw, order=rng.permutation(st.D))     # any order gives the same state
+        assert_state_equal(g, "o3_s%d" % (s + 1), st.n_k_v, st.n_d_k, st.n_zk, st.flat_z(), name)
+    if "o3_digest" in g:
+        assert orc.state_digest(st) == str(g["o3_digest"])
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_c_oracle(c_oracle, name, mode):
+    g = load_golden(name)
+    cs = c_state(c_oracle, g)
+    stream = int(g["stream"]) if "stream" in g else 0
+    for s in range(int(g["sweeps"])):
+        cs.sweep(mode, int(g["seed"]), s, stream=stream, threads=1 if mode == 0 else 3)
+        assert_state_equal(g, "o%d_s%d" % (2 + mode, s + 1), cs.n_k_v, cs.n_d_k, cs.n_zk, cs.z, name)
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_readouts(name):
+    """get_phi / get_theta / perplexity restated in the oracle vs the reference's outputs."""
+    g = load_golden(name)
+    st = oracle_state(g, prefix="o3_s%d_" % int(g["sweeps"]))
+    np.testing.assert_array_equal(orc.get_phi(st), g["o3_phi"])
+    np.testing.assert_array_equal(orc.get_theta(st), g["o3_theta"])
+    assert abs(orc.perplexity(st) / float(g["o3_perplexity"]) - 1.0) < 1e-12
+
+
+def test_sublda_phantom_and_get_ph():
+    g = load_golden("sublda")
+    # the fixture exhibits the CascadeLDA.py:382-385 quirk: n_k_v row sums exceed n_zk
+    assert g["init_n_k_v"].sum() > g["init_n_zk"].sum()
+    st0 = oracle_state(g)
+    rebuilt = orc.State(st0.docs, st0.freqs, st0.labs, st0.V, st0.alpha, st0.beta, st0.z_dn, phantom=True)
+    np.testing.assert_array_equal(rebuilt.n_k_v, g["init_n_k_v"])
+    st = oracle_state(g, prefix="o3_s%d_" % int(g["sweeps"]))
+    np.testing.assert_array_equal(orc.get_ph(st), g["o3_ph"])
