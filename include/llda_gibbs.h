@@ -1,0 +1,131 @@
+/* llda_gibbs.h -- C ABI of the MI355X-native collapsed-Gibbs sweep for Labeled LDA / CascadeLDA.
+ *
+ * The reference (KenHBS/LDA_thesis) is pure Python and has no FFI boundary of its own; the hot path
+ * is the method  LabeledLDA.training_iteration  (/root/reference/LabeledLDA.py:101-125), byte-for-byte
+ * the same body as  SubLDA.training_iteration  (/root/reference/CascadeLDA.py:397-421).  This header
+ * is the boundary a maintainer binds (ctypes stub in INTEGRATION.md) to replace those two methods,
+ * the count initialisation loops (LabeledLDA.py:89-92, CascadeLDA.py:382-385) and the thinning
+ * read-outs (LabeledLDA.py:231-239, :256-265).
+ *
+ * Conventions
+ *   - every pointer marked [dev] is a DEVICE pointer (HBM of the current HIP device); the library
+ *     allocates nothing persistent and owns none of the buffers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all entry points only
+ *     ENQUEUE work and return without synchronising unless stated otherwise;
+ *   - return value 0 = success, negative = LLDA_E_* (see llda_strerror); HIP failures are returned
+ *     as LLDA_E_HIP and the hipError_t is available from llda_last_hip_error(); nothing throws;
+ *   - one host thread per device; entry points are re-entrant across devices.
+ *
+ * Device layout ("group layout")
+ *   The K topics of a document are spread over G lanes x T slots; per-topic arrays are stored in
+ *   device order  pos = lane*T + slot  with padded row length KP = G*T:
+ *       n_kw  [V][KP] int32   word-major  (the reference's n_k_v (K,V) transposed + permuted)
+ *       n_dk  [D][KP] int32   (the reference's n_d_k (D,K) permuted)
+ *       n_k   [KP]    int32   (the reference's n_zk permuted)
+ *       z     [S]     int32   topic of every site, stored as device POSITION (not topic id)
+ *       lab_mask [D][G] uint16   bit s of [d][g] = labs[d][topic at (g,s)]
+ *   llda_layout() returns the permutation so the host can convert to and from reference order.
+ */
+#ifndef LLDA_GIBBS_H
+#define LLDA_GIBBS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLDA_ABI_VERSION 1
+#define LLDA_MAX_K 1024
+#define LLDA_MAX_LEAVES 8
+#define LLDA_MAX_ROUNDS 4
+
+enum {
+    LLDA_OK = 0,
+    LLDA_E_BAD_K = -1,      /* K outside 1..1024 or more than 8 pairwise leaves            */
+    LLDA_E_BAD_ARG = -2,    /* NULL pointer, negative size, layout fields do not match K   */
+    LLDA_E_HIP = -3,        /* a HIP runtime call failed (see llda_last_hip_error)          */
+    LLDA_E_NO_DEVICE = -4   /* no gfx950 device visible                                     */
+};
+
+/* Layout of K topics over the lanes of a wavefront (host-side description). */
+typedef struct llda_layout {
+    int32_t K;                       /* number of topics (labels incl. 'root')                */
+    int32_t n_leaves;                /* numpy pairwise-sum leaves                             */
+    int32_t G;                       /* lanes per document: 8, 16, 32 or 64                   */
+    int32_t T;                       /* slots per lane: 1, 2, 4, 8, 12 or 16                  */
+    int32_t KP;                      /* G*T                                                   */
+    int32_t tail;                    /* K % 8 of the last leaf                                */
+    int32_t tail_row;                /* slot that holds the tail topics                       */
+    int32_t n_rounds;                /* leaf-combine rounds                                   */
+    int32_t leaf_start[LLDA_MAX_LEAVES];
+    int32_t leaf_len[LLDA_MAX_LEAVES];
+    int32_t rounds[LLDA_MAX_ROUNDS][LLDA_MAX_LEAVES];   /* partner leaf per round (self = idle) */
+    int32_t topic_pos[LLDA_MAX_K];   /* topic id -> device position                           */
+    int32_t pos_topic[LLDA_MAX_K];   /* device position -> topic id, -1 in the padding        */
+} llda_layout;
+
+/* Arguments of one sweep over a shard of documents.
+ * Replaces the loop body of LabeledLDA.training_iteration (LabeledLDA.py:106-125) for documents
+ * [doc_base, doc_base + D) under per-document snapshot semantics: every document reads the
+ * sweep-start n_kw / n_k plus its own changes; count changes are accumulated into the *_delta
+ * buffers with integer atomics (order independent => deterministic). */
+typedef struct llda_sweep_args {
+    const int64_t  *doc_off;     /* [dev] [D+1] site offsets                                  */
+    const int32_t  *doc_order;   /* [dev] [D] processing order (local doc ids) or NULL        */
+    const int32_t  *word;        /* [dev] [S] word id of every site (unique, ascending per doc) */
+    const int32_t  *freq;        /* [dev] [S] frequency f of every site                        */
+    int32_t        *z;           /* [dev] [S] in/out: device position of the site's topic      */
+    const uint16_t *lab_mask;    /* [dev] [D*G] lane masks                                     */
+    int32_t        *n_dk;        /* [dev] [D*KP] in/out                                        */
+    const int32_t  *n_kw;        /* [dev] [V*KP] sweep-start snapshot (read only)              */
+    int32_t        *n_kw_delta;  /* [dev] [V*KP] += sweep changes                              */
+    const int32_t  *n_k;         /* [dev] [KP] sweep-start snapshot (read only)                */
+    int32_t        *n_k_delta;   /* [dev] [KP] += sweep changes                                */
+    int32_t        *status;      /* [dev] optional (may be NULL): bit 0 is set when a site had no
+                                    topic with positive probability (the reference would raise)  */
+    int64_t  D;                  /* local documents                                            */
+    int64_t  V;                  /* vocabulary size (rows of n_kw; also enters den = n_k + V*beta) */
+    int32_t  K;                  /* topics                                                     */
+    int32_t  docs_per_group;     /* documents a lane group walks per workgroup (>=1; 0 = auto) */
+    double   alpha, beta;        /* priors (LabeledLDA.py:55-56)                               */
+    uint64_t seed;               /* RNG key                                                    */
+    uint32_t sweep;              /* RNG counter word 3                                         */
+    uint32_t stream_id;          /* RNG counter word 2 (sub-problem id for CascadeLDA)         */
+    int64_t  doc_base;           /* global id of local document 0 (RNG counter word 1)         */
+} llda_sweep_args;
+
+/* ---- host-only (no device needed) ---- */
+int         llda_abi_version(void);
+const char *llda_strerror(int code);
+int         llda_last_hip_error(void);
+/* Fill *out for K topics.  Mirrors numpy's pairwise-sum recursion (np.sum at LabeledLDA.py:117). */
+int         llda_layout_init(int32_t K, llda_layout *out);
+
+/* ---- device entry points (enqueue on `stream`) ---- */
+/* One Gibbs sweep over the shard: LabeledLDA.py:101-125 / CascadeLDA.py:397-421. */
+int llda_sweep(const llda_sweep_args *args, void *stream);
+
+/* n_kw[i] += delta[i]; delta[i] = 0  for i < n   (end-of-sweep fold, after the all-reduce of delta). */
+int llda_apply_delta(int32_t *counts, int32_t *delta, int64_t n, void *stream);
+
+/* Count initialisation from assignments: LabeledLDA.py:89-92.  n_dk, n_kw, n_k must be zeroed by the
+ * caller; z holds device positions.  (The SubLDA phantom-column quirk, CascadeLDA.py:382-385, is a
+ * host-side initialisation and is uploaded as data.) */
+int llda_count_init(const int64_t *doc_off, const int32_t *word, const int32_t *freq,
+                    const int32_t *z, int64_t D, int32_t K,
+                    int32_t *n_dk, int32_t *n_kw, int32_t *n_k, void *stream);
+
+/* log-likelihood read-out (LabeledLDA.py:256-265): out_doc[d] (dev, double[D]) = sum over the sites
+ * of document d of  -log( sum_k phi[k][w] * theta[d][k] ),  phi/theta as get_phi/get_theta
+ * (LabeledLDA.py:231-239); sites are NOT weighted by frequency (reference quirk).
+ * perplexity = exp( sum_d out_doc[d] / S ). */
+int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab_mask,
+                const int32_t *n_dk, const int32_t *n_kw, const int32_t *n_k,
+                int64_t D, int64_t V, int32_t K, double alpha, double beta,
+                double *out_doc, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLDA_GIBBS_H */

@@ -1,0 +1,141 @@
+"""ctypes binding of the HIP library (include/llda_gibbs.h).
+
+The product path has NO CPU fallback: if ``libllda_gibbs.so`` is missing this module raises, and
+every device entry point raises on a non-zero return code.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libllda_gibbs.so")
+
+MAX_K = 1024
+MAX_LEAVES = 8
+MAX_ROUNDS = 4
+ABI_VERSION = 1
+
+_c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
+_c_p, _c_d = ctypes.c_void_p, ctypes.c_double
+
+
+class LldaLayout(ctypes.Structure):
+    """struct llda_layout (include/llda_gibbs.h)."""
+    _fields_ = [("K", _c_i32), ("n_leaves", _c_i32), ("G", _c_i32), ("T", _c_i32), ("KP", _c_i32),
+                ("tail", _c_i32), ("tail_row", _c_i32), ("n_rounds", _c_i32),
+                ("leaf_start", _c_i32 * MAX_LEAVES), ("leaf_len", _c_i32 * MAX_LEAVES),
+                ("rounds", (_c_i32 * MAX_LEAVES) * MAX_ROUNDS),
+                ("topic_pos", _c_i32 * MAX_K), ("pos_topic", _c_i32 * MAX_K)]
+
+
+class LldaSweepArgs(ctypes.Structure):
+    """struct llda_sweep_args (include/llda_gibbs.h)."""
+    _fields_ = [("doc_off", _c_p), ("doc_order", _c_p), ("word", _c_p), ("freq", _c_p), ("z", _c_p),
+                ("lab_mask", _c_p), ("n_dk", _c_p), ("n_kw", _c_p), ("n_kw_delta", _c_p),
+                ("n_k", _c_p), ("n_k_delta", _c_p), ("status", _c_p),
+                ("D", _c_i64), ("V", _c_i64), ("K", _c_i32), ("docs_per_group", _c_i32),
+                ("alpha", _c_d), ("beta", _c_d), ("seed", _c_u64), ("sweep", _c_u32),
+                ("stream_id", _c_u32), ("doc_base", _c_i64)]
+
+
+EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_layout_init",
+           "llda_sweep", "llda_apply_delta", "llda_count_init", "llda_loglik")
+
+_LIB = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library; raise if it is not built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise NativeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (or make -C lda_thesis_amd/csrc). There is no CPU fallback."
+                          % LIB_PATH)
+    # torch ships its own libamdhip64 / libhsa-runtime64: import it first so this library binds to
+    # the SAME HIP runtime instance as the tensors and streams it is handed (loading ours first pulls
+    # in /opt/rocm's copy and kernel launches then fail with hipErrorNoDevice).
+    import torch  # noqa: F401
+    L = ctypes.CDLL(LIB_PATH)
+    L.llda_abi_version.restype = ctypes.c_int
+    L.llda_abi_version.argtypes = []
+    L.llda_strerror.restype = ctypes.c_char_p
+    L.llda_strerror.argtypes = [ctypes.c_int]
+    L.llda_last_hip_error.restype = ctypes.c_int
+    L.llda_last_hip_error.argtypes = []
+    L.llda_layout_init.restype = ctypes.c_int
+    L.llda_layout_init.argtypes = [_c_i32, ctypes.POINTER(LldaLayout)]
+    L.llda_sweep.restype = ctypes.c_int
+    L.llda_sweep.argtypes = [ctypes.POINTER(LldaSweepArgs), _c_p]
+    L.llda_apply_delta.restype = ctypes.c_int
+    L.llda_apply_delta.argtypes = [_c_p, _c_p, _c_i64, _c_p]
+    L.llda_count_init.restype = ctypes.c_int
+    L.llda_count_init.argtypes = [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i32, _c_p, _c_p, _c_p, _c_p]
+    L.llda_loglik.restype = ctypes.c_int
+    L.llda_loglik.argtypes = [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i32, _c_d, _c_d,
+                              _c_p, _c_p]
+    if L.llda_abi_version() != ABI_VERSION:
+        raise NativeError("libllda_gibbs.so ABI %d != binding ABI %d" % (L.llda_abi_version(), ABI_VERSION))
+    _LIB = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        L = lib()
+        raise NativeError("%s failed: %s (code %d, hipError %d)"
+                          % (what, L.llda_strerror(rc).decode(), rc, L.llda_last_hip_error()))
+
+
+def layout_init(K):
+    """llda_layout_init -> dict of numpy arrays / ints (host only, needs no device)."""
+    out = LldaLayout()
+    check(lib().llda_layout_init(int(K), ctypes.byref(out)), "llda_layout_init(K=%d)" % K)
+    return dict(K=out.K, n_leaves=out.n_leaves, G=out.G, T=out.T, KP=out.KP, tail=out.tail,
+                tail_row=out.tail_row, n_rounds=out.n_rounds,
+                leaf_start=np.array(out.leaf_start[:out.n_leaves]),
+                leaf_len=np.array(out.leaf_len[:out.n_leaves]),
+                rounds=np.array([list(r) for r in out.rounds])[:out.n_rounds],
+                topic_pos=np.array(out.topic_pos[:out.K], dtype=np.int32),
+                pos_topic=np.array(out.pos_topic[:out.KP], dtype=np.int32))
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
+          status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0):
+    """llda_sweep on the current torch stream.  All array arguments are torch CUDA tensors."""
+    a = LldaSweepArgs(_ptr(doc_off), _ptr(doc_order), _ptr(word), _ptr(freq), _ptr(z), _ptr(lab_mask),
+                      _ptr(n_dk), _ptr(n_kw), _ptr(n_kw_delta), _ptr(n_k), _ptr(n_k_delta), _ptr(status),
+                      int(D), int(V), int(K), int(docs_per_group), float(alpha), float(beta),
+                      int(seed) & 0xFFFFFFFFFFFFFFFF, int(sweep) & 0xFFFFFFFF,
+                      int(stream_id) & 0xFFFFFFFF, int(doc_base))
+    check(lib().llda_sweep(ctypes.byref(a), _stream()), "llda_sweep")
+
+
+def apply_delta(counts, delta):
+    check(lib().llda_apply_delta(_ptr(counts), _ptr(delta), counts.numel(), _stream()), "llda_apply_delta")
+
+
+def count_init(doc_off, word, freq, z, D, K, n_dk, n_kw, n_k):
+    check(lib().llda_count_init(_ptr(doc_off), _ptr(word), _ptr(freq), _ptr(z), int(D), int(K),
+                                _ptr(n_dk), _ptr(n_kw), _ptr(n_k), _stream()), "llda_count_init")
+
+
+def loglik(doc_off, word, lab_mask, n_dk, n_kw, n_k, D, V, K, alpha, beta, out_doc):
+    check(lib().llda_loglik(_ptr(doc_off), _ptr(word), _ptr(lab_mask), _ptr(n_dk), _ptr(n_kw), _ptr(n_k),
+                            int(D), int(V), int(K), float(alpha), float(beta), _ptr(out_doc), _stream()),
+          "llda_loglik")

@@ -1,0 +1,672 @@
+// llda_gibbs.hip -- collapsed-Gibbs sweep for Labeled LDA / CascadeLDA on MI355X (gfx950, wave64).
+//
+// Hot path replaced: LabeledLDA.training_iteration (/root/reference/LabeledLDA.py:101-125) ==
+// SubLDA.training_iteration (/root/reference/CascadeLDA.py:397-421).  C ABI: include/llda_gibbs.h.
+//
+// Execution model:
+//   * one lane GROUP of G = 8..64 lanes per document (64/G documents per wavefront), T topic slots
+//     per lane; topic k lives at (lane, slot) chosen so that numpy's pairwise summation order
+//     (np.sum at LabeledLDA.py:117) is lane-local: one accumulator chain = one lane walking its
+//     slots, the 8 accumulators of a 128-topic leaf = 8 neighbouring lanes;
+//   * n_dk row, n_k (as seen by this document) and the label mask of the document stay in VGPRs for
+//     the whole document; the n_kw row of the current word is one contiguous KP*4-byte read
+//     (word-major layout), prefetched one site ahead;
+//   * categorical draw = per-lane prefix over the slots + Hillis-Steele scan over the G lanes +
+//     one keyed Philox4x32-10 uniform;
+//   * count updates: int32 atomics into n_kw_delta (HBM/L2) and, through an LDS accumulator per
+//     workgroup, into n_k_delta.  Snapshot semantics + integer atomics => bit-deterministic.
+// No MFMA (gather/scan, not a contraction).  fp64 throughout; FMA contraction is OFF because the
+// reference rounds after every numpy ufunc.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "llda_gibbs.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+thread_local int g_last_hip_error = 0;
+
+struct KParams {
+    const int64_t *doc_off;
+    const int32_t *doc_order;
+    const int32_t *word;
+    const int32_t *freq;
+    int32_t *z;
+    const uint16_t *lab_mask;
+    int32_t *n_dk;
+    const int32_t *n_kw;
+    int32_t *n_kw_delta;
+    const int32_t *n_k;
+    int32_t *n_k_delta;
+    int32_t *status;
+    int64_t D;
+    int64_t doc_base;
+    double alpha, beta, vbeta;
+    uint32_t key0, key1, sweep, stream_id;
+    int32_t dpg;
+    int32_t last_leaf;      // index of the last (tail-carrying) leaf
+    int32_t tail, tail_row;
+    int32_t n_rounds;
+    uint32_t rounds_pk[LLDA_MAX_ROUNDS];   // 4 bits per leaf: partner leaf
+};
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11).  Counter (c0..c3), key (k0,k1).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3,
+                                              uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// T contiguous int32 starting at p (p is 4*T-byte aligned when T is a multiple of 4).
+template <int T>
+__device__ __forceinline__ void load_row(const int32_t *__restrict__ p, int (&x)[T])
+{
+    if constexpr (T % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < T / 4; ++i) {
+            const int4 v = reinterpret_cast<const int4 *>(p)[i];
+            x[4 * i + 0] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+        }
+    } else if constexpr (T == 2) {
+        const int2 v = *reinterpret_cast<const int2 *>(p);
+        x[0] = v.x; x[1] = v.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) x[i] = p[i];
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void store_row(int32_t *__restrict__ p, const int (&x)[T])
+{
+    if constexpr (T % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < T / 4; ++i)
+            reinterpret_cast<int4 *>(p)[i] = make_int4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+    } else if constexpr (T == 2) {
+        *reinterpret_cast<int2 *>(p) = make_int2(x[0], x[1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) p[i] = x[i];
+    }
+}
+
+// Sum of the group's K scores in numpy's pairwise order.  Every lane of the group returns S.
+//   chain : per-lane sequential sum over its slots (one of numpy's 8 accumulators)
+//   xor butterfly 1,2,4 : ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))   (fp add is commutative)
+//   tail  : n % 8 leftovers of the last leaf, added sequentially
+//   leaves: combined along numpy's recursion tree by the partner schedule
+template <int G, int T, bool HAS_TAIL>
+__device__ __forceinline__ double group_sum(const double (&w)[T], const KParams &P, int lig)
+{
+    const int leaf = lig >> 3;
+    double acc = 0.0, tv = 0.0;
+#pragma unroll
+    for (int s = 0; s < T; ++s) {
+        if (HAS_TAIL && s == P.tail_row && leaf == P.last_leaf) tv = w[s];
+        else acc = acc + w[s];
+    }
+    acc = acc + __shfl_xor(acc, 1, G);
+    acc = acc + __shfl_xor(acc, 2, G);
+    acc = acc + __shfl_xor(acc, 4, G);
+    if (HAS_TAIL) {
+        for (int t = 0; t < P.tail; ++t) {
+            const double o = __shfl(tv, P.last_leaf * 8 + t, G);
+            if (leaf == P.last_leaf) acc = acc + o;
+        }
+    }
+    if (G > 8) {
+#pragma unroll
+        for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) {
+            if (r < P.n_rounds) {
+                const int partner = (P.rounds_pk[r] >> (4 * leaf)) & 15;
+                const double o = __shfl(acc, partner * 8 + (lig & 7), G);
+                if (partner != leaf) acc = acc + o;
+            }
+        }
+        acc = __shfl(acc, 0, G);
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The sweep kernel
+// ---------------------------------------------------------------------------------------------
+template <int G, int T, bool HAS_TAIL>
+__global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
+{
+    constexpr int KP = G * T;
+    constexpr int GPB = 256 / G;              // lane groups (documents in flight) per workgroup
+    __shared__ int s_nk[KP];                  // workgroup accumulator of the n_k changes
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int lig = tid & (G - 1);            // lane in group
+    const int grp = tid / G;
+    const int gbase = lane & ~(G - 1);        // first wave-lane of this group
+    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+
+    for (int it = 0; it < P.dpg; ++it) {
+        const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
+        if (idx >= P.D) break;
+        const int64_t d = P.doc_order ? (int64_t)P.doc_order[idx] : idx;
+        const int64_t s0 = P.doc_off[d];
+        const int len = (int)(P.doc_off[d + 1] - s0);
+        if (len <= 0) continue;
+
+        int ndk[T], nk[T];
+        int32_t *ndk_row = P.n_dk + d * KP + lig * T;
+        load_row<T>(ndk_row, ndk);
+        load_row<T>(P.n_k + lig * T, nk);
+        const uint32_t mask = P.lab_mask[d * G + lig];
+        const uint32_t gdoc = (uint32_t)(d + P.doc_base);
+
+        // site 0 prefetch
+        int xn[T];
+        int v_n = P.word[s0], f_n = P.freq[s0], zo_n = P.z[s0];
+        load_row<T>(P.n_kw + (int64_t)v_n * KP + lig * T, xn);
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+
+        for (int n = 0; n < len; ++n) {
+            const int v = v_n, f = f_n, zo = zo_n;
+            int x[T];
+#pragma unroll
+            for (int s = 0; s < T; ++s) x[s] = xn[s];
+            {   // prefetch the next site (clamped: the last site is simply fetched twice)
+                const int64_t in = s0 + (n + 1 < len ? n + 1 : n);
+                v_n = P.word[in]; f_n = P.freq[in]; zo_n = P.z[in];
+                load_row<T>(P.n_kw + (int64_t)v_n * KP + lig * T, xn);
+            }
+
+            // keyed uniform: one Philox block serves sites 2b and 2b+1
+            if ((n & 1) == 0) {
+                r0 = (uint32_t)(n >> 1); r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
+                philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
+            }
+            const uint32_t ra = (n & 1) ? r2 : r0, rb = (n & 1) ? r3 : r1;
+            const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+
+            // remove the site (LabeledLDA.py:109-111)
+            {
+                const int lo = zo / T, so = zo - lo * T;
+                const int code = (lig == lo) ? so : -1;
+#pragma unroll
+                for (int s = 0; s < T; ++s) {
+                    const int dl = (code == s) ? f : 0;
+                    ndk[s] -= dl; nk[s] -= dl; x[s] -= dl;
+                }
+            }
+
+            // scores (LabeledLDA.py:113-116): prob = lab * a * (num_b / den_b)
+            double w[T];
+#pragma unroll
+            for (int s = 0; s < T; ++s) {
+                const double a = (double)ndk[s] + P.alpha;
+                const double num_b = (double)x[s] + P.beta;
+                const double den_b = (double)nk[s] + P.vbeta;
+                const double ws = a * (num_b / den_b);
+                w[s] = ((mask >> s) & 1u) ? ws : 0.0;
+            }
+
+            // prob /= np.sum(prob)  (LabeledLDA.py:117)
+            const double S = group_sum<G, T, HAS_TAIL>(w, P, lig);
+            double q[T];
+#pragma unroll
+            for (int s = 0; s < T; ++s) w[s] = w[s] / S;
+
+            // keyed categorical draw (oracle/llda_oracle.py draw_keyed)
+            q[0] = w[0];
+#pragma unroll
+            for (int s = 1; s < T; ++s) q[s] = q[s - 1] + w[s];
+            double X = q[T - 1];
+#pragma unroll
+            for (int dd = 1; dd < G; dd <<= 1) {
+                const double y = __shfl_up(X, dd, G);
+                if (lig >= dd) X = y + X;
+            }
+            const double tot = __shfl(X, G - 1, G);
+            const double t = u * tot;
+            const double prev = __shfl_up(X, 1, G);
+            const double tg = t - (lig ? prev : 0.0);
+            uint32_t fm = 0, pm = 0;
+#pragma unroll
+            for (int s = 0; s < T; ++s) {
+                const bool pos = w[s] > 0.0;
+                pm |= (pos ? 1u : 0u) << s;
+                fm |= ((pos && q[s] > tg) ? 1u : 0u) << s;
+            }
+            const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
+            const uint64_t gp = (__ballot(pm != 0) >> gbase) & gmask;
+            int zn = zo;
+            if (gp != 0) {
+                const bool hit = gf != 0;
+                const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1
+                                   : 63 - (int)__clzll((unsigned long long)gp);
+                const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(pm | 1u));
+                const int ss = __shfl(my, sl, G);
+                zn = sl * T + ss;
+            } else if (lig == 0 && P.status) {
+                atomicOr(P.status, 1);          // no topic with positive probability
+            }
+
+            // add the site back (LabeledLDA.py:121-125)
+            {
+                const int ln = zn / T, sn = zn - ln * T;
+                const int code = (lig == ln) ? sn : -1;
+#pragma unroll
+                for (int s = 0; s < T; ++s) {
+                    const int dl = (code == s) ? f : 0;
+                    ndk[s] += dl; nk[s] += dl;
+                }
+            }
+            if (lig == 0) {
+                P.z[s0 + n] = zn;
+                if (zn != zo) {
+                    int32_t *row = P.n_kw_delta + (int64_t)v * KP;
+                    atomicAdd(row + zo, -f);
+                    atomicAdd(row + zn, f);
+                }
+            }
+        }
+
+        // document done: fold its n_dk change into the workgroup's n_k accumulator, store the row
+        int old[T];
+        load_row<T>(ndk_row, old);
+#pragma unroll
+        for (int s = 0; s < T; ++s) {
+            const int dl = ndk[s] - old[s];
+            if (dl) atomicAdd(&s_nk[lig * T + s], dl);
+        }
+        store_row<T>(ndk_row, ndk);
+    }
+
+    __syncthreads();
+    for (int i = tid; i < KP; i += 256) {
+        const int dl = s_nk[i];
+        if (dl) atomicAdd(P.n_k_delta + i, dl);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// log-likelihood read-out (LabeledLDA.py:231-239, 256-265), same group layout
+// ---------------------------------------------------------------------------------------------
+struct LParams {
+    const int64_t *doc_off;
+    const int32_t *word;
+    const uint16_t *lab_mask;
+    const int32_t *n_dk;
+    const int32_t *n_kw;
+    const int32_t *n_k;
+    double *out_doc;
+    int64_t D;
+    double alpha, beta, vbeta;
+};
+
+template <int G>
+__device__ __forceinline__ double group_allsum(double x)
+{
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) x = x + __shfl_xor(x, d, G);
+    return x;
+}
+
+template <int G, int T>
+__global__ void __launch_bounds__(256) llda_loglik_kernel(const LParams P)
+{
+    constexpr int KP = G * T;
+    constexpr int GPB = 256 / G;
+    const int tid = threadIdx.x;
+    const int lig = tid & (G - 1);
+    const int64_t d = (int64_t)blockIdx.x * GPB + tid / G;
+    if (d >= P.D) return;
+    int ndk[T], nk[T];
+    load_row<T>(P.n_dk + d * KP + lig * T, ndk);
+    load_row<T>(P.n_k + lig * T, nk);
+    const uint32_t mask = P.lab_mask[d * G + lig];
+    double th[T], rden[T], rs = 0.0;
+#pragma unroll
+    for (int s = 0; s < T; ++s) {
+        th[s] = (double)ndk[s] + (((mask >> s) & 1u) ? P.alpha : 0.0);     // n_d_k + labs*alpha
+        rs = rs + th[s];
+        rden[s] = (double)nk[s] + P.vbeta;
+    }
+    rs = group_allsum<G>(rs);
+#pragma unroll
+    for (int s = 0; s < T; ++s) th[s] = th[s] / rs;
+    double acc = 0.0;
+    for (int64_t i = P.doc_off[d]; i < P.doc_off[d + 1]; ++i) {
+        int x[T];
+        load_row<T>(P.n_kw + (int64_t)P.word[i] * KP + lig * T, x);
+        double dot = 0.0;
+#pragma unroll
+        for (int s = 0; s < T; ++s) dot = dot + th[s] * (((double)x[s] + P.beta) / rden[s]);
+        dot = group_allsum<G>(dot);
+        acc = acc - log(dot);
+    }
+    if (lig == 0) P.out_doc[d] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers: fold deltas, build counts from assignments
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) llda_apply_delta_kernel(int32_t *__restrict__ counts,
+                                                               int32_t *__restrict__ delta, int64_t n4,
+                                                               int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int4 *c4 = reinterpret_cast<int4 *>(counts);
+    int4 *d4 = reinterpret_cast<int4 *>(delta);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        int4 c = c4[i];
+        const int4 d = d4[i];
+        if (d.x | d.y | d.z | d.w) {
+            c.x += d.x; c.y += d.y; c.z += d.z; c.w += d.w;
+            c4[i] = c;
+            d4[i] = make_int4(0, 0, 0, 0);
+        }
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        counts[i] += delta[i];
+        delta[i] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) llda_count_init_kernel(const int64_t *__restrict__ doc_off,
+                                                              const int32_t *__restrict__ word,
+                                                              const int32_t *__restrict__ freq,
+                                                              const int32_t *__restrict__ z, int64_t D, int KP,
+                                                              int32_t *n_dk, int32_t *n_kw, int32_t *n_k)
+{
+    // one wavefront per document; lanes stride over its sites
+    const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (d >= D) return;
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = doc_off[d] + lane; i < doc_off[d + 1]; i += 64) {
+        const int f = freq[i], p = z[i];
+        atomicAdd(n_dk + d * KP + p, f);
+        atomicAdd(n_kw + (int64_t)word[i] * KP + p, f);
+        atomicAdd(n_k + p, f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+void add_leaves(llda_layout *L, int n, int start)
+{
+    if (n <= 128) {
+        if (L->n_leaves < LLDA_MAX_LEAVES) {
+            L->leaf_start[L->n_leaves] = start;
+            L->leaf_len[L->n_leaves] = n;
+        }
+        L->n_leaves++;
+        return;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    add_leaves(L, n2, start);
+    add_leaves(L, n - n2, start + n2);
+}
+
+// numpy's recursion over leaf ranges [first, first+count): returns depth, fills the schedule
+int schedule(llda_layout *L, int n, int *next_leaf, int *first_out, int *count_out)
+{
+    if (n <= 128) {
+        *first_out = (*next_leaf)++;
+        *count_out = 1;
+        return 0;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    int lf, lc, rf, rc;
+    const int dl = schedule(L, n2, next_leaf, &lf, &lc);
+    const int dr = schedule(L, n - n2, next_leaf, &rf, &rc);
+    const int d = (dl > dr ? dl : dr);      // this node combines in round d
+    if (d < LLDA_MAX_ROUNDS) {
+        for (int a = lf; a < lf + lc; ++a) L->rounds[d][a] = rf;
+        for (int b = rf; b < rf + rc; ++b) L->rounds[d][b] = lf;
+    }
+    if (d + 1 > L->n_rounds) L->n_rounds = d + 1;
+    *first_out = lf;
+    *count_out = lc + rc;
+    return d + 1;
+}
+
+int hip_fail(hipError_t e)
+{
+    g_last_hip_error = (int)e;
+    return LLDA_E_HIP;
+}
+
+template <int G, int T>
+int launch_sweep(const KParams &P, bool has_tail, int64_t blocks, hipStream_t st)
+{
+    if (has_tail)
+        hipLaunchKernelGGL((llda_sweep_kernel<G, T, true>), dim3((unsigned)blocks), dim3(256), 0, st, P);
+    else
+        hipLaunchKernelGGL((llda_sweep_kernel<G, T, false>), dim3((unsigned)blocks), dim3(256), 0, st, P);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
+}
+
+template <int G>
+int dispatch_sweep_T(int T, const KParams &P, bool has_tail, int64_t blocks, hipStream_t st)
+{
+    if constexpr (G == 8) {
+        switch (T) {
+        case 1: return launch_sweep<8, 1>(P, has_tail, blocks, st);
+        case 2: return launch_sweep<8, 2>(P, has_tail, blocks, st);
+        case 4: return launch_sweep<8, 4>(P, has_tail, blocks, st);
+        case 8: return launch_sweep<8, 8>(P, has_tail, blocks, st);
+        }
+    }
+    switch (T) {
+    case 12: return launch_sweep<G, 12>(P, has_tail, blocks, st);
+    case 16: return launch_sweep<G, 16>(P, has_tail, blocks, st);
+    }
+    return LLDA_E_BAD_K;
+}
+
+template <int G, int T>
+int launch_loglik(const LParams &P, hipStream_t st)
+{
+    const int64_t blocks = (P.D + (256 / G) - 1) / (256 / G);
+    hipLaunchKernelGGL((llda_loglik_kernel<G, T>), dim3((unsigned)blocks), dim3(256), 0, st, P);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
+}
+
+template <int G>
+int dispatch_loglik_T(int T, const LParams &P, hipStream_t st)
+{
+    if constexpr (G == 8) {
+        switch (T) {
+        case 1: return launch_loglik<8, 1>(P, st);
+        case 2: return launch_loglik<8, 2>(P, st);
+        case 4: return launch_loglik<8, 4>(P, st);
+        case 8: return launch_loglik<8, 8>(P, st);
+        }
+    }
+    switch (T) {
+    case 12: return launch_loglik<G, 12>(P, st);
+    case 16: return launch_loglik<G, 16>(P, st);
+    }
+    return LLDA_E_BAD_K;
+}
+
+}  // namespace
+
+extern "C" {
+
+int llda_abi_version(void) { return LLDA_ABI_VERSION; }
+
+int llda_last_hip_error(void) { return g_last_hip_error; }
+
+const char *llda_strerror(int code)
+{
+    switch (code) {
+    case LLDA_OK: return "ok";
+    case LLDA_E_BAD_K: return "K outside 1..1024 or more than 8 pairwise leaves";
+    case LLDA_E_BAD_ARG: return "bad argument";
+    case LLDA_E_HIP: return "HIP runtime error";
+    case LLDA_E_NO_DEVICE: return "no HIP device";
+    default: return "unknown error";
+    }
+}
+
+int llda_layout_init(int32_t K, llda_layout *L)
+{
+    if (!L) return LLDA_E_BAD_ARG;
+    if (K < 1 || K > LLDA_MAX_K) return LLDA_E_BAD_K;
+    memset(L, 0, sizeof *L);
+    L->K = K;
+    add_leaves(L, K, 0);
+    if (L->n_leaves > LLDA_MAX_LEAVES) return LLDA_E_BAD_K;
+    int P = 1;
+    while (P < L->n_leaves) P *= 2;
+    L->G = 8 * P;
+    int t = 0;
+    for (int p = 0; p < L->n_leaves; ++p) {
+        const int r = (L->leaf_len[p] + 7) / 8;
+        if (r > t) t = r;
+    }
+    if (t > 2) t = (t + 3) / 4 * 4;
+    L->T = t;
+    L->KP = L->G * t;
+    L->tail = L->leaf_len[L->n_leaves - 1] % 8;
+    L->tail_row = L->leaf_len[L->n_leaves - 1] / 8;
+    for (int i = 0; i < LLDA_MAX_K; ++i) L->pos_topic[i] = -1;
+    for (int p = 0; p < L->n_leaves; ++p)
+        for (int rel = 0; rel < L->leaf_len[p]; ++rel) {
+            const int pos = (8 * p + (rel & 7)) * t + (rel >> 3);
+            L->topic_pos[L->leaf_start[p] + rel] = pos;
+            L->pos_topic[pos] = L->leaf_start[p] + rel;
+        }
+    for (int r = 0; r < LLDA_MAX_ROUNDS; ++r)
+        for (int p = 0; p < LLDA_MAX_LEAVES; ++p) L->rounds[r][p] = p;
+    int next = 0, first, count;
+    schedule(L, K, &next, &first, &count);
+    if (L->n_rounds > LLDA_MAX_ROUNDS) return LLDA_E_BAD_K;
+    return LLDA_OK;
+}
+
+int llda_sweep(const llda_sweep_args *a, void *stream)
+{
+    if (!a || !a->doc_off || !a->word || !a->freq || !a->z || !a->lab_mask || !a->n_dk || !a->n_kw ||
+        !a->n_kw_delta || !a->n_k || !a->n_k_delta || a->D < 0 || a->V < 1)
+        return LLDA_E_BAD_ARG;
+    llda_layout L;
+    const int rc = llda_layout_init(a->K, &L);
+    if (rc) return rc;
+    if (a->D == 0) return LLDA_OK;
+
+    KParams P;
+    memset(&P, 0, sizeof P);
+    P.doc_off = a->doc_off; P.doc_order = a->doc_order; P.word = a->word; P.freq = a->freq; P.z = a->z;
+    P.lab_mask = a->lab_mask; P.n_dk = a->n_dk; P.n_kw = a->n_kw; P.n_kw_delta = a->n_kw_delta;
+    P.n_k = a->n_k; P.n_k_delta = a->n_k_delta; P.status = a->status;
+    P.D = a->D; P.doc_base = a->doc_base;
+    P.alpha = a->alpha; P.beta = a->beta;
+    P.vbeta = (double)a->V * a->beta;                       // V * beta evaluated first (LabeledLDA.py:115)
+    P.key0 = (uint32_t)a->seed; P.key1 = (uint32_t)(a->seed >> 32);
+    P.sweep = a->sweep; P.stream_id = a->stream_id;
+    P.last_leaf = L.n_leaves - 1; P.tail = L.tail; P.tail_row = L.tail_row; P.n_rounds = L.n_rounds;
+    for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) {
+        uint32_t pk = 0;
+        for (int p = 0; p < LLDA_MAX_LEAVES; ++p) pk |= (uint32_t)L.rounds[r][p] << (4 * p);
+        P.rounds_pk[r] = pk;
+    }
+    const int gpb = 256 / L.G;
+    int dpg = a->docs_per_group;
+    if (dpg < 1) {
+        // auto: aim for >= 16 workgroups per CU so the hardware dispatcher balances ragged documents
+        const int64_t want_blocks = 256 * 16;
+        dpg = (int)((a->D + want_blocks * gpb - 1) / (want_blocks * gpb));
+        if (dpg < 1) dpg = 1;
+        if (dpg > 8) dpg = 8;
+    }
+    P.dpg = dpg;
+    const int64_t per_block = (int64_t)gpb * dpg;
+    const int64_t blocks = (a->D + per_block - 1) / per_block;
+    if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool has_tail = L.tail != 0;
+    switch (L.G) {
+    case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, blocks, st);
+    case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, blocks, st);
+    case 32: return dispatch_sweep_T<32>(L.T, P, has_tail, blocks, st);
+    case 64: return dispatch_sweep_T<64>(L.T, P, has_tail, blocks, st);
+    }
+    return LLDA_E_BAD_K;
+}
+
+int llda_apply_delta(int32_t *counts, int32_t *delta, int64_t n, void *stream)
+{
+    if (!counts || !delta || n < 0) return LLDA_E_BAD_ARG;
+    if (n == 0) return LLDA_OK;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(counts) | reinterpret_cast<uintptr_t>(delta)) & 15) == 0;
+    const int64_t n4 = aligned ? n / 4 : 0;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(llda_apply_delta_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       counts, delta, n4, n);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
+}
+
+int llda_count_init(const int64_t *doc_off, const int32_t *word, const int32_t *freq, const int32_t *z,
+                    int64_t D, int32_t K, int32_t *n_dk, int32_t *n_kw, int32_t *n_k, void *stream)
+{
+    if (!doc_off || !word || !freq || !z || !n_dk || !n_kw || !n_k || D < 0) return LLDA_E_BAD_ARG;
+    llda_layout L;
+    const int rc = llda_layout_init(K, &L);
+    if (rc) return rc;
+    if (D == 0) return LLDA_OK;
+    const int64_t blocks = (D + 3) / 4;
+    if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
+    hipLaunchKernelGGL(llda_count_init_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       doc_off, word, freq, z, D, L.KP, n_dk, n_kw, n_k);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
+}
+
+int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab_mask, const int32_t *n_dk,
+                const int32_t *n_kw, const int32_t *n_k, int64_t D, int64_t V, int32_t K, double alpha,
+                double beta, double *out_doc, void *stream)
+{
+    if (!doc_off || !word || !lab_mask || !n_dk || !n_kw || !n_k || !out_doc || D < 0 || V < 1)
+        return LLDA_E_BAD_ARG;
+    llda_layout L;
+    const int rc = llda_layout_init(K, &L);
+    if (rc) return rc;
+    if (D == 0) return LLDA_OK;
+    LParams P;
+    P.doc_off = doc_off; P.word = word; P.lab_mask = lab_mask; P.n_dk = n_dk; P.n_kw = n_kw; P.n_k = n_k;
+    P.out_doc = out_doc; P.D = D; P.alpha = alpha; P.beta = beta; P.vbeta = (double)V * beta;
+    hipStream_t st = (hipStream_t)stream;
+    switch (L.G) {
+    case 8: return dispatch_loglik_T<8>(L.T, P, st);
+    case 16: return dispatch_loglik_T<16>(L.T, P, st);
+    case 32: return dispatch_loglik_T<32>(L.T, P, st);
+    case 64: return dispatch_loglik_T<64>(L.T, P, st);
+    }
+    return LLDA_E_BAD_K;
+}
+
+}  // extern "C"

@@ -1,0 +1,204 @@
+"""Device-resident state of the collapsed Gibbs sampler and the sweep driver.
+
+State mirrors the reference's sufficient statistics (/root/reference/LabeledLDA.py:73-79,
+CascadeLDA.py:358-372) but lives in HBM as PyTorch-ROCm tensors in the group layout of
+``layout.py``:
+
+    n_kw  (V, KP) int32   <->  reference n_k_v (K, V) int64      (word-major + permuted)
+    n_dk  (D, KP) int32   <->  reference n_d_k (D, K) int64
+    n_k   (KP,)   int32   <->  reference n_zk  (K,)   int64
+    z     (S,)    int32   <->  reference z_dn  (list of D int arrays), stored as device positions
+    CSR corpus: doc_off (D+1) int64, word (S) int32, freq (S) int32   <->  docs / freqs lists
+    lab_mask (D, G) int16 bit masks                                   <->  labs (D, K) float 0/1
+
+One sweep = ``llda_sweep`` (HIP, include/llda_gibbs.h) under per-document snapshot semantics,
+then -- when the documents are sharded over several GPUs -- one RCCL all-reduce (SUM, int32) of the
+n_kw / n_k deltas over xGMI, then ``llda_apply_delta``.  Integer sums are exact and order
+independent, so the state after a sweep is bit-identical for any number of GPUs.
+"""
+import numpy as np
+import torch
+
+from . import _native
+from .layout import group_layout
+
+
+def shard_documents(doc_off, world_size):
+    """Contiguous document ranges balanced by site count: returns world_size+1 document bounds."""
+    doc_off = np.asarray(doc_off, dtype=np.int64)
+    D = doc_off.shape[0] - 1
+    total = int(doc_off[-1])
+    bounds = [0]
+    for r in range(1, world_size):
+        target = total * r // world_size
+        b = int(np.searchsorted(doc_off, target, side="left"))
+        bounds.append(min(max(b, bounds[-1]), D))
+    bounds.append(D)
+    return bounds
+
+
+def _dist_active(group):
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+class GibbsSampler(object):
+    """One shard of documents on one device.
+
+    Parameters
+    ----------
+    doc_off, word, freq : CSR corpus of the LOCAL documents (numpy or torch).
+    z        : topic id (reference numbering) of every local site.
+    K, V     : topics (labels incl. root) and vocabulary size.
+    labs     : None (all topics allowed: the dense mask of LocalLDA.py:60-84), a (D, K) 0/1 array
+               (reference ``labs``), or a CSR pair (lab_off, lab_idx) of allowed topic ids.
+    counts   : None -> counts are built on the device from z (LabeledLDA.py:89-92) and, when
+               sharded, all-reduced; or a dict(n_d_k=(D,K), n_k_v=(K,V), n_zk=(K,)) in reference
+               layout for the LOCAL documents / GLOBAL matrices (keeps e.g. SubLDA's phantom columns).
+    seed, stream_id, doc_base : RNG key / counter words (doc_base = global id of local doc 0).
+    group    : torch.distributed process group (None = default group when initialised).
+    backend  : module with the _native entry points (tests inject a CPU checker here; the product
+               always uses the HIP library).
+    """
+
+    def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
+                 stream_id=0, doc_base=0, device=None, group=None, backend=None, sort_docs=True,
+                 docs_per_group=0):
+        self.backend = backend if backend is not None else _native
+        if backend is None:
+            _native.lib()                                   # fail loudly when the extension is missing
+            if not torch.cuda.is_available():
+                raise _native.NativeError("no HIP device visible: the sampler has no CPU fallback")
+        self.device = torch.device(device if device is not None else
+                                   ("cuda:%d" % torch.cuda.current_device() if backend is None else "cpu"))
+        self.K, self.V = int(K), int(V)
+        self.alpha, self.beta = float(alpha), float(beta)
+        self.seed, self.stream_id, self.doc_base = int(seed), int(stream_id), int(doc_base)
+        self.group = group
+        self.docs_per_group = int(docs_per_group)
+        self.sweeps_done = 0
+        self.layout = lay = group_layout(self.K)
+        dev = self.device
+
+        def as_dev(a, dtype):
+            if isinstance(a, torch.Tensor):
+                return a.to(device=dev, dtype=dtype).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(np.asarray(a))).to(device=dev, dtype=dtype)
+
+        self.doc_off = as_dev(doc_off, torch.int64)
+        self.word = as_dev(word, torch.int32)
+        self.freq = as_dev(freq, torch.int32)
+        self.D = int(self.doc_off.shape[0] - 1)
+        self.S = int(self.word.shape[0])
+        self._topic_pos = torch.from_numpy(lay.topic_pos.astype(np.int64)).to(dev)
+        self._pos_topic = torch.from_numpy(lay.pos_topic.astype(np.int64)).to(dev)
+        self.z = self._topic_pos[as_dev(z, torch.int64)].to(torch.int32)
+
+        self.lab_mask = self._make_masks(labs)
+        lens = (self.doc_off[1:] - self.doc_off[:-1])
+        self.doc_order = None
+        if sort_docs and self.D > 1 and int(lens.min()) != int(lens.max()):
+            # longest documents first, neighbours in a wavefront get similar lengths
+            self.doc_order = torch.sort(lens, descending=True, stable=True).indices.to(torch.int32)
+
+        KP = lay.KP
+        self.n_dk = torch.zeros((self.D, KP), dtype=torch.int32, device=dev)
+        self.n_kw = torch.zeros((self.V, KP), dtype=torch.int32, device=dev)
+        self.n_k = torch.zeros((KP,), dtype=torch.int32, device=dev)
+        self.n_kw_delta = torch.zeros((self.V, KP), dtype=torch.int32, device=dev)
+        self.n_k_delta = torch.zeros((KP,), dtype=torch.int32, device=dev)
+        self.status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        if counts is None:
+            self.backend.count_init(self.doc_off, self.word, self.freq, self.z, self.D, self.K,
+                                    self.n_dk, self.n_kw, self.n_k)
+            if _dist_active(self.group):
+                import torch.distributed as dist
+                dist.all_reduce(self.n_kw, group=self.group)
+                dist.all_reduce(self.n_k, group=self.group)
+        else:
+            self.n_dk[:, self._topic_pos] = as_dev(counts["n_d_k"], torch.int32)
+            self.n_kw[:, self._topic_pos] = as_dev(np.asarray(counts["n_k_v"]).T, torch.int32)
+            self.n_k[self._topic_pos] = as_dev(counts["n_zk"], torch.int32)
+
+    # ------------------------------------------------------------------ masks
+    def _make_masks(self, labs):
+        lay, dev = self.layout, self.device
+        if labs is None:
+            row = lay.lane_masks(np.ones((1, self.K)))[0].astype(np.int64)
+            m = torch.from_numpy(row).to(dev).expand(self.D, lay.G)
+        elif isinstance(labs, tuple):
+            lab_off, lab_idx = labs
+            lab_off = torch.as_tensor(np.asarray(lab_off), dtype=torch.int64, device=dev)
+            lab_idx = torch.as_tensor(np.asarray(lab_idx).astype(np.int64), dtype=torch.int64, device=dev)
+            counts = lab_off[1:] - lab_off[:-1]
+            rows = torch.repeat_interleave(torch.arange(self.D, device=dev), counts)
+            pos = self._topic_pos[lab_idx]
+            m = torch.zeros((self.D, lay.G), dtype=torch.int64, device=dev)
+            m.index_put_((rows, pos // lay.T), torch.ones_like(pos) << (pos % lay.T), accumulate=True)
+        else:
+            labs = np.asarray(labs)
+            if labs.shape != (self.D, self.K):
+                raise ValueError("labs must be (D, K) = (%d, %d)" % (self.D, self.K))
+            m = torch.from_numpy(lay.lane_masks(labs).astype(np.int64)).to(dev)
+        # stored as the uint16 bit pattern in an int16 tensor
+        m = torch.where(m >= 32768, m - 65536, m).to(torch.int16).contiguous()
+        return m
+
+    # ------------------------------------------------------------------ the hot path
+    def sweep(self):
+        """One Gibbs sweep over the local documents + exchange + fold."""
+        self.backend.sweep(doc_off=self.doc_off, doc_order=self.doc_order, word=self.word, freq=self.freq,
+                           z=self.z, lab_mask=self.lab_mask, n_dk=self.n_dk, n_kw=self.n_kw,
+                           n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=self.n_k_delta,
+                           status=self.status, D=self.D, V=self.V, K=self.K, alpha=self.alpha,
+                           beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
+                           stream_id=self.stream_id, doc_base=self.doc_base,
+                           docs_per_group=self.docs_per_group)
+        if _dist_active(self.group):
+            import torch.distributed as dist
+            dist.all_reduce(self.n_kw_delta, group=self.group)      # RCCL over xGMI: SUM int32
+            dist.all_reduce(self.n_k_delta, group=self.group)
+        self.backend.apply_delta(self.n_kw, self.n_kw_delta)
+        self.backend.apply_delta(self.n_k, self.n_k_delta)
+        self.sweeps_done += 1
+
+    def check_status(self):
+        """Raise like the reference would (numpy's multinomial rejects a NaN pvals vector)."""
+        if int(self.status.item()) != 0:
+            raise ValueError("a site had no topic with positive probability (pvals would be NaN)")
+
+    # ------------------------------------------------------------------ read-outs
+    def loglik_sum(self):
+        """sum over local sites of -log(phi[:, w] . theta_d)  (LabeledLDA.py:256-265), on device."""
+        out = torch.zeros((self.D,), dtype=torch.float64, device=self.device)
+        self.backend.loglik(self.doc_off, self.word, self.lab_mask, self.n_dk, self.n_kw, self.n_k,
+                            self.D, self.V, self.K, self.alpha, self.beta, out)
+        return float(out.sum().item())
+
+    def perplexity(self):
+        total, sites = self.loglik_sum(), float(self.S)
+        if _dist_active(self.group):
+            import torch.distributed as dist
+            t = torch.tensor([total, sites], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, group=self.group)
+            total, sites = float(t[0]), float(t[1])
+        return float(np.exp(total / sites))
+
+    # ------------------------------------------------------------------ reference-layout views
+    def n_d_k(self):
+        return self.n_dk[:, self._topic_pos].cpu().numpy().astype(np.int64)
+
+    def n_k_v(self):
+        return self.n_kw[:, self._topic_pos].t().contiguous().cpu().numpy().astype(np.int64)
+
+    def n_zk(self):
+        return self.n_k[self._topic_pos].cpu().numpy().astype(np.int64)
+
+    def z_topics(self):
+        """flat array of topic ids (reference numbering) of the local sites."""
+        return self._pos_topic[self.z.to(torch.int64)].cpu().numpy().astype(np.int64)
+
+    def z_dn(self):
+        z = self.z_topics()
+        off = self.doc_off.cpu().numpy()
+        return [z[off[d]:off[d + 1]].copy() for d in range(self.D)]

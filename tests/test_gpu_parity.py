@@ -1,0 +1,116 @@
+"""GPU parity: the HIP sweep (through the C ABI) against golden vectors produced by the unmodified
+reference under per-document snapshot semantics (O3), and against the C oracle on seeded inputs.
+Bit-exact for every integer array after every sweep."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from helpers import assert_state_equal, c_state
+
+pytestmark = pytest.mark.gpu
+
+TINY = golden_names("tiny_")
+
+
+def make_sampler(g, counts=True, **kw):
+    from lda_thesis_amd.sampler import GibbsSampler
+    c = dict(n_d_k=g["init_n_d_k"], n_k_v=g["init_n_k_v"], n_zk=g["init_n_zk"]) if counts else None
+    return GibbsSampler(g["doc_off"], g["word"], g["freq"], g["init_z"], int(g["K"]), int(g["V"]),
+                        float(g["alpha"]), float(g["beta"]), labs=g["labs"], counts=c,
+                        seed=int(g["seed"]), stream_id=int(g["stream"]) if "stream" in g else 0, **kw)
+
+
+@pytest.mark.parametrize("name", TINY + ["sublda"])
+def test_sweeps_match_reference_o3(name):
+    g = load_golden(name)
+    s = make_sampler(g)
+    for i in range(int(g["sweeps"])):
+        s.sweep()
+        assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics(), name)
+    s.check_status()
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_count_init_matches_reference(name):
+    g = load_golden(name)
+    s = make_sampler(g, counts=False)
+    np.testing.assert_array_equal(s.n_k_v(), g["init_n_k_v"])
+    np.testing.assert_array_equal(s.n_d_k(), g["init_n_d_k"])
+    np.testing.assert_array_equal(s.n_zk(), g["init_n_zk"])
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_label_csr_equals_dense_labs(name):
+    g = load_golden(name)
+    from lda_thesis_amd.sampler import GibbsSampler
+    rows, cols = np.nonzero(g["labs"])
+    off = np.zeros(int(g["D"]) + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=int(g["D"])), out=off[1:])
+    a = make_sampler(g)
+    b = GibbsSampler(g["doc_off"], g["word"], g["freq"], g["init_z"], int(g["K"]), int(g["V"]),
+                     float(g["alpha"]), float(g["beta"]), labs=(off, cols), seed=int(g["seed"]))
+    assert (a.lab_mask == b.lab_mask).all()
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_perplexity_matches_reference(name):
+    """log-likelihood read-out: 1e-5 relative is the bar in BASELINE.json; we hold 1e-9."""
+    g = load_golden(name)
+    s = make_sampler(g)
+    for _ in range(int(g["sweeps"])):
+        s.sweep()
+    assert abs(s.perplexity() / float(g["o3_perplexity"]) - 1.0) < 1e-9
+
+
+@pytest.mark.parametrize("docs_per_group", [1, 3])
+@pytest.mark.parametrize("sort_docs", [False, True])
+def test_schedule_independence(docs_per_group, sort_docs):
+    """work distribution (document order, documents per group) must not change the result."""
+    g = load_golden("tiny_k40")
+    s = make_sampler(g, docs_per_group=docs_per_group, sort_docs=sort_docs)
+    for i in range(int(g["sweeps"])):
+        s.sweep()
+    assert_state_equal(g, "o3_s%d" % int(g["sweeps"]), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics())
+
+
+def synth(rng, D, V, K, n_lo, n_hi, dense, fmax=3):
+    lens = rng.integers(n_lo, n_hi + 1, size=D)
+    doc_off = np.zeros(D + 1, dtype=np.int64)
+    np.cumsum(lens, out=doc_off[1:])
+    word = np.concatenate([np.sort(rng.choice(V, size=n, replace=False)) for n in lens]).astype(np.int32)
+    freq = rng.integers(1, fmax + 1, size=int(doc_off[-1])).astype(np.int32)
+    labs = np.ones((D, K), dtype=np.uint8)
+    if not dense:
+        labs = (rng.random((D, K)) < min(1.0, 6.0 / K)).astype(np.uint8)
+        labs[:, 0] = 1
+    z = np.empty(int(doc_off[-1]), dtype=np.int64)
+    for d in range(D):
+        allowed = np.nonzero(labs[d])[0]
+        z[doc_off[d]:doc_off[d + 1]] = rng.choice(allowed, size=lens[d])
+    return doc_off, word, freq, labs, z
+
+
+@pytest.mark.parametrize("K,dense,D,V", [(7, True, 300, 200), (64, True, 400, 500), (128, True, 300, 1000),
+                                         (392, False, 300, 800), (512, True, 96, 2000), (1024, True, 40, 600),
+                                         (300, True, 64, 500), (100, False, 1000, 300)])
+def test_seeded_inputs_vs_c_oracle(c_oracle, K, dense, D, V):
+    """larger seeded inputs: HIP == C oracle (snapshot mode) after 3 sweeps, every integer."""
+    from lda_thesis_amd.sampler import GibbsSampler
+    rng = np.random.default_rng(K * 7 + D)
+    doc_off, word, freq, labs, z = synth(rng, D, V, K, 1, 90, dense)
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=99, doc_base=1000)
+    n_dk0, n_kv0, n_k0 = s.n_d_k(), s.n_k_v(), s.n_zk()
+    cs = c_oracle.CState(doc_off, word, freq, z, labs, n_dk0, n_kv0, n_k0, V, 0.1, 0.01)
+    for i in range(3):
+        s.sweep()
+        cs.sweep(1, 99, i, doc_base=1000, threads=4)
+        np.testing.assert_array_equal(s.z_topics(), cs.z)
+        np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
+        np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+        np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+    s.check_status()
+    # invariants
+    tot = int((freq.astype(np.int64)).sum())
+    assert s.n_zk().sum() == tot and s.n_k_v().sum() == tot
+    assert (s.n_d_k().sum(0) == s.n_zk()).all() and (s.n_k_v().sum(1) == s.n_zk()).all()
+    assert (s.n_d_k()[labs == 0] == 0).all() and s.n_d_k().min() >= 0 and s.n_k_v().min() >= 0
