@@ -1,0 +1,195 @@
+"""bench.py -- Gibbs-sweep throughput of the HIP sampler on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload synth2|synth1|abstracts]
+
+A "step" is one full Gibbs sweep (every site of every local document resampled once + the per-sweep
+exchange/fold).  Default workload (weak scaling): every GPU holds 125 000 synthetic documents x 300
+sites, K = 512 dense label mask, V = 100 000 -- the per-GPU shard of BASELINE.json configs[3]
+(1M docs over 8 GPUs); at --gpus 8 the job IS that config.  Inputs are resident in HBM before the
+timed region.  One JSON line is printed by rank 0.
+
+Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+                   --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from lda_thesis_amd.corpus import synthetic_corpus          # noqa: E402
+from lda_thesis_amd.sampler import GibbsSampler              # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (docs per GPU, sites per doc, V, K, description)
+    "synth2": (125000, 300, 100000, 512,
+               "synthetic 1M docs x 300 tokens, K=512 dense mask, V=100k, doc-sharded: 125k docs per GPU "
+               "(BASELINE configs[3])"),
+    "synth1": (100000, 200, 50000, 128,
+               "synthetic 100k docs x 200 tokens, K=128 dense mask, V=50k (BASELINE configs[2])"),
+}
+
+
+def algorithmic_bytes(sites, docs, A):
+    """per site 4*A + 32, per document 12*A + 16 (A = live topics)."""
+    return sites * (4 * A + 32) + docs * (12 * A + 16)
+
+
+def cpu_baseline(sampler, doc_off, word, freq, n_docs_py, n_docs_c):
+    """Reference CPU path restated (oracle/) on a bounded sample of the SAME workload, timed on this
+    host.  'port' = numpy per-site loop issuing the op sequence of LabeledLDA.py:108-125 on one core
+    (the reference is single-threaded python/numpy)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import llda_oracle as orc
+    import c_oracle
+    K, V = sampler.K, sampler.V
+    n_k_v = sampler.n_k_v()
+    n_zk = sampler.n_zk()
+    n_d_k = sampler.n_dk[:max(n_docs_py, n_docs_c), sampler._topic_pos].cpu().numpy().astype(np.int64)
+    z = sampler._pos_topic[sampler.z[:int(doc_off[max(n_docs_py, n_docs_c)])].to(torch.int64)].cpu().numpy()
+    out = {}
+    # --- numpy loop (like-for-like with the reference) ---
+    off = doc_off[:n_docs_py + 1]
+    docs = [word[off[d]:off[d + 1]].tolist() for d in range(n_docs_py)]
+    freqs = [freq[off[d]:off[d + 1]].tolist() for d in range(n_docs_py)]
+    st = orc.State(docs, freqs, np.ones((n_docs_py, K)), V, sampler.alpha, sampler.beta,
+                   [z[off[d]:off[d + 1]] for d in range(n_docs_py)])
+    st.n_k_v, st.n_zk, st.n_d_k = n_k_v.copy(), n_zk.copy(), n_d_k[:n_docs_py].copy()
+    np.random.seed(1)
+    t0 = time.perf_counter()
+    orc.sweep_sequential(st, None)
+    dt = time.perf_counter() - t0
+    sites = int(off[-1])
+    out["numpy"] = dict(value=sites / dt / 1e6, seconds=dt, sites=sites, docs=n_docs_py)
+    # --- C restatement, 1 thread and all cores (snapshot semantics = what the GPU computes) ---
+    cores = os.cpu_count() or 1
+    offc = doc_off[:n_docs_c + 1]
+    nc = int(offc[-1])
+    for label, threads in (("c_1thread", 1), ("c_allcores", cores)):
+        cs = c_oracle.CState(offc, word[:nc], freq[:nc], z[:nc], np.ones((n_docs_c, K), dtype=np.uint8),
+                             n_d_k[:n_docs_c], n_k_v, n_zk, V, sampler.alpha, sampler.beta)
+        t0 = time.perf_counter()
+        cs.sweep(1, sampler.seed, 0, threads=threads)
+        dt = time.perf_counter() - t0
+        out[label] = dict(value=nc / dt / 1e6, seconds=dt, sites=nc, docs=n_docs_c, threads=threads)
+    return out, cores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="synth2", choices=sorted(WORKLOADS))
+    ap.add_argument("--docs", type=int, default=0, help="override documents per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--docs-per-group", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    Dg, N, V, K, desc = WORKLOADS[args.workload]
+    if args.docs:
+        Dg = args.docs
+    alpha, beta = 0.1, 0.01
+    doc_off, word, freq, z = synthetic_corpus(Dg, N, V, K, seed=1234 + rank, device=dev)
+    sampler = GibbsSampler(doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=42,
+                           doc_base=rank * Dg, device=dev, docs_per_group=args.docs_per_group)
+    del z
+    sites_local = sampler.S
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        sampler.sweep()
+    sampler.kernel_events = []
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sampler.sweep()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    sampler.check_status()
+    kern_ms = [a.elapsed_time(b) for a, b in sampler.kernel_events]
+    sampler.kernel_events = None
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_sites = sites_local * world
+        ms = dt / args.steps * 1e3
+        value = total_sites * args.steps / dt / 1e6
+        kavg = float(np.mean(kern_ms)) if kern_ms else float("nan")
+        alg = algorithmic_bytes(sites_local, Dg, K)
+        achieved = alg / (kavg * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("%s:%d" % (args.workload, Dg))
+        line = {
+            "metric": "million tokens resampled/sec (Gibbs sweep)",
+            "value": value, "unit": "Mtokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "docs_per_gpu": Dg, "sites_per_doc": N, "K": K, "V": V,
+                       "alpha": alpha, "beta": beta, "label_mask": "dense", "sites_per_sweep": total_sites,
+                       "exchange": "RCCL all-reduce of int32 n_kw/n_k deltas per sweep" if world > 1 else "none",
+                       "semantics": "per-document snapshot (bit-exact vs the reference under O3)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "llda_sweep_kernel", "kernel_ms": kavg,
+                         "algorithmic_bytes_per_launch": alg},
+        }
+        if world == 1 and not args.no_cpu:
+            h_off = doc_off.cpu().numpy()
+            n_py, n_c = min(Dg, 400), min(Dg, 1000)
+            nmax = int(h_off[max(n_py, n_c)])
+            base, cores = cpu_baseline(sampler, h_off, word[:nmax].cpu().numpy(), freq[:nmax].cpu().numpy(),
+                                       n_py, n_c)
+            line["cpu_baseline"] = {
+                "value": base["numpy"]["value"], "unit": "Mtokens/s", "cores": 1, "kind": "port",
+                "sample": "first %d docs (%d sites) of the same workload, 1 sweep, numpy per-site loop "
+                          "restating LabeledLDA.py:108-125 (oracle/llda_oracle.py sweep_sequential), %.1f s"
+                          % (n_py, base["numpy"]["sites"], base["numpy"]["seconds"]),
+                "c_port_1thread_Mtokens_s": base["c_1thread"]["value"],
+                "c_port_allcores_Mtokens_s": base["c_allcores"]["value"],
+                "c_port_sample": "first %d docs (%d sites), oracle/llda_oracle.c snapshot mode" %
+                                 (n_c, base["c_1thread"]["sites"]),
+                "host_cores": cores,
+            }
+            line["speedup_vs_cpu_port"] = value / base["numpy"]["value"]
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

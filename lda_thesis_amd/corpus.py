@@ -1,0 +1,69 @@
+"""Corpus containers and synthetic corpora (CSR form the sampler eats).
+
+The reference keeps documents as python lists of (word id, frequency) tuples produced by gensim's
+``doc2bow`` (/root/reference/LabeledLDA.py:64,80-84): word ids inside a document are unique and
+ascending.  Here a corpus is three flat arrays -- ``doc_off`` (D+1), ``word`` (S), ``freq`` (S).
+"""
+import numpy as np
+import torch
+
+
+def csr_from_doc_tups(doc_tups):
+    """list of [(word id, freq), ...] (doc2bow output) -> (doc_off int64, word int32, freq int32)."""
+    lens = np.fromiter((len(d) for d in doc_tups), dtype=np.int64, count=len(doc_tups))
+    doc_off = np.zeros(len(doc_tups) + 1, dtype=np.int64)
+    np.cumsum(lens, out=doc_off[1:])
+    word = np.fromiter((v for d in doc_tups for v, _ in d), dtype=np.int32, count=int(doc_off[-1]))
+    freq = np.fromiter((f for d in doc_tups for _, f in d), dtype=np.int32, count=int(doc_off[-1]))
+    return doc_off, word, freq
+
+
+def zipf_cdf(V, s=1.0, device="cpu"):
+    w = 1.0 / torch.arange(1, V + 1, dtype=torch.float64, device=device) ** s
+    cdf = torch.cumsum(w, 0)
+    return cdf / cdf[-1].clone()
+
+
+def synthetic_corpus(D, N, V, K, seed, device, chunk=32768, oversample=3):
+    """D documents of exactly N distinct word ids each (ascending, f = 1): successive sampling
+    WITHOUT replacement from Zipf(s=1) over V words; initial topics uniform over K.
+    Generated on ``device`` with a torch.Generator seeded by ``seed``.
+    Returns (doc_off int64 (D+1), word int32 (D*N), freq int32, z int64 topic ids)."""
+    if N > V:
+        raise ValueError("cannot draw %d distinct words from a vocabulary of %d" % (N, V))
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+    cdf = zipf_cdf(V, 1.0, dev)
+    M = min(max(oversample * N, N + 64), 64 * N)
+    words = torch.empty((D, N), dtype=torch.int32, device=dev)
+    for lo in range(0, D, chunk):
+        hi = min(D, lo + chunk)
+        n = hi - lo
+        todo = torch.arange(n, device=dev)
+        out = torch.empty((n, N), dtype=torch.int64, device=dev)
+        m = M
+        while todo.numel():
+            u = torch.rand((todo.numel(), m), dtype=torch.float64, device=dev, generator=gen)
+            cand = torch.searchsorted(cdf, u).clamp_(max=V - 1)
+            # first occurrence of every value in draw order
+            sv, si = torch.sort(cand, dim=1, stable=True)
+            first = torch.ones_like(sv, dtype=torch.bool)
+            first[:, 1:] = sv[:, 1:] != sv[:, :-1]
+            keep = torch.zeros_like(first)
+            keep.scatter_(1, si, first)
+            rank = torch.cumsum(keep.to(torch.int32), dim=1)
+            ok = rank[:, -1] >= N
+            sel = keep & (rank <= N)
+            rows_ok = torch.nonzero(ok).flatten()
+            if rows_ok.numel():
+                picked = cand[rows_ok][sel[rows_ok]].view(rows_ok.numel(), N)
+                out[todo[rows_ok]] = torch.sort(picked, dim=1).values
+            todo = todo[~ok]
+            m = min(2 * m, 64 * N)
+        words[lo:hi] = out.to(torch.int32)
+    doc_off = torch.arange(0, D + 1, dtype=torch.int64, device=dev) * N
+    word = words.reshape(-1)
+    freq = torch.ones_like(word)
+    z = torch.randint(0, K, (D * N,), dtype=torch.int64, device=dev, generator=gen)
+    return doc_off, word, freq, z

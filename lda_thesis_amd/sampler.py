@@ -77,6 +77,7 @@ class GibbsSampler(object):
         self.group = group
         self.docs_per_group = int(docs_per_group)
         self.sweeps_done = 0
+        self.kernel_events = None      # set to [] to record a (start, end) HIP event pair per sweep kernel
         self.layout = lay = group_layout(self.K)
         dev = self.device
 
@@ -147,6 +148,10 @@ class GibbsSampler(object):
     # ------------------------------------------------------------------ the hot path
     def sweep(self):
         """One Gibbs sweep over the local documents + exchange + fold."""
+        ev = None
+        if self.kernel_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()              # same stream the kernel is enqueued on (torch's current stream)
         self.backend.sweep(doc_off=self.doc_off, doc_order=self.doc_order, word=self.word, freq=self.freq,
                            z=self.z, lab_mask=self.lab_mask, n_dk=self.n_dk, n_kw=self.n_kw,
                            n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=self.n_k_delta,
@@ -154,6 +159,9 @@ class GibbsSampler(object):
                            beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
                            stream_id=self.stream_id, doc_base=self.doc_base,
                            docs_per_group=self.docs_per_group)
+        if ev is not None:
+            ev[1].record()
+            self.kernel_events.append(ev)
         if _dist_active(self.group):
             import torch.distributed as dist
             dist.all_reduce(self.n_kw_delta, group=self.group)      # RCCL over xGMI: SUM int32
