@@ -1,0 +1,337 @@
+"""Drop-in module for the reference's ``CascadeLDA.py``: an ensemble of small Labeled-LDA problems,
+one per parent node of the label tree, each trained by the HIP Gibbs sweep.
+
+Surface mirrored (``from CascadeLDA import *`` in /root/reference/evaluate_CascadeLDA.py:1, which also
+relies on ``np`` and ``re`` leaking through): ``load_corpus``, ``partition_label``, ``CascadeLDA``,
+``SubLDA``, ``split_data``, ``prune_dict``, ``train_it``.
+
+Scheduling (BASELINE.json configs[4]): the 1 + 19 + 102 sub-problems of the abstracts corpus share
+nothing but the read-only corpus, so with ``torch.distributed`` initialised they are spread over the
+ranks (longest-processing-time first, one sub-problem at a time per GPU) and the rows of ``ph`` are
+combined at the end; there is no collective while training ("replicas only").
+"""
+import csv
+import re
+import sys
+
+import numpy as np
+
+from . import text as _text
+from .corpus import csr_from_doc_tups
+from .sampler import GibbsSampler
+
+__all__ = ["np", "re", "load_corpus", "partition_label", "CascadeLDA", "SubLDA", "split_data",
+           "prune_dict", "train_it"]
+
+_JEL = re.compile(r"[A-Z]\d{2}")
+
+
+def partition_label(lab, d):
+    """'E32' -> ['E', 'E3', 'E32'] (all prefixes up to depth d): reference CascadeLDA.py:52-53."""
+    return [lab[:i + 1] for i in range(d)]
+
+
+def load_corpus(filename, d=3):
+    """As LabeledLDA.load_corpus but every label is expanded to all its prefixes
+    (reference CascadeLDA.py:8-49)."""
+    limit = sys.maxsize
+    while True:
+        try:
+            csv.field_size_limit(limit)
+            break
+        except OverflowError:
+            limit //= 10
+    texts, labs, seen = [], [], {}
+    with open(filename, "r") as fh:
+        for row in csv.reader(fh):
+            field = row[2]
+            if len(field) > 3:
+                parts = [p for tok in field.split(" ") if _JEL.search(tok) for p in partition_label(tok, d)]
+                lab = list(set(parts))
+            else:
+                lab = partition_label(field, d)
+            for x in lab:
+                seen.setdefault(x, 1)
+            texts.append(row[1])
+            labs.append(lab)
+    print("Stemming documents ....")
+    return _text.preprocess_documents(texts), labs, list(seen.keys())
+
+
+class SubLDA(object):
+    """One Labeled-LDA sub-problem (reference CascadeLDA.py:347-434).  ``docs`` are doc2bow tuples.
+
+    The reference's count initialisation (CascadeLDA.py:382-385) indexes ``n_k_v`` with the whole
+    (word id, frequency) tuple, so column ``frequency`` is bumped as well as column ``word id``.
+    Those phantom counts feed the sampler and ``get_ph`` for the rest of training; they are reproduced
+    here on the host and uploaded as the initial ``n_kw``."""
+
+    def __init__(self, docs, labs, labelset, dicti, alpha=0.001, beta=0.001, seed=None, stream_id=0,
+                 device=None, defer=False):
+        labelset.insert(0, "root")
+        self.labelmap = {lab: i for i, lab in enumerate(labelset)}
+        self.K = len(self.labelmap)
+        self.dicti = dicti
+        self.lablist = labelset
+        self.alpha = alpha
+        self.beta = beta
+        self.labs = np.array([self.set_label(lab) for lab in labs])
+        self.doc_tups = docs
+        self.V = len(dicti)
+        self.D = len(docs)
+        self.ph = np.zeros((self.K, self.V), dtype=float)
+
+        self.docs, self.freqs, z0 = [], [], []
+        for doc, lab in zip(self.doc_tups, self.labs):
+            if not doc:
+                raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
+            ids, freqs = zip(*doc)
+            self.docs.append(list(ids))
+            self.freqs.append(list(freqs))
+            z0.append(np.random.choice(self.K, size=len(doc), p=lab / lab.sum()))
+        self._z0 = np.concatenate(z0) if z0 else np.zeros(0, dtype=np.int64)
+        self.seed = seed
+        self.stream_id = stream_id
+        self._device = device
+        self._sampler = None
+        self.n_sites = int(self._z0.shape[0])
+        if not defer:
+            self._upload()
+
+    def _initial_counts(self):
+        doc_off, word, freq = csr_from_doc_tups(self.doc_tups)
+        z = self._z0
+        f64 = freq.astype(np.int64)
+        if f64.size and int(f64.max()) >= self.V:
+            raise IndexError("index %d is out of bounds for axis 1 with size %d" % (int(f64.max()), self.V))
+        rows = np.repeat(np.arange(self.D), np.diff(doc_off))
+        n_zk = np.bincount(z, weights=f64, minlength=self.K).astype(np.int64)
+        n_d_k = np.zeros((self.D, self.K), dtype=np.int64)
+        np.add.at(n_d_k, (rows, z), f64)
+        n_k_v = np.zeros((self.K, self.V), dtype=np.int64)
+        np.add.at(n_k_v, (z, word), f64)
+        ghost = freq != word                     # n_k_v[z, (id, f)] += f touches column f too (once if f == id)
+        np.add.at(n_k_v, (z[ghost], freq[ghost]), f64[ghost])
+        return (doc_off, word, freq), dict(n_d_k=n_d_k, n_k_v=n_k_v, n_zk=n_zk)
+
+    def _upload(self):
+        if self._sampler is None:
+            if self.seed is None:
+                self.seed = int(np.random.randint(0, 2 ** 31 - 1))
+            (doc_off, word, freq), counts = self._initial_counts()
+            self._sampler = GibbsSampler(doc_off, word, freq, self._z0, self.K, self.V, self.alpha,
+                                         self.beta, labs=self.labs, counts=counts, seed=self.seed,
+                                         stream_id=self.stream_id, device=self._device)
+        return self._sampler
+
+    @property
+    def n_zk(self):
+        return self._upload().n_zk()
+
+    @property
+    def n_d_k(self):
+        return self._upload().n_d_k()
+
+    @property
+    def n_k_v(self):
+        return self._upload().n_k_v()
+
+    @property
+    def z_dn(self):
+        return self._upload().z_dn()
+
+    def set_label(self, label):
+        vec = np.zeros(len(self.labelmap))
+        vec[0] = 1.0
+        for x in label:
+            vec[self.labelmap[x]] = 1.0
+        return vec
+
+    def get_ph(self):
+        """row-normalised n_k_v without smoothing (phantom columns included): CascadeLDA.py:394-395."""
+        n_k_v = self.n_k_v
+        return n_k_v / n_k_v.sum(axis=1, keepdims=True)
+
+    def training_iteration(self):
+        """One Gibbs sweep: reference CascadeLDA.py:397-421 (same body as LabeledLDA.py:101-125)."""
+        self._upload().sweep()
+
+    def run_training(self, it=120, thinning=15):
+        """reference CascadeLDA.py:423-434: snapshot ph when (i+1)/thinning is integral."""
+        for i in range(it):
+            self.training_iteration()
+            s = (i + 1) / thinning
+            if s == int(s):
+                print("Training iteration #", i + 1)
+                self._sampler.check_status()
+                cur_ph = self.get_ph()
+                if s > 1:
+                    m = (s - 1) / s
+                    self.ph = m * self.ph + (1 - m) * cur_ph
+                else:
+                    self.ph = cur_ph
+
+    def release(self):
+        """drop the device state (the ensemble driver keeps only ph)."""
+        self._sampler = None
+
+
+class CascadeLDA(object):
+    """Hierarchy of SubLDA problems (reference CascadeLDA.py:56-184)."""
+
+    def __init__(self, docs, labs, labelset, dicti, alpha=0.001, beta=0.001, seed=None, device=None,
+                 group=None):
+        labelset.insert(0, "root")
+        self.labelmap = {lab: i for i, lab in enumerate(labelset)}
+        self.dicti = dicti
+        self.K = len(self.labelmap)
+        self.lablist = labelset
+        self.alpha = alpha
+        self.beta = beta
+        self.vocab = list(dicti.values())
+        self.w_to_v = dicti.token2id
+        self.v_to_w = dicti.id2token
+        self.labs = np.array([self.set_label(lab) for lab in labs])
+        self.doc_tups = [dicti.doc2bow(x) for x in docs]
+        self.docs, self.freqs = [], []
+        for doc in self.doc_tups:
+            if not doc:
+                raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
+            ids, freqs = zip(*doc)
+            self.docs.append(ids)
+            self.freqs.append(freqs)
+        self.D = len(docs)
+        self.V = len(self.vocab)
+        self.ph = np.zeros((self.K, self.V), dtype=float)
+        self.perplx = []
+        self.l1 = [[x for x in lab if len(x) == 1] for lab in labs]
+        self.l2 = [[x for x in lab if len(x) == 2] for lab in labs]
+        self.l3 = [[x for x in lab if len(x) == 3] for lab in labs]
+        self.lablist_l1 = [x for x in self.lablist if len(x) == 1]
+        self.lablist_l2 = [x for x in self.lablist if len(x) == 2]
+        self.lablist_l3 = [x for x in self.lablist if len(x) == 3]
+        self.rawlabs = labs
+        self.seed = seed
+        self._device = device
+        self._group = group
+
+    def set_label(self, label):
+        vec = np.zeros(len(self.labelmap))
+        vec[0] = 1.0
+        for x in label:
+            vec[self.labelmap[x]] = 1.0
+        return vec
+
+    def term_to_id(self, term):
+        if term not in self.w_to_v:
+            voca_id = len(self.vocab)
+            self.w_to_v[term] = voca_id
+            self.vocab.append(term)
+        else:
+            voca_id = self.w_to_v[term]
+        return voca_id
+
+    def sub_corpus(self, parent):
+        """documents carrying ``parent`` with only its child labels kept: CascadeLDA.py:113-127."""
+        level = len(parent)
+        lab_level = self.l2 if level == 1 else self.l3
+        present = [i for i, lab in enumerate(self.rawlabs) if parent in lab]
+        doc_tups = [self.doc_tups[p] for p in present]
+        labs = [[x for x in lab_level[p] if x[:level] == parent] for p in present]
+        labset = sorted(set(x for sub in labs for x in sub))
+        return doc_tups, labs, labset
+
+    def get_sub_ph(self, subdocs, sublabs, sublabset, it=150, thinning=12):
+        sub = SubLDA(subdocs, sublabs, sublabset, self.dicti, alpha=self.alpha, beta=self.beta,
+                     seed=self.seed, device=self._device)
+        sub.run_training(it=it, thinning=thinning)
+        return sub.get_ph()
+
+    # ---- ensemble driver ----
+    def enumerate_subproblems(self):
+        """All sub-problems in the reference's visiting order (CascadeLDA.py:135-184):
+        root, then for every level-1 label l: l, then every level-2 label under l.
+        Returns a list of dicts {parent, doc_tups, labs, labset}."""
+        tasks = [dict(parent="root", doc_tups=self.doc_tups, labs=self.l1, labset=self.lablist_l1)]
+        for l in [x for x in self.lablist_l1 if x != "root"]:
+            doc_tups, labs, labset = self.sub_corpus(parent=l)
+            tasks.append(dict(parent=l, doc_tups=doc_tups, labs=labs, labset=labset))
+            for l2 in [x for x in self.lablist_l2 if x[0] == l]:
+                doc_tups, labs, labset = self.sub_corpus(parent=l2)
+                tasks.append(dict(parent=l2, doc_tups=doc_tups, labs=labs, labset=labset))
+        return tasks
+
+    def go_down_tree(self, it, s):
+        """Train every sub-problem and scatter its topic-word rows into ``self.ph``
+        (reference CascadeLDA.py:135-184).  Sub-problem i uses RNG stream id i."""
+        import torch.distributed as dist
+        world, rank = 1, 0
+        if dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(self._group), dist.get_rank(self._group)
+        if self.seed is None:
+            self.seed = int(np.random.randint(0, 2 ** 31 - 1))
+        tasks = self.enumerate_subproblems()
+        # host initialisation of every sub-problem, in visiting order, on every rank (identical
+        # consumption of numpy's global stream); device state only for the ones trained here
+        subs = []
+        for i, t in enumerate(tasks):
+            subs.append(SubLDA(t["doc_tups"], t["labs"], t["labset"], self.dicti, alpha=self.alpha,
+                               beta=self.beta, seed=self.seed, stream_id=i, device=self._device, defer=True))
+        owner = lpt_assign([sub.n_sites for sub in subs], world)
+        for i, (t, sub) in enumerate(zip(tasks, subs)):
+            labset = t["labset"]                  # 'root' was inserted at position 0 by SubLDA
+            if owner[i] == rank:
+                if i > 0:
+                    print(" --- ")
+                    print("Working on parent node", t["parent"])
+                sub.run_training(it=it, thinning=s)
+                sub_ph = sub.get_ph()             # final state, as get_sub_ph returns (CascadeLDA.py:129-133)
+                sub.release()
+                if i == 0:
+                    ids = [self.labelmap[x] for x in labset]          # root problem keeps its 'root' row
+                    self.ph[ids, :] = sub_ph
+                else:
+                    ids = [self.labelmap[x] for x in labset[1:]]
+                    self.ph[ids, :] = sub_ph[1:, :]
+            labset.remove("root")
+        if world > 1:
+            import torch
+            dev = self._device if self._device is not None else "cuda"
+            buf = torch.from_numpy(self.ph).to(dev)
+            dist.all_reduce(buf, group=self._group)                   # rows are disjoint: sum = union
+            self.ph = buf.cpu().numpy()
+        return owner
+
+
+def lpt_assign(costs, n_workers):
+    """longest-processing-time-first assignment of tasks to workers; returns owner[task]."""
+    load = [0] * n_workers
+    owner = [0] * len(costs)
+    for i in sorted(range(len(costs)), key=lambda j: (-costs[j], j)):
+        w = min(range(n_workers), key=lambda k: (load[k], k))
+        owner[i] = w
+        load[w] += costs[i]
+    return owner
+
+
+def split_data(f="thesis_data.csv", d=3):
+    a, b, c = load_corpus(f, d)
+    zipped = list(zip(a, b))
+    np.random.shuffle(zipped)
+    a, b = zip(*zipped)
+    split = int(len(a) * 0.9)
+    return (a[:split], b[:split], c), (a[split:], b[split:], c)
+
+
+def prune_dict(docs, lower=0.1, upper=0.9):
+    dicti = _text.Dictionary(docs)
+    dicti.filter_extremes(no_above=upper, no_below=int(lower * len(docs)))
+    return dicti
+
+
+def train_it(train_data, it=150, s=12, l=0.02, u=0.98, al=0.001, be=0.001):
+    a, b, c = train_data
+    dicti = prune_dict(a, lower=l, upper=u)
+    cascade = CascadeLDA(a, b, c, dicti, alpha=al, beta=be)
+    cascade.go_down_tree(it=it, s=s)
+    return cascade

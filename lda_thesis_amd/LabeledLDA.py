@@ -1,0 +1,237 @@
+"""Drop-in module for the reference's ``LabeledLDA.py`` with the Gibbs sweep on MI355X.
+
+Surface mirrored (names reached through ``from LabeledLDA import *`` in
+/root/reference/evaluate_LabeledLDA.py:1): ``load_corpus``, class ``LabeledLDA``, ``split_data``,
+``prune_dict``, ``train_it``, ``test_it`` and the leaked ``np``.
+
+What differs from the reference:
+  * ``training_iteration()`` (reference LabeledLDA.py:101-125) is one launch of the HIP sweep kernel
+    over all documents (per-document snapshot semantics, keyed Philox draw) instead of a python loop;
+  * the sufficient statistics live in HBM; ``n_d_k``, ``n_k_v``, ``n_zk``, ``z_dn`` are properties that
+    materialise them on the host in the reference's shapes and dtypes (LabeledLDA.py:73-79);
+  * ``perplexity()`` (LabeledLDA.py:256-265) and the test-time fold-in sampler run on the device.
+Text preparation uses ``lda_thesis_amd.text`` instead of gensim (not installable here).
+"""
+import csv
+import re
+import sys
+
+import numpy as np
+
+from . import text as _text
+from .corpus import csr_from_doc_tups
+from .sampler import GibbsSampler
+
+__all__ = ["np", "load_corpus", "LabeledLDA", "split_data", "prune_dict", "train_it", "test_it"]
+
+_JEL = re.compile(r"[A-Z]\d{2}")
+
+
+def _raise_csv_limit():
+    limit = sys.maxsize
+    while True:
+        try:
+            csv.field_size_limit(limit)
+            return
+        except OverflowError:
+            limit //= 10
+
+
+def _parse_labels(field, d):
+    """label column -> list of labels truncated to depth d (reference LabeledLDA.py:31-41)."""
+    if len(field) > 3:
+        return [tok[:d] for tok in field.split(" ") if _JEL.search(tok)]
+    return [field[:d]]
+
+
+def load_corpus(filename, d):
+    """CSV rows (id, text, space separated JEL codes) -> (token lists, label lists, labelset).
+    Same outputs as reference LabeledLDA.py:7-46; tokenisation by lda_thesis_amd.text."""
+    _raise_csv_limit()
+    texts, labs, seen = [], [], {}
+    with open(filename, "r") as fh:
+        for row in csv.reader(fh):
+            lab = _parse_labels(row[2], d)
+            for x in lab:
+                seen.setdefault(x, 1)
+            texts.append(row[1])
+            labs.append(list(set(lab)))
+    print("Stemming documents ....")
+    return _text.preprocess_documents(texts), labs, list(seen.keys())
+
+
+class LabeledLDA(object):
+    """Labeled LDA trained by collapsed Gibbs sampling on the GPU.
+
+    Constructor arguments as the reference (LabeledLDA.py:50); ``seed`` keys the device RNG (default:
+    one draw from numpy's global stream after the initial assignments, so ``np.random.seed`` makes a
+    whole run reproducible) and ``device`` picks the GPU."""
+
+    def __init__(self, docs, labs, labelset, dicti, alpha, beta, seed=None, device=None):
+        labelset.insert(0, "root")                    # the caller's list is extended, as in the reference
+        self.labelmap = {lab: i for i, lab in enumerate(labelset)}
+        self.K = len(self.labelmap)
+        self.dicti = dicti
+        self.alpha = alpha
+        self.beta = beta
+        self.vocab = list(dicti.values())
+        self.w_to_v = dicti.token2id
+        self.v_to_w = dicti.id2token
+        self.labs = np.array([self.set_label(lab) for lab in labs])
+        self.doc_tups = [dicti.doc2bow(x) for x in docs]
+        self.D = len(docs)
+        self.V = len(self.vocab)
+        self.ph_hat = np.zeros((self.K, self.V), dtype=float)
+        self.th_hat = np.zeros((self.D, self.K), dtype=float)
+        self.cur_perplx = []
+
+        # initial assignments: one np.random.choice per document over its allowed topics
+        # (same calls, same order as reference LabeledLDA.py:80-88 => same stream under np.random.seed)
+        self.docs, self.freqs, z0 = [], [], []
+        for doc, lab in zip(self.doc_tups, self.labs):
+            if not doc:
+                raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
+            ids, freqs = zip(*doc)
+            self.docs.append(list(ids))
+            self.freqs.append(list(freqs))
+            z0.append(np.random.choice(self.K, size=len(doc), p=lab / lab.sum()))
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+        self.seed = seed
+        doc_off, word, freq = csr_from_doc_tups(self.doc_tups)
+        self._doc_off = doc_off
+        self._sampler = GibbsSampler(doc_off, word, freq, np.concatenate(z0) if z0 else np.zeros(0, np.int64),
+                                     self.K, self.V, alpha, beta, labs=self.labs, counts=None, seed=seed,
+                                     device=device)
+
+    # ---- state in the reference's shapes / dtypes ----
+    @property
+    def n_zk(self):
+        return self._sampler.n_zk()
+
+    @property
+    def n_d_k(self):
+        return self._sampler.n_d_k()
+
+    @property
+    def n_k_v(self):
+        return self._sampler.n_k_v()
+
+    @property
+    def z_dn(self):
+        return self._sampler.z_dn()
+
+    def set_label(self, label):
+        vec = np.zeros(len(self.labelmap))
+        vec[0] = 1.0
+        for x in label:
+            vec[self.labelmap[x]] = 1.0
+        return vec
+
+    # ---- training ----
+    def training_iteration(self):
+        """One Gibbs sweep over every (document, word) site: reference LabeledLDA.py:101-125."""
+        self._sampler.sweep()
+
+    def run_training(self, iters, thinning):
+        """Sweep loop with thinning read-outs and running means: reference LabeledLDA.py:127-153."""
+        for n in range(iters):
+            self.training_iteration()
+            print('Running iteration # %d ' % (n + 1))
+            if (n + 1) % thinning != 0:
+                continue
+            self._sampler.check_status()
+            cur_ph, cur_th = self.get_phi(), self.get_theta()
+            self.cur_perplx.append(self.perplexity())
+            s = (n + 1) / thinning
+            if s == 1:
+                self.ph_hat, self.th_hat = cur_ph, cur_th
+            elif s > 1:
+                keep = (s - 1) / s
+                self.ph_hat = keep * self.ph_hat + (1 / s * cur_ph)
+                self.th_hat = keep * self.th_hat + (1 / s * cur_th)
+            if (self.ph_hat < 0).any():
+                raise ValueError('A negative value occurred in self.ph_hat while saving iteration %d ' % n)
+            if np.isnan(self.ph_hat).any():
+                raise ValueError('A nan has creeped into ph_hat')
+            if (self.ph_hat.sum(axis=0) == 0).any():
+                raise ValueError('A word in dictionary has no z-value')
+
+    # ---- read-outs ----
+    def get_phi(self):
+        """(n_k_v + beta) / (n_zk + V*beta): reference LabeledLDA.py:231-234."""
+        return (self.n_k_v + self.beta) / (self.n_zk[:, np.newaxis] + self.V * self.beta)
+
+    def get_theta(self):
+        """(n_d_k + labs*alpha) / row sums: reference LabeledLDA.py:236-239."""
+        num = self.n_d_k + self.labs * self.alpha
+        return num / num.sum(axis=1)[:, np.newaxis]
+
+    def perplexity(self):
+        """exp(-sum_sites log(phi[:, w] . theta_d) / #sites), sites unweighted by frequency
+        (reference LabeledLDA.py:256-265); evaluated by the llda_loglik HIP kernel."""
+        return self._sampler.perplexity()
+
+    def topwords_per_topic(self, topwords=10):
+        ph = self.get_phi()
+        names = list(self.labelmap.keys())
+        return [[names[k]] + [self.v_to_w[v] for v in np.argsort(-ph[k, :])[:topwords]]
+                for k in range(self.K)]
+
+    # ---- predictions ----
+    def get_pred(self, single_th, n=5):
+        names = np.array(list(self.labelmap.keys()))
+        order = np.argsort(-single_th)[:n]
+        loads = np.flip(np.sort(single_th), axis=0)[:n]
+        return list(zip(names[order], loads))
+
+    def get_preds(self, all_th, n=5):
+        return [self.get_pred(all_th[d, :], n) for d in range(all_th.shape[0])]
+
+    # ---- pickling: pull the device state to the host (evaluate_LabeledLDA.py:142-145 pickles the model)
+    def __getstate__(self):
+        state = {k: v for k, v in self.__dict__.items() if k != "_sampler"}
+        state["_host_state"] = dict(n_zk=self.n_zk, n_d_k=self.n_d_k, n_k_v=self.n_k_v,
+                                    z=self._sampler.z_topics(), sweeps_done=self._sampler.sweeps_done)
+        return state
+
+    def __setstate__(self, state):
+        host = state.pop("_host_state")
+        self.__dict__.update(state)
+        doc_off, word, freq = csr_from_doc_tups(self.doc_tups)
+        self._sampler = GibbsSampler(doc_off, word, freq, host["z"], self.K, self.V, self.alpha, self.beta,
+                                     labs=self.labs, counts=host, seed=self.seed)
+        self._sampler.sweeps_done = host["sweeps_done"]
+
+
+def split_data(f, d=2):
+    """shuffle + 90/10 split: reference LabeledLDA.py:268-278 (the labelset list object is shared)."""
+    a, b, c = load_corpus(f, d)
+    zipped = list(zip(a, b))
+    np.random.shuffle(zipped)
+    a, b = zip(*zipped)
+    split = int(len(a) * 0.9)
+    return (a[:split], b[:split], c), (a[split:], b[split:], c)
+
+
+def prune_dict(docs, lower=0.1, upper=0.9):
+    dicti = _text.Dictionary(docs)
+    dicti.filter_extremes(no_above=upper, no_below=lower * len(docs))
+    return dicti
+
+
+def train_it(traindata, it=30, s=3, al=0.001, be=0.001, l=0.05, u=0.95):
+    a, b, c = traindata
+    dicti = prune_dict(a, lower=l, upper=u)
+    llda = LabeledLDA(a, b, c, dicti, al, be)
+    llda.run_training(it, s)
+    return llda
+
+
+def test_it(model, testdata, it=500, thinning=25, n=5):
+    known = set(model.vocab)
+    testdocs = [[x for x in doc if x in known] for doc in testdata[0]]
+    th_hat = model.run_test(testdocs, it, thinning)
+    preds = model.get_preds(th_hat, n)
+    th_hat = [[round(x, 4) for x in single_th] for single_th in th_hat]
+    return th_hat, preds

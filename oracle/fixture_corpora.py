@@ -1,0 +1,71 @@
+"""Seeded toy corpora behind tests/golden/tiny_*.npz  --  TEST INFRASTRUCTURE.
+
+Kept apart from gen_golden.py (which imports the reference and therefore only runs in the build
+container) so that tests can rebuild the very same token/label lists and drive the drop-in classes
+through their public constructors.
+"""
+import numpy as np
+
+
+def synth_corpus(rng, D, V, n_labels, max_labs, len_lo, len_hi):
+    vocab = ["w%04d" % i for i in range(V)]
+    pz = 1.0 / np.arange(1, V + 1)
+    pz /= pz.sum()
+    docs, labs = [], []
+    labelset = ["L%03d" % i for i in range(n_labels)]
+    for d in range(D):
+        n = int(rng.integers(len_lo, len_hi + 1))
+        docs.append([vocab[i] for i in rng.choice(V, size=n, p=pz)])
+        nl = int(rng.integers(0, max_labs + 1)) if n_labels else 0
+        labs.append([labelset[i] for i in rng.choice(n_labels, size=min(nl, n_labels), replace=False)]
+                    if nl else [])
+    return docs, labs, labelset
+
+
+TINY = [
+    # name        D    V   labels max_labs  lens      alpha beta  sweeps
+    ("k05",      40,  60,    4,   3,      (3, 25),   0.1, 0.01, 3),    # K<8: sequential np.sum
+    ("k12",      60, 120,   11,   4,      (5, 40),   0.1, 0.01, 3),    # one row + tail
+    ("k20dense", 50, 100,   19,  19,      (5, 40),   0.5, 0.1,  3),    # Cascade-root sized
+    ("k40",      60, 150,   39,   6,      (5, 50),   0.1, 0.01, 3),
+    ("k128",     40, 200,  127,  30,      (10, 60),  0.1, 0.01, 2),    # exactly one full leaf
+    ("k130",     40, 200,  129,  30,      (10, 60),  0.1, 0.01, 2),    # two leaves, tail 2
+    ("k200",     30, 150,  199,  40,      (10, 60),  0.001, 0.001, 2),
+    ("k392",     30, 150,  391,   7,      (10, 60),  0.1, 0.01, 2),    # abstracts-shaped, 4 leaves
+    ("k512",     24, 150,  511, 200,      (10, 60),  0.1, 0.01, 2),    # 4 full leaves
+    ("k777",     16, 120,  776, 300,      (10, 50),  0.1, 0.01, 2),    # unbalanced tree
+]
+
+
+def tiny_corpus(name):
+    """-> (docs, labs, labelset, alpha, beta, sweeps, numpy_seed) of fixture tiny_<name>."""
+    for (nm, D, V, nl, ml, (lo, hi), alpha, beta, sweeps) in TINY:
+        if nm == name:
+            rng = np.random.default_rng(sum(map(ord, name)))
+            docs, labs, labelset = synth_corpus(rng, D, V, nl, ml, lo, hi)
+            return docs, labs, labelset, alpha, beta, sweeps, 1000 + len(name)
+    raise KeyError(name)
+
+
+def cascade_corpus(seed=11, D=90, V=140):
+    """Toy hierarchical corpus in the shape CascadeLDA.load_corpus produces: every document's label
+    list holds ALL prefixes of its 3-character codes (e.g. 'B', 'B2', 'B21')."""
+    rng = np.random.default_rng(seed)
+    codes = ["A11", "A12", "A21", "A22", "A23", "B11", "B21", "B22", "C31", "C32", "C33"]
+    vocab = ["t%04d" % i for i in range(V)]
+    pz = 1.0 / np.arange(1, V + 1)
+    pz /= pz.sum()
+    docs, labs, seen = [], [], {}
+    for _ in range(D):
+        n = int(rng.integers(8, 45))
+        docs.append([vocab[i] for i in rng.choice(V, size=n, p=pz)])
+        picked = [codes[i] for i in rng.choice(len(codes), size=int(rng.integers(1, 4)), replace=False)]
+        lab = []
+        for c in picked:
+            for p in (c[:1], c[:2], c[:3]):
+                if p not in lab:
+                    lab.append(p)
+        for x in lab:
+            seen.setdefault(x, 1)
+        labs.append(lab)
+    return docs, labs, list(seen.keys())

@@ -29,6 +29,7 @@ sys.path.insert(0, HERE)
 import llda_oracle as orc          # noqa: E402
 import refshim                     # noqa: E402
 from lda_thesis_amd.text import Dictionary  # noqa: E402
+from fixture_corpora import TINY, synth_corpus  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 REF_L, REF_C = refshim.import_reference()
@@ -72,7 +73,7 @@ def run_o2(module, m, seed, sweeps, stream=0):
     return out
 
 
-def o3_sweep(module, cls, m, draw, sweep, order=None, doc_base=0):
+def o3_sweep(module, cls, m, draw, sweep, order=None, doc_base=0, method=None):
     """One per-document-snapshot sweep using the reference's own training_iteration on views."""
     draw.sweep = sweep
     draw.plan = None
@@ -94,7 +95,7 @@ def o3_sweep(module, cls, m, draw, sweep, order=None, doc_base=0):
         save_zk = m.n_zk.copy()
         draw.doc = d + doc_base
         draw.site = 0
-        cls.training_iteration(view)                # UNMODIFIED reference code
+        (method or cls.training_iteration)(view)    # UNMODIFIED reference code
         delta_kv[:, ids] += m.n_k_v[:, ids] - save_kv
         delta_zk += m.n_zk - save_zk
         m.n_k_v[:, ids] = save_kv
@@ -129,36 +130,6 @@ def pack(prefix, states, out):
 
 
 # ------------------------------------------------------------------------------------------
-def synth_corpus(rng, D, V, n_labels, max_labs, len_lo, len_hi):
-    vocab = ["w%04d" % i for i in range(V)]
-    pz = 1.0 / np.arange(1, V + 1)
-    pz /= pz.sum()
-    docs, labs = [], []
-    labelset = ["L%03d" % i for i in range(n_labels)]
-    for d in range(D):
-        n = int(rng.integers(len_lo, len_hi + 1))
-        docs.append([vocab[i] for i in rng.choice(V, size=n, p=pz)])
-        nl = int(rng.integers(0, max_labs + 1)) if n_labels else 0
-        labs.append([labelset[i] for i in rng.choice(n_labels, size=min(nl, n_labels), replace=False)]
-                    if nl else [])
-    return docs, labs, labelset
-
-
-TINY = [
-    # name        D    V   labels max_labs  lens      alpha beta  sweeps
-    ("k05",      40,  60,    4,   3,      (3, 25),   0.1, 0.01, 3),    # K<8: sequential np.sum
-    ("k12",      60, 120,   11,   4,      (5, 40),   0.1, 0.01, 3),    # one row + tail
-    ("k20dense", 50, 100,   19,  19,      (5, 40),   0.5, 0.1,  3),    # Cascade-root sized
-    ("k40",      60, 150,   39,   6,      (5, 50),   0.1, 0.01, 3),
-    ("k128",     40, 200,  127,  30,      (10, 60),  0.1, 0.01, 2),    # exactly one full leaf
-    ("k130",     40, 200,  129,  30,      (10, 60),  0.1, 0.01, 2),    # two leaves, tail 2
-    ("k200",     30, 150,  199,  40,      (10, 60),  0.001, 0.001, 2),
-    ("k392",     30, 150,  391,   7,      (10, 60),  0.1, 0.01, 2),    # abstracts-shaped, 4 leaves
-    ("k512",     24, 150,  511, 200,      (10, 60),  0.1, 0.01, 2),    # 4 full leaves
-    ("k777",     16, 120,  776, 300,      (10, 50),  0.1, 0.01, 2),    # unbalanced tree
-]
-
-
 def gen_tiny():
     for (name, D, V, nl, ml, (lo, hi), alpha, beta, sweeps) in TINY:
         rng = np.random.default_rng(sum(map(ord, name)))
@@ -293,6 +264,81 @@ def gen_abstracts200():
     np.savez_compressed(os.path.join(GOLDEN, "abstracts_d3_s200.npz"), **out)
 
 
+def gen_runtraining():
+    """run_training(4, 2) of the reference with its sweep replaced by the O3 sweep (the reference's
+    own training_iteration on per-document views): pins ph_hat / th_hat / cur_perplx and, for SubLDA,
+    ph -- i.e. the thinning logic of LabeledLDA.py:127-153 and CascadeLDA.py:423-434."""
+    from fixture_corpora import tiny_corpus
+    docs, labs, labelset, alpha, beta, _, npseed = tiny_corpus("k12")
+    dicti = Dictionary(docs)
+    np.random.seed(npseed)
+    m = REF_L.LabeledLDA(docs, labs, list(labelset), dicti, alpha, beta)
+    draw = orc.KeyedDraw(12345, 0)
+    counter = [0]
+
+    def sweep_l():
+        o3_sweep(REF_L, REF_L.LabeledLDA, m, draw, counter[0])
+        counter[0] += 1
+    m.training_iteration = sweep_l                 # instance attribute; run_training itself is untouched
+    m.run_training(5, 2)
+    out = dict(ph_hat=m.ph_hat, th_hat=m.th_hat, cur_perplx=np.array(m.cur_perplx), iters=5, thinning=2,
+               seed=12345)
+    # SubLDA
+    doc_tups = [dicti.doc2bow(x) for x in docs]
+    np.random.seed(npseed + 1)
+    sub = REF_C.SubLDA(doc_tups, labs, list(labelset), dicti, alpha=alpha, beta=beta)
+    draw2 = orc.KeyedDraw(12345, 3)
+    c2 = [0]
+
+    def sweep_s():
+        o3_sweep(REF_C, REF_C.SubLDA, sub, draw2, c2[0])
+        c2[0] += 1
+    sub.training_iteration = sweep_s
+    sub.run_training(it=6, thinning=2)
+    out.update(sub_ph=sub.ph, sub_get_ph=sub.get_ph(), sub_it=6, sub_thinning=2, sub_stream=3,
+               sub_init_n_k_v=None)
+    del out["sub_init_n_k_v"]
+    np.savez_compressed(os.path.join(GOLDEN, "runtraining_k12.npz"), **out)
+    print("runtraining_k12: perplx", m.cur_perplx)
+
+
+def gen_cascade():
+    """CascadeLDA.go_down_tree(it=4, s=2) of the reference on a toy label tree, every SubLDA sweep
+    executed as an O3 sweep (the reference's own SubLDA.training_iteration on per-document views),
+    sub-problem i keyed with RNG stream id i.  Pins the ensemble driver (CascadeLDA.py:113-184)."""
+    from fixture_corpora import cascade_corpus
+    docs, labs, labelset = cascade_corpus()
+    dicti = Dictionary(docs)
+    alpha, beta, seed = 0.1, 0.01, 2468
+    np.random.seed(5)
+    c = REF_C.CascadeLDA(docs, labs, list(labelset), dicti, alpha, beta)
+    cls = REF_C.SubLDA
+    orig_init, orig_sweep = cls.__init__, cls.training_iteration
+    counter = [0]
+    sizes = []
+
+    def init(self, *a, **k):
+        orig_init(self, *a, **k)
+        self._stream, self._sweeps = counter[0], 0
+        counter[0] += 1
+        sizes.append((self.D, self.K, sum(len(d) for d in self.docs)))
+
+    def sweep(self):
+        draw = orc.KeyedDraw(seed, self._stream)
+        o3_sweep(REF_C, cls, self, draw, self._sweeps, method=orig_sweep)
+        self._sweeps += 1
+
+    cls.__init__, cls.training_iteration = init, sweep        # in-memory wrappers; bodies untouched
+    try:
+        c.go_down_tree(it=4, s=2)
+    finally:
+        cls.__init__, cls.training_iteration = orig_init, orig_sweep
+    np.savez_compressed(os.path.join(GOLDEN, "cascade_toy.npz"), ph=c.ph, seed=seed, alpha=alpha,
+                        beta=beta, np_seed=5, it=4, s=2, sizes=np.array(sizes),
+                        labelset=np.array(list(c.labelmap.keys())))
+    print("cascade_toy: %d sub-problems, K=%d, ph sum %.6f" % (len(sizes), c.K, np.nansum(c.ph)))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     what = sys.argv[1:] or ["tiny", "sublda"]
@@ -300,6 +346,10 @@ if __name__ == "__main__":
         gen_tiny()
     if "sublda" in what:
         gen_sublda()
+    if "runtraining" in what:
+        gen_runtraining()
+    if "cascade" in what:
+        gen_cascade()
     if "abstracts" in what:
         gen_abstracts()
     if "abstracts200" in what:

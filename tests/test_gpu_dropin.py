@@ -1,0 +1,119 @@
+"""The drop-in classes (lda_thesis_amd.LabeledLDA / CascadeLDA) driven through the reference's own
+constructor and method names, against golden vectors produced by the reference classes themselves."""
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from helpers import assert_state_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def build_model(name, seed=12345):
+    from fixture_corpora import tiny_corpus
+    from lda_thesis_amd.LabeledLDA import LabeledLDA
+    from lda_thesis_amd.text import Dictionary
+    docs, labs, labelset, alpha, beta, sweeps, npseed = tiny_corpus(name)
+    dicti = Dictionary(docs)
+    ls = list(labelset)
+    np.random.seed(npseed)
+    m = LabeledLDA(docs, labs, ls, dicti, alpha, beta, seed=seed)
+    return m, ls, sweeps
+
+
+@pytest.mark.parametrize("name", ["k05", "k12", "k20dense", "k40", "k130", "k392"])
+def test_labeledlda_init_and_sweeps(name):
+    g = load_golden("tiny_" + name)
+    m, ls, sweeps = build_model(name)
+    assert ls[0] == "root" and m.labelmap["root"] == 0 and m.K == int(g["K"]) and m.V == int(g["V"])
+    # same np.random.choice stream as the reference constructor => identical initial state
+    assert_state_equal(g, "init", m.n_k_v, m.n_d_k, m.n_zk, np.concatenate(m.z_dn), name + " init")
+    assert m.n_k_v.dtype == np.int64 and m.n_k_v.shape == (m.K, m.V) and m.n_d_k.shape == (m.D, m.K)
+    for i in range(sweeps):
+        m.training_iteration()
+        assert_state_equal(g, "o3_s%d" % (i + 1), m.n_k_v, m.n_d_k, m.n_zk, np.concatenate(m.z_dn), name)
+    np.testing.assert_array_equal(m.get_phi(), g["o3_phi"])
+    np.testing.assert_array_equal(m.get_theta(), g["o3_theta"])
+    assert abs(m.perplexity() / float(g["o3_perplexity"]) - 1) < 1e-9        # bar: 1e-5 relative
+
+
+def test_run_training_matches_reference(capsys):
+    g = load_golden("runtraining_k12")
+    m, _, _ = build_model("k12", seed=int(g["seed"]))
+    m.run_training(int(g["iters"]), int(g["thinning"]))
+    out = capsys.readouterr().out
+    assert out.count("Running iteration # ") == int(g["iters"])
+    np.testing.assert_array_equal(m.ph_hat, g["ph_hat"])
+    np.testing.assert_array_equal(m.th_hat, g["th_hat"])
+    np.testing.assert_allclose(np.array(m.cur_perplx), g["cur_perplx"], rtol=1e-9)
+
+
+def test_pickle_roundtrip_continues_identically():
+    g = load_golden("tiny_k12")
+    m, _, sweeps = build_model("k12")
+    m.training_iteration()
+    m2 = pickle.loads(pickle.dumps(m))
+    for i in range(1, sweeps):
+        m2.training_iteration()
+    assert_state_equal(g, "o3_s%d" % sweeps, m2.n_k_v, m2.n_d_k, m2.n_zk, np.concatenate(m2.z_dn))
+
+
+def test_empty_document_raises_like_reference():
+    from lda_thesis_amd.LabeledLDA import LabeledLDA
+    from lda_thesis_amd.text import Dictionary
+    docs = [["aa", "bb"], ["zz"]]
+    dicti = Dictionary([docs[0]])                       # 'zz' is out of vocabulary
+    with pytest.raises(ValueError):
+        LabeledLDA(docs, [["x"], ["x"]], ["x"], dicti, 0.1, 0.01)
+
+
+def test_sublda_phantom_init_and_run_training(capsys):
+    from fixture_corpora import tiny_corpus
+    from lda_thesis_amd.CascadeLDA import SubLDA
+    from lda_thesis_amd.text import Dictionary
+    g = load_golden("runtraining_k12")
+    docs, labs, labelset, alpha, beta, _, npseed = tiny_corpus("k12")
+    dicti = Dictionary(docs)
+    doc_tups = [dicti.doc2bow(x) for x in docs]
+    np.random.seed(npseed + 1)
+    sub = SubLDA(doc_tups, labs, list(labelset), dicti, alpha=alpha, beta=beta, seed=int(g["seed"]),
+                 stream_id=int(g["sub_stream"]))
+    assert sub.n_k_v.sum() > sub.n_zk.sum()             # phantom columns (CascadeLDA.py:382-385)
+    sub.run_training(it=int(g["sub_it"]), thinning=int(g["sub_thinning"]))
+    assert "Training iteration # 2" in capsys.readouterr().out
+    np.testing.assert_array_equal(sub.ph, g["sub_ph"])
+    np.testing.assert_array_equal(sub.get_ph(), g["sub_get_ph"])
+
+
+def test_sublda_golden_phantom_counts():
+    """host-side phantom initialisation == the reference's n_k_v for the sublda fixture."""
+    from lda_thesis_amd.CascadeLDA import SubLDA
+    g = load_golden("sublda")
+    sub = SubLDA.__new__(SubLDA)
+    off = g["doc_off"]
+    sub.doc_tups = [list(zip(g["word"][off[d]:off[d + 1]].tolist(), g["freq"][off[d]:off[d + 1]].tolist()))
+                    for d in range(int(g["D"]))]
+    sub._z0, sub.D, sub.K, sub.V = g["init_z"].astype(np.int64), int(g["D"]), int(g["K"]), int(g["V"])
+    _, counts = sub._initial_counts()
+    np.testing.assert_array_equal(counts["n_k_v"], g["init_n_k_v"])
+    np.testing.assert_array_equal(counts["n_d_k"], g["init_n_d_k"])
+    np.testing.assert_array_equal(counts["n_zk"], g["init_n_zk"])
+
+
+def test_cascade_go_down_tree_matches_reference(capsys):
+    from fixture_corpora import cascade_corpus
+    from lda_thesis_amd.CascadeLDA import CascadeLDA
+    from lda_thesis_amd.text import Dictionary
+    g = load_golden("cascade_toy")
+    docs, labs, labelset = cascade_corpus()
+    dicti = Dictionary(docs)
+    np.random.seed(int(g["np_seed"]))
+    c = CascadeLDA(docs, labs, list(labelset), dicti, float(g["alpha"]), float(g["beta"]), seed=int(g["seed"]))
+    assert list(c.labelmap.keys()) == [str(x) for x in g["labelset"]]
+    c.go_down_tree(it=int(g["it"]), s=int(g["s"]))
+    assert "root" not in c.lablist_l1                   # inserted by SubLDA, removed again (quirk 1)
+    np.testing.assert_array_equal(c.ph, g["ph"])
+    out = capsys.readouterr().out
+    assert out.count("Working on parent node") == len(g["sizes"]) - 1
