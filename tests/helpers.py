@@ -32,3 +32,64 @@ def assert_state_equal(g, key, n_k_v, n_d_k, n_zk, z, what=""):
     np.testing.assert_array_equal(np.asarray(n_zk).astype(np.int64), g[key + "_n_zk"].astype(np.int64), err_msg=what + " n_zk")
     np.testing.assert_array_equal(np.asarray(n_d_k).astype(np.int64), g[key + "_n_d_k"].astype(np.int64), err_msg=what + " n_d_k")
     np.testing.assert_array_equal(np.asarray(n_k_v).astype(np.int64), g[key + "_n_k_v"].astype(np.int64), err_msg=what + " n_k_v")
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU stand-in for lda_thesis_amd._native, for HOST-LOGIC tests only (sharding, exchange, layout
+# conversions): the device entry points are replaced by the C oracle working on CPU torch tensors.
+# The product never takes this path: GibbsSampler(backend=None) requires the HIP library + a GPU.
+# ------------------------------------------------------------------------------------------------
+class OracleBackend(object):
+    def __init__(self, co):
+        self.co = co
+
+    @staticmethod
+    def _lay(K):
+        from lda_thesis_amd.layout import group_layout
+        return group_layout(K)
+
+    def count_init(self, doc_off, word, freq, z, D, K, n_dk, n_kw, n_k):
+        lay = self._lay(K)
+        off = doc_off.numpy()
+        rows = np.repeat(np.arange(D), np.diff(off))
+        f = freq.numpy().astype(np.int64)
+        zz = z.numpy().astype(np.int64)
+        a = np.zeros(tuple(n_dk.shape), dtype=np.int64)
+        np.add.at(a, (rows, zz), f)
+        b = np.zeros(tuple(n_kw.shape), dtype=np.int64)
+        np.add.at(b, (word.numpy().astype(np.int64), zz), f)
+        c = np.bincount(zz, weights=f, minlength=lay.KP).astype(np.int64)
+        import torch
+        n_dk += torch.from_numpy(a).to(n_dk.dtype)
+        n_kw += torch.from_numpy(b).to(n_kw.dtype)
+        n_k += torch.from_numpy(c).to(n_k.dtype)
+
+    def sweep(self, *, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
+              status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0):
+        import torch
+        lay = self._lay(K)
+        tp = lay.topic_pos.astype(np.int64)
+        bits = lab_mask.numpy().astype(np.int64) & 0xFFFF
+        dev_labs = ((bits[:, :, None] >> np.arange(lay.T)) & 1).reshape(D, lay.KP)
+        labs = dev_labs[:, tp].astype(np.uint8)
+        old_kv = n_kw.numpy()[:, tp].T.astype(np.int64)
+        old_k = n_k.numpy()[tp].astype(np.int64)
+        cs = self.co.CState(doc_off.numpy(), word.numpy(), freq.numpy(), lay.pos_topic[z.numpy()], labs,
+                            n_dk.numpy()[:, tp], old_kv, old_k, V, alpha, beta)
+        cs.sweep(1, seed, sweep, stream=stream_id, doc_base=doc_base, threads=2)
+        z.copy_(torch.from_numpy(lay.topic_pos[cs.z].astype(np.int32)))
+        n_dk[:, torch.from_numpy(tp)] = torch.from_numpy(cs.n_d_k.astype(np.int32))
+        d_kv = np.zeros(tuple(n_kw.shape), dtype=np.int32)
+        d_kv[:, tp] = (cs.n_k_v - old_kv).T
+        n_kw_delta += torch.from_numpy(d_kv)
+        d_k = np.zeros(lay.KP, dtype=np.int32)
+        d_k[tp] = cs.n_zk - old_k
+        n_k_delta += torch.from_numpy(d_k)
+
+    @staticmethod
+    def apply_delta(counts, delta):
+        counts += delta
+        delta.zero_()
+
+    def loglik(self, *a, **k):
+        raise NotImplementedError

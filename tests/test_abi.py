@@ -1,0 +1,84 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/llda_gibbs.h declares.
+Host-only entry points are exercised; device entry points are only checked for argument validation
+(they return before touching HIP)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "llda_gibbs.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(llda_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    for s in ("llda_sweep", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_layout_init",
+              "llda_abi_version", "llda_strerror", "llda_last_hip_error"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from lda_thesis_amd import _native
+    L = _native.lib()
+    for s in declared_symbols():
+        assert hasattr(L, s), "libllda_gibbs.so does not export %s" % s
+    assert set(_native.EXPORTS) <= set(declared_symbols())
+    assert L.llda_abi_version() == _native.ABI_VERSION
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from lda_thesis_amd import _native
+    monkeypatch.setattr(_native, "_LIB", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeError):
+        _native.lib()
+
+
+def test_sampler_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from lda_thesis_amd import _native
+    from lda_thesis_amd.sampler import GibbsSampler
+    with pytest.raises(_native.NativeError):
+        GibbsSampler(np.array([0, 1]), np.array([0]), np.array([1]), np.array([0]), 2, 3, 0.1, 0.01)
+
+
+@pytest.mark.parametrize("K", [1, 5, 8, 12, 20, 64, 100, 128, 129, 130, 200, 255, 256, 392, 512, 513, 777, 968, 1024])
+def test_layout_init_matches_python_layout(K):
+    from lda_thesis_amd import _native
+    from lda_thesis_amd.layout import GroupLayout
+    a, b = _native.layout_init(K), GroupLayout(K)
+    for k in ("G", "T", "KP", "tail", "tail_row", "n_rounds"):
+        assert a[k] == getattr(b, k), k
+    assert a["n_leaves"] == b.m
+    np.testing.assert_array_equal(a["topic_pos"], b.topic_pos)
+    np.testing.assert_array_equal(a["pos_topic"], b.pos_topic)
+    for r in range(a["n_rounds"]):
+        np.testing.assert_array_equal(a["rounds"][r], b.rounds[r])
+
+
+@pytest.mark.parametrize("K", [0, -3, 1025, 969, 1023])
+def test_layout_init_rejects_bad_k(K):
+    from lda_thesis_amd import _native
+    out = _native.LldaLayout()
+    assert _native.lib().llda_layout_init(K, ctypes.byref(out)) == -1        # LLDA_E_BAD_K
+
+
+def test_device_entry_points_validate_arguments():
+    from lda_thesis_amd import _native
+    L = _native.lib()
+    assert L.llda_sweep(None, None) == -2
+    a = _native.LldaSweepArgs()
+    assert L.llda_sweep(ctypes.byref(a), None) == -2                          # NULL pointers
+    assert L.llda_apply_delta(None, None, 4, None) == -2
+    assert L.llda_count_init(None, None, None, None, 1, 8, None, None, None, None) == -2
+    assert L.llda_loglik(None, None, None, None, None, None, 1, 1, 8, 0.1, 0.1, None, None) == -2
+    assert b"argument" in L.llda_strerror(-2)

@@ -1,0 +1,88 @@
+"""N > 1 host path on CPU: two gloo ranks, documents sharded by site count, per-sweep all-reduce of
+the integer deltas, fold.  The device entry points are replaced by the C oracle (tests/helpers.py
+OracleBackend) -- this checks the sharding / exchange / layout logic of GibbsSampler, not the kernel.
+The state after every sweep must equal the single-process O3 golden of the reference."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, counts_mode, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import c_oracle
+    from helpers import OracleBackend
+    from lda_thesis_amd.sampler import GibbsSampler, shard_documents
+    g = load_golden(name)
+    off = g["doc_off"]
+    b = shard_documents(off, world)
+    lo, hi = b[rank], b[rank + 1]
+    s0, s1 = int(off[lo]), int(off[hi])
+    counts = None
+    if counts_mode == "given":          # global n_k_v / n_zk replicas, local n_d_k rows
+        counts = dict(n_d_k=g["init_n_d_k"][lo:hi], n_k_v=g["init_n_k_v"], n_zk=g["init_n_zk"])
+    s = GibbsSampler(off[lo:hi + 1] - off[lo], g["word"][s0:s1], g["freq"][s0:s1], g["init_z"][s0:s1],
+                     int(g["K"]), int(g["V"]), float(g["alpha"]), float(g["beta"]), labs=g["labs"][lo:hi],
+                     counts=counts, seed=int(g["seed"]), doc_base=lo, device="cpu",
+                     backend=OracleBackend(c_oracle))
+    ok = True
+    for i in range(int(g["sweeps"])):
+        s.sweep()
+        key = "o3_s%d_" % (i + 1)
+        ok &= np.array_equal(s.n_k_v(), g[key + "n_k_v"])          # full replica on every rank
+        ok &= np.array_equal(s.n_zk(), g[key + "n_zk"])
+        ok &= np.array_equal(s.n_d_k(), g[key + "n_d_k"][lo:hi])
+        ok &= np.array_equal(s.z_topics(), g[key + "z"][s0:s1])
+    q.put((rank, bool(ok), hi - lo))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,counts_mode", [("tiny_k40", "built"), ("tiny_k392", "given"), ("tiny_k12", "built")])
+def test_two_rank_sharded_sweeps_match_single_process_golden(name, counts_mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, counts_mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert sum(n for _, _, n in res) == int(load_golden(name)["D"])
+
+
+def test_single_process_oracle_backend_matches_golden(c_oracle):
+    """sanity of the stand-in itself (world size 1, no process group)."""
+    from helpers import OracleBackend, assert_state_equal
+    from lda_thesis_amd.sampler import GibbsSampler
+    g = load_golden("tiny_k130")
+    s = GibbsSampler(g["doc_off"], g["word"], g["freq"], g["init_z"], int(g["K"]), int(g["V"]),
+                     float(g["alpha"]), float(g["beta"]), labs=g["labs"], seed=int(g["seed"]), device="cpu",
+                     backend=OracleBackend(c_oracle))
+    np.testing.assert_array_equal(s.n_k_v(), g["init_n_k_v"])
+    for i in range(int(g["sweeps"])):
+        s.sweep()
+        assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics())

@@ -1,0 +1,131 @@
+"""Host-side logic that needs no GPU: layout algebra, sharding, scheduling, corpus/label handling."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=120, deadline=None)
+@given(st.integers(1, 968))
+def test_layout_is_a_permutation_with_aligned_rows(K):
+    from lda_thesis_amd.layout import GroupLayout
+    L = GroupLayout(K)
+    assert L.G in (8, 16, 32, 64) and L.T in (1, 2, 4, 8, 12, 16) and L.KP == L.G * L.T
+    assert sorted(L.topic_pos.tolist()) == sorted(set(L.topic_pos.tolist())) and L.topic_pos.max() < L.KP
+    assert (L.pos_topic[L.topic_pos] == np.arange(K)).all() and (L.pos_topic >= 0).sum() == K
+    x = np.arange(1, K + 1)
+    np.testing.assert_array_equal(L.from_device(L.to_device(x)), x)
+    # chain structure: topic k sits in lane 8*leaf + (rel & 7), slot rel >> 3
+    for p, (start, n) in enumerate(L.leaves):
+        for rel in (0, n - 1):
+            pos = L.topic_pos[start + rel]
+            assert pos // L.T == 8 * p + (rel & 7) and pos % L.T == rel >> 3
+
+
+def test_lane_masks_roundtrip():
+    from lda_thesis_amd.layout import GroupLayout
+    rng = np.random.default_rng(0)
+    for K in (5, 20, 130, 392):
+        L = GroupLayout(K)
+        labs = (rng.random((7, K)) < 0.3).astype(np.uint8)
+        m = L.lane_masks(labs).astype(np.int64)
+        dev = ((m[:, :, None] >> np.arange(L.T)) & 1).reshape(7, L.KP)
+        np.testing.assert_array_equal(dev[:, L.topic_pos], labs)
+        assert dev.sum() == labs.sum()                      # nothing set in the padding
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(st.integers(0, 50), min_size=1, max_size=60), st.integers(1, 8))
+def test_shard_documents_covers_everything_in_order(lens, world):
+    from lda_thesis_amd.sampler import shard_documents
+    off = np.concatenate([[0], np.cumsum(lens)])
+    b = shard_documents(off, world)
+    assert b[0] == 0 and b[-1] == len(lens) and len(b) == world + 1
+    assert all(b[i] <= b[i + 1] for i in range(world))
+
+
+def test_shard_documents_balances_sites():
+    from lda_thesis_amd.sampler import shard_documents
+    off = np.arange(0, 8001, 8)
+    b = shard_documents(off, 8)
+    assert [b[i + 1] - b[i] for i in range(8)] == [125] * 8
+
+
+def test_lpt_assign():
+    from lda_thesis_amd.CascadeLDA import lpt_assign
+    costs = [200, 80, 50, 49, 30, 30, 10, 5]
+    owner = lpt_assign(costs, 3)
+    loads = [sum(c for c, o in zip(costs, owner) if o == w) for w in range(3)]
+    assert max(loads) == 200 and sorted(owner)[0] == 0 and len(set(owner)) == 3
+    assert lpt_assign(costs, 1) == [0] * 8
+
+
+def test_dictionary_and_bow():
+    from lda_thesis_amd.text import Dictionary
+    docs = [["b", "a", "b"], ["c", "a"], ["d"]]
+    d = Dictionary(docs)
+    assert d.token2id == {"a": 0, "b": 1, "c": 2, "d": 3} and len(d) == 4
+    assert d.doc2bow(["b", "zz", "a", "b"]) == [(0, 1), (1, 2)]
+    assert d.values() == ["a", "b", "c", "d"]
+    d.filter_extremes(no_below=2, no_above=1.0)
+    assert d.token2id == {"a": 0} and d.doc2bow(["a", "b"]) == [(0, 1)]
+
+
+def test_preprocess_and_stemmer():
+    from lda_thesis_amd.text import porter_stem, simple_preprocess
+    assert simple_preprocess("The 3 Models of <b>Growth</b>, and a tax!") == ["models", "growth", "tax"]
+    for w, s in [("caresses", "caress"), ("ponies", "poni"), ("relational", "relat"), ("hopping", "hop"),
+                 ("generalization", "gener"), ("economics", "econom"), ("taxes", "tax")]:
+        assert porter_stem(w) == s, (w, porter_stem(w))
+
+
+def test_load_corpus_label_parsing(tmp_path):
+    from lda_thesis_amd import CascadeLDA as C, LabeledLDA as L
+    p = tmp_path / "c.csv"
+    p.write_text('id1,"growth and taxes","E32 H20 xx"\nid2,"labor markets",J\nid3,"empty labels",\n'
+                 'id4,"more growth","E32 E31"\n')
+    docs, labs, labelset = L.load_corpus(str(p), 2)
+    assert [sorted(x) for x in labs] == [["E3", "H2"], ["J"], [""], ["E3"]]
+    assert labelset == ["E3", "H2", "J", ""]
+    assert docs[0] == ["growth", "taxes"]
+    docs, labs, labelset = C.load_corpus(str(p), 3)
+    assert sorted(labs[0]) == ["E", "E3", "E32", "H", "H2", "H20"]
+    assert labs[1] == ["J", "J", "J"] and labs[2] == ["", "", ""]
+    assert C.partition_label("E32", 3) == ["E", "E3", "E32"]
+
+
+def test_csr_from_doc_tups():
+    from lda_thesis_amd.corpus import csr_from_doc_tups
+    off, w, f = csr_from_doc_tups([[(1, 2), (5, 1)], [(0, 3)]])
+    assert off.tolist() == [0, 2, 3] and w.tolist() == [1, 5, 0] and f.tolist() == [2, 1, 3]
+
+
+def test_cascade_enumeration_order_and_subcorpus():
+    from fixture_corpora import cascade_corpus
+    from lda_thesis_amd.CascadeLDA import CascadeLDA
+    from lda_thesis_amd.text import Dictionary
+    docs, labs, labelset = cascade_corpus()
+    c = CascadeLDA(docs, labs, list(labelset), Dictionary(docs), 0.1, 0.01)
+    tasks = c.enumerate_subproblems()
+    parents = [t["parent"] for t in tasks]
+    assert parents[0] == "root" and set(parents[1:]) == set(c.lablist_l1 + c.lablist_l2)
+    # depth-first: every level-2 parent follows its level-1 parent before the next level-1 label
+    for i, p in enumerate(parents[1:], 1):
+        if len(p) == 2:
+            j = max(k for k in range(i) if len(parents[k]) == 1)
+            assert parents[j] == p[0]
+    t = tasks[parents.index("A")]
+    assert t["labset"] == sorted(t["labset"]) and all(x[0] == "A" and len(x) == 2 for x in t["labset"])
+    assert all(any(True for _ in lab) or True for lab in t["labs"]) and len(t["doc_tups"]) == len(t["labs"])
+
+
+def test_synthetic_corpus_properties():
+    import torch
+    from lda_thesis_amd.corpus import synthetic_corpus
+    off, w, f, z = synthetic_corpus(200, 30, 500, 16, seed=3, device="cpu", chunk=64)
+    w = w.view(200, 30)
+    assert (w[:, 1:] > w[:, :-1]).all() and int(w.max()) < 500 and int(w.min()) >= 0
+    assert (f == 1).all() and off[-1] == 6000 and int(z.max()) < 16
+    off2, w2, _, _ = synthetic_corpus(200, 30, 500, 16, seed=3, device="cpu", chunk=64)
+    assert torch.equal(w2.view(200, 30), w)
+    head = (w < 50).float().mean()
+    assert head > 0.3                               # Zipf: the 10% most frequent ids dominate
