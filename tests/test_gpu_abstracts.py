@@ -1,0 +1,73 @@
+"""BASELINE.json configs[1]: Labeled LDA on abstracts_data.csv, depth 3 (D=4171, K=392), bit-exact
+integer state vs the reference under O3 at a fixed seed; log-likelihood within 1e-5 relative.
+
+The fixture holds the tokenised corpus (the build's own tokenizer), the initial assignments drawn by
+the reference constructor, and SHA-256 digests of (n_k_v, n_d_k, n_zk, z) after sweeps 1, 2, 4 --
+and after 50/100/200 in abstracts_d3_s200.npz -- computed by running the reference's unmodified
+training_iteration (oracle/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import llda_oracle as orc
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def make(g):
+    from lda_thesis_amd.sampler import GibbsSampler
+    return GibbsSampler(g["doc_off"], g["word"].astype(np.int32), g["freq"].astype(np.int32),
+                        g["z_init"].astype(np.int64), int(g["K"]), int(g["V"]), float(g["alpha"]),
+                        float(g["beta"]), labs=(g["lab_off"], g["lab_idx"].astype(np.int64)), counts=None,
+                        seed=int(g["seed"]))
+
+
+def digest(s):
+    return orc.digest(s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics())
+
+
+def test_abstracts_first_sweeps_bit_exact():
+    g = load_golden("abstracts_d3")
+    s = make(g)
+    assert s.D == 4171 and s.K == 392
+    for i in range(1, 5):
+        s.sweep()
+        if "o3_digest_s%d" % i in g:
+            np.testing.assert_array_equal(s.n_zk(), g["o3_n_zk_s%d" % i])
+            assert digest(s) == str(g["o3_digest_s%d" % i]), "sweep %d" % i
+    np.testing.assert_array_equal(s.z_topics(), g["o3_z_s4"])
+    assert abs(s.perplexity() / float(g["o3_perplexity_s4"]) - 1) < 1e-5
+    s.check_status()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "abstracts_d3_s200.npz")),
+                    reason="200-sweep reference digests not generated yet")
+def test_abstracts_200_sweeps_bit_exact():
+    g = load_golden("abstracts_d3")
+    h = load_golden("abstracts_d3_s200")
+    s = make(g)
+    for i in range(1, 201):
+        s.sweep()
+        if i in (50, 100, 200):
+            assert digest(s) == str(h["o3_digest_s%d" % i]), "sweep %d" % i
+    np.testing.assert_array_equal(s.z_topics(), h["o3_z_s200"])
+    assert abs(s.perplexity() / float(h["o3_perplexity_s200"]) - 1) < 1e-5
+
+
+def test_abstracts_c_oracle_agrees_for_20_sweeps(c_oracle):
+    """longer horizon than the committed reference digests, against the C restatement."""
+    g = load_golden("abstracts_d3")
+    s = make(g)
+    labs = np.zeros((s.D, s.K), dtype=np.uint8)
+    rows = np.repeat(np.arange(s.D), np.diff(g["lab_off"]))
+    labs[rows, g["lab_idx"]] = 1
+    cs = c_oracle.CState(g["doc_off"], g["word"].astype(np.int32), g["freq"].astype(np.int32),
+                         g["z_init"].astype(np.int32), labs, s.n_d_k(), s.n_k_v(), s.n_zk(), s.V, 0.1, 0.01)
+    for i in range(20):
+        s.sweep()
+        cs.sweep(1, int(g["seed"]), i, threads=os.cpu_count() or 1)
+    np.testing.assert_array_equal(s.z_topics(), cs.z)
+    np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+    np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
