@@ -125,6 +125,11 @@ int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab
                 int64_t D, int64_t V, int32_t K, double alpha, double beta,
                 double *out_doc, void *stream);
 
+/* Device self test of the kernel's division shortcut: runs >= n random (a, b) pairs through
+ * "q = a * RN(1/b) + two exact-residual corrections" and through the hardware IEEE division and adds
+ * the number of differing results to *mismatches_dev (dev, uint64, zeroed by the caller).  Expected: 0. */
+int llda_selftest_div(uint64_t seed, int64_t n, unsigned long long *mismatches_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

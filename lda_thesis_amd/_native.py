@@ -40,7 +40,7 @@ class LldaSweepArgs(ctypes.Structure):
 
 
 EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_layout_init",
-           "llda_sweep", "llda_apply_delta", "llda_count_init", "llda_loglik")
+           "llda_sweep", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_selftest_div")
 
 _LIB = None
 
@@ -80,6 +80,8 @@ def lib():
     L.llda_loglik.restype = ctypes.c_int
     L.llda_loglik.argtypes = [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i32, _c_d, _c_d,
                               _c_p, _c_p]
+    L.llda_selftest_div.restype = ctypes.c_int
+    L.llda_selftest_div.argtypes = [_c_u64, _c_i64, _c_p, _c_p]
     if L.llda_abi_version() != ABI_VERSION:
         raise NativeError("libllda_gibbs.so ABI %d != binding ABI %d" % (L.llda_abi_version(), ABI_VERSION))
     _LIB = L
@@ -139,3 +141,12 @@ def loglik(doc_off, word, lab_mask, n_dk, n_kw, n_k, D, V, K, alpha, beta, out_d
     check(lib().llda_loglik(_ptr(doc_off), _ptr(word), _ptr(lab_mask), _ptr(n_dk), _ptr(n_kw), _ptr(n_k),
                             int(D), int(V), int(K), float(alpha), float(beta), _ptr(out_doc), _stream()),
           "llda_loglik")
+
+
+def selftest_div(n, seed=1):
+    """llda_selftest_div: number of (a, b) pairs (out of >= n) where the kernel's reciprocal-based
+    division differs from the hardware IEEE division.  Must be 0."""
+    import torch
+    bad = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    check(lib().llda_selftest_div(int(seed), int(n), _ptr(bad), _stream()), "llda_selftest_div")
+    return int(bad.item())

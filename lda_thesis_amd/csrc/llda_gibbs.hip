@@ -103,6 +103,67 @@ __device__ __forceinline__ void store_row(int32_t *__restrict__ p, const int (&x
     }
 }
 
+// One-hot slot updates without compares (hipcc turns "(bit) * f" back into v_cmp + v_cndmask and
+// spills the masks): m = v_bfe_i32(onehot, S, 1) is 0 or -1, value += m * g via v_mad_i32_i24
+// (|g| < 2^23: g is a word frequency inside one document).
+template <int S>
+__device__ __forceinline__ int onehot_bit(uint32_t oh)
+{
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(oh), "n"(S));
+    return m;
+}
+__device__ __forceinline__ int mad_i24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// a[S] += m_S * g and b[S] += m_S * g for every slot S (m_S = 0 / -1)
+template <int T, int S = 0>
+__device__ __forceinline__ void onehot_add2(int (&a)[T], int (&b)[T], uint32_t oh, int g)
+{
+    if constexpr (S < T) {
+        const int m = onehot_bit<S>(oh);
+        a[S] = mad_i24(m, g, a[S]);
+        b[S] = mad_i24(m, g, b[S]);
+        onehot_add2<T, S + 1>(a, b, oh, g);
+    }
+}
+template <int T, int S = 0>
+__device__ __forceinline__ void onehot_add1(int (&a)[T], uint32_t oh, int g)
+{
+    if constexpr (S < T) {
+        a[S] = mad_i24(onehot_bit<S>(oh), g, a[S]);
+        onehot_add1<T, S + 1>(a, oh, g);
+    }
+}
+
+template <int T, int S = 0>
+__device__ __forceinline__ void scores(double (&w)[T], const int (&ndk)[T], const int (&nkb)[T], const int (&x)[T],
+                                       uint32_t mask, double alpha, double beta, double vbeta)
+{
+    if constexpr (S < T) {
+        const double a = (double)ndk[S] + alpha;
+        const double num_b = (double)x[S] + beta;
+        const double den_b = (double)(nkb[S] + ndk[S]) + vbeta;
+        const double ws = a * (num_b / den_b);
+        const long long m = (long long)onehot_bit<S>(mask);          // 0 or -1, sign-extended
+        w[S] = __longlong_as_double(__double_as_longlong(ws) & m);
+        scores<T, S + 1>(w, ndk, nkb, x, mask, alpha, beta, vbeta);
+    }
+}
+
+// a / b given y = RN(1/b) (IEEE), correctly rounded: q0 = RN(a y); two exact-residual corrections.
+__device__ __forceinline__ double div_by(double a, double b, double y)
+{
+    const double q0 = a * y;
+    const double r0 = __builtin_fma(-b, q0, a);
+    const double q1 = __builtin_fma(r0, y, q0);
+    const double r1 = __builtin_fma(-b, q1, a);
+    return __builtin_fma(r1, y, q1);
+}
+
 // Sum of the group's K scores in numpy's pairwise order.  Every lane of the group returns S.
 //   chain : per-lane sequential sum over its slots (one of numpy's 8 accumulators)
 //   xor butterfly 1,2,4 : ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))   (fp add is commutative)
@@ -144,7 +205,9 @@ __device__ __forceinline__ double group_sum(const double (&w)[T], const KParams 
 // ---------------------------------------------------------------------------------------------
 // The sweep kernel
 // ---------------------------------------------------------------------------------------------
-template <int G, int T, bool HAS_TAIL>
+// FAST: alpha, beta >= 1e-6, so every label-allowed topic has a strictly positive probability and the
+// "p > 0" tests of the draw can be read off the label mask (host-checked in llda_sweep).
+template <int G, int T, bool HAS_TAIL, bool FAST>
 __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
 {
     constexpr int KP = G * T;
@@ -169,10 +232,12 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
         const int len = (int)(P.doc_off[d + 1] - s0);
         if (len <= 0) continue;
 
-        int ndk[T], nk[T];
-        int32_t *ndk_row = P.n_dk + d * KP + lig * T;
+        int ndk[T], nkb[T];           // nkb = n_k(sweep start) - n_dk(sweep start): n_k seen by the
+        int32_t *ndk_row = P.n_dk + d * KP + lig * T;   // document is nkb + ndk at any time
         load_row<T>(ndk_row, ndk);
-        load_row<T>(P.n_k + lig * T, nk);
+        load_row<T>(P.n_k + lig * T, nkb);
+#pragma unroll
+        for (int s = 0; s < T; ++s) nkb[s] -= ndk[s];
         const uint32_t mask = P.lab_mask[d * G + lig];
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
 
@@ -193,67 +258,76 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
                 load_row<T>(P.n_kw + (int64_t)v_n * KP + lig * T, xn);
             }
 
-            // keyed uniform: one Philox block serves sites 2b and 2b+1
-            if ((n & 1) == 0) {
-                r0 = (uint32_t)(n >> 1); r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
+            // keyed uniform: one Philox block serves sites 2b and 2b+1; the G lanes of the group
+            // compute G consecutive blocks at once (every 2G sites) and hand them out by shuffle
+            if ((n & (2 * G - 1)) == 0) {
+                r0 = (uint32_t)(n >> 1) + (uint32_t)lig; r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
                 philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
             }
-            const uint32_t ra = (n & 1) ? r2 : r0, rb = (n & 1) ? r3 : r1;
+            const int holder = (n >> 1) & (G - 1);
+            const uint32_t ra = (uint32_t)__shfl((int)((n & 1) ? r2 : r0), holder, G);
+            const uint32_t rb = (uint32_t)__shfl((int)((n & 1) ? r3 : r1), holder, G);
             const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
 
-            // remove the site (LabeledLDA.py:109-111)
+            // remove the site (LabeledLDA.py:109-111): -f at z_old in n_dk (hence in the n_k this document
+            // sees) and in the fetched n_kw row
             {
                 const int lo = zo / T, so = zo - lo * T;
-                const int code = (lig == lo) ? so : -1;
-#pragma unroll
-                for (int s = 0; s < T; ++s) {
-                    const int dl = (code == s) ? f : 0;
-                    ndk[s] -= dl; nk[s] -= dl; x[s] -= dl;
-                }
+                const uint32_t oh = (lig == lo) ? (1u << so) : 0u;
+                onehot_add2<T>(ndk, x, oh, f);          // m = -1 at the slot: += (-1) * f
             }
 
-            // scores (LabeledLDA.py:113-116): prob = lab * a * (num_b / den_b)
+            // scores (LabeledLDA.py:113-116): prob = lab * a * (num_b / den_b); lab in {0,1} is applied as
+            // an all-ones / all-zeros bit mask on the product (0 * finite = +0.0 exactly)
             double w[T];
-#pragma unroll
-            for (int s = 0; s < T; ++s) {
-                const double a = (double)ndk[s] + P.alpha;
-                const double num_b = (double)x[s] + P.beta;
-                const double den_b = (double)nk[s] + P.vbeta;
-                const double ws = a * (num_b / den_b);
-                w[s] = ((mask >> s) & 1u) ? ws : 0.0;
-            }
+            scores<T>(w, ndk, nkb, x, mask, P.alpha, P.beta, P.vbeta);
 
             // prob /= np.sum(prob)  (LabeledLDA.py:117)
             const double S = group_sum<G, T, HAS_TAIL>(w, P, lig);
-            double q[T];
+            // p = fl(w / S) for every slot through ONE IEEE reciprocal y = RN(1/S) and two
+            // residual corrections per slot (Markstein: with y correctly rounded and q1 faithful,
+            // q2 = RN(q1 + (w - S q1) y) is the correctly rounded quotient).  Checked against the
+            // hardware division by llda_selftest_div.
+            const double y = 1.0 / S;
 #pragma unroll
-            for (int s = 0; s < T; ++s) w[s] = w[s] / S;
+            for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);
 
             // keyed categorical draw (oracle/llda_oracle.py draw_keyed)
+            double q[T];
             q[0] = w[0];
 #pragma unroll
             for (int s = 1; s < T; ++s) q[s] = q[s - 1] + w[s];
             double X = q[T - 1];
 #pragma unroll
             for (int dd = 1; dd < G; dd <<= 1) {
-                const double y = __shfl_up(X, dd, G);
-                if (lig >= dd) X = y + X;
+                const double yy = __shfl_up(X, dd, G);
+                if (lig >= dd) X = yy + X;
             }
             const double tot = __shfl(X, G - 1, G);
             const double t = u * tot;
             const double prev = __shfl_up(X, 1, G);
             const double tg = t - (lig ? prev : 0.0);
             uint32_t fm = 0, pm = 0;
+            if (FAST) {
+                // q is non-decreasing along the slots, so {s : q[s] > tg} is the suffix starting at
+                // cnt = #{s : q[s] <= tg}; positive-probability slots are the label-mask bits.
+                int cnt = 0;
 #pragma unroll
-            for (int s = 0; s < T; ++s) {
-                const bool pos = w[s] > 0.0;
-                pm |= (pos ? 1u : 0u) << s;
-                fm |= ((pos && q[s] > tg) ? 1u : 0u) << s;
+                for (int s = 0; s < T; ++s) cnt += (q[s] <= tg) ? 1 : 0;
+                pm = mask;
+                fm = mask & (0xFFFFu << cnt);
+            } else {
+#pragma unroll
+                for (int s = 0; s < T; ++s) {
+                    const bool pos = w[s] > 0.0;
+                    pm |= (pos ? 1u : 0u) << s;
+                    fm |= ((pos && q[s] > tg) ? 1u : 0u) << s;
+                }
             }
             const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
             const uint64_t gp = (__ballot(pm != 0) >> gbase) & gmask;
             int zn = zo;
-            if (gp != 0) {
+            if (gp != 0 && S > 0.0) {
                 const bool hit = gf != 0;
                 const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1
                                    : 63 - (int)__clzll((unsigned long long)gp);
@@ -267,12 +341,8 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
             // add the site back (LabeledLDA.py:121-125)
             {
                 const int ln = zn / T, sn = zn - ln * T;
-                const int code = (lig == ln) ? sn : -1;
-#pragma unroll
-                for (int s = 0; s < T; ++s) {
-                    const int dl = (code == s) ? f : 0;
-                    ndk[s] += dl; nk[s] += dl;
-                }
+                const uint32_t oh = (lig == ln) ? (1u << sn) : 0u;
+                onehot_add1<T>(ndk, oh, -f);            // (-1) * (-f) = +f
             }
             if (lig == 0) {
                 P.z[s0 + n] = zn;
@@ -359,6 +429,36 @@ __global__ void __launch_bounds__(256) llda_loglik_kernel(const LParams P)
         acc = acc - log(dot);
     }
     if (lig == 0) P.out_doc[d] = acc;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// self test: div_by (reciprocal + two corrections) against the hardware IEEE division
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) llda_selftest_div_kernel(uint64_t seed, int iters, unsigned long long *bad)
+{
+    uint32_t mism = 0;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = 0; i < iters; ++i) {
+        uint32_t c0 = tid, c1 = (uint32_t)i, c2 = 0x5e1f7e57u, c3 = 0;
+        philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+        // b: a sum-like positive double with a random 52-bit significand and exponent in [-20, 40];
+        // a: anything from 0 to 2^60 times smaller than b up to a few times b
+        const uint64_t mb = ((uint64_t)(c0 & 0xFFFFFu) << 32) | c1;
+        const uint64_t ma = ((uint64_t)(c2 & 0xFFFFFu) << 32) | c3;
+        const int eb = (int)((c0 >> 20) % 61) - 20;
+        const int ea = eb + 2 - (int)((c2 >> 20) % 64);
+        double b = __longlong_as_double((long long)(((uint64_t)(1023 + eb) << 52) | mb));
+        double a = __longlong_as_double((long long)(((uint64_t)(1023 + ea) << 52) | ma));
+        if ((i & 7) == 7) {            // integer-valued operands, the shape of the count terms
+            b = (double)(c0 >> 4) + 1000.0 * 1.0000000000000002;
+            a = (double)(c2 >> 12) * 0.1;
+        }
+        if ((i & 63) == 63) a = 0.0;
+        const double y = 1.0 / b;
+        if (div_by(a, b, y) != a / b) ++mism;
+    }
+    if (mism) atomicAdd(bad, (unsigned long long)mism);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -454,30 +554,34 @@ int hip_fail(hipError_t e)
 }
 
 template <int G, int T>
-int launch_sweep(const KParams &P, bool has_tail, int64_t blocks, hipStream_t st)
+int launch_sweep(const KParams &P, bool has_tail, bool fast, int64_t blocks, hipStream_t st)
 {
-    if (has_tail)
-        hipLaunchKernelGGL((llda_sweep_kernel<G, T, true>), dim3((unsigned)blocks), dim3(256), 0, st, P);
-    else
-        hipLaunchKernelGGL((llda_sweep_kernel<G, T, false>), dim3((unsigned)blocks), dim3(256), 0, st, P);
+    const dim3 grid((unsigned)blocks), block(256);
+    if (has_tail) {
+        if (fast) hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, true>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, false>), grid, block, 0, st, P);
+    } else {
+        if (fast) hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, false>), grid, block, 0, st, P);
+    }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
 }
 
 template <int G>
-int dispatch_sweep_T(int T, const KParams &P, bool has_tail, int64_t blocks, hipStream_t st)
+int dispatch_sweep_T(int T, const KParams &P, bool has_tail, bool fast, int64_t blocks, hipStream_t st)
 {
     if constexpr (G == 8) {
         switch (T) {
-        case 1: return launch_sweep<8, 1>(P, has_tail, blocks, st);
-        case 2: return launch_sweep<8, 2>(P, has_tail, blocks, st);
-        case 4: return launch_sweep<8, 4>(P, has_tail, blocks, st);
-        case 8: return launch_sweep<8, 8>(P, has_tail, blocks, st);
+        case 1: return launch_sweep<8, 1>(P, has_tail, fast, blocks, st);
+        case 2: return launch_sweep<8, 2>(P, has_tail, fast, blocks, st);
+        case 4: return launch_sweep<8, 4>(P, has_tail, fast, blocks, st);
+        case 8: return launch_sweep<8, 8>(P, has_tail, fast, blocks, st);
         }
     }
     switch (T) {
-    case 12: return launch_sweep<G, 12>(P, has_tail, blocks, st);
-    case 16: return launch_sweep<G, 16>(P, has_tail, blocks, st);
+    case 12: return launch_sweep<G, 12>(P, has_tail, fast, blocks, st);
+    case 16: return launch_sweep<G, 16>(P, has_tail, fast, blocks, st);
     }
     return LLDA_E_BAD_K;
 }
@@ -606,11 +710,13 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool has_tail = L.tail != 0;
+    // with alpha, beta >= 1e-6 and int32 counts no label-allowed score can underflow to zero
+    const bool fast = a->alpha >= 1e-6 && a->beta >= 1e-6;
     switch (L.G) {
-    case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, blocks, st);
-    case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, blocks, st);
-    case 32: return dispatch_sweep_T<32>(L.T, P, has_tail, blocks, st);
-    case 64: return dispatch_sweep_T<64>(L.T, P, has_tail, blocks, st);
+    case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, fast, blocks, st);
+    case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, fast, blocks, st);
+    case 32: return dispatch_sweep_T<32>(L.T, P, has_tail, fast, blocks, st);
+    case 64: return dispatch_sweep_T<64>(L.T, P, has_tail, fast, blocks, st);
     }
     return LLDA_E_BAD_K;
 }
@@ -667,6 +773,19 @@ int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab
     case 64: return dispatch_loglik_T<64>(L.T, P, st);
     }
     return LLDA_E_BAD_K;
+}
+
+int llda_selftest_div(uint64_t seed, int64_t n, unsigned long long *mismatches_dev, void *stream)
+{
+    if (!mismatches_dev || n < 1) return LLDA_E_BAD_ARG;
+    const int iters = 1024;
+    int64_t threads = (n + iters - 1) / iters;
+    int64_t blocks = (threads + 255) / 256;
+    if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
+    hipLaunchKernelGGL(llda_selftest_div_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       seed, iters, mismatches_dev);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
 }
 
 }  // extern "C"

@@ -114,3 +114,10 @@ def test_seeded_inputs_vs_c_oracle(c_oracle, K, dense, D, V):
     assert s.n_zk().sum() == tot and s.n_k_v().sum() == tot
     assert (s.n_d_k().sum(0) == s.n_zk()).all() and (s.n_k_v().sum(1) == s.n_zk()).all()
     assert (s.n_d_k()[labs == 0] == 0).all() and s.n_d_k().min() >= 0 and s.n_k_v().min() >= 0
+
+
+def test_reciprocal_division_equals_ieee_division():
+    """the kernel's p = w/S shortcut (one IEEE reciprocal + two exact-residual corrections) must be
+    the correctly rounded quotient: 4e9 random pairs against the hardware division."""
+    from lda_thesis_amd import _native
+    assert _native.selftest_div(4_000_000_000, seed=7) == 0
