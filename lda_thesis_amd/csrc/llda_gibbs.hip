@@ -50,6 +50,7 @@ struct KParams {
     int32_t last_leaf;      // index of the last (tail-carrying) leaf
     int32_t tail, tail_row;
     int32_t n_rounds;
+    int32_t xor_tree;       // leaves combine as p^1, p^2, p^4 (balanced recursion, no padded leaves)
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];   // 4 bits per leaf: partner leaf
 };
 
@@ -164,13 +165,107 @@ __device__ __forceinline__ double div_by(double a, double b, double y)
     return __builtin_fma(r1, y, q1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cross-lane moves of doubles without an LDS round trip (DPP / permlane), gfx950.
+// ---------------------------------------------------------------------------------------------
+// DPP move; lanes whose source lane is outside the row (row_shr) or the wave (wave_shr) receive 0.0.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane j <- lane 7-j of its 8-lane half (an "xor 4" once quads are uniform)
+constexpr int DPP_ROW_SHR = 0x110;      // + n
+constexpr int DPP_ROW_ROR = 0x120;      // + n
+constexpr int DPP_WAVE_SHR1 = 0x138;
+
+// v_permlane16_swap vdst, src: odd 16-lane rows of vdst <-> even rows of src.  With both operands x:
+// r[0] = [R0,R0,R2,R2] (odd rows see the row below), r[1] = [R1,R1,R3,R3] (even rows see the row above).
+__device__ __forceinline__ void rows_swapped(double x, double &below, double &above)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+    below = __hiloint2double((int)hi[0], (int)lo[0]);
+    above = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double xor16_f64(double x, int lane)
+{
+    double below, above;
+    rows_swapped(x, below, above);
+    return (lane & 16) ? below : above;
+}
+// v_permlane32_swap vdst, src: upper half of vdst <-> lower half of src.  r[0] = [lo,lo], r[1] = [hi,hi].
+__device__ __forceinline__ double xor32_f64(double x, int lane)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+    return (lane & 32) ? __hiloint2double((int)hi[0], (int)lo[0]) : __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                            __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+// value of the last lane of the caller's group
+template <int G>
+__device__ __forceinline__ double bcast_last(double x, int lane)
+{
+    if constexpr (G == 64) {
+        return readlane_f64(x, 63);
+    } else if constexpr (G == 32) {
+        const double a = readlane_f64(x, 31), b = readlane_f64(x, 63);
+        return (lane & 32) ? b : a;
+    } else if constexpr (G == 16) {
+        const double a = readlane_f64(x, 15), b = readlane_f64(x, 31), c = readlane_f64(x, 47), d = readlane_f64(x, 63);
+        const double ab = (lane & 16) ? b : a, cd = (lane & 16) ? d : c;
+        return (lane & 32) ? cd : ab;
+    } else {
+        return __shfl(x, G - 1, G);
+    }
+}
+// one Hillis-Steele step of the inclusive scan over the G lanes of a group: X[g] = X[g-D] + X[g], g >= D
+template <int G, int D>
+__device__ __forceinline__ double scan_step(double X, int lig)
+{
+    if constexpr (G == 64) {
+        const double y = __shfl_up(X, D, G);
+        return (lig >= D) ? y + X : X;
+    } else if constexpr (G == 32) {
+        if constexpr (D < 16) {
+            const double y = dpp_f64<DPP_ROW_ROR + D>(X);      // lane i <- lane (i-D) mod 16 of its row
+            double below, above;
+            rows_swapped(y, below, above);                     // odd rows: the same rotation of the row below
+            const double src = ((lig & 15) >= D) ? y : ((lig >= 16) ? below : 0.0);
+            return src + X;
+        } else {
+            double below, above;
+            rows_swapped(X, below, above);
+            return ((lig >= 16) ? below : 0.0) + X;
+        }
+    } else {
+        const double y = dpp_f64<DPP_ROW_SHR + D>(X);          // 0.0 shifted in at the row start
+        if constexpr (G == 16) return y + X;
+        else return ((lig >= D) ? y : 0.0) + X;                // 8-lane groups share a row
+    }
+}
+template <int G, int D = 1>
+__device__ __forceinline__ double group_scan(double X, int lig)
+{
+    if constexpr (D < G) return group_scan<G, D * 2>(scan_step<G, D>(X, lig), lig);
+    else return X;
+}
+
 // Sum of the group's K scores in numpy's pairwise order.  Every lane of the group returns S.
 //   chain : per-lane sequential sum over its slots (one of numpy's 8 accumulators)
 //   xor butterfly 1,2,4 : ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))   (fp add is commutative)
 //   tail  : n % 8 leftovers of the last leaf, added sequentially
 //   leaves: combined along numpy's recursion tree by the partner schedule
 template <int G, int T, bool HAS_TAIL>
-__device__ __forceinline__ double group_sum(const double (&w)[T], const KParams &P, int lig)
+__device__ __forceinline__ double group_sum(const double (&w)[T], const KParams &P, int lig, int lane)
 {
     const int leaf = lig >> 3;
     double acc = 0.0, tv = 0.0;
@@ -179,27 +274,45 @@ __device__ __forceinline__ double group_sum(const double (&w)[T], const KParams 
         if (HAS_TAIL && s == P.tail_row && leaf == P.last_leaf) tv = w[s];
         else acc = acc + w[s];
     }
-    acc = acc + __shfl_xor(acc, 1, G);
-    acc = acc + __shfl_xor(acc, 2, G);
-    acc = acc + __shfl_xor(acc, 4, G);
+    acc = acc + dpp_f64<DPP_XOR1>(acc);
+    acc = acc + dpp_f64<DPP_XOR2>(acc);
+    acc = acc + dpp_f64<DPP_HALF_MIRROR>(acc);
     if (HAS_TAIL) {
         for (int t = 0; t < P.tail; ++t) {
             const double o = __shfl(tv, P.last_leaf * 8 + t, G);
             if (leaf == P.last_leaf) acc = acc + o;
         }
     }
-    if (G > 8) {
+    if constexpr (G > 8) {
+        if (P.xor_tree) {
+            // balanced recursion (leaf p pairs with p^1, then p^2, p^4): lane xor 8 / 16 / 32
+            acc = acc + dpp_f64<DPP_ROW_ROR + 8>(acc);
+            if constexpr (G > 16) acc = acc + xor16_f64(acc, lane);
+            if constexpr (G > 32) acc = acc + xor32_f64(acc, lane);
+        } else {
 #pragma unroll
-        for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) {
-            if (r < P.n_rounds) {
-                const int partner = (P.rounds_pk[r] >> (4 * leaf)) & 15;
-                const double o = __shfl(acc, partner * 8 + (lig & 7), G);
-                if (partner != leaf) acc = acc + o;
+            for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) {
+                if (r < P.n_rounds) {
+                    const int partner = (P.rounds_pk[r] >> (4 * leaf)) & 15;
+                    const double o = __shfl(acc, partner * 8 + (lig & 7), G);
+                    if (partner != leaf) acc = acc + o;
+                }
             }
+            acc = __shfl(acc, 0, G);
         }
-        acc = __shfl(acc, 0, G);
     }
     return acc;
+}
+
+// store the new assignment of a site and move its count in n_kw_delta (int32 atomics, no return value)
+__device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, int f, int zo, int zn, int KP)
+{
+    P.z[i] = zn;
+    if (zn != zo) {
+        int32_t *row = P.n_kw_delta + (int64_t)v * KP;
+        atomicAdd(row + zo, -f);
+        atomicAdd(row + zn, f);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -241,21 +354,38 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
         const uint32_t mask = P.lab_mask[d * G + lig];
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
 
-        // site 0 prefetch
+        // Software pipeline of the memory operations: at the top of iteration n the registers hold the
+        // scalars (word, freq, z) of site n, the row of site n is in flight (xn) and so are the scalars of
+        // site n+1.  Right after the single s_waitcnt vmcnt(0) of the iteration (first use of xn) the body
+        // issues, in this order: the z store + two n_kw_delta atomics of site n-1, the row of site n+1,
+        // the scalars of site n+2 -- so nothing the next wait covers is younger than one full site.
+        int v_c = P.word[s0], f_c = P.freq[s0], zo_c = P.z[s0];
+        const int64_t i1 = s0 + (len > 1 ? 1 : 0);
+        int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1];
         int xn[T];
-        int v_n = P.word[s0], f_n = P.freq[s0], zo_n = P.z[s0];
-        load_row<T>(P.n_kw + (int64_t)v_n * KP + lig * T, xn);
+        load_row<T>(P.n_kw + (int64_t)v_c * KP + lig * T, xn);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        int64_t pend_i = -1;
+        int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0;
 
         for (int n = 0; n < len; ++n) {
-            const int v = v_n, f = f_n, zo = zo_n;
+            const int v = v_c, f = f_c, zo = zo_c;
             int x[T];
 #pragma unroll
             for (int s = 0; s < T; ++s) x[s] = xn[s];
-            {   // prefetch the next site (clamped: the last site is simply fetched twice)
-                const int64_t in = s0 + (n + 1 < len ? n + 1 : n);
-                v_n = P.word[in]; f_n = P.freq[in]; zo_n = P.z[in];
-                load_row<T>(P.n_kw + (int64_t)v_n * KP + lig * T, xn);
+#ifndef ABL_NOCOMMIT
+            if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
+#endif
+#ifndef ABL_NOLOAD
+            load_row<T>(P.n_kw + (int64_t)v_1 * KP + lig * T, xn);        // row of site n+1 (clamped)
+#else
+#pragma unroll
+            for (int s = 0; s < T; ++s) xn[s] = (v_1 + s) & 7;            // ablation: no n_kw traffic
+#endif
+            v_c = v_1; f_c = f_1; zo_c = zo_1;
+            {
+                const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);  // scalars of site n+2 (clamped)
+                v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
             }
 
             // keyed uniform: one Philox block serves sites 2b and 2b+1; the G lanes of the group
@@ -283,7 +413,7 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
             scores<T>(w, ndk, nkb, x, mask, P.alpha, P.beta, P.vbeta);
 
             // prob /= np.sum(prob)  (LabeledLDA.py:117)
-            const double S = group_sum<G, T, HAS_TAIL>(w, P, lig);
+            const double S = group_sum<G, T, HAS_TAIL>(w, P, lig, lane);
             // p = fl(w / S) for every slot through ONE IEEE reciprocal y = RN(1/S) and two
             // residual corrections per slot (Markstein: with y correctly rounded and q1 faithful,
             // q2 = RN(q1 + (w - S q1) y) is the correctly rounded quotient).  Checked against the
@@ -297,15 +427,10 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
             q[0] = w[0];
 #pragma unroll
             for (int s = 1; s < T; ++s) q[s] = q[s - 1] + w[s];
-            double X = q[T - 1];
-#pragma unroll
-            for (int dd = 1; dd < G; dd <<= 1) {
-                const double yy = __shfl_up(X, dd, G);
-                if (lig >= dd) X = yy + X;
-            }
-            const double tot = __shfl(X, G - 1, G);
+            const double X = group_scan<G>(q[T - 1], lig);
+            const double tot = bcast_last<G>(X, lane);
             const double t = u * tot;
-            const double prev = __shfl_up(X, 1, G);
+            const double prev = dpp_f64<DPP_WAVE_SHR1>(X);
             const double tg = t - (lig ? prev : 0.0);
             uint32_t fm = 0, pm = 0;
             if (FAST) {
@@ -344,15 +469,9 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
                 const uint32_t oh = (lig == ln) ? (1u << sn) : 0u;
                 onehot_add1<T>(ndk, oh, -f);            // (-1) * (-f) = +f
             }
-            if (lig == 0) {
-                P.z[s0 + n] = zn;
-                if (zn != zo) {
-                    int32_t *row = P.n_kw_delta + (int64_t)v * KP;
-                    atomicAdd(row + zo, -f);
-                    atomicAdd(row + zn, f);
-                }
-            }
+            pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn;
         }
+        if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
 
         // document done: fold its n_dk change into the workgroup's n_k accumulator, store the row
         int old[T];
@@ -690,6 +809,14 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     P.key0 = (uint32_t)a->seed; P.key1 = (uint32_t)(a->seed >> 32);
     P.sweep = a->sweep; P.stream_id = a->stream_id;
     P.last_leaf = L.n_leaves - 1; P.tail = L.tail; P.tail_row = L.tail_row; P.n_rounds = L.n_rounds;
+    {
+        const int P2 = L.G / 8;
+        int xt = (L.n_leaves == P2) ? 1 : 0;
+        for (int r = 0; (1 << r) < P2 && xt; ++r)
+            for (int p = 0; p < P2; ++p)
+                if (L.rounds[r][p] != (p ^ (1 << r))) xt = 0;
+        P.xor_tree = xt;
+    }
     for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) {
         uint32_t pk = 0;
         for (int p = 0; p < LLDA_MAX_LEAVES; ++p) pk |= (uint32_t)L.rounds[r][p] << (4 * p);
