@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 1
+#define LLDA_ABI_VERSION 2
 #define LLDA_MAX_K 1024
 #define LLDA_MAX_LEAVES 8
 #define LLDA_MAX_ROUNDS 4
@@ -88,6 +88,9 @@ typedef struct llda_sweep_args {
     int64_t  V;                  /* vocabulary size (rows of n_kw; also enters den = n_k + V*beta) */
     int32_t  K;                  /* topics                                                     */
     int32_t  docs_per_group;     /* documents a lane group walks per workgroup (>=1; 0 = auto) */
+    int32_t  dense_mask;         /* 1 = lab_mask allows every topic in every document (the kernel may
+                                    then skip applying it); 0 = general                            */
+    int32_t  reserved;           /* must be 0                                                  */
     double   alpha, beta;        /* priors (LabeledLDA.py:55-56)                               */
     uint64_t seed;               /* RNG key                                                    */
     uint32_t sweep;              /* RNG counter word 3                                         */

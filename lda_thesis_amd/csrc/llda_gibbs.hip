@@ -165,6 +165,39 @@ __device__ __forceinline__ double div_by(double a, double b, double y)
     return __builtin_fma(r1, y, q1);
 }
 
+// FAST variant of the scores: den_b = fl(n_k + V*beta) as this document sees it and RN(1/den_b) are cached
+// per (slot, thread) in LDS -- they change for at most two topics per site -- so num_b / den_b costs one
+// multiply and four FMAs instead of an IEEE division.  DENSE: every topic allowed, no mask to apply.
+template <int T, bool DENSE, int S = 0>
+__device__ __forceinline__ void scores_cached(double (&w)[T], const int (&ndk)[T], const int (&x)[T],
+                                              const double (*s_den)[256], const double (*s_rcp)[256], int tid,
+                                              uint32_t mask, double alpha, double beta)
+{
+    if constexpr (S < T) {
+        const double a = (double)ndk[S] + alpha;
+        const double num_b = (double)x[S] + beta;
+        const double ws = a * div_by(num_b, s_den[S][tid], s_rcp[S][tid]);
+        if constexpr (DENSE) {
+            w[S] = ws;
+        } else {
+            const long long m = (long long)onehot_bit<S>(mask);
+            w[S] = __longlong_as_double(__double_as_longlong(ws) & m);
+        }
+        scores_cached<T, DENSE, S + 1>(w, ndk, x, s_den, s_rcp, tid, mask, alpha, beta);
+    }
+}
+
+// n_k of one topic changes by df: refresh the cached den / reciprocal of (slot, thread).  den holds
+// fl(n_k + V*beta) with V*beta < 2^40 and n_k < 2^31, so rint(den - V*beta) recovers n_k exactly.
+__device__ __forceinline__ void den_update(double (*s_den)[256], double (*s_rcp)[256], int slot, int tid,
+                                           double vbeta, int df)
+{
+    const int nk = (int)rint(s_den[slot][tid] - vbeta) + df;
+    const double den = (double)nk + vbeta;
+    s_den[slot][tid] = den;
+    s_rcp[slot][tid] = 1.0 / den;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Cross-lane moves of doubles without an LDS round trip (DPP / permlane), gfx950.
 // ---------------------------------------------------------------------------------------------
@@ -320,12 +353,16 @@ __device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, 
 // ---------------------------------------------------------------------------------------------
 // FAST: alpha, beta >= 1e-6, so every label-allowed topic has a strictly positive probability and the
 // "p > 0" tests of the draw can be read off the label mask (host-checked in llda_sweep).
-template <int G, int T, bool HAS_TAIL, bool FAST>
+// DENSE (implies FAST, K == KP): every document allows every topic, the label mask is not applied.
+template <int G, int T, bool HAS_TAIL, bool FAST, bool DENSE>
 __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
 {
     constexpr int KP = G * T;
     constexpr int GPB = 256 / G;              // lane groups (documents in flight) per workgroup
     __shared__ int s_nk[KP];                  // workgroup accumulator of the n_k changes
+    // FAST: [slot][thread] caches (conflict-free 8-byte accesses, dynamic slot index for free)
+    __shared__ double s_den[FAST ? T : 1][256];
+    __shared__ double s_rcp[FAST ? T : 1][256];
 
     const int tid = threadIdx.x;
     for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
@@ -349,8 +386,17 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
         int32_t *ndk_row = P.n_dk + d * KP + lig * T;   // document is nkb + ndk at any time
         load_row<T>(ndk_row, ndk);
         load_row<T>(P.n_k + lig * T, nkb);
+        if constexpr (FAST) {
 #pragma unroll
-        for (int s = 0; s < T; ++s) nkb[s] -= ndk[s];
+            for (int s = 0; s < T; ++s) {
+                const double den = (double)nkb[s] + P.vbeta;       // sweep-start n_k
+                s_den[s][tid] = den;
+                s_rcp[s][tid] = 1.0 / den;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < T; ++s) nkb[s] -= ndk[s];
+        }
         const uint32_t mask = P.lab_mask[d * G + lig];
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
 
@@ -367,6 +413,10 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         int64_t pend_i = -1;
         int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0;
+        if constexpr (FAST) {         // site 0 leaves its topic: n_k[z_old] -= f  (later sites: end of loop body)
+            const int lo = zo_c / T;
+            if (lig == lo) den_update(s_den, s_rcp, zo_c - lo * T, tid, P.vbeta, -f_c);
+        }
 
         for (int n = 0; n < len; ++n) {
             const int v = v_c, f = f_c, zo = zo_c;
@@ -410,7 +460,8 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
             // scores (LabeledLDA.py:113-116): prob = lab * a * (num_b / den_b); lab in {0,1} is applied as
             // an all-ones / all-zeros bit mask on the product (0 * finite = +0.0 exactly)
             double w[T];
-            scores<T>(w, ndk, nkb, x, mask, P.alpha, P.beta, P.vbeta);
+            if constexpr (FAST) scores_cached<T, DENSE>(w, ndk, x, s_den, s_rcp, tid, mask, P.alpha, P.beta);
+            else scores<T>(w, ndk, nkb, x, mask, P.alpha, P.beta, P.vbeta);
 
             // prob /= np.sum(prob)  (LabeledLDA.py:117)
             const double S = group_sum<G, T, HAS_TAIL>(w, P, lig, lane);
@@ -468,6 +519,16 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
                 const int ln = zn / T, sn = zn - ln * T;
                 const uint32_t oh = (lig == ln) ? (1u << sn) : 0u;
                 onehot_add1<T>(ndk, oh, -f);            // (-1) * (-f) = +f
+                if constexpr (FAST) {
+                    // n_k as this document sees it: +f at the new topic now, and already -f' at the old
+                    // topic of the NEXT site (its scalars are in registers), so the cached values are
+                    // final long before the next site's scores read them
+                    if (lig == ln) den_update(s_den, s_rcp, sn, tid, P.vbeta, f);
+                    if (n + 1 < len) {
+                        const int lo2 = zo_c / T;
+                        if (lig == lo2) den_update(s_den, s_rcp, zo_c - lo2 * T, tid, P.vbeta, -f_c);
+                    }
+                }
             }
             pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn;
         }
@@ -673,34 +734,36 @@ int hip_fail(hipError_t e)
 }
 
 template <int G, int T>
-int launch_sweep(const KParams &P, bool has_tail, bool fast, int64_t blocks, hipStream_t st)
+int launch_sweep(const KParams &P, bool has_tail, bool fast, bool dense, int64_t blocks, hipStream_t st)
 {
     const dim3 grid((unsigned)blocks), block(256);
-    if (has_tail) {
-        if (fast) hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, true>), grid, block, 0, st, P);
-        else hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, false>), grid, block, 0, st, P);
+    if (dense) {
+        hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true, true>), grid, block, 0, st, P);
+    } else if (has_tail) {
+        if (fast) hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, true, false>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, false, false>), grid, block, 0, st, P);
     } else {
-        if (fast) hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true>), grid, block, 0, st, P);
-        else hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, false>), grid, block, 0, st, P);
+        if (fast) hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true, false>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, false, false>), grid, block, 0, st, P);
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
 }
 
 template <int G>
-int dispatch_sweep_T(int T, const KParams &P, bool has_tail, bool fast, int64_t blocks, hipStream_t st)
+int dispatch_sweep_T(int T, const KParams &P, bool has_tail, bool fast, bool dense, int64_t blocks, hipStream_t st)
 {
     if constexpr (G == 8) {
         switch (T) {
-        case 1: return launch_sweep<8, 1>(P, has_tail, fast, blocks, st);
-        case 2: return launch_sweep<8, 2>(P, has_tail, fast, blocks, st);
-        case 4: return launch_sweep<8, 4>(P, has_tail, fast, blocks, st);
-        case 8: return launch_sweep<8, 8>(P, has_tail, fast, blocks, st);
+        case 1: return launch_sweep<8, 1>(P, has_tail, fast, dense, blocks, st);
+        case 2: return launch_sweep<8, 2>(P, has_tail, fast, dense, blocks, st);
+        case 4: return launch_sweep<8, 4>(P, has_tail, fast, dense, blocks, st);
+        case 8: return launch_sweep<8, 8>(P, has_tail, fast, dense, blocks, st);
         }
     }
     switch (T) {
-    case 12: return launch_sweep<G, 12>(P, has_tail, fast, blocks, st);
-    case 16: return launch_sweep<G, 16>(P, has_tail, fast, blocks, st);
+    case 12: return launch_sweep<G, 12>(P, has_tail, fast, dense, blocks, st);
+    case 16: return launch_sweep<G, 16>(P, has_tail, fast, dense, blocks, st);
     }
     return LLDA_E_BAD_K;
 }
@@ -838,12 +901,15 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     hipStream_t st = (hipStream_t)stream;
     const bool has_tail = L.tail != 0;
     // with alpha, beta >= 1e-6 and int32 counts no label-allowed score can underflow to zero
-    const bool fast = a->alpha >= 1e-6 && a->beta >= 1e-6;
+    // ... and with V*beta < 2^40 the integer n_k is recoverable from the cached fl(n_k + V*beta)
+    const bool fast = a->alpha >= 1e-6 && a->beta >= 1e-6 && P.vbeta < 1099511627776.0;
+    // all-ones label masks and no padded slots: the mask need not be applied at all
+    const bool dense = fast && a->dense_mask != 0 && L.K == L.KP;
     switch (L.G) {
-    case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, fast, blocks, st);
-    case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, fast, blocks, st);
-    case 32: return dispatch_sweep_T<32>(L.T, P, has_tail, fast, blocks, st);
-    case 64: return dispatch_sweep_T<64>(L.T, P, has_tail, fast, blocks, st);
+    case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, fast, dense, blocks, st);
+    case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, fast, dense, blocks, st);
+    case 32: return dispatch_sweep_T<32>(L.T, P, has_tail, fast, dense, blocks, st);
+    case 64: return dispatch_sweep_T<64>(L.T, P, has_tail, fast, dense, blocks, st);
     }
     return LLDA_E_BAD_K;
 }

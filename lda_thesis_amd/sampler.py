@@ -96,6 +96,7 @@ class GibbsSampler(object):
         self.z = self._topic_pos[as_dev(z, torch.int64)].to(torch.int32)
 
         self.lab_mask = self._make_masks(labs)
+        self.dense_mask = labs is None
         lens = (self.doc_off[1:] - self.doc_off[:-1])
         self.doc_order = None
         if sort_docs and self.D > 1 and int(lens.min()) != int(lens.max()):
@@ -158,7 +159,7 @@ class GibbsSampler(object):
                            status=self.status, D=self.D, V=self.V, K=self.K, alpha=self.alpha,
                            beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
                            stream_id=self.stream_id, doc_base=self.doc_base,
-                           docs_per_group=self.docs_per_group)
+                           docs_per_group=self.docs_per_group, dense_mask=self.dense_mask)
         if ev is not None:
             ev[1].record()
             self.kernel_events.append(ev)
