@@ -128,6 +128,22 @@ int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab
                 int64_t D, int64_t V, int32_t K, double alpha, double beta,
                 double *out_doc, void *stream);
 
+/* Test-time fold-in sampler for held-out documents: LabeledLDA.prep4test + run_test
+ * (LabeledLDA.py:155-212).  ph = ph_hat, phn = ph_hat with every word column divided by its column
+ * sum (the host's `probs /= probs.sum(axis=0)`, LabeledLDA.py:162-167), both (V, KP) doubles, word-major,
+ * device order, zero in the padding.  Per document: initial assignments drawn from phn (RNG sweep word
+ * 0xFFFFFFFF), then `iters` sweeps of  prob = (n_dk + alpha) * ph[:, v]; prob /= prob.sum();
+ * while prob.sum() > 1: prob /= 1.0000005;  draw.  Every `thinning` sweeps n_dk / sum(n_dk) enters a
+ * running average which is written to th (D, KP).  Outputs z (device positions) and n_dk (D, KP) hold
+ * the final state (with iters = 0: the prep4test start state).  word_init (may be NULL = word) selects
+ * the phn row of every site for the initial draw: the reference replaces ALL columns of a document by
+ * the uniform 1/K when one of them cannot be normalised, which the host expresses by pointing that
+ * document's sites at an extra uniform row. */
+int llda_foldin(const int64_t *doc_off, const int32_t *word, const int32_t *word_init, const int32_t *freq,
+                const double *ph, const double *phn, int64_t D, int64_t V, int32_t K, double alpha, int32_t iters,
+                int32_t thinning, uint64_t seed, uint32_t stream_id, int64_t doc_base, int32_t *z,
+                int32_t *n_dk, double *th, int32_t *status, void *stream);
+
 /* Device self test of the kernel's division shortcut: runs >= n random (a, b) pairs through
  * "q = a * RN(1/b) + two exact-residual corrections" and through the hardware IEEE division and adds
  * the number of differing results to *mismatches_dev (dev, uint64, zeroed by the caller).  Expected: 0. */

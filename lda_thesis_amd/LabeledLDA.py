@@ -178,6 +178,25 @@ class LabeledLDA(object):
         return [[names[k]] + [self.v_to_w[v] for v in np.argsort(-ph[k, :])[:topwords]]
                 for k in range(self.K)]
 
+    # ---- test time (reference LabeledLDA.py:155-212), on the device ----
+    def prep4test(self, doc, seed=None, stream_id=None):
+        """start state (ids, freqs, z_dn, n_dk) of one held-out token list: LabeledLDA.py:155-177."""
+        from .foldin import TEST_STREAM, fold_in
+        tups = self.dicti.doc2bow(doc)
+        r = fold_in(self.ph_hat, self.alpha, [tups], 0, 1, self.seed if seed is None else seed,
+                    TEST_STREAM if stream_id is None else stream_id)
+        ids, freqs = zip(*tups)
+        return ids, freqs, list(r["z"][0]), r["n_dk"][0]
+
+    def run_test(self, newdocs, it, thinning, seed=None, stream_id=None):
+        """thinned average of n_dk / sum(n_dk) over ``it`` fold-in sweeps per held-out document
+        (LabeledLDA.py:179-212); all documents and sweeps in one llda_foldin launch."""
+        from .foldin import TEST_STREAM, fold_in
+        tups = [self.dicti.doc2bow(x) for x in newdocs]
+        r = fold_in(self.ph_hat, self.alpha, tups, it, thinning, self.seed if seed is None else seed,
+                    TEST_STREAM if stream_id is None else stream_id)
+        return r["th_hat"]
+
     # ---- predictions ----
     def get_pred(self, single_th, n=5):
         names = np.array(list(self.labelmap.keys()))

@@ -40,7 +40,7 @@ class LldaSweepArgs(ctypes.Structure):
 
 
 EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_layout_init",
-           "llda_sweep", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_selftest_div")
+           "llda_sweep", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin", "llda_selftest_div")
 
 _LIB = None
 
@@ -80,6 +80,9 @@ def lib():
     L.llda_loglik.restype = ctypes.c_int
     L.llda_loglik.argtypes = [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i32, _c_d, _c_d,
                               _c_p, _c_p]
+    L.llda_foldin.restype = ctypes.c_int
+    L.llda_foldin.argtypes = [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i32, _c_d, _c_i32, _c_i32,
+                              _c_u64, _c_u32, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]
     L.llda_selftest_div.restype = ctypes.c_int
     L.llda_selftest_div.argtypes = [_c_u64, _c_i64, _c_p, _c_p]
     if L.llda_abi_version() != ABI_VERSION:
@@ -152,3 +155,12 @@ def selftest_div(n, seed=1):
     bad = torch.zeros((1,), dtype=torch.int64, device="cuda")
     check(lib().llda_selftest_div(int(seed), int(n), _ptr(bad), _stream()), "llda_selftest_div")
     return int(bad.item())
+
+
+def foldin(doc_off, word, word_init, freq, ph, phn, D, V, K, alpha, iters, thinning, seed, stream_id, doc_base,
+           z, n_dk, th, status):
+    check(lib().llda_foldin(_ptr(doc_off), _ptr(word), _ptr(word_init), _ptr(freq), _ptr(ph), _ptr(phn), int(D),
+                            int(V), int(K),
+                            float(alpha), int(iters), int(thinning), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                            int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(z), _ptr(n_dk), _ptr(th),
+                            _ptr(status), _stream()), "llda_foldin")

@@ -337,6 +337,54 @@ __device__ __forceinline__ double group_sum(const double (&w)[T], const KParams 
     return acc;
 }
 
+// Keyed categorical draw over the group's K probabilities p (device order, oracle/llda_oracle.py
+// draw_keyed): q = per-lane prefix over the slots, X = Hillis-Steele scan of the lane totals,
+// t = u * X[G-1]; result = first position with p > 0 and q > t - X[lane-1], else the last position with
+// p > 0; -1 if there is none (or !valid).  FAST: "p > 0" is read off the label mask.
+template <int G, int T, bool FAST>
+__device__ __forceinline__ int draw_position(const double (&w)[T], double u, uint32_t mask, bool valid, int lig, int lane)
+{
+    const int gbase = lane & ~(G - 1);
+    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    double q[T];
+    q[0] = w[0];
+#pragma unroll
+    for (int s = 1; s < T; ++s) q[s] = q[s - 1] + w[s];
+    const double X = group_scan<G>(q[T - 1], lig);
+    const double tot = bcast_last<G>(X, lane);
+    const double t = u * tot;
+    const double prev = dpp_f64<DPP_WAVE_SHR1>(X);
+    const double tg = t - (lig ? prev : 0.0);
+    uint32_t fm = 0, pm = 0;
+    if (FAST) {
+        // q is non-decreasing along the slots, so {s : q[s] > tg} is the suffix starting at
+        // cnt = #{s : q[s] <= tg}; positive-probability slots are the label-mask bits.
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < T; ++s) cnt += (q[s] <= tg) ? 1 : 0;
+        pm = mask;
+        fm = mask & (0xFFFFu << cnt);
+    } else {
+#pragma unroll
+        for (int s = 0; s < T; ++s) {
+            const bool pos = w[s] > 0.0;
+            pm |= (pos ? 1u : 0u) << s;
+            fm |= ((pos && q[s] > tg) ? 1u : 0u) << s;
+        }
+    }
+    const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
+    const uint64_t gp = (__ballot(pm != 0) >> gbase) & gmask;
+    int zn = -1;
+    if (gp != 0 && valid) {
+        const bool hit = gf != 0;
+        const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)gp);
+        const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(pm | 1u));
+        const int ss = __shfl(my, sl, G);
+        zn = sl * T + ss;
+    }
+    return zn;
+}
+
 // store the new assignment of a site and move its count in n_kw_delta (int32 atomics, no return value)
 __device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, int f, int zo, int zn, int KP)
 {
@@ -371,8 +419,6 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
     const int lane = tid & 63;
     const int lig = tid & (G - 1);            // lane in group
     const int grp = tid / G;
-    const int gbase = lane & ~(G - 1);        // first wave-lane of this group
-    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
 
     for (int it = 0; it < P.dpg; ++it) {
         const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
@@ -474,44 +520,10 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
             for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);
 
             // keyed categorical draw (oracle/llda_oracle.py draw_keyed)
-            double q[T];
-            q[0] = w[0];
-#pragma unroll
-            for (int s = 1; s < T; ++s) q[s] = q[s - 1] + w[s];
-            const double X = group_scan<G>(q[T - 1], lig);
-            const double tot = bcast_last<G>(X, lane);
-            const double t = u * tot;
-            const double prev = dpp_f64<DPP_WAVE_SHR1>(X);
-            const double tg = t - (lig ? prev : 0.0);
-            uint32_t fm = 0, pm = 0;
-            if (FAST) {
-                // q is non-decreasing along the slots, so {s : q[s] > tg} is the suffix starting at
-                // cnt = #{s : q[s] <= tg}; positive-probability slots are the label-mask bits.
-                int cnt = 0;
-#pragma unroll
-                for (int s = 0; s < T; ++s) cnt += (q[s] <= tg) ? 1 : 0;
-                pm = mask;
-                fm = mask & (0xFFFFu << cnt);
-            } else {
-#pragma unroll
-                for (int s = 0; s < T; ++s) {
-                    const bool pos = w[s] > 0.0;
-                    pm |= (pos ? 1u : 0u) << s;
-                    fm |= ((pos && q[s] > tg) ? 1u : 0u) << s;
-                }
-            }
-            const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
-            const uint64_t gp = (__ballot(pm != 0) >> gbase) & gmask;
-            int zn = zo;
-            if (gp != 0 && S > 0.0) {
-                const bool hit = gf != 0;
-                const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1
-                                   : 63 - (int)__clzll((unsigned long long)gp);
-                const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(pm | 1u));
-                const int ss = __shfl(my, sl, G);
-                zn = sl * T + ss;
-            } else if (lig == 0 && P.status) {
-                atomicOr(P.status, 1);          // no topic with positive probability
+            int zn = draw_position<G, T, FAST>(w, u, mask, S > 0.0, lig, lane);
+            if (zn < 0) {
+                zn = zo;
+                if (lig == 0 && P.status) atomicOr(P.status, 1);    // no topic with positive probability
             }
 
             // add the site back (LabeledLDA.py:121-125)
@@ -611,6 +623,155 @@ __global__ void __launch_bounds__(256) llda_loglik_kernel(const LParams P)
     if (lig == 0) P.out_doc[d] = acc;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Test-time fold-in sampler: LabeledLDA.prep4test / run_test (LabeledLDA.py:155-212).
+// One lane group per held-out document; topic-word loadings ph_hat are fixed, only the document's n_dk
+// moves.  phn = ph_hat with every word column normalised (prep4test, LabeledLDA.py:162-167, done by
+// the host); both matrices are word-major in device order: (V, KP) doubles.
+// ---------------------------------------------------------------------------------------------
+struct FParams {
+    const int64_t *doc_off;
+    const int32_t *word;
+    const int32_t *word_init; // row of phn used by prep4test (== word unless a document fell back to uniform)
+    const int32_t *freq;
+    int32_t *z;              // [S] out: final assignments (device positions)
+    const double *ph;        // [V*KP]
+    const double *phn;       // [V*KP]
+    int32_t *n_dk;           // [D*KP] out: final counts
+    double *th;              // [D*KP] out: thinned average of n_dk / sum(n_dk)
+    int32_t *status;
+    int64_t D;
+    int64_t doc_base;
+    double alpha;
+    uint32_t key0, key1, stream_id;
+    int32_t iters, thinning;
+    int32_t last_leaf, tail, tail_row, n_rounds, xor_tree;
+    uint32_t rounds_pk[LLDA_MAX_ROUNDS];
+};
+
+template <int T>
+__device__ __forceinline__ void load_row_f64(const double *__restrict__ p, double (&x)[T])
+{
+    if constexpr (T % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < T / 2; ++i) {
+            const double2 v = reinterpret_cast<const double2 *>(p)[i];
+            x[2 * i] = v.x; x[2 * i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) x[i] = p[i];
+    }
+}
+
+// `while prob.sum() > 1: prob /= c`  (LabeledLDA.py:170-171, 192-193); c_rcp = RN(1/c)
+template <int G, int T, bool HAS_TAIL>
+__device__ __forceinline__ void shrink_to_one(double (&p)[T], double c, double c_rcp, const KParams &K, int lig, int lane)
+{
+    for (int guard = 0; guard < 64; ++guard) {
+        const double s = group_sum<G, T, HAS_TAIL>(p, K, lig, lane);
+        if (!(s > 1.0)) break;                     // group-uniform: every lane holds the same s
+#pragma unroll
+        for (int k = 0; k < T; ++k) p[k] = div_by(p[k], c, c_rcp);
+    }
+}
+
+template <int G, int T, bool HAS_TAIL>
+__global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
+{
+    constexpr int KP = G * T;
+    constexpr int GPB = 256 / G;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int lig = tid & (G - 1);
+    const int64_t d = (int64_t)blockIdx.x * GPB + tid / G;
+    if (d >= P.D) return;
+    KParams K;                                     // the summation schedule group_sum() reads
+    K.last_leaf = P.last_leaf; K.tail = P.tail; K.tail_row = P.tail_row; K.n_rounds = P.n_rounds;
+    K.xor_tree = P.xor_tree;
+#pragma unroll
+    for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) K.rounds_pk[r] = P.rounds_pk[r];
+
+    const int64_t s0 = P.doc_off[d];
+    const int len = (int)(P.doc_off[d + 1] - s0);
+    const uint32_t gdoc = (uint32_t)(d + P.doc_base);
+    int ndk[T];
+    double avg[T];
+#pragma unroll
+    for (int s = 0; s < T; ++s) { ndk[s] = 0; avg[s] = 0.0; }
+    int ntot = 0;
+    const double c0 = 1.0000000005, c0r = 1.0 / c0, c1 = 1.0000005, c1r = 1.0 / c1;
+
+    // sweep = -1: prep4test (initial assignments from the normalised loadings), then `iters` sweeps
+    for (int sweep = -1; sweep < P.iters; ++sweep) {
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        for (int n = 0; n < len; ++n) {
+            const int v = P.word[s0 + n], f = P.freq[s0 + n];
+            if ((n & (2 * G - 1)) == 0) {
+                r0 = (uint32_t)(n >> 1) + (uint32_t)lig; r1 = gdoc; r2 = P.stream_id; r3 = (uint32_t)sweep;
+                philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
+            }
+            const int holder = (n >> 1) & (G - 1);
+            const uint32_t ra = (uint32_t)__shfl((int)((n & 1) ? r2 : r0), holder, G);
+            const uint32_t rb = (uint32_t)__shfl((int)((n & 1) ? r3 : r1), holder, G);
+            const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+
+            double w[T];
+            int zo = -1;
+            if (sweep < 0) {
+                load_row_f64<T>(P.phn + (int64_t)P.word_init[s0 + n] * KP + lig * T, w);
+                shrink_to_one<G, T, HAS_TAIL>(w, c0, c0r, K, lig, lane);
+                ntot += f;
+            } else {
+                zo = P.z[s0 + n];
+                {
+                    const int lo = zo / T, so = zo - lo * T;
+                    onehot_add1<T>(ndk, (lig == lo) ? (1u << so) : 0u, f);       // n_dk[z] -= f
+                }
+                double b[T];
+                load_row_f64<T>(P.ph + (int64_t)v * KP + lig * T, b);
+#pragma unroll
+                for (int s = 0; s < T; ++s) w[s] = ((double)ndk[s] + P.alpha) * b[s];   // num_a * b
+                const double S = group_sum<G, T, HAS_TAIL>(w, K, lig, lane);
+                const double y = 1.0 / S;
+#pragma unroll
+                for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);                  // prob /= prob.sum()
+                shrink_to_one<G, T, HAS_TAIL>(w, c1, c1r, K, lig, lane);
+            }
+            int zn = draw_position<G, T, false>(w, u, 0u, true, lig, lane);
+            if (zn < 0) {                         // all-zero / NaN probabilities: the reference would raise
+                zn = zo < 0 ? 0 : zo;
+                if (lig == 0 && P.status) atomicOr(P.status, 1);
+            }
+            {
+                const int ln = zn / T, sn = zn - ln * T;
+                onehot_add1<T>(ndk, (lig == ln) ? (1u << sn) : 0u, -f);          // n_dk[new_z] += f
+            }
+            if (lig == 0) P.z[s0 + n] = zn;
+        }
+        // thinned running average of the document-topic state (LabeledLDA.py:199-211)
+        if (sweep >= 0 && (sweep + 1) % P.thinning == 0) {
+            const int s2 = (sweep + 1) / P.thinning;
+            const double tot = (double)ntot;
+            if (s2 == 1) {
+#pragma unroll
+                for (int s = 0; s < T; ++s) avg[s] = (double)ndk[s] / tot;
+            } else {
+                const double f_old = (double)(s2 - 1) / (double)s2, f_new = 1.0 / (double)s2;
+#pragma unroll
+                for (int s = 0; s < T; ++s) {
+                    const double old_part = f_old * avg[s];
+                    const double new_part = f_new * ((double)ndk[s] / tot);
+                    avg[s] = old_part + new_part;
+                }
+            }
+        }
+    }
+    store_row<T>(P.n_dk + d * KP + lig * T, ndk);
+#pragma unroll
+    for (int s = 0; s < T; ++s) P.th[d * KP + lig * T + s] = avg[s];
+}
 
 // ---------------------------------------------------------------------------------------------
 // self test: div_by (reciprocal + two corrections) against the hardware IEEE division
@@ -795,6 +956,52 @@ int dispatch_loglik_T(int T, const LParams &P, hipStream_t st)
     return LLDA_E_BAD_K;
 }
 
+template <int G, int T>
+int launch_foldin(const FParams &P, bool has_tail, hipStream_t st)
+{
+    const int64_t blocks = (P.D + (256 / G) - 1) / (256 / G);
+    if (has_tail) hipLaunchKernelGGL((llda_foldin_kernel<G, T, true>), dim3((unsigned)blocks), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((llda_foldin_kernel<G, T, false>), dim3((unsigned)blocks), dim3(256), 0, st, P);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
+}
+
+template <int G>
+int dispatch_foldin_T(int T, const FParams &P, bool has_tail, hipStream_t st)
+{
+    if constexpr (G == 8) {
+        switch (T) {
+        case 1: return launch_foldin<8, 1>(P, has_tail, st);
+        case 2: return launch_foldin<8, 2>(P, has_tail, st);
+        case 4: return launch_foldin<8, 4>(P, has_tail, st);
+        case 8: return launch_foldin<8, 8>(P, has_tail, st);
+        }
+    }
+    switch (T) {
+    case 12: return launch_foldin<G, 12>(P, has_tail, st);
+    case 16: return launch_foldin<G, 16>(P, has_tail, st);
+    }
+    return LLDA_E_BAD_K;
+}
+
+// the summation schedule shared by llda_sweep and llda_foldin
+void fill_schedule(const llda_layout &L, int32_t &last_leaf, int32_t &tail, int32_t &tail_row, int32_t &n_rounds,
+                   int32_t &xor_tree, uint32_t (&rounds_pk)[LLDA_MAX_ROUNDS])
+{
+    last_leaf = L.n_leaves - 1; tail = L.tail; tail_row = L.tail_row; n_rounds = L.n_rounds;
+    const int P2 = L.G / 8;
+    int xt = (L.n_leaves == P2) ? 1 : 0;
+    for (int r = 0; (1 << r) < P2 && xt; ++r)
+        for (int p = 0; p < P2; ++p)
+            if (L.rounds[r][p] != (p ^ (1 << r))) xt = 0;
+    xor_tree = xt;
+    for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) {
+        uint32_t pk = 0;
+        for (int p = 0; p < LLDA_MAX_LEAVES; ++p) pk |= (uint32_t)L.rounds[r][p] << (4 * p);
+        rounds_pk[r] = pk;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -871,20 +1078,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     P.vbeta = (double)a->V * a->beta;                       // V * beta evaluated first (LabeledLDA.py:115)
     P.key0 = (uint32_t)a->seed; P.key1 = (uint32_t)(a->seed >> 32);
     P.sweep = a->sweep; P.stream_id = a->stream_id;
-    P.last_leaf = L.n_leaves - 1; P.tail = L.tail; P.tail_row = L.tail_row; P.n_rounds = L.n_rounds;
-    {
-        const int P2 = L.G / 8;
-        int xt = (L.n_leaves == P2) ? 1 : 0;
-        for (int r = 0; (1 << r) < P2 && xt; ++r)
-            for (int p = 0; p < P2; ++p)
-                if (L.rounds[r][p] != (p ^ (1 << r))) xt = 0;
-        P.xor_tree = xt;
-    }
-    for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) {
-        uint32_t pk = 0;
-        for (int p = 0; p < LLDA_MAX_LEAVES; ++p) pk |= (uint32_t)L.rounds[r][p] << (4 * p);
-        P.rounds_pk[r] = pk;
-    }
+    fill_schedule(L, P.last_leaf, P.tail, P.tail_row, P.n_rounds, P.xor_tree, P.rounds_pk);
     const int gpb = 256 / L.G;
     int dpg = a->docs_per_group;
     if (dpg < 1) {
@@ -964,6 +1158,37 @@ int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab
     case 16: return dispatch_loglik_T<16>(L.T, P, st);
     case 32: return dispatch_loglik_T<32>(L.T, P, st);
     case 64: return dispatch_loglik_T<64>(L.T, P, st);
+    }
+    return LLDA_E_BAD_K;
+}
+
+int llda_foldin(const int64_t *doc_off, const int32_t *word, const int32_t *word_init, const int32_t *freq,
+                const double *ph, const double *phn, int64_t D, int64_t V, int32_t K, double alpha, int32_t iters,
+                int32_t thinning, uint64_t seed, uint32_t stream_id, int64_t doc_base, int32_t *z,
+                int32_t *n_dk, double *th, int32_t *status, void *stream)
+{
+    if (!doc_off || !word || !freq || !ph || !phn || !z || !n_dk || !th || D < 0 || V < 1 || iters < 0 ||
+        thinning < 1)
+        return LLDA_E_BAD_ARG;
+    llda_layout L;
+    const int rc = llda_layout_init(K, &L);
+    if (rc) return rc;
+    if (D == 0) return LLDA_OK;
+    FParams P;
+    memset(&P, 0, sizeof P);
+    P.doc_off = doc_off; P.word = word; P.word_init = word_init ? word_init : word; P.freq = freq; P.z = z;
+    P.ph = ph; P.phn = phn; P.n_dk = n_dk;
+    P.th = th; P.status = status; P.D = D; P.doc_base = doc_base; P.alpha = alpha;
+    P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.stream_id = stream_id;
+    P.iters = iters; P.thinning = thinning;
+    fill_schedule(L, P.last_leaf, P.tail, P.tail_row, P.n_rounds, P.xor_tree, P.rounds_pk);
+    hipStream_t st = (hipStream_t)stream;
+    const bool has_tail = L.tail != 0;
+    switch (L.G) {
+    case 8: return dispatch_foldin_T<8>(L.T, P, has_tail, st);
+    case 16: return dispatch_foldin_T<16>(L.T, P, has_tail, st);
+    case 32: return dispatch_foldin_T<32>(L.T, P, has_tail, st);
+    case 64: return dispatch_foldin_T<64>(L.T, P, has_tail, st);
     }
     return LLDA_E_BAD_K;
 }

@@ -339,6 +339,56 @@ def gen_cascade():
     print("cascade_toy: %d sub-problems, K=%d, ph sum %.6f" % (len(sizes), c.K, np.nansum(c.ph)))
 
 
+def gen_runtest():
+    """LabeledLDA.run_test of the reference (LabeledLDA.py:155-212) with the keyed draw injected: the
+    prep4test draws of document d use RNG sweep word 0xFFFFFFFF, iteration i uses sweep i; sites are
+    counted from 0 inside each (document, sweep)."""
+    from fixture_corpora import tiny_corpus
+    for name, it, thin in (("k12", 6, 2), ("k40", 5, 1), ("k130", 4, 3)):
+        docs, labs, labelset, alpha, beta, _, npseed = tiny_corpus(name)
+        dicti = Dictionary(docs)
+        np.random.seed(npseed)
+        m = REF_L.LabeledLDA(docs, labs, list(labelset), dicti, alpha, beta)
+        draw = orc.KeyedDraw(12345, 0)
+        c = [0]
+
+        def sweep_l():
+            o3_sweep(REF_L, REF_L.LabeledLDA, m, draw, c[0])
+            c[0] += 1
+        m.training_iteration = sweep_l
+        m.run_training(4, 2)
+        # held-out documents: resampled tokens of the same vocabulary (+ frequencies > 1)
+        rng = np.random.default_rng(len(name))
+        vocab = list(dicti.token2id.keys())
+        newdocs = [[vocab[i] for i in rng.integers(0, len(vocab), size=int(rng.integers(3, 30)))] for _ in range(9)]
+        tdraw = orc.KeyedDraw(777, 2)
+        plan = []
+        for d, nd in enumerate(newdocs):
+            L = len(dicti.doc2bow(nd))
+            plan += [(orc.SWEEP_INIT, d, n) for n in range(L)]
+            for i in range(it):
+                plan += [(i, d, n) for n in range(L)]
+        it_plan = iter(plan)
+
+        def keyed(n_, prob):
+            tdraw.sweep, tdraw.doc, tdraw.site = next(it_plan)
+            tdraw.plan = None
+            return tdraw(n_, prob)
+        set_draw(REF_L, keyed)
+        ph_before = m.ph_hat.copy()
+        th = m.run_test(newdocs, it, thin)
+        set_draw(REF_L, np.random.multinomial)
+        assert np.array_equal(ph_before, m.ph_hat)
+        bows = [dicti.doc2bow(nd) for nd in newdocs]
+        off = np.zeros(len(bows) + 1, dtype=np.int64)
+        np.cumsum([len(b) for b in bows], out=off[1:])
+        np.savez_compressed(os.path.join(GOLDEN, "runtest_%s.npz" % name), ph_hat=m.ph_hat, alpha=alpha, it=it,
+                            thinning=thin, seed=777, stream=2, th_hat=th, doc_off=off,
+                            word=np.array([v for b in bows for v, _ in b], dtype=np.int32),
+                            freq=np.array([f for b in bows for _, f in b], dtype=np.int32))
+        print("runtest_%s: th_hat %s sum %.6f" % (name, th.shape, th.sum()))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     what = sys.argv[1:] or ["tiny", "sublda"]
@@ -348,6 +398,8 @@ if __name__ == "__main__":
         gen_sublda()
     if "runtraining" in what:
         gen_runtraining()
+    if "runtest" in what:
+        gen_runtest()
     if "cascade" in what:
         gen_cascade()
     if "abstracts" in what:

@@ -476,3 +476,75 @@ def digest(n_k_v, n_d_k, n_zk, z_flat):
 
 def state_digest(st):
     return digest(st.n_k_v, st.n_d_k, st.n_zk, st.flat_z())
+
+
+# ----------------------------------------------------------------------------------------------
+# Test-time fold-in sampler (reference LabeledLDA.py:155-212)  --  restated
+# ----------------------------------------------------------------------------------------------
+SWEEP_INIT = 0xFFFFFFFF      # RNG "sweep" word used for the prep4test draws
+
+
+def prep4test(ph_hat, ids, freqs, draw):
+    """LabeledLDA.prep4test (LabeledLDA.py:155-177) for one document given as word ids / frequencies.
+    ``draw`` has numpy.random.multinomial's call shape.  Returns (z list, n_dk)."""
+    K = ph_hat.shape[0]
+    z_dn = []
+    n_dk = np.zeros(K, dtype=int)
+    probs = ph_hat[:, list(ids)]
+    with np.errstate(divide="raise", invalid="raise"):
+        try:
+            probs /= probs.sum(axis=0)
+        except FloatingPointError:
+            probs = 1 / K * np.ones_like(probs)
+    for n, f in enumerate(freqs):
+        prob = probs[:, n]
+        while prob.sum() > 1:
+            prob /= 1.0000000005
+        new_z = draw(1, prob).argmax()
+        z_dn.append(new_z)
+        n_dk[new_z] += f
+    return z_dn, n_dk
+
+
+def run_test(ph_hat, alpha, docs, freqs, it, thinning, draw_for):
+    """LabeledLDA.run_test (LabeledLDA.py:179-212).  ``docs``/``freqs``: lists of id / frequency lists;
+    ``draw_for(d, sweep)`` returns the draw callable for document d and sweep (SWEEP_INIT or i)."""
+    K = ph_hat.shape[0]
+    th_hat = np.zeros((len(docs), K), dtype=float)
+    for d, (doc, fr) in enumerate(zip(docs, freqs)):
+        z_dn, n_dk = prep4test(ph_hat, doc, fr, draw_for(d, SWEEP_INIT))
+        avg_state = None
+        for i in range(it):
+            draw = draw_for(d, i)
+            for n, (v, f, z) in enumerate(zip(doc, fr, z_dn)):
+                n_dk[z] -= f
+                num_a = n_dk + alpha
+                b = ph_hat[:, v]
+                prob = num_a * b
+                prob /= prob.sum()
+                while prob.sum() > 1:
+                    prob /= 1.0000005
+                new_z = draw(1, prob).argmax()
+                z_dn[n] = new_z
+                n_dk[new_z] += f
+            s = (i + 1) / thinning
+            s2 = int(s)
+            if s == s2:
+                this_state = n_dk / n_dk.sum()
+                if s2 == 1:
+                    avg_state = this_state
+                else:
+                    old = (s2 - 1) / s2 * avg_state
+                    new = (1 / s2) * this_state
+                    avg_state = old + new
+                th_hat[d, :] = avg_state
+    return th_hat
+
+
+def keyed_draw_for(seed, stream=0, doc_base=0):
+    """draw_for factory: one KeyedDraw per (document, sweep), sites counted from 0."""
+    def draw_for(d, sweep):
+        k = KeyedDraw(seed, stream)
+        k.sweep, k.doc, k.site = sweep, d + doc_base, 0
+        return k
+    return draw_for

@@ -117,3 +117,51 @@ def test_cascade_go_down_tree_matches_reference(capsys):
     np.testing.assert_array_equal(c.ph, g["ph"])
     out = capsys.readouterr().out
     assert out.count("Working on parent node") == len(g["sizes"]) - 1
+
+
+@pytest.mark.parametrize("name", ["k12", "k40", "k130"])
+def test_fold_in_matches_reference_run_test(name):
+    """llda_foldin (prep4test + run_test on the device) vs the reference's run_test with the keyed draw."""
+    from lda_thesis_amd.foldin import fold_in
+    g = load_golden("runtest_" + name)
+    off = g["doc_off"]
+    tups = [list(zip(g["word"][off[d]:off[d + 1]].tolist(), g["freq"][off[d]:off[d + 1]].tolist()))
+            for d in range(len(off) - 1)]
+    r = fold_in(g["ph_hat"], float(g["alpha"]), tups, int(g["it"]), int(g["thinning"]), int(g["seed"]),
+                stream_id=int(g["stream"]))
+    np.testing.assert_array_equal(r["th_hat"], g["th_hat"])
+    assert (r["n_dk"].sum(1) == [sum(f for _, f in t) for t in tups]).all()
+
+
+def test_fold_in_against_numpy_oracle_on_seeded_inputs():
+    """bigger K / longer documents / more sweeps than the committed golden, vs oracle/llda_oracle.run_test."""
+    import llda_oracle as orc
+    from lda_thesis_amd.foldin import fold_in
+    rng = np.random.default_rng(5)
+    for K, V in ((7, 40), (64, 90), (200, 60), (512, 50)):
+        ph = rng.random((K, V)) ** 3
+        ph[rng.random((K, V)) < 0.2] = 0.0
+        ph /= ph.sum(axis=1, keepdims=True)
+        docs, freqs, tups = [], [], []
+        for d in range(12):
+            ids = np.sort(rng.choice(V, size=int(rng.integers(1, 25)), replace=False)).tolist()
+            fr = rng.integers(1, 4, size=len(ids)).tolist()
+            docs.append(ids); freqs.append(fr); tups.append(list(zip(ids, fr)))
+        want = orc.run_test(ph, 0.3, docs, freqs, 7, 3, orc.keyed_draw_for(99, 4, doc_base=10))
+        got = fold_in(ph, 0.3, tups, 7, 3, 99, stream_id=4, doc_base=10)
+        np.testing.assert_array_equal(got["th_hat"], want)
+
+
+def test_labeledlda_run_test_method():
+    g = load_golden("runtest_k12")
+    m, _, _ = build_model("k12", seed=12345)
+    m.run_training(4, 2)
+    np.testing.assert_array_equal(m.ph_hat, g["ph_hat"])            # same trained model as the fixture
+    off = g["doc_off"]
+    inv = {v: k for k, v in m.dicti.token2id.items()}
+    newdocs = [[inv[w] for w, f in zip(g["word"][off[d]:off[d + 1]], g["freq"][off[d]:off[d + 1]]) for _ in range(f)]
+               for d in range(len(off) - 1)]
+    th = m.run_test(newdocs, int(g["it"]), int(g["thinning"]), seed=int(g["seed"]), stream_id=int(g["stream"]))
+    np.testing.assert_array_equal(th, g["th_hat"])
+    ids, freqs, z_dn, n_dk = m.prep4test(newdocs[0])
+    assert len(z_dn) == len(ids) and n_dk.sum() == sum(freqs)
