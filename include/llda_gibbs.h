@@ -128,21 +128,41 @@ int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab
                 int64_t D, int64_t V, int32_t K, double alpha, double beta,
                 double *out_doc, void *stream);
 
-/* Test-time fold-in sampler for held-out documents: LabeledLDA.prep4test + run_test
- * (LabeledLDA.py:155-212).  ph = ph_hat, phn = ph_hat with every word column divided by its column
- * sum (the host's `probs /= probs.sum(axis=0)`, LabeledLDA.py:162-167), both (V, KP) doubles, word-major,
- * device order, zero in the padding.  Per document: initial assignments drawn from phn (RNG sweep word
- * 0xFFFFFFFF), then `iters` sweeps of  prob = (n_dk + alpha) * ph[:, v]; prob /= prob.sum();
- * while prob.sum() > 1: prob /= 1.0000005;  draw.  Every `thinning` sweeps n_dk / sum(n_dk) enters a
- * running average which is written to th (D, KP).  Outputs z (device positions) and n_dk (D, KP) hold
- * the final state (with iters = 0: the prep4test start state).  word_init (may be NULL = word) selects
- * the phn row of every site for the initial draw: the reference replaces ALL columns of a document by
- * the uniform 1/K when one of them cannot be normalised, which the host expresses by pointing that
- * document's sites at an extra uniform row. */
-int llda_foldin(const int64_t *doc_off, const int32_t *word, const int32_t *word_init, const int32_t *freq,
-                const double *ph, const double *phn, int64_t D, int64_t V, int32_t K, double alpha, int32_t iters,
-                int32_t thinning, uint64_t seed, uint32_t stream_id, int64_t doc_base, int32_t *z,
-                int32_t *n_dk, double *th, int32_t *status, void *stream);
+/* Test-time fold-in sampler for held-out documents: one lane group per document, the topic-word
+ * loadings are fixed and only the document's n_dk moves.  Covers
+ *   LabeledLDA.prep4test + run_test        (LabeledLDA.py:155-212)
+ *   CascadeLDA.prep4test + cascade_test    (CascadeLDA.py:186-247)
+ *   CascadeLDA.prep4test + run_test        (CascadeLDA.py:299-344)
+ * Per document: initial assignments drawn from the rows init_rows[init_idx[site]] (probabilities
+ * prepared by the host exactly as the reference's prep4test does; RNG sweep word 0xFFFFFFFF) after
+ * `while prob.sum() > 1: prob /= c_init`; then `iters` sweeps of
+ *     prob = (n_dk + alpha) * ph[:, v];  prob /= prob.sum();
+ *     [beta_fallback: if prob.sum() == 0 (0/0 raises in the reference): prob = (n_dk+alpha)*(ph[:,v]+beta), renormalise]
+ *     while prob.sum() > 1: prob /= c_loop;   draw
+ * Every `thinning` sweeps n_dk / sum(n_dk) enters a running average (avg_mode 0:
+ * (s-1)/s*avg + (1/s)*cur; 1: m*avg + (1-m)*cur, m = (s-1)/s), written to th (D, KP).  z (device
+ * positions) and n_dk (D, KP) receive the final state (iters = 0: the prep4test start state). */
+typedef struct llda_foldin_args {
+    const int64_t *doc_off;     /* [dev] [D+1]                                                  */
+    const int32_t *word;        /* [dev] [S]                                                    */
+    const int32_t *init_idx;    /* [dev] [S] row of init_rows for every site                     */
+    const int32_t *freq;        /* [dev] [S]                                                    */
+    const double  *ph;          /* [dev] [V*KP] loadings, word-major, device order, 0 in padding */
+    const double  *init_rows;   /* [dev] [R*KP] initial probabilities, device order             */
+    const uint8_t *slot_valid;  /* [dev] [KP] 1 where a slot holds a topic                       */
+    int32_t *z;                 /* [dev] [S] out                                                 */
+    int32_t *n_dk;              /* [dev] [D*KP] out                                              */
+    double  *th;                /* [dev] [D*KP] out                                              */
+    int32_t *status;            /* [dev] optional: bit 0 = a site had no positive probability    */
+    int64_t D;
+    int64_t doc_base;           /* RNG counter word 1 of document 0                              */
+    int32_t K, iters, thinning, beta_fallback, avg_mode, reserved;
+    double alpha, beta, c_init, c_loop;
+    uint64_t seed;
+    uint32_t stream_id, reserved2;
+} llda_foldin_args;
+
+int llda_foldin(const llda_foldin_args *args, void *stream);
 
 /* Device self test of the kernel's division shortcut: runs >= n random (a, b) pairs through
  * "q = a * RN(1/b) + two exact-residual corrections" and through the hardware IEEE division and adds

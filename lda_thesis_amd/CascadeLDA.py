@@ -247,6 +247,92 @@ class CascadeLDA(object):
         sub.run_training(it=it, thinning=thinning)
         return sub.get_ph()
 
+    # ---- test time (reference CascadeLDA.py:186-344), on the device ----
+    def _test_stream(self, labels):
+        """RNG stream of one cascade_test call: depends on the level and on the first label."""
+        from .foldin import CASCADE_STREAM
+        return CASCADE_STREAM + self.K * len(labels[-1]) + self.labelmap[labels[0]]
+
+    def prep4test(self, doc, ph, seed=None, stream_id=0, doc_id=None):
+        """start state (ids, freqs, z_dn, n_dk) for loadings ``ph`` (CascadeLDA.py:186-208)."""
+        from .foldin import cascade_fold_in, doc_key
+        tup = self.dicti.doc2bow(doc)
+        r = cascade_fold_in(ph, self.alpha, self.beta, [tup], 0, 1, self._seed(seed), stream_id,
+                            [doc_key(tup) if doc_id is None else doc_id], device=self._device)
+        ids, freqs = zip(*tup)
+        return ids, freqs, list(r["z"][0]), r["n_dk"][0]
+
+    def _seed(self, seed):
+        if seed is not None:
+            return seed
+        if self.seed is None:
+            self.seed = int(np.random.randint(0, 2 ** 31 - 1))
+        return self.seed
+
+    def cascade_test(self, doc, it, thinning, labels, seed=None, doc_id=None):
+        """thinned document-topic average over the label subset ``labels`` (CascadeLDA.py:210-247)."""
+        from .foldin import cascade_fold_in, doc_key
+        ids = [self.labelmap[x] for x in labels]
+        tup = self.dicti.doc2bow(doc)
+        r = cascade_fold_in(self.ph[ids, :], self.alpha, self.beta, [tup], it, thinning, self._seed(seed),
+                            self._test_stream(labels), [doc_key(tup) if doc_id is None else doc_id],
+                            device=self._device)
+        return r["th_hat"][0]
+
+    @staticmethod
+    def _head(th_hat, labels, threshold):
+        """labels whose sorted loads are needed to pass ``threshold`` cumulative mass, with their loads."""
+        loads = np.sort(th_hat)[::-1]
+        n = sum(np.cumsum(loads) < threshold) + 1
+        order = np.argsort(th_hat)[::-1][:n]
+        return [labels[i] for i in order], loads[:n]
+
+    def test_down_tree(self, doc, it, thinning, threshold, seed=None, doc_id=None):
+        """walk the label tree: level 1 over all one-character labels, then the children of every label
+        kept at the level above (CascadeLDA.py:249-297).  Returns (level_1, level_2, level_3)."""
+        kw = dict(seed=seed, doc_id=doc_id)
+        labels = self.lablist_l1
+        keep, loads = self._head(self.cascade_test(doc, it, thinning, labels, **kw), labels, threshold)
+        level_1, level_2, level_3 = list(zip(keep, loads)), [], []
+        if "root" in keep:
+            keep.remove("root")
+        for parent in keep:
+            pat = re.compile("^" + parent + "[0-9]{1}$")
+            labels = list(filter(pat.match, self.lablist))
+            labels.insert(0, parent)
+            keep2, loads2 = self._head(self.cascade_test(doc, it, thinning, labels, **kw), labels, threshold)
+            level_2.append(list(zip(keep2, loads2)))
+            if parent in keep2:
+                keep2.remove(parent)
+            for parent2 in keep2:
+                pat = re.compile("^" + parent2 + "[0-9]{1}$")
+                labels = list(filter(pat.match, self.lablist))
+                labels.insert(0, parent2)
+                keep3, loads3 = self._head(self.cascade_test(doc, it, thinning, labels, **kw), labels, threshold)
+                level_3.append(list(zip(keep3, loads3)))
+        return level_1, level_2, level_3
+
+    def run_test(self, docs, it, thinning, depth="all", seed=None):
+        """flat test over all labels (or the labels of one depth): CascadeLDA.py:299-344."""
+        from .foldin import CASCADE_STREAM, cascade_fold_in
+        inds = None
+        if depth in [1, 2, 3]:
+            inds = np.where([len(x) in [depth, 4] for x in self.lablist])[0]
+        elif depth == "all":
+            inds = range(self.K)
+        ph = self.ph[inds, :]
+        if len(docs) and it < thinning:
+            raise UnboundLocalError("local variable 'th' referenced before assignment")
+        tups = [self.dicti.doc2bow(x) for x in docs]
+        r = cascade_fold_in(ph, self.alpha, self.beta, tups, it, thinning, self._seed(seed),
+                            CASCADE_STREAM + 0xFFFF, np.arange(len(tups)), flat=True, device=self._device)
+        for _ in tups:
+            for i in range(it):
+                if (i + 1) % thinning == 0:
+                    print("----")
+                    print("Testing iteration #", i + 1)
+        return r["th_hat"]
+
     # ---- ensemble driver ----
     def enumerate_subproblems(self):
         """All sub-problems in the reference's visiting order (CascadeLDA.py:135-184):

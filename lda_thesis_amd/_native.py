@@ -29,6 +29,16 @@ class LldaLayout(ctypes.Structure):
                 ("topic_pos", _c_i32 * MAX_K), ("pos_topic", _c_i32 * MAX_K)]
 
 
+class LldaFoldinArgs(ctypes.Structure):
+    """struct llda_foldin_args (include/llda_gibbs.h)."""
+    _fields_ = [("doc_off", _c_p), ("word", _c_p), ("init_idx", _c_p), ("freq", _c_p), ("ph", _c_p),
+                ("init_rows", _c_p), ("slot_valid", _c_p), ("z", _c_p), ("n_dk", _c_p), ("th", _c_p),
+                ("status", _c_p), ("D", _c_i64), ("doc_base", _c_i64), ("K", _c_i32), ("iters", _c_i32),
+                ("thinning", _c_i32), ("beta_fallback", _c_i32), ("avg_mode", _c_i32), ("reserved", _c_i32),
+                ("alpha", _c_d), ("beta", _c_d), ("c_init", _c_d), ("c_loop", _c_d), ("seed", _c_u64),
+                ("stream_id", _c_u32), ("reserved2", _c_u32)]
+
+
 class LldaSweepArgs(ctypes.Structure):
     """struct llda_sweep_args (include/llda_gibbs.h)."""
     _fields_ = [("doc_off", _c_p), ("doc_order", _c_p), ("word", _c_p), ("freq", _c_p), ("z", _c_p),
@@ -81,8 +91,7 @@ def lib():
     L.llda_loglik.argtypes = [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i32, _c_d, _c_d,
                               _c_p, _c_p]
     L.llda_foldin.restype = ctypes.c_int
-    L.llda_foldin.argtypes = [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i32, _c_d, _c_i32, _c_i32,
-                              _c_u64, _c_u32, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]
+    L.llda_foldin.argtypes = [ctypes.POINTER(LldaFoldinArgs), _c_p]
     L.llda_selftest_div.restype = ctypes.c_int
     L.llda_selftest_div.argtypes = [_c_u64, _c_i64, _c_p, _c_p]
     if L.llda_abi_version() != ABI_VERSION:
@@ -157,10 +166,11 @@ def selftest_div(n, seed=1):
     return int(bad.item())
 
 
-def foldin(doc_off, word, word_init, freq, ph, phn, D, V, K, alpha, iters, thinning, seed, stream_id, doc_base,
-           z, n_dk, th, status):
-    check(lib().llda_foldin(_ptr(doc_off), _ptr(word), _ptr(word_init), _ptr(freq), _ptr(ph), _ptr(phn), int(D),
-                            int(V), int(K),
-                            float(alpha), int(iters), int(thinning), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                            int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(z), _ptr(n_dk), _ptr(th),
-                            _ptr(status), _stream()), "llda_foldin")
+def foldin(*, doc_off, word, init_idx, freq, ph, init_rows, slot_valid, z, n_dk, th, status, D, K, iters, thinning,
+           alpha, beta, c_init, c_loop, seed, stream_id, doc_base=0, beta_fallback=False, avg_mode=0):
+    a = LldaFoldinArgs(_ptr(doc_off), _ptr(word), _ptr(init_idx), _ptr(freq), _ptr(ph), _ptr(init_rows),
+                       _ptr(slot_valid), _ptr(z), _ptr(n_dk), _ptr(th), _ptr(status), int(D), int(doc_base), int(K),
+                       int(iters), int(thinning), 1 if beta_fallback else 0, int(avg_mode), 0, float(alpha),
+                       float(beta), float(c_init), float(c_loop), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                       int(stream_id) & 0xFFFFFFFF, 0)
+    check(lib().llda_foldin(ctypes.byref(a), _stream()), "llda_foldin")

@@ -633,19 +633,23 @@ __global__ void __launch_bounds__(256) llda_loglik_kernel(const LParams P)
 struct FParams {
     const int64_t *doc_off;
     const int32_t *word;
-    const int32_t *word_init; // row of phn used by prep4test (== word unless a document fell back to uniform)
+    const int32_t *init_idx; // row of `phn` holding the initial probabilities of every site
     const int32_t *freq;
     int32_t *z;              // [S] out: final assignments (device positions)
     const double *ph;        // [V*KP]
     const double *phn;       // [V*KP]
     int32_t *n_dk;           // [D*KP] out: final counts
     double *th;              // [D*KP] out: thinned average of n_dk / sum(n_dk)
+    const uint8_t *slot_valid; // [KP] 1 for slots that hold a topic (0 in the padding)
     int32_t *status;
     int64_t D;
     int64_t doc_base;
-    double alpha;
+    double alpha, beta;
+    double c_init, c_loop;   // the reference's "while prob.sum() > 1: prob /= c" constants
     uint32_t key0, key1, stream_id;
     int32_t iters, thinning;
+    int32_t beta_fallback;   // CascadeLDA.cascade_test: prob.sum() == 0 -> prob = num_a * (b + beta)
+    int32_t avg_mode;        // 0: (s-1)/s*avg + (1/s)*cur   1: m*avg + (1-m)*cur with m = (s-1)/s
     int32_t last_leaf, tail, tail_row, n_rounds, xor_tree;
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];
 };
@@ -669,7 +673,7 @@ __device__ __forceinline__ void load_row_f64(const double *__restrict__ p, doubl
 template <int G, int T, bool HAS_TAIL>
 __device__ __forceinline__ void shrink_to_one(double (&p)[T], double c, double c_rcp, const KParams &K, int lig, int lane)
 {
-    for (int guard = 0; guard < 64; ++guard) {
+    for (int guard = 0; guard < (1 << 28); ++guard) {   // the reference loops until the sum is <= 1
         const double s = group_sum<G, T, HAS_TAIL>(p, K, lig, lane);
         if (!(s > 1.0)) break;                     // group-uniform: every lane holds the same s
 #pragma unroll
@@ -701,7 +705,7 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
 #pragma unroll
     for (int s = 0; s < T; ++s) { ndk[s] = 0; avg[s] = 0.0; }
     int ntot = 0;
-    const double c0 = 1.0000000005, c0r = 1.0 / c0, c1 = 1.0000005, c1r = 1.0 / c1;
+    const double c0 = P.c_init, c0r = 1.0 / c0, c1 = P.c_loop, c1r = 1.0 / c1;
 
     // sweep = -1: prep4test (initial assignments from the normalised loadings), then `iters` sweeps
     for (int sweep = -1; sweep < P.iters; ++sweep) {
@@ -720,7 +724,7 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
             double w[T];
             int zo = -1;
             if (sweep < 0) {
-                load_row_f64<T>(P.phn + (int64_t)P.word_init[s0 + n] * KP + lig * T, w);
+                load_row_f64<T>(P.phn + (int64_t)P.init_idx[s0 + n] * KP + lig * T, w);
                 shrink_to_one<G, T, HAS_TAIL>(w, c0, c0r, K, lig, lane);
                 ntot += f;
             } else {
@@ -733,7 +737,15 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
                 load_row_f64<T>(P.ph + (int64_t)v * KP + lig * T, b);
 #pragma unroll
                 for (int s = 0; s < T; ++s) w[s] = ((double)ndk[s] + P.alpha) * b[s];   // num_a * b
-                const double S = group_sum<G, T, HAS_TAIL>(w, K, lig, lane);
+                double S = group_sum<G, T, HAS_TAIL>(w, K, lig, lane);
+                if (P.beta_fallback && S == 0.0) {     // 0/0 raises in the reference (CascadeLDA.py:225-230)
+#pragma unroll
+                    for (int s = 0; s < T; ++s) {
+                        const bool real = P.slot_valid[lig * T + s] != 0;
+                        w[s] = real ? ((double)ndk[s] + P.alpha) * (b[s] + P.beta) : 0.0;
+                    }
+                    S = group_sum<G, T, HAS_TAIL>(w, K, lig, lane);
+                }
                 const double y = 1.0 / S;
 #pragma unroll
                 for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);                  // prob /= prob.sum()
@@ -757,12 +769,20 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
             if (s2 == 1) {
 #pragma unroll
                 for (int s = 0; s < T; ++s) avg[s] = (double)ndk[s] / tot;
-            } else {
+            } else if (P.avg_mode == 0) {          // LabeledLDA.py:204-209, CascadeLDA.py:240-246
                 const double f_old = (double)(s2 - 1) / (double)s2, f_new = 1.0 / (double)s2;
 #pragma unroll
                 for (int s = 0; s < T; ++s) {
                     const double old_part = f_old * avg[s];
                     const double new_part = f_new * ((double)ndk[s] / tot);
+                    avg[s] = old_part + new_part;
+                }
+            } else {                               // CascadeLDA.run_test, CascadeLDA.py:337-341
+                const double m = (double)(s2 - 1) / (double)s2, m1 = 1.0 - m;
+#pragma unroll
+                for (int s = 0; s < T; ++s) {
+                    const double old_part = m * avg[s];
+                    const double new_part = m1 * ((double)ndk[s] / tot);
                     avg[s] = old_part + new_part;
                 }
             }
@@ -1162,25 +1182,23 @@ int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab
     return LLDA_E_BAD_K;
 }
 
-int llda_foldin(const int64_t *doc_off, const int32_t *word, const int32_t *word_init, const int32_t *freq,
-                const double *ph, const double *phn, int64_t D, int64_t V, int32_t K, double alpha, int32_t iters,
-                int32_t thinning, uint64_t seed, uint32_t stream_id, int64_t doc_base, int32_t *z,
-                int32_t *n_dk, double *th, int32_t *status, void *stream)
+int llda_foldin(const llda_foldin_args *a, void *stream)
 {
-    if (!doc_off || !word || !freq || !ph || !phn || !z || !n_dk || !th || D < 0 || V < 1 || iters < 0 ||
-        thinning < 1)
+    if (!a || !a->doc_off || !a->word || !a->init_idx || !a->freq || !a->ph || !a->init_rows || !a->z || !a->n_dk ||
+        !a->th || !a->slot_valid || a->D < 0 || a->iters < 0 || a->thinning < 1)
         return LLDA_E_BAD_ARG;
     llda_layout L;
-    const int rc = llda_layout_init(K, &L);
+    const int rc = llda_layout_init(a->K, &L);
     if (rc) return rc;
-    if (D == 0) return LLDA_OK;
+    if (a->D == 0) return LLDA_OK;
     FParams P;
     memset(&P, 0, sizeof P);
-    P.doc_off = doc_off; P.word = word; P.word_init = word_init ? word_init : word; P.freq = freq; P.z = z;
-    P.ph = ph; P.phn = phn; P.n_dk = n_dk;
-    P.th = th; P.status = status; P.D = D; P.doc_base = doc_base; P.alpha = alpha;
-    P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.stream_id = stream_id;
-    P.iters = iters; P.thinning = thinning;
+    P.doc_off = a->doc_off; P.word = a->word; P.init_idx = a->init_idx; P.freq = a->freq; P.z = a->z;
+    P.ph = a->ph; P.phn = a->init_rows; P.n_dk = a->n_dk; P.th = a->th; P.slot_valid = a->slot_valid;
+    P.status = a->status; P.D = a->D; P.doc_base = a->doc_base; P.alpha = a->alpha; P.beta = a->beta;
+    P.c_init = a->c_init; P.c_loop = a->c_loop;
+    P.key0 = (uint32_t)a->seed; P.key1 = (uint32_t)(a->seed >> 32); P.stream_id = a->stream_id;
+    P.iters = a->iters; P.thinning = a->thinning; P.beta_fallback = a->beta_fallback; P.avg_mode = a->avg_mode;
     fill_schedule(L, P.last_leaf, P.tail, P.tail_row, P.n_rounds, P.xor_tree, P.rounds_pk);
     hipStream_t st = (hipStream_t)stream;
     const bool has_tail = L.tail != 0;

@@ -1,10 +1,18 @@
-"""Test-time fold-in sampler on the device: the reference's ``prep4test`` / ``run_test``
-(/root/reference/LabeledLDA.py:155-212) for a batch of held-out documents.
+"""Test-time fold-in samplers on the device (``llda_foldin``, include/llda_gibbs.h).
 
-The topic-word loadings ``ph_hat`` are fixed; every document only moves its own ``n_dk``, so documents
-are independent: one lane group per document, all ``it`` sweeps inside one kernel launch
-(``llda_foldin``, include/llda_gibbs.h).
+Held-out documents are independent of one another -- the topic-word loadings are fixed and each
+document only moves its own ``n_dk`` -- so a whole batch runs as one kernel launch, one lane group per
+document, all sweeps inside the kernel.  Three reference code paths map onto it:
+
+  LabeledLDA.prep4test / run_test          /root/reference/LabeledLDA.py:155-212
+  CascadeLDA.prep4test / cascade_test      /root/reference/CascadeLDA.py:186-247
+  CascadeLDA.prep4test / run_test          /root/reference/CascadeLDA.py:299-344
+
+The initial probabilities (``prep4test``) are prepared on the host with the reference's own numpy
+expressions -- they are a K x len(doc) elementwise normalisation -- and handed to the kernel as rows.
 """
+import zlib
+
 import numpy as np
 import torch
 
@@ -12,63 +20,118 @@ from . import _native
 from .corpus import csr_from_doc_tups
 from .layout import group_layout
 
-TEST_STREAM = 0x7E57        # default RNG stream id of test-time draws
+TEST_STREAM = 0x7E57            # default RNG stream id of LabeledLDA test-time draws
+CASCADE_STREAM = 0xC0DE0000     # + K_global * level + label id of the first label of the call
 
 
-def normalised_loadings(ph_hat):
-    """columns of ph_hat divided by their sums -- the ``probs /= probs.sum(axis=0)`` of prep4test
-    (LabeledLDA.py:162-167).  Returns (phn (K, V), bad (V,) bool): ``bad`` marks words whose column
-    cannot be normalised (sum 0 or not finite -> numpy raises FloatingPointError in the reference and the
-    WHOLE document falls back to the uniform 1/K)."""
-    colsum = ph_hat.sum(axis=0)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        phn = ph_hat / colsum
-    bad = ~np.isfinite(phn).all(axis=0) | (colsum == 0)
-    return phn, bad
+def doc_key(doc_tup):
+    """RNG document id of a held-out document for APIs that get no index (test_down_tree(doc, ...)):
+    CRC-32 of its (ids, freqs)."""
+    ids, freqs = zip(*doc_tup)
+    return zlib.crc32(np.asarray(list(ids) + list(freqs), dtype=np.int32).tobytes())
 
 
-def fold_in(ph_hat, alpha, doc_tups, it, thinning, seed, stream_id=TEST_STREAM, doc_base=0, device=None):
-    """Run prep4test + ``it`` Gibbs sweeps for every document in ``doc_tups`` (doc2bow lists).
-    Returns dict(th_hat (D, K) float64, n_dk (D, K) int64, z list of per-document topic arrays)."""
+def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, seed, stream_id, doc_ids, c_init,
+            c_loop, beta_fallback, avg_mode, device=None):
+    """ph (K, V) float64; init_rows (R, K) float64; init_idx[S] row per site.  doc_ids: RNG id per doc
+    (consecutive ids run as one launch with doc_base; arbitrary ids run one launch per document)."""
     _native.lib()
     if not torch.cuda.is_available():
         raise _native.NativeError("no HIP device visible: the fold-in sampler has no CPU fallback")
     dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
-    K, V = ph_hat.shape
-    for doc in doc_tups:
-        if not doc:
-            raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
+    K, V = ph.shape
     lay = group_layout(K)
     doc_off, word, freq = csr_from_doc_tups(doc_tups)
     D = len(doc_tups)
-    phn, bad = normalised_loadings(np.asarray(ph_hat, dtype=np.float64))
-    word_init = word
-    if bad.any():
-        rows = np.repeat(np.arange(D), np.diff(doc_off))
-        doc_bad = np.zeros(D, dtype=bool)
-        np.logical_or.at(doc_bad, rows, bad[word])
-        word_init = np.where(doc_bad[rows], V, word).astype(np.int32)
-        phn = np.where(bad, 0.0, phn)
 
-    def to_dev(m, extra_uniform):
-        out = np.zeros((V + 1, lay.KP), dtype=np.float64)
-        out[:V, lay.topic_pos] = m.T
-        if extra_uniform:
-            out[V, lay.topic_pos] = 1 / K
+    def rows_to_dev(m):                       # (R, K) -> (R, KP) device order
+        out = np.zeros((m.shape[0], lay.KP), dtype=np.float64)
+        out[:, lay.topic_pos] = m
         return torch.from_numpy(out).to(dev)
 
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)
-    d_off, d_word, d_winit, d_freq = t(doc_off, torch.int64), t(word, torch.int32), t(word_init, torch.int32), t(freq, torch.int32)
-    d_ph, d_phn = to_dev(np.asarray(ph_hat, dtype=np.float64), False), to_dev(phn, True)
+    d_off, d_word, d_freq = t(doc_off, torch.int64), t(word, torch.int32), t(freq, torch.int32)
+    d_idx = t(np.asarray(init_idx, dtype=np.int32), torch.int32)
+    d_ph, d_init = rows_to_dev(np.ascontiguousarray(ph.T)), rows_to_dev(init_rows)
+    valid = t((lay.pos_topic >= 0).astype(np.uint8), torch.uint8)
     z = torch.zeros((max(int(doc_off[-1]), 1),), dtype=torch.int32, device=dev)
     n_dk = torch.zeros((D, lay.KP), dtype=torch.int32, device=dev)
     th = torch.zeros((D, lay.KP), dtype=torch.float64, device=dev)
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
-    _native.foldin(d_off, d_word, d_winit, d_freq, d_ph, d_phn, D, V, K, alpha, it, thinning, seed, stream_id,
-                   doc_base, z, n_dk, th, status)
+    common = dict(word=d_word, init_idx=d_idx, freq=d_freq, ph=d_ph, init_rows=d_init, slot_valid=valid, z=z,
+                  status=status, K=K, iters=it, thinning=thinning, alpha=alpha, beta=beta, c_init=c_init,
+                  c_loop=c_loop, seed=seed, stream_id=stream_id, beta_fallback=beta_fallback, avg_mode=avg_mode)
+    doc_ids = np.asarray(doc_ids, dtype=np.int64)
+    if D and (np.diff(doc_ids) == 1).all():
+        _native.foldin(doc_off=d_off, n_dk=n_dk, th=th, D=D, doc_base=int(doc_ids[0]), **common)
+    else:
+        for d in range(D):                    # unrelated RNG ids: one document per launch (views, no copies)
+            _native.foldin(doc_off=d_off[d:d + 2], n_dk=n_dk[d:d + 1], th=th[d:d + 1], D=1,
+                           doc_base=int(doc_ids[d]), **common)
     if int(status.item()) != 0:
-        raise ValueError("pvals < 0, pvals > 1 or pvals contains NaNs")     # what numpy's multinomial reports
+        raise ValueError("pvals < 0, pvals > 1 or pvals contains NaNs")     # numpy.random.multinomial's complaint
     tp = torch.from_numpy(lay.topic_pos.astype(np.int64)).to(dev)
     zt = torch.from_numpy(lay.pos_topic.astype(np.int64)).to(dev)[z.to(torch.int64)].cpu().numpy()
     return dict(th_hat=th[:, tp].cpu().numpy(), n_dk=n_dk[:, tp].cpu().numpy().astype(np.int64),
-                z=[zt[doc_off[d]:doc_off[d + 1]] for d in range(D)], doc_off=doc_off, word=word, freq=freq)
+                z=[zt[doc_off[d]:doc_off[d + 1]] for d in range(D)])
+
+
+# ------------------------------------------------------------------------------------------------
+# LabeledLDA
+# ------------------------------------------------------------------------------------------------
+def fold_in(ph_hat, alpha, doc_tups, it, thinning, seed, stream_id=TEST_STREAM, doc_base=0, device=None):
+    """LabeledLDA.prep4test + run_test for a batch of doc2bow lists.  Returns dict(th_hat (D, K),
+    n_dk (D, K), z)."""
+    ph_hat = np.asarray(ph_hat, dtype=np.float64)
+    K, V = ph_hat.shape
+    for doc in doc_tups:
+        if not doc:
+            raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
+    # probs = ph_hat[:, doc]; probs /= probs.sum(axis=0)  -- per word; a document with a column that
+    # cannot be normalised falls back to the uniform 1/K for ALL its sites (LabeledLDA.py:162-167)
+    colsum = ph_hat.sum(axis=0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        phn = ph_hat / colsum
+    bad = ~np.isfinite(phn).all(axis=0) | (colsum == 0)
+    doc_off, word, _ = csr_from_doc_tups(doc_tups)
+    init_idx = word.copy()
+    rows = np.vstack([np.where(bad, 0.0, phn).T, np.full((1, K), 1 / K)])          # row V = uniform
+    if bad.any():
+        site_doc = np.repeat(np.arange(len(doc_tups)), np.diff(doc_off))
+        doc_bad = np.zeros(len(doc_tups), dtype=bool)
+        np.logical_or.at(doc_bad, site_doc, bad[word])
+        init_idx = np.where(doc_bad[site_doc], V, word)
+    return _launch(ph_hat, rows, init_idx, doc_tups, alpha=alpha, beta=0.0, it=it, thinning=thinning, seed=seed,
+                   stream_id=stream_id, doc_ids=np.arange(len(doc_tups)) + doc_base, c_init=1.0000000005,
+                   c_loop=1.0000005, beta_fallback=False, avg_mode=0, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# CascadeLDA
+# ------------------------------------------------------------------------------------------------
+def cascade_init_rows(ph, beta, doc_tups):
+    """CascadeLDA.prep4test (CascadeLDA.py:193-198) for every document: smoothed, column-normalised
+    loadings with the first ('generic') row overwritten by 1/len(doc).  Returns (rows (S, K), idx)."""
+    out = []
+    for tup in doc_tups:
+        ids = [v for v, _ in tup]
+        probs = ph[:, ids]
+        probs += beta
+        probs /= probs.sum(axis=0)
+        probs[0, :] = 1 / len(ids)
+        out.append(probs.T)
+    rows = np.vstack(out) if out else np.zeros((0, ph.shape[0]))
+    return rows, np.arange(rows.shape[0])
+
+
+def cascade_fold_in(ph, alpha, beta, doc_tups, it, thinning, seed, stream_id, doc_ids, flat=False, device=None):
+    """CascadeLDA.cascade_test (flat=False) / CascadeLDA.run_test (flat=True) for a batch of documents
+    against the label subset whose loadings are ``ph`` (K_sub, V)."""
+    ph = np.ascontiguousarray(ph, dtype=np.float64)
+    for doc in doc_tups:
+        if not doc:
+            raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
+    rows, idx = cascade_init_rows(ph, beta, doc_tups)
+    return _launch(ph, rows, idx, doc_tups, alpha=alpha, beta=beta, it=it, thinning=thinning, seed=seed,
+                   stream_id=stream_id, doc_ids=doc_ids, c_init=1.0000005, c_loop=1.000005,
+                   beta_fallback=not flat, avg_mode=1 if flat else 0, device=device)

@@ -389,6 +389,89 @@ def gen_runtest():
         print("runtest_%s: th_hat %s sum %.6f" % (name, th.shape, th.sum()))
 
 
+def _doc_key(tup):
+    import zlib
+    ids, freqs = zip(*tup)
+    return zlib.crc32(np.asarray(list(ids) + list(freqs), dtype=np.int32).tobytes())
+
+
+def gen_cascade_test():
+    """CascadeLDA test time of the reference (cascade_test, test_down_tree, run_test; CascadeLDA.py:186-344)
+    on the cascade_toy model, keyed draw injected.  cascade_test calls are keyed by
+    stream = 0xC0DE0000 + K*level + labelmap[labels[0]] and doc = CRC-32 of the document's bag of words;
+    run_test by stream 0xC0DE0000 + 0xFFFF and the document index."""
+    from fixture_corpora import cascade_corpus
+    g = np.load(os.path.join(GOLDEN, "cascade_toy.npz"))
+    docs, labs, labelset = cascade_corpus()
+    dicti = Dictionary(docs)
+    np.random.seed(int(g["np_seed"]))
+    c = REF_C.CascadeLDA(docs, labs, list(labelset), dicti, float(g["alpha"]), float(g["beta"]))
+    c.ph = g["ph"].copy()
+    c.lablist_l1 = [x for x in c.lablist if len(x) == 1]          # state after go_down_tree: no 'root'
+    seed = 4321
+    rng = np.random.default_rng(8)
+    vocab = list(dicti.token2id.keys())
+    newdocs = [[vocab[i] for i in rng.integers(0, len(vocab), size=int(rng.integers(4, 30)))] for _ in range(7)]
+    orig_ct = REF_C.CascadeLDA.cascade_test
+    draw = orc.KeyedDraw(seed, 0)
+
+    def ct(self, doc, it, thinning, labels):
+        tup = self.dicti.doc2bow(doc)
+        L, did = len(tup), _doc_key(tup)
+        draw.stream = 0xC0DE0000 + self.K * len(labels[-1]) + self.labelmap[labels[0]]
+        plan = [(orc.SWEEP_INIT, did, n) for n in range(L)] + [(i, did, n) for i in range(it) for n in range(L)]
+        it_plan = iter(plan)
+
+        def keyed(n_, prob):
+            draw.sweep, draw.doc, draw.site = next(it_plan)
+            draw.plan = None
+            return draw(n_, prob)
+        set_draw(REF_C, keyed)
+        return orig_ct(self, doc, it, thinning, labels)
+
+    REF_C.CascadeLDA.cascade_test = ct
+    out = dict(seed=seed, it=5, thinning=2, threshold=0.95)
+    try:
+        trees = [c.test_down_tree(x, 5, 2, 0.95) for x in newdocs]
+        single = c.cascade_test(newdocs[0], 4, 1, ["A", "A1", "A2"])
+    finally:
+        REF_C.CascadeLDA.cascade_test = orig_ct
+    import json
+    out["trees"] = np.array(json.dumps([[[(l, float(v)) for l, v in lvl] if i == 0 else
+                                          [[(l, float(v)) for l, v in grp] for grp in lvl]
+                                          for i, lvl in enumerate(tr)] for tr in trees]))
+    out["single_A"] = single
+    # flat run_test (depth all and depth 2)
+    for depth in ("all", 1, 2):
+        bows = [dicti.doc2bow(nd) for nd in newdocs]
+        draw2 = orc.KeyedDraw(seed, 0xC0DE0000 + 0xFFFF)
+        plan = []
+        for d, b in enumerate(bows):
+            plan += [(orc.SWEEP_INIT, d, n) for n in range(len(b))]
+            plan += [(i, d, n) for i in range(4) for n in range(len(b))]
+        it_plan = iter(plan)
+
+        def keyed2(n_, prob):
+            draw2.sweep, draw2.doc, draw2.site = next(it_plan)
+            draw2.plan = None
+            return draw2(n_, prob)
+        set_draw(REF_C, keyed2)
+        try:
+            out["flat_%s" % depth] = c.run_test(newdocs, 4, 2, depth=depth)
+        except (ValueError, FloatingPointError):
+            # a word with zero loading on every selected label: prob = 0/0 = NaN and numpy's
+            # multinomial raises ValueError in the reference -- recorded as "raises"
+            out["flat_%s_raises" % depth] = np.array(1)
+    set_draw(REF_C, np.random.multinomial)
+    bows = [dicti.doc2bow(nd) for nd in newdocs]
+    off = np.zeros(len(bows) + 1, dtype=np.int64)
+    np.cumsum([len(b) for b in bows], out=off[1:])
+    out.update(doc_off=off, word=np.array([v for b in bows for v, _ in b], dtype=np.int32),
+               freq=np.array([f for b in bows for _, f in b], dtype=np.int32))
+    np.savez_compressed(os.path.join(GOLDEN, "cascade_test_toy.npz"), **out)
+    print("cascade_test_toy: %d docs, tree[0] level_1 = %s" % (len(newdocs), trees[0][0]))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     what = sys.argv[1:] or ["tiny", "sublda"]
@@ -398,6 +481,8 @@ if __name__ == "__main__":
         gen_sublda()
     if "runtraining" in what:
         gen_runtraining()
+    if "cascadetest" in what:
+        gen_cascade_test()
     if "runtest" in what:
         gen_runtest()
     if "cascade" in what:

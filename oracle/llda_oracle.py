@@ -548,3 +548,89 @@ def keyed_draw_for(seed, stream=0, doc_base=0):
         k.sweep, k.doc, k.site = sweep, d + doc_base, 0
         return k
     return draw_for
+
+
+# ----------------------------------------------------------------------------------------------
+# CascadeLDA test time (reference CascadeLDA.py:186-247, 299-344)  --  restated
+# ----------------------------------------------------------------------------------------------
+def cascade_prep4test(ph, beta, ids, freqs, draw):
+    ld = len(ids)
+    n_dk = np.zeros(ph.shape[0], dtype=int)
+    z_dn = []
+    probs = ph[:, list(ids)]
+    probs += beta
+    probs /= probs.sum(axis=0)
+    probs[0, :] = 1 / ld
+    for n, freq in enumerate(freqs):
+        prob = probs[:, n]
+        while prob.sum() > 1:
+            prob /= 1.0000005
+        new_z = draw(1, prob).argmax()
+        z_dn.append(new_z)
+        n_dk[new_z] += freq
+    return z_dn, n_dk
+
+
+def cascade_test(ph, alpha, beta, ids, freqs, it, thinning, draw_for_sweep):
+    """CascadeLDA.cascade_test (CascadeLDA.py:210-247) on the label subset with loadings ph."""
+    z_dn, n_dk = cascade_prep4test(ph, beta, ids, freqs, draw_for_sweep(SWEEP_INIT))
+    avg_state = np.zeros(ph.shape[0], dtype=float)
+    for i in range(it):
+        draw = draw_for_sweep(i)
+        for n, (v, f, z) in enumerate(zip(ids, freqs, z_dn)):
+            n_dk[z] -= f
+            num_a = n_dk + alpha
+            b = ph[:, v]
+            prob = num_a * b
+            try:
+                with np.errstate(invalid="raise"):
+                    prob /= prob.sum()
+            except FloatingPointError:
+                prob = num_a * (b + beta)
+                prob /= prob.sum()
+            while prob.sum() > 1:
+                prob /= 1.000005
+            new_z = draw(1, prob).argmax()
+            z_dn[n] = new_z
+            n_dk[new_z] += f
+        s = (i + 1) / thinning
+        s2 = int(s)
+        if s == s2:
+            this_state = n_dk / n_dk.sum()
+            if s2 == 1:
+                avg_state = this_state
+            else:
+                avg_state = (s2 - 1) / s2 * avg_state + (1 / s2) * this_state
+    return avg_state
+
+
+def cascade_run_test(ph, alpha, beta, docs, freqs, it, thinning, draw_for):
+    """CascadeLDA.run_test (CascadeLDA.py:299-344), flat test over the rows of ph."""
+    th_hat = np.zeros((len(docs), ph.shape[0]), dtype=float)
+    for d, (ids, fr) in enumerate(zip(docs, freqs)):
+        z_dn, n_zk = cascade_prep4test(ph, beta, ids, fr, draw_for(d, SWEEP_INIT))
+        th = None
+        for i in range(it):
+            draw = draw_for(d, i)
+            for n, (v, f) in enumerate(zip(ids, fr)):
+                z = z_dn[n]
+                n_zk[z] -= f
+                num_a = n_zk + alpha
+                b = ph[:, v]
+                prob = num_a * b
+                prob /= prob.sum()
+                while prob.sum() > 1:
+                    prob /= 1.000005
+                new_z = draw(1, prob).argmax()
+                z_dn[n] = new_z
+                n_zk[new_z] += f
+            s = (i + 1) / thinning
+            if s == int(s):
+                cur_th = n_zk / n_zk.sum()
+                if s > 1:
+                    m = (s - 1) / s
+                    th = m * th + (1 - m) * cur_th
+                else:
+                    th = cur_th
+        th_hat[d, :] = th
+    return th_hat
