@@ -472,6 +472,62 @@ def gen_cascade_test():
     print("cascade_test_toy: %d docs, tree[0] level_1 = %s" % (len(newdocs), trees[0][0]))
 
 
+def gen_evaluate():
+    """input/output pairs of the reference's evaluation functions (evaluate_LabeledLDA.py:8-107,
+    evaluate_CascadeLDA.py:95-127) and of its label parsing (load_corpus of both modules on a synthetic
+    CSV), produced by importing the reference scripts."""
+    import importlib.util
+    import json
+    import tempfile
+    sys.modules["LabeledLDA"], sys.modules["CascadeLDA"] = REF_L, REF_C
+    mods = {}
+    for name in ("evaluate_LabeledLDA", "evaluate_CascadeLDA"):
+        spec = importlib.util.spec_from_file_location("_ref_" + name, os.path.join(refshim.REFERENCE_DIR, name + ".py"))
+        mods[name] = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mods[name])
+    EL, EC = mods["evaluate_LabeledLDA"], mods["evaluate_CascadeLDA"]
+    rng = np.random.default_rng(21)
+    D, K = 14, 9
+    th = np.round(rng.dirichlet(np.ones(K) * 0.4, size=D), 4)
+    th[3, 2] = th[3, 5]                                     # tied scores
+    y = (rng.random((D, K)) < 0.3).astype(int)
+    y[:, 0] |= (y.sum(1) == 0)                              # every document has a positive ...
+    y[np.arange(D), (np.argmax(y, 1) + 1) % K] = 0          # ... and a negative
+    tps, tns, fps, fns, fprs, tprs = EL.rates(th, y)
+    out = dict(th=th, y=y, n_error1=EL.n_error(th, y, 1), n_error2=EL.n_error(th, y, 2),
+               auc=EL.macro_auc_roc(fprs, tprs), f1=EL.get_f1(tps, fps, tns, fns),
+               rates=np.array(json.dumps([[[float(v) for v in doc] for doc in part] for part in (tps, tns, fps, fns, fprs, tprs)])))
+    labmap = {"root": 0, "A": 1, "B": 2, "A1": 3, "A2": 4, "B1": 5, "A11": 6, "A12": 7, "A21": 8, "B11": 9}
+    strings = [["A", "A1", "zz"], [], ["B11", "root"]]
+    out["binary_yreal"] = EL.binary_yreal(strings, labmap)
+
+    class M(object):
+        labelmap = labmap
+    l1p = [[("A", 0.7), ("B", 0.25)], [("B", 0.96)]]
+    l2p = [[[("A", 0.5), ("A1", 0.3), ("A2", 0.2)], [("B", 0.6), ("B1", 0.4)]], [[("B1", 0.8), ("B", 0.2)]]]
+    l3p = [[[("A1", 0.6), ("A11", 0.3), ("A12", 0.1)], [("A2", 0.9), ("A21", 0.1)], [("B1", 0.5), ("B11", 0.5)]],
+           [[("B11", 0.7), ("B1", 0.3)]]]
+    out["setup_theta"] = EC.setup_theta(l1p, l2p, l3p, M())
+    out["setup_theta_in"] = np.array(json.dumps([l1p, l2p, l3p, labmap]))
+    # label parsing of both load_corpus variants
+    csv_text = ('d1,"Growth and taxes in open economies","E32 H20 xx"\nd2,"Labor markets",J\n'
+                'd3,"No labels at all",\nd4,"More growth, more taxes","E32 E31"\n'
+                'd5,"Single code",D12\nd6,"Two codes","C1 D120"\n')
+    with tempfile.NamedTemporaryFile("w", suffix=".csv", delete=False) as fh:
+        fh.write(csv_text)
+    parsed = {}
+    for d in (1, 2, 3):
+        _, labs, labelset = REF_L.load_corpus(fh.name, d)
+        parsed["llda_%d" % d] = [[sorted(x) for x in labs], labelset]
+    _, labs, labelset = REF_C.load_corpus(fh.name, 3)
+    parsed["cascade_3"] = [[sorted(set(x)) for x in labs], labelset]
+    os.unlink(fh.name)
+    out["csv_text"] = np.array(csv_text)
+    out["parsed"] = np.array(json.dumps(parsed))
+    np.savez_compressed(os.path.join(GOLDEN, "evaluate.npz"), **out)
+    print("evaluate: auc %.6f f1 %.6f n_error1 %.4f" % (out["auc"], out["f1"], out["n_error1"]))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     what = sys.argv[1:] or ["tiny", "sublda"]
@@ -481,6 +537,8 @@ if __name__ == "__main__":
         gen_sublda()
     if "runtraining" in what:
         gen_runtraining()
+    if "evaluate" in what:
+        gen_evaluate()
     if "cascadetest" in what:
         gen_cascade_test()
     if "runtest" in what:
