@@ -243,3 +243,40 @@ def test_cascade_fold_in_against_numpy_oracle():
         want = orc.cascade_run_test(ph, 0.2, 0.01, [[v for v, _ in t] for t in tups], [[f for _, f in t] for t in tups],
                                     4, 2, orc.keyed_draw_for(77, 999))
         np.testing.assert_array_equal(flat["th_hat"], want)
+
+
+def _write_csv(path, n=120, seed=3):
+    rng = np.random.default_rng(seed)
+    codes = ["A11", "A12", "A21", "B11", "B21", "B22", "C31"]
+    words = ["growth", "taxes", "labor", "market", "policy", "trade", "capital", "wages", "prices", "credit",
+             "banking", "income", "health", "energy", "education", "housing", "export", "budget", "inflation"]
+    topic_words = {c: rng.choice(len(words), size=6, replace=False) for c in codes}
+    lines = []
+    for i in range(n):
+        labs = [codes[j] for j in rng.choice(len(codes), size=int(rng.integers(1, 3)), replace=False)]
+        toks = [words[int(rng.choice(topic_words[labs[int(rng.integers(len(labs)))]]))] for _ in range(int(rng.integers(12, 40)))]
+        lines.append('d%d,"%s","%s"' % (i, " ".join(toks), " ".join(labs)))
+    path.write_text("\n".join(lines) + "\n")
+
+
+def test_cli_harness_labeled_lda_end_to_end(tmp_path, capsys, monkeypatch):
+    from lda_thesis_amd import evaluate_LabeledLDA as H
+    monkeypatch.chdir(tmp_path)
+    _write_csv(tmp_path / "toy.csv")
+    np.random.seed(0)
+    H.main(["-f", str(tmp_path / "toy.csv"), "-d", "3", "-i", "20", "-s", "5", "-p"])
+    out = capsys.readouterr().out
+    assert "Model:               Labeled LDA" in out and "AUC ROC:" in out and out.count("Running iteration #") == 20
+    auc = float(out.split("AUC ROC:")[1].split()[0])
+    assert auc > 0.7                                   # topics are recoverable in this toy corpus
+    assert (tmp_path / "LabeledLDA_model.pkl").exists()
+
+
+def test_cli_harness_cascade_end_to_end(tmp_path, capsys, monkeypatch):
+    from lda_thesis_amd import evaluate_CascadeLDA as H
+    monkeypatch.chdir(tmp_path)
+    _write_csv(tmp_path / "toy.csv")
+    np.random.seed(1)
+    H.main(["-f", str(tmp_path / "toy.csv"), "-i", "8", "-s", "2", "-d", "3"])
+    out = capsys.readouterr().out
+    assert out.count("Model:               CascadeLDA") == 3 and out.count("AUC ROC:") == 3
