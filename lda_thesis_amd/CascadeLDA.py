@@ -121,7 +121,7 @@ class SubLDA(object):
             (doc_off, word, freq), counts = self._initial_counts()
             self._sampler = GibbsSampler(doc_off, word, freq, self._z0, self.K, self.V, self.alpha,
                                          self.beta, labs=self.labs, counts=counts, seed=self.seed,
-                                         stream_id=self.stream_id, device=self._device)
+                                         stream_id=self.stream_id, device=self._device, sharded=False)
         return self._sampler
 
     @property
@@ -382,7 +382,7 @@ class CascadeLDA(object):
             labset.remove("root")
         if world > 1:
             import torch
-            dev = self._device if self._device is not None else "cuda"
+            dev = self._device if self._device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
             buf = torch.from_numpy(self.ph).to(dev)
             dist.all_reduce(buf, group=self._group)                   # rows are disjoint: sum = union
             self.ph = buf.cpu().numpy()

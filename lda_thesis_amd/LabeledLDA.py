@@ -20,11 +20,31 @@ import numpy as np
 
 from . import text as _text
 from .corpus import csr_from_doc_tups
-from .sampler import GibbsSampler
+from .sampler import GibbsSampler, shard_documents
 
 __all__ = ["np", "load_corpus", "LabeledLDA", "split_data", "prune_dict", "train_it", "test_it"]
 
 _JEL = re.compile(r"[A-Z]\d{2}")
+
+
+def _world_size():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _gather_rows(local):
+    """concatenate the per-rank slices of a document- or site-indexed array (read-out path, host side)."""
+    if _world_size() == 1:
+        return local
+    import torch.distributed as dist
+    parts = [None] * _world_size()
+    dist.all_gather_object(parts, local)
+    return np.concatenate(parts, axis=0)
 
 
 def _raise_csv_limit():
@@ -100,9 +120,15 @@ class LabeledLDA(object):
         self.seed = seed
         doc_off, word, freq = csr_from_doc_tups(self.doc_tups)
         self._doc_off = doc_off
-        self._sampler = GibbsSampler(doc_off, word, freq, np.concatenate(z0) if z0 else np.zeros(0, np.int64),
-                                     self.K, self.V, alpha, beta, labs=self.labs, counts=None, seed=seed,
-                                     device=device)
+        z0 = np.concatenate(z0) if z0 else np.zeros(0, np.int64)
+        # with torch.distributed initialised the documents are sharded over the ranks by site count
+        # (every rank builds the same model object from the same data; it keeps only its slice on the GPU)
+        self._bounds = shard_documents(doc_off, _world_size())
+        lo, hi = self._bounds[_rank()], self._bounds[_rank() + 1]
+        s0, s1 = int(doc_off[lo]), int(doc_off[hi])
+        self._sampler = GibbsSampler(doc_off[lo:hi + 1] - doc_off[lo], word[s0:s1], freq[s0:s1], z0[s0:s1],
+                                     self.K, self.V, alpha, beta, labs=self.labs[lo:hi], counts=None, seed=seed,
+                                     doc_base=lo, device=device)
 
     # ---- state in the reference's shapes / dtypes ----
     @property
@@ -111,7 +137,7 @@ class LabeledLDA(object):
 
     @property
     def n_d_k(self):
-        return self._sampler.n_d_k()
+        return _gather_rows(self._sampler.n_d_k())
 
     @property
     def n_k_v(self):
@@ -119,7 +145,8 @@ class LabeledLDA(object):
 
     @property
     def z_dn(self):
-        return self._sampler.z_dn()
+        z = _gather_rows(self._sampler.z_topics())
+        return [z[self._doc_off[d]:self._doc_off[d + 1]].copy() for d in range(self.D)]
 
     def set_label(self, label):
         vec = np.zeros(len(self.labelmap))
@@ -211,15 +238,21 @@ class LabeledLDA(object):
     def __getstate__(self):
         state = {k: v for k, v in self.__dict__.items() if k != "_sampler"}
         state["_host_state"] = dict(n_zk=self.n_zk, n_d_k=self.n_d_k, n_k_v=self.n_k_v,
-                                    z=self._sampler.z_topics(), sweeps_done=self._sampler.sweeps_done)
+                                    z=_gather_rows(self._sampler.z_topics()),
+                                    sweeps_done=self._sampler.sweeps_done)
         return state
 
     def __setstate__(self, state):
         host = state.pop("_host_state")
         self.__dict__.update(state)
         doc_off, word, freq = csr_from_doc_tups(self.doc_tups)
-        self._sampler = GibbsSampler(doc_off, word, freq, host["z"], self.K, self.V, self.alpha, self.beta,
-                                     labs=self.labs, counts=host, seed=self.seed)
+        self._bounds = shard_documents(doc_off, _world_size())
+        lo, hi = self._bounds[_rank()], self._bounds[_rank() + 1]
+        s0, s1 = int(doc_off[lo]), int(doc_off[hi])
+        counts = dict(n_d_k=host["n_d_k"][lo:hi], n_k_v=host["n_k_v"], n_zk=host["n_zk"])
+        self._sampler = GibbsSampler(doc_off[lo:hi + 1] - doc_off[lo], word[s0:s1], freq[s0:s1], host["z"][s0:s1],
+                                     self.K, self.V, self.alpha, self.beta, labs=self.labs[lo:hi], counts=counts,
+                                     seed=self.seed, doc_base=lo)
         self._sampler.sweeps_done = host["sweeps_done"]
 
 

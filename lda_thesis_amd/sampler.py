@@ -57,13 +57,16 @@ class GibbsSampler(object):
                layout for the LOCAL documents / GLOBAL matrices (keeps e.g. SubLDA's phantom columns).
     seed, stream_id, doc_base : RNG key / counter words (doc_base = global id of local doc 0).
     group    : torch.distributed process group (None = default group when initialised).
+    sharded  : True (default) = the local documents are one shard of a corpus spread over the ranks
+               of ``group``: deltas are all-reduced every sweep.  False = a self-contained problem
+               (e.g. one CascadeLDA sub-problem per GPU): no collective at all.
     backend  : module with the _native entry points (tests inject a CPU checker here; the product
                always uses the HIP library).
     """
 
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
                  stream_id=0, doc_base=0, device=None, group=None, backend=None, sort_docs=True,
-                 docs_per_group=0):
+                 docs_per_group=0, sharded=True):
         self.backend = backend if backend is not None else _native
         if backend is None:
             _native.lib()                                   # fail loudly when the extension is missing
@@ -75,6 +78,7 @@ class GibbsSampler(object):
         self.alpha, self.beta = float(alpha), float(beta)
         self.seed, self.stream_id, self.doc_base = int(seed), int(stream_id), int(doc_base)
         self.group = group
+        self.sharded = bool(sharded)
         self.docs_per_group = int(docs_per_group)
         self.sweeps_done = 0
         self.kernel_events = None      # set to [] to record a (start, end) HIP event pair per sweep kernel
@@ -113,7 +117,7 @@ class GibbsSampler(object):
         if counts is None:
             self.backend.count_init(self.doc_off, self.word, self.freq, self.z, self.D, self.K,
                                     self.n_dk, self.n_kw, self.n_k)
-            if _dist_active(self.group):
+            if self.sharded and _dist_active(self.group):
                 import torch.distributed as dist
                 dist.all_reduce(self.n_kw, group=self.group)
                 dist.all_reduce(self.n_k, group=self.group)
@@ -163,7 +167,7 @@ class GibbsSampler(object):
         if ev is not None:
             ev[1].record()
             self.kernel_events.append(ev)
-        if _dist_active(self.group):
+        if self.sharded and _dist_active(self.group):
             import torch.distributed as dist
             dist.all_reduce(self.n_kw_delta, group=self.group)      # RCCL over xGMI: SUM int32
             dist.all_reduce(self.n_k_delta, group=self.group)
@@ -186,7 +190,7 @@ class GibbsSampler(object):
 
     def perplexity(self):
         total, sites = self.loglik_sum(), float(self.S)
-        if _dist_active(self.group):
+        if self.sharded and _dist_active(self.group):
             import torch.distributed as dist
             t = torch.tensor([total, sites], dtype=torch.float64, device=self.device)
             dist.all_reduce(t, group=self.group)
