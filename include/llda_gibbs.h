@@ -83,14 +83,17 @@ typedef struct llda_sweep_args {
     const int32_t  *n_k;         /* [dev] [KP] sweep-start snapshot (read only)                */
     int32_t        *n_k_delta;   /* [dev] [KP] += sweep changes                                */
     int32_t        *status;      /* [dev] optional (may be NULL): bit 0 is set when a site had no
-                                    topic with positive probability (the reference would raise)  */
+                                    topic with positive probability (the reference would raise);
+                                    bit 1 (informational) when some site took the exact tier      */
     int64_t  D;                  /* local documents                                            */
     int64_t  V;                  /* vocabulary size (rows of n_kw; also enters den = n_k + V*beta) */
     int32_t  K;                  /* topics                                                     */
     int32_t  docs_per_group;     /* documents a lane group walks per workgroup (>=1; 0 = auto) */
     int32_t  dense_mask;         /* 1 = lab_mask allows every topic in every document (the kernel may
                                     then skip applying it); 0 = general                            */
-    int32_t  reserved;           /* must be 0                                                  */
+    int32_t  debug_margin;       /* 0 in production.  Test hook of the two-tier draw: n > 0 widens the
+                                    tier-1 safety margin to 2^-n of the total score (more sites take the
+                                    exact tier), n < 0 sends every site through the exact tier        */
     double   alpha, beta;        /* priors (LabeledLDA.py:55-56)                               */
     uint64_t seed;               /* RNG key                                                    */
     uint32_t sweep;              /* RNG counter word 3                                         */

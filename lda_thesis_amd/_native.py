@@ -45,7 +45,7 @@ class LldaSweepArgs(ctypes.Structure):
                 ("lab_mask", _c_p), ("n_dk", _c_p), ("n_kw", _c_p), ("n_kw_delta", _c_p),
                 ("n_k", _c_p), ("n_k_delta", _c_p), ("status", _c_p),
                 ("D", _c_i64), ("V", _c_i64), ("K", _c_i32), ("docs_per_group", _c_i32),
-                ("dense_mask", _c_i32), ("reserved", _c_i32), ("alpha", _c_d), ("beta", _c_d), ("seed", _c_u64), ("sweep", _c_u32),
+                ("dense_mask", _c_i32), ("debug_margin", _c_i32), ("alpha", _c_d), ("beta", _c_d), ("seed", _c_u64), ("sweep", _c_u32),
                 ("stream_id", _c_u32), ("doc_base", _c_i64)]
 
 
@@ -131,11 +131,11 @@ def _stream():
 
 def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
           status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
-          dense_mask=False):
+          dense_mask=False, debug_margin=0):
     """llda_sweep on the current torch stream.  All array arguments are torch CUDA tensors."""
     a = LldaSweepArgs(_ptr(doc_off), _ptr(doc_order), _ptr(word), _ptr(freq), _ptr(z), _ptr(lab_mask),
                       _ptr(n_dk), _ptr(n_kw), _ptr(n_kw_delta), _ptr(n_k), _ptr(n_k_delta), _ptr(status),
-                      int(D), int(V), int(K), int(docs_per_group), 1 if dense_mask else 0, 0,
+                      int(D), int(V), int(K), int(docs_per_group), 1 if dense_mask else 0, int(debug_margin),
                       float(alpha), float(beta),
                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(sweep) & 0xFFFFFFFF,
                       int(stream_id) & 0xFFFFFFFF, int(doc_base))

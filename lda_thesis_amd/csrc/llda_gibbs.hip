@@ -19,6 +19,7 @@
 // reference rounds after every numpy ufunc.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include <string.h>
 
 #include "llda_gibbs.h"
@@ -51,6 +52,7 @@ struct KParams {
     int32_t tail, tail_row;
     int32_t n_rounds;
     int32_t xor_tree;       // leaves combine as p^1, p^2, p^4 (balanced recursion, no padded leaves)
+    double margin_rel;      // tier-1 decision margin relative to the total score (2^-40; debug: wider / inf)
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];   // 4 bits per leaf: partner leaf
 };
 
@@ -385,6 +387,89 @@ __device__ __forceinline__ int draw_position(const double (&w)[T], double u, uin
     return zn;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-tier draw (FAST kernels).  The integer state only depends on WHICH topic the draw picks, i.e. on
+// the signs of  E[g][s] = q[g][s] - (t - X[g-1])  in the exact fp64 pipeline above.  Tier 1 evaluates
+// the same comparison from unnormalised, cheaply rounded scores
+//     w~ = a * (num_b * RN(1/den_b)),   Q~ = prefix(w~),   X~ = scan,   T~ = u * X~[G-1] - X~[g-1]
+// (no division, no pairwise sum, no normalisation).  Relative to the total every quantity differs from
+// its exact counterpart by at most a few hundred units of 2^-53 (DESIGN.md section 4.3 derives
+// |E~ - E| <= 2^-44 of the total), so whenever every |Q~ - T~| exceeds 2^-40 of the total the signs -- and
+// with them the chosen position -- are those of the exact pipeline.  Otherwise (probability ~1e-9 per
+// site) the group falls back to the exact tier.  Returns false when the group must fall back.
+// ---------------------------------------------------------------------------------------------
+template <int T, bool DENSE, int S = 0>
+__device__ __forceinline__ void prefix_scores_fast(double (&qw)[T], const int (&ndk)[T], const int (&x)[T],
+                                                   const double (*s_rcp)[256], int tid, uint32_t mask,
+                                                   double alpha, double beta)
+{
+    if constexpr (S < T) {
+        const double a = (double)ndk[S] + alpha;
+        const double num_b = (double)x[S] + beta;
+        double ws = a * (num_b * s_rcp[S][tid]);
+        if constexpr (!DENSE) {
+            const long long m = (long long)onehot_bit<S>(mask);
+            ws = __longlong_as_double(__double_as_longlong(ws) & m);
+        }
+        if constexpr (S == 0) qw[0] = ws;
+        else qw[S] = qw[S - 1] + ws;
+        prefix_scores_fast<T, DENSE, S + 1>(qw, ndk, x, s_rcp, tid, mask, alpha, beta);
+    }
+}
+
+template <int G, int T>
+__device__ __forceinline__ bool draw_fast(const double (&qw)[T], double u, uint32_t mask, double margin_rel,
+                                          int lig, int lane, int &zn)
+{
+    const int gbase = lane & ~(G - 1);
+    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    const double X = group_scan<G>(qw[T - 1], lig);
+    const double tot = bcast_last<G>(X, lane);
+    const double prev = dpp_f64<DPP_WAVE_SHR1>(X);
+    const double tg = u * tot - (lig ? prev : 0.0);
+    const double margin = tot * margin_rel;
+    const double lo = tg - margin, hi = tg + margin;
+    int cnt_lo = 0, cnt_hi = 0;
+#pragma unroll
+    for (int s = 0; s < T; ++s) {
+        cnt_lo += (qw[s] <= lo) ? 1 : 0;
+        cnt_hi += (qw[s] <= hi) ? 1 : 0;
+    }
+    const bool unsure = (cnt_lo != cnt_hi) || !(tot > 0.0) || !(margin < tot);
+    if (((__ballot(unsure) >> gbase) & gmask) != 0) return false;
+    const uint32_t fm = mask & (0xFFFFu << cnt_lo);
+    const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
+    const uint64_t gp = (__ballot(mask != 0) >> gbase) & gmask;
+    const bool hit = gf != 0;
+    const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)(gp | 1ull));
+    const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
+    zn = sl * T + __shfl(my, sl, G);
+    return true;
+}
+
+// Exact tier of the FAST kernels: the reference's fp64 pipeline bit for bit --
+// scores through the cached den / RN(1/den), numpy-ordered sum, p = fl(w/S), keyed draw.  Returns the
+// chosen device position or -1.  Deliberately not inlined: it runs for ~1e-9 of the sites.
+template <int G, int T, bool HAS_TAIL, bool DENSE>
+__device__ __noinline__ int exact_tier_cached(const int *ndk_c, const int *x_c, const double (*s_den)[256],
+                                              const double (*s_rcp)[256], int tid, uint32_t mask, double u, int lig,
+                                              int lane, const KParams *P)
+{
+    int ndk[T], x[T];
+#pragma unroll
+    for (int s = 0; s < T; ++s) { ndk[s] = ndk_c[s]; x[s] = x_c[s]; }
+    double w[T];
+    scores_cached<T, DENSE>(w, ndk, x, s_den, s_rcp, tid, mask, P->alpha, P->beta);
+    // prob /= np.sum(prob)  (LabeledLDA.py:117): p = fl(w / S) through ONE IEEE reciprocal y = RN(1/S) and
+    // two residual corrections per slot (Markstein: with y correctly rounded and q1 faithful,
+    // q2 = RN(q1 + (w - S q1) y) is the correctly rounded quotient; llda_selftest_div checks it)
+    const double S = group_sum<G, T, HAS_TAIL>(w, *P, lig, lane);
+    const double y = 1.0 / S;
+#pragma unroll
+    for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);
+    return draw_position<G, T, true>(w, u, mask, S > 0.0, lig, lane);
+}
+
 // store the new assignment of a site and move its count in n_kw_delta (int32 atomics, no return value)
 __device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, int f, int zo, int zn, int KP)
 {
@@ -503,24 +588,34 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
                 onehot_add2<T>(ndk, x, oh, f);          // m = -1 at the slot: += (-1) * f
             }
 
-            // scores (LabeledLDA.py:113-116): prob = lab * a * (num_b / den_b); lab in {0,1} is applied as
-            // an all-ones / all-zeros bit mask on the product (0 * finite = +0.0 exactly)
-            double w[T];
-            if constexpr (FAST) scores_cached<T, DENSE>(w, ndk, x, s_den, s_rcp, tid, mask, P.alpha, P.beta);
-            else scores<T>(w, ndk, nkb, x, mask, P.alpha, P.beta, P.vbeta);
-
-            // prob /= np.sum(prob)  (LabeledLDA.py:117)
-            const double S = group_sum<G, T, HAS_TAIL>(w, P, lig, lane);
-            // p = fl(w / S) for every slot through ONE IEEE reciprocal y = RN(1/S) and two
-            // residual corrections per slot (Markstein: with y correctly rounded and q1 faithful,
-            // q2 = RN(q1 + (w - S q1) y) is the correctly rounded quotient).  Checked against the
-            // hardware division by llda_selftest_div.
-            const double y = 1.0 / S;
+            int zn = -1;
+            bool decided = false;
+            if constexpr (FAST) {
+                // tier 1: decide from cheaply rounded, unnormalised prefix sums when the margin allows
+                double qw[T];
+                prefix_scores_fast<T, DENSE>(qw, ndk, x, s_rcp, tid, mask, P.alpha, P.beta);
+                decided = draw_fast<G, T>(qw, u, mask, P.margin_rel, lig, lane, zn);
+            }
+            if (!decided) {
+                if constexpr (FAST) {
+                    // exact tier, out of line (taken ~1e-9 of the time): works on scratch copies so the
+                    // hot loop's register allocation does not see it
+                    int ndk_c[T], x_c[T];
 #pragma unroll
-            for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);
-
-            // keyed categorical draw (oracle/llda_oracle.py draw_keyed)
-            int zn = draw_position<G, T, FAST>(w, u, mask, S > 0.0, lig, lane);
+                    for (int s = 0; s < T; ++s) { ndk_c[s] = ndk[s]; x_c[s] = x[s]; }
+                    zn = exact_tier_cached<G, T, HAS_TAIL, DENSE>(ndk_c, x_c, s_den, s_rcp, tid, mask, u, lig, lane, &P);
+                    if (lig == 0 && P.status) atomicOr(P.status, 2);   // bit 1: the exact tier ran (informational)
+                } else {
+                    // scores (LabeledLDA.py:113-116): prob = lab * a * (num_b / den_b)
+                    double w[T];
+                    scores<T>(w, ndk, nkb, x, mask, P.alpha, P.beta, P.vbeta);
+                    const double S = group_sum<G, T, HAS_TAIL>(w, P, lig, lane);      // np.sum(prob)
+                    const double y = 1.0 / S;
+#pragma unroll
+                    for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);            // prob /= np.sum(prob)
+                    zn = draw_position<G, T, false>(w, u, mask, S > 0.0, lig, lane);
+                }
+            }
             if (zn < 0) {
                 zn = zo;
                 if (lig == 0 && P.status) atomicOr(P.status, 1);    // no topic with positive probability
@@ -1119,6 +1214,8 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     const bool fast = a->alpha >= 1e-6 && a->beta >= 1e-6 && P.vbeta < 1099511627776.0;
     // all-ones label masks and no padded slots: the mask need not be applied at all
     const bool dense = fast && a->dense_mask != 0 && L.K == L.KP;
+    // debug_margin: 0 = production margin 2^-40; n > 0 = 2^-n (wider: more fallbacks); < 0 = always exact tier
+    P.margin_rel = a->debug_margin == 0 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
     switch (L.G) {
     case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, fast, dense, blocks, st);
     case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, fast, dense, blocks, st);

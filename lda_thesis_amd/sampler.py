@@ -81,6 +81,7 @@ class GibbsSampler(object):
         self.sharded = bool(sharded)
         self.docs_per_group = int(docs_per_group)
         self.sweeps_done = 0
+        self.debug_margin = 0          # test hook of the two-tier draw (include/llda_gibbs.h)
         self.kernel_events = None      # set to [] to record a (start, end) HIP event pair per sweep kernel
         self.layout = lay = group_layout(self.K)
         dev = self.device
@@ -163,7 +164,8 @@ class GibbsSampler(object):
                            status=self.status, D=self.D, V=self.V, K=self.K, alpha=self.alpha,
                            beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
                            stream_id=self.stream_id, doc_base=self.doc_base,
-                           docs_per_group=self.docs_per_group, dense_mask=self.dense_mask)
+                           docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
+                           debug_margin=self.debug_margin)
         if ev is not None:
             ev[1].record()
             self.kernel_events.append(ev)
@@ -177,7 +179,7 @@ class GibbsSampler(object):
 
     def check_status(self):
         """Raise like the reference would (numpy's multinomial rejects a NaN pvals vector)."""
-        if int(self.status.item()) != 0:
+        if int(self.status.item()) & 1:
             raise ValueError("a site had no topic with positive probability (pvals would be NaN)")
 
     # ------------------------------------------------------------------ read-outs

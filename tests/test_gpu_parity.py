@@ -20,10 +20,15 @@ def make_sampler(g, counts=True, **kw):
                         seed=int(g["seed"]), stream_id=int(g["stream"]) if "stream" in g else 0, **kw)
 
 
+# debug_margin: 0 = production two-tier draw (cheap decision when |Q - T| > 2^-40 of the total, exact fp64
+# pipeline otherwise); -1 = every site through the exact tier; 6 = margin 2^-6, i.e. a few per cent of the
+# sites fall back, mixing both tiers inside one wavefront
+@pytest.mark.parametrize("margin", [0, -1, 6])
 @pytest.mark.parametrize("name", TINY + ["sublda"])
-def test_sweeps_match_reference_o3(name):
+def test_sweeps_match_reference_o3(name, margin):
     g = load_golden(name)
     s = make_sampler(g)
+    s.debug_margin = margin
     for i in range(int(g["sweeps"])):
         s.sweep()
         assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics(), name)
@@ -99,6 +104,7 @@ def test_seeded_inputs_vs_c_oracle(c_oracle, K, dense, D, V):
     rng = np.random.default_rng(K * 7 + D)
     doc_off, word, freq, labs, z = synth(rng, D, V, K, 1, 90, dense)
     s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=99, doc_base=1000)
+    s.debug_margin = [0, 6, -1][(K + D) % 3]
     n_dk0, n_kv0, n_k0 = s.n_d_k(), s.n_k_v(), s.n_zk()
     cs = c_oracle.CState(doc_off, word, freq, z, labs, n_dk0, n_kv0, n_k0, V, 0.1, 0.01)
     for i in range(3):
@@ -121,3 +127,36 @@ def test_reciprocal_division_equals_ieee_division():
     the correctly rounded quotient: 4e9 random pairs against the hardware division."""
     from lda_thesis_amd import _native
     assert _native.selftest_div(4_000_000_000, seed=7) == 0
+
+
+def test_two_tier_draw_equals_exact_tier_on_a_large_dense_workload():
+    """production margin vs all-exact on 2e5 sites x 4 sweeps (K=512 dense, Zipf words): identical
+    assignments and counts; and the production run must actually have used tier 1 (status bit 1 only set
+    by exact-tier visits, which are ~1e-9 per site)."""
+    import torch
+    from lda_thesis_amd.corpus import synthetic_corpus
+    from lda_thesis_amd.sampler import GibbsSampler
+    off, w, f, z = synthetic_corpus(1000, 200, 20000, 512, seed=9, device="cuda")
+    runs = []
+    for margin in (0, -1):
+        s = GibbsSampler(off, w, f, z, 512, 20000, 0.1, 0.01, labs=None, seed=5)
+        s.debug_margin = margin
+        for _ in range(4):
+            s.sweep()
+        runs.append((s.z.clone(), s.n_kw.clone(), s.n_dk.clone(), int(s.status.item())))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    assert runs[1][3] & 2 and not (runs[0][3] & 1)
+    # masked variant (K=392-like sparse masks go through the non-dense FAST kernel)
+    labs = (torch.rand((1000, 392), device="cuda") < 0.02).cpu().numpy().astype("uint8")
+    labs[:, 0] = 1
+    import numpy as np
+    rng = np.random.default_rng(0)
+    zz = np.concatenate([rng.choice(np.nonzero(labs[d])[0], size=200) for d in range(1000)])
+    runs = []
+    for margin in (0, -1):
+        s = GibbsSampler(off, w, f, zz, 392, 20000, 0.1, 0.01, labs=labs, seed=6)
+        s.debug_margin = margin
+        for _ in range(4):
+            s.sweep()
+        runs.append((s.z.clone(), s.n_kw.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
