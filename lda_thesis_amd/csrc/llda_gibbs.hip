@@ -53,6 +53,7 @@ struct KParams {
     int32_t n_rounds;
     int32_t xor_tree;       // leaves combine as p^1, p^2, p^4 (balanced recursion, no padded leaves)
     double margin_rel;      // tier-1 decision margin relative to the total score (2^-40; debug: wider / inf)
+    float margin0_rel;      // tier-0 (fp32) margin (2^-16; >= 1 disables tier 0)
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];   // 4 bits per leaf: partner leaf
 };
 
@@ -447,6 +448,105 @@ __device__ __forceinline__ bool draw_fast(const double (&qw)[T], double u, uint3
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tier 0: the same decision in fp32.  Every quantity is within 91 * 2^-24 (< 2^-17.4) of the total of its
+// real-number value, the exact pipeline within 2^-44; with a margin of 2^-16 of
+// the total a "sure" fp32 decision therefore has the signs of the exact pipeline.  About 1.6 % of the
+// sites (K = 512) are "unsure" and go on to tier 1.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
+}
+
+template <int T, bool DENSE, int S = 0>
+__device__ __forceinline__ void prefix_scores_f32(float (&qw)[T], const int (&ndk)[T], const int (&x)[T],
+                                                  const double (*s_rcp)[256], int tid, uint32_t mask,
+                                                  float alpha, float beta)
+{
+    if constexpr (S < T) {
+        const float a = (float)ndk[S] + alpha;
+        const float num_b = (float)x[S] + beta;
+        float ws = a * (num_b * (float)s_rcp[S][tid]);
+        if constexpr (!DENSE) ws = __int_as_float(__float_as_int(ws) & onehot_bit<S>(mask));
+        if constexpr (S == 0) qw[0] = ws;
+        else qw[S] = qw[S - 1] + ws;
+        prefix_scores_f32<T, DENSE, S + 1>(qw, ndk, x, s_rcp, tid, mask, alpha, beta);
+    }
+}
+
+// inclusive scan over the G lanes of a group (any association order will do here)
+template <int G>
+__device__ __forceinline__ float group_scan_f32(float X, int lig)
+{
+    if constexpr (G == 8) {
+        float y;
+        y = dpp_f32<DPP_ROW_SHR + 1>(X); X += (lig >= 1) ? y : 0.0f;
+        y = dpp_f32<DPP_ROW_SHR + 2>(X); X += (lig >= 2) ? y : 0.0f;
+        y = dpp_f32<DPP_ROW_SHR + 4>(X); X += (lig >= 4) ? y : 0.0f;
+    } else {
+        X += dpp_f32<DPP_ROW_SHR + 1>(X);
+        X += dpp_f32<DPP_ROW_SHR + 2>(X);
+        X += dpp_f32<DPP_ROW_SHR + 4>(X);
+        X += dpp_f32<DPP_ROW_SHR + 8>(X);
+        if constexpr (G >= 32) X += dpp_f32<0x142, 0xA>(X);     // row_bcast:15 into rows 1 and 3
+        if constexpr (G == 64) X += dpp_f32<0x143, 0xC>(X);     // row_bcast:31 into rows 2 and 3
+    }
+    return X;
+}
+
+template <int G>
+__device__ __forceinline__ float bcast_last_f32(float x, int lane)
+{
+    if constexpr (G == 64) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+    } else if constexpr (G == 32) {
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 31));
+        const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+        return (lane & 32) ? b : a;
+    } else if constexpr (G == 16) {
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 15));
+        const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 31));
+        const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 47));
+        const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+        const float ab = (lane & 16) ? b : a, cd = (lane & 16) ? d : c;
+        return (lane & 32) ? cd : ab;
+    } else {
+        return __shfl(x, G - 1, G);
+    }
+}
+
+template <int G, int T>
+__device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uint32_t mask, float margin_rel,
+                                              int lig, int lane, int &zn)
+{
+    const int gbase = lane & ~(G - 1);
+    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    const float X = group_scan_f32<G>(qw[T - 1], lig);
+    const float tot = bcast_last_f32<G>(X, lane);
+    const float prev = dpp_f32<DPP_WAVE_SHR1>(X);
+    const float tg = u * tot - (lig ? prev : 0.0f);
+    const float margin = tot * margin_rel;
+    const float lo = tg - margin, hi = tg + margin;
+    int cnt_lo = 0, cnt_hi = 0;
+#pragma unroll
+    for (int s = 0; s < T; ++s) {
+        cnt_lo += (qw[s] <= lo) ? 1 : 0;
+        cnt_hi += (qw[s] <= hi) ? 1 : 0;
+    }
+    const bool unsure = (cnt_lo != cnt_hi) || !(tot > 0.0f) || !(margin < tot) || !(tot < 3.0e38f);
+    if (((__ballot(unsure) >> gbase) & gmask) != 0) return false;
+    const uint32_t fm = mask & (0xFFFFu << cnt_lo);
+    const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
+    const uint64_t gp = (__ballot(mask != 0) >> gbase) & gmask;
+    const bool hit = gf != 0;
+    const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)(gp | 1ull));
+    const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
+    zn = sl * T + __shfl(my, sl, G);
+    return true;
+}
+
 // Exact tier of the FAST kernels: the reference's fp64 pipeline bit for bit --
 // scores through the cached den / RN(1/den), numpy-ordered sum, p = fl(w/S), keyed draw.  Returns the
 // chosen device position or -1.  Deliberately not inlined: it runs for ~1e-9 of the sites.
@@ -591,7 +691,14 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
             int zn = -1;
             bool decided = false;
             if constexpr (FAST) {
-                // tier 1: decide from cheaply rounded, unnormalised prefix sums when the margin allows
+                if (P.margin0_rel < 1.0f) {       // tier 0: fp32
+                    float qf[T];
+                    prefix_scores_f32<T, DENSE>(qf, ndk, x, s_rcp, tid, mask, (float)P.alpha, (float)P.beta);
+                    decided = draw_fast_f32<G, T>(qf, (float)u, mask, P.margin0_rel, lig, lane, zn);
+                }
+            }
+            if constexpr (FAST) if (!decided) {
+                // tier 1: decide from cheaply rounded, unnormalised fp64 prefix sums when the margin allows
                 double qw[T];
                 prefix_scores_fast<T, DENSE>(qw, ndk, x, s_rcp, tid, mask, P.alpha, P.beta);
                 decided = draw_fast<G, T>(qw, u, mask, P.margin_rel, lig, lane, zn);
@@ -1215,7 +1322,8 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     // all-ones label masks and no padded slots: the mask need not be applied at all
     const bool dense = fast && a->dense_mask != 0 && L.K == L.KP;
     // debug_margin: 0 = production margin 2^-40; n > 0 = 2^-n (wider: more fallbacks); < 0 = always exact tier
-    P.margin_rel = a->debug_margin == 0 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
+    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
+    P.margin0_rel = a->debug_margin == 0 ? 0x1p-16f : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
     switch (L.G) {
     case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, fast, dense, blocks, st);
     case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, fast, dense, blocks, st);
