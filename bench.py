@@ -135,6 +135,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     sampler.check_status()
+    tier = sampler.status.cpu().numpy().astype(np.int64)
     kern_ms = [a.elapsed_time(b) for a, b in sampler.kernel_events]
     sampler.kernel_events = None
     if dist is not None:
@@ -167,6 +168,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "llda_sweep_kernel", "kernel_ms": kavg,
                          "algorithmic_bytes_per_launch": alg},
+            "draw_tiers": {"sites": int(sites_local) * (args.steps + args.warmup),
+                           "fp32_tier_unsure": int(tier[1]), "exact_tier": int(tier[2])},
         }
         if world == 1 and not args.no_cpu:
             h_off = doc_off.cpu().numpy()

@@ -82,9 +82,11 @@ typedef struct llda_sweep_args {
     int32_t        *n_kw_delta;  /* [dev] [V*KP] += sweep changes                              */
     const int32_t  *n_k;         /* [dev] [KP] sweep-start snapshot (read only)                */
     int32_t        *n_k_delta;   /* [dev] [KP] += sweep changes                                */
-    int32_t        *status;      /* [dev] optional (may be NULL): bit 0 is set when a site had no
+    int32_t        *status;      /* [dev] optional (may be NULL), int32[4]: word 0 bit 0 is set when a site had no
                                     topic with positive probability (the reference would raise);
-                                    bit 1 (informational) when some site took the exact tier      */
+                                    bit 1 (informational) when some site took the exact tier;
+                                    word 1 += sites the fp32 tier was unsure about, word 2 += sites that
+                                    reached the exact tier (statistics)                           */
     int64_t  D;                  /* local documents                                            */
     int64_t  V;                  /* vocabulary size (rows of n_kw; also enters den = n_k + V*beta) */
     int32_t  K;                  /* topics                                                     */

@@ -168,37 +168,36 @@ __device__ __forceinline__ double div_by(double a, double b, double y)
     return __builtin_fma(r1, y, q1);
 }
 
-// FAST variant of the scores: den_b = fl(n_k + V*beta) as this document sees it and RN(1/den_b) are cached
-// per (slot, thread) in LDS -- they change for at most two topics per site -- so num_b / den_b costs one
-// multiply and four FMAs instead of an IEEE division.  DENSE: every topic allowed, no mask to apply.
+// Scores of the cold fp64 tiers of the FAST kernels: n_k as this document sees it is cached per
+// (slot, thread) in LDS (s_nkc); den_b and num_b / den_b are evaluated exactly as the reference does.
+// DENSE: every topic allowed, no mask to apply.
 template <int T, bool DENSE, int S = 0>
-__device__ __forceinline__ void scores_cached(double (&w)[T], const int (&ndk)[T], const int (&x)[T],
-                                              const double (*s_den)[256], const double (*s_rcp)[256], int tid,
-                                              uint32_t mask, double alpha, double beta)
+__device__ __forceinline__ void scores_cold(double (&w)[T], const int (&ndk)[T], const int (&x)[T],
+                                            const int (*s_nkc)[256], int tid, uint32_t mask, double alpha,
+                                            double beta, double vbeta)
 {
     if constexpr (S < T) {
         const double a = (double)ndk[S] + alpha;
         const double num_b = (double)x[S] + beta;
-        const double ws = a * div_by(num_b, s_den[S][tid], s_rcp[S][tid]);
+        const double den_b = (double)s_nkc[S][tid] + vbeta;
+        const double ws = a * (num_b / den_b);
         if constexpr (DENSE) {
             w[S] = ws;
         } else {
             const long long m = (long long)onehot_bit<S>(mask);
             w[S] = __longlong_as_double(__double_as_longlong(ws) & m);
         }
-        scores_cached<T, DENSE, S + 1>(w, ndk, x, s_den, s_rcp, tid, mask, alpha, beta);
+        scores_cold<T, DENSE, S + 1>(w, ndk, x, s_nkc, tid, mask, alpha, beta, vbeta);
     }
 }
 
-// n_k of one topic changes by df: refresh the cached den / reciprocal of (slot, thread).  den holds
-// fl(n_k + V*beta) with V*beta < 2^40 and n_k < 2^31, so rint(den - V*beta) recovers n_k exactly.
-__device__ __forceinline__ void den_update(double (*s_den)[256], double (*s_rcp)[256], int slot, int tid,
-                                           double vbeta, int df)
+// n_k of one topic changes by df: refresh the cached count and the fp32 reciprocal of den = n_k + V*beta
+// used by the tier-0 decision (any fp32 value within a few 2^-24 of 1/den will do there)
+__device__ __forceinline__ void den_update(int (*s_nkc)[256], float (*s_rcp)[256], int slot, int tid, float vbeta32, int df)
 {
-    const int nk = (int)rint(s_den[slot][tid] - vbeta) + df;
-    const double den = (double)nk + vbeta;
-    s_den[slot][tid] = den;
-    s_rcp[slot][tid] = 1.0 / den;
+    const int nk = s_nkc[slot][tid] + df;
+    s_nkc[slot][tid] = nk;
+    s_rcp[slot][tid] = __builtin_amdgcn_rcpf((float)nk + vbeta32);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -300,16 +299,11 @@ __device__ __forceinline__ double group_scan(double X, int lig)
 //   xor butterfly 1,2,4 : ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))   (fp add is commutative)
 //   tail  : n % 8 leftovers of the last leaf, added sequentially
 //   leaves: combined along numpy's recursion tree by the partner schedule
-template <int G, int T, bool HAS_TAIL>
-__device__ __forceinline__ double group_sum(const double (&w)[T], const KParams &P, int lig, int lane)
+// cross-lane part of the sum: acc = this lane's chain, tv = this lane's tail element
+template <int G, bool HAS_TAIL>
+__device__ __forceinline__ double group_sum_tail(double acc, double tv, const KParams &P, int lig, int lane)
 {
     const int leaf = lig >> 3;
-    double acc = 0.0, tv = 0.0;
-#pragma unroll
-    for (int s = 0; s < T; ++s) {
-        if (HAS_TAIL && s == P.tail_row && leaf == P.last_leaf) tv = w[s];
-        else acc = acc + w[s];
-    }
     acc = acc + dpp_f64<DPP_XOR1>(acc);
     acc = acc + dpp_f64<DPP_XOR2>(acc);
     acc = acc + dpp_f64<DPP_HALF_MIRROR>(acc);
@@ -338,6 +332,19 @@ __device__ __forceinline__ double group_sum(const double (&w)[T], const KParams 
         }
     }
     return acc;
+}
+
+template <int G, int T, bool HAS_TAIL>
+__device__ __forceinline__ double group_sum(const double (&w)[T], const KParams &P, int lig, int lane)
+{
+    const int leaf = lig >> 3;
+    double acc = 0.0, tv = 0.0;
+#pragma unroll
+    for (int s = 0; s < T; ++s) {
+        if (HAS_TAIL && s == P.tail_row && leaf == P.last_leaf) tv = w[s];
+        else acc = acc + w[s];
+    }
+    return group_sum_tail<G, HAS_TAIL>(acc, tv, P, lig, lane);
 }
 
 // Keyed categorical draw over the group's K probabilities p (device order, oracle/llda_oracle.py
@@ -401,20 +408,20 @@ __device__ __forceinline__ int draw_position(const double (&w)[T], double u, uin
 // ---------------------------------------------------------------------------------------------
 template <int T, bool DENSE, int S = 0>
 __device__ __forceinline__ void prefix_scores_fast(double (&qw)[T], const int (&ndk)[T], const int (&x)[T],
-                                                   const double (*s_rcp)[256], int tid, uint32_t mask,
-                                                   double alpha, double beta)
+                                                   const int (*s_nkc)[256], int tid, uint32_t mask,
+                                                   double alpha, double beta, double vbeta)
 {
     if constexpr (S < T) {
         const double a = (double)ndk[S] + alpha;
         const double num_b = (double)x[S] + beta;
-        double ws = a * (num_b * s_rcp[S][tid]);
+        double ws = a * (num_b * (1.0 / ((double)s_nkc[S][tid] + vbeta)));
         if constexpr (!DENSE) {
             const long long m = (long long)onehot_bit<S>(mask);
             ws = __longlong_as_double(__double_as_longlong(ws) & m);
         }
         if constexpr (S == 0) qw[0] = ws;
         else qw[S] = qw[S - 1] + ws;
-        prefix_scores_fast<T, DENSE, S + 1>(qw, ndk, x, s_rcp, tid, mask, alpha, beta);
+        prefix_scores_fast<T, DENSE, S + 1>(qw, ndk, x, s_nkc, tid, mask, alpha, beta, vbeta);
     }
 }
 
@@ -462,13 +469,13 @@ __device__ __forceinline__ float dpp_f32(float x)
 
 template <int T, bool DENSE, int S = 0>
 __device__ __forceinline__ void prefix_scores_f32(float (&qw)[T], const int (&ndk)[T], const int (&x)[T],
-                                                  const double (*s_rcp)[256], int tid, uint32_t mask,
+                                                  const float (*s_rcp)[256], int tid, uint32_t mask,
                                                   float alpha, float beta)
 {
     if constexpr (S < T) {
         const float a = (float)ndk[S] + alpha;
         const float num_b = (float)x[S] + beta;
-        float ws = a * (num_b * (float)s_rcp[S][tid]);
+        float ws = a * (num_b * s_rcp[S][tid]);
         if constexpr (!DENSE) ws = __int_as_float(__float_as_int(ws) & onehot_bit<S>(mask));
         if constexpr (S == 0) qw[0] = ws;
         else qw[S] = qw[S - 1] + ws;
@@ -547,27 +554,94 @@ __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uin
     return true;
 }
 
-// Exact tier of the FAST kernels: the reference's fp64 pipeline bit for bit --
-// scores through the cached den / RN(1/den), numpy-ordered sum, p = fl(w/S), keyed draw.  Returns the
-// chosen device position or -1.  Deliberately not inlined: it runs for ~1e-9 of the sites.
+// Cold tiers of the FAST kernels, out of line: they run for the ~1.6 % of the sites
+// tier 0 is unsure about and work on scratch copies, so the hot loop's register allocation never sees them.
+//   tier 1: the decision from unnormalised fp64 prefix sums, margin 2^-40 of the total;
+//   exact : the reference's fp64 pipeline bit for bit -- scores, numpy-ordered sum, p = fl(w/S) through
+//           ONE IEEE reciprocal y = RN(1/S) and two residual corrections per slot (Markstein: with y
+//           correctly rounded and q1 faithful, q2 = RN(q1 + (w - S q1) y) is the correctly rounded
+//           quotient; llda_selftest_div checks it against the hardware division), keyed draw.
+// Returns the chosen device position or -1.
 template <int G, int T, bool HAS_TAIL, bool DENSE>
-__device__ __noinline__ int exact_tier_cached(const int *ndk_c, const int *x_c, const double (*s_den)[256],
-                                              const double (*s_rcp)[256], int tid, uint32_t mask, double u, int lig,
-                                              int lane, const KParams *P)
+__device__ __noinline__ int cold_tiers(const int *ndk, const int *x, const int (*s_nkc)[256], int tid,
+                                       uint32_t mask, double u, int lig, int lane, const KParams *P)
 {
-    int ndk[T], x[T];
-#pragma unroll
-    for (int s = 0; s < T; ++s) { ndk[s] = ndk_c[s]; x[s] = x_c[s]; }
+    // Written as rolled loops over scratch arrays on purpose: few registers, so that this rarely taken
+    // function does not dictate the kernel's register allocation (occupancy of the hot loop).
+    const int gbase = lane & ~(G - 1);
+    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    const double alpha = P->alpha, beta = P->beta, vbeta = P->vbeta;
+    const uint32_t lmask = DENSE ? 0xFFFFu : mask;
     double w[T];
-    scores_cached<T, DENSE>(w, ndk, x, s_den, s_rcp, tid, mask, P->alpha, P->beta);
-    // prob /= np.sum(prob)  (LabeledLDA.py:117): p = fl(w / S) through ONE IEEE reciprocal y = RN(1/S) and
-    // two residual corrections per slot (Markstein: with y correctly rounded and q1 faithful,
-    // q2 = RN(q1 + (w - S q1) y) is the correctly rounded quotient; llda_selftest_div checks it)
-    const double S = group_sum<G, T, HAS_TAIL>(w, *P, lig, lane);
+    if (lig == 0 && P->status) atomicAdd(P->status + 1, 1);      // statistics: sites tier 0 was unsure about
+    // ---- tier 1: unnormalised fp64 prefix sums, margin 2^-40 of the total ----
+    {
+        double run = 0.0;
+#pragma unroll 1
+        for (int s = 0; s < T; ++s) {
+            const double ws = ((double)ndk[s] + alpha) * (((double)x[s] + beta) * (1.0 / ((double)s_nkc[s][tid] + vbeta)));
+            run = run + (((lmask >> s) & 1u) ? ws : 0.0);
+            w[s] = run;
+        }
+        const double X = group_scan<G>(run, lig);
+        const double tot = bcast_last<G>(X, lane);
+        const double prev = dpp_f64<DPP_WAVE_SHR1>(X);
+        const double tg = u * tot - (lig ? prev : 0.0);
+        const double margin = tot * P->margin_rel;
+        int cnt_lo = 0, cnt_hi = 0;
+#pragma unroll 1
+        for (int s = 0; s < T; ++s) {
+            cnt_lo += (w[s] <= tg - margin) ? 1 : 0;
+            cnt_hi += (w[s] <= tg + margin) ? 1 : 0;
+        }
+        const bool unsure = (cnt_lo != cnt_hi) || !(tot > 0.0) || !(margin < tot);
+        if (((__ballot(unsure) >> gbase) & gmask) == 0) {
+            const uint32_t fm = mask & (0xFFFFu << cnt_lo);
+            const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
+            const uint64_t gp = (__ballot(mask != 0) >> gbase) & gmask;
+            const bool hit = gf != 0;
+            const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)(gp | 1ull));
+            const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
+            return sl * T + __shfl(my, sl, G);
+        }
+    }
+    // ---- exact tier: the reference's fp64 pipeline, bit for bit ----
+    if (lig == 0 && P->status) { atomicOr(P->status, 2); atomicAdd(P->status + 2, 1); }   // the exact tier ran
+    const int leaf = lig >> 3;
+    double acc = 0.0, tv = 0.0;
+#pragma unroll 1
+    for (int s = 0; s < T; ++s) {
+        // prob = lab * a * (num_b / den_b)   (LabeledLDA.py:113-116)
+        const double ws = ((double)ndk[s] + alpha) * (((double)x[s] + beta) / ((double)s_nkc[s][tid] + vbeta));
+        const double v = ((lmask >> s) & 1u) ? ws : 0.0;
+        w[s] = v;
+        if (HAS_TAIL && s == P->tail_row && leaf == P->last_leaf) tv = v;
+        else acc = acc + v;
+    }
+    const double S = group_sum_tail<G, HAS_TAIL>(acc, tv, *P, lig, lane);      // np.sum(prob), LabeledLDA.py:117
     const double y = 1.0 / S;
-#pragma unroll
-    for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);
-    return draw_position<G, T, true>(w, u, mask, S > 0.0, lig, lane);
+    // prob /= np.sum(prob); keyed draw: per-lane prefix, Hillis-Steele scan, first slot with p > 0 and q > t - X[g-1]
+    double run = 0.0;
+#pragma unroll 1
+    for (int s = 0; s < T; ++s) {
+        run = (s == 0) ? div_by(w[s], S, y) : run + div_by(w[s], S, y);
+        w[s] = run;
+    }
+    const double X = group_scan<G>(run, lig);
+    const double tot = bcast_last<G>(X, lane);
+    const double prev = dpp_f64<DPP_WAVE_SHR1>(X);
+    const double tg = u * tot - (lig ? prev : 0.0);
+    int cnt = 0;
+#pragma unroll 1
+    for (int s = 0; s < T; ++s) cnt += (w[s] <= tg) ? 1 : 0;
+    const uint32_t fm = mask & (0xFFFFu << cnt);
+    const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
+    const uint64_t gp = (__ballot(mask != 0) >> gbase) & gmask;
+    if (gp == 0 || !(S > 0.0)) return -1;
+    const bool hit = gf != 0;
+    const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)gp);
+    const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
+    return sl * T + __shfl(my, sl, G);
 }
 
 // store the new assignment of a site and move its count in n_kw_delta (int32 atomics, no return value)
@@ -587,15 +661,18 @@ __device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, 
 // FAST: alpha, beta >= 1e-6, so every label-allowed topic has a strictly positive probability and the
 // "p > 0" tests of the draw can be read off the label mask (host-checked in llda_sweep).
 // DENSE (implies FAST, K == KP): every document allows every topic, the label mask is not applied.
+#ifndef LLDA_WAVES
+#define LLDA_WAVES 3          // waves per SIMD the register allocator must leave room for (164 VGPRs, no spill)
+#endif
 template <int G, int T, bool HAS_TAIL, bool FAST, bool DENSE>
-__global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
+__global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KParams P)
 {
     constexpr int KP = G * T;
     constexpr int GPB = 256 / G;              // lane groups (documents in flight) per workgroup
     __shared__ int s_nk[KP];                  // workgroup accumulator of the n_k changes
     // FAST: [slot][thread] caches (conflict-free 8-byte accesses, dynamic slot index for free)
-    __shared__ double s_den[FAST ? T : 1][256];
-    __shared__ double s_rcp[FAST ? T : 1][256];
+    __shared__ int s_nkc[FAST ? T : 1][256];     // n_k as the document sees it
+    __shared__ float s_rcp[FAST ? T : 1][256];   // fp32 reciprocal of n_k + V*beta (tier 0)
 
     const int tid = threadIdx.x;
     for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
@@ -604,6 +681,7 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
     const int lane = tid & 63;
     const int lig = tid & (G - 1);            // lane in group
     const int grp = tid / G;
+    const float vbeta32 = (float)P.vbeta;
 
     for (int it = 0; it < P.dpg; ++it) {
         const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
@@ -620,9 +698,8 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
         if constexpr (FAST) {
 #pragma unroll
             for (int s = 0; s < T; ++s) {
-                const double den = (double)nkb[s] + P.vbeta;       // sweep-start n_k
-                s_den[s][tid] = den;
-                s_rcp[s][tid] = 1.0 / den;
+                s_nkc[s][tid] = nkb[s];                            // sweep-start n_k
+                s_rcp[s][tid] = __builtin_amdgcn_rcpf((float)nkb[s] + vbeta32);
             }
         } else {
 #pragma unroll
@@ -646,7 +723,7 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
         int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0;
         if constexpr (FAST) {         // site 0 leaves its topic: n_k[z_old] -= f  (later sites: end of loop body)
             const int lo = zo_c / T;
-            if (lig == lo) den_update(s_den, s_rcp, zo_c - lo * T, tid, P.vbeta, -f_c);
+            if (lig == lo) den_update(s_nkc, s_rcp, zo_c - lo * T, tid, vbeta32, -f_c);
         }
 
         for (int n = 0; n < len; ++n) {
@@ -697,21 +774,12 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
                     decided = draw_fast_f32<G, T>(qf, (float)u, mask, P.margin0_rel, lig, lane, zn);
                 }
             }
-            if constexpr (FAST) if (!decided) {
-                // tier 1: decide from cheaply rounded, unnormalised fp64 prefix sums when the margin allows
-                double qw[T];
-                prefix_scores_fast<T, DENSE>(qw, ndk, x, s_rcp, tid, mask, P.alpha, P.beta);
-                decided = draw_fast<G, T>(qw, u, mask, P.margin_rel, lig, lane, zn);
-            }
             if (!decided) {
                 if constexpr (FAST) {
-                    // exact tier, out of line (taken ~1e-9 of the time): works on scratch copies so the
-                    // hot loop's register allocation does not see it
                     int ndk_c[T], x_c[T];
 #pragma unroll
                     for (int s = 0; s < T; ++s) { ndk_c[s] = ndk[s]; x_c[s] = x[s]; }
-                    zn = exact_tier_cached<G, T, HAS_TAIL, DENSE>(ndk_c, x_c, s_den, s_rcp, tid, mask, u, lig, lane, &P);
-                    if (lig == 0 && P.status) atomicOr(P.status, 2);   // bit 1: the exact tier ran (informational)
+                    zn = cold_tiers<G, T, HAS_TAIL, DENSE>(ndk_c, x_c, s_nkc, tid, mask, u, lig, lane, &P);
                 } else {
                     // scores (LabeledLDA.py:113-116): prob = lab * a * (num_b / den_b)
                     double w[T];
@@ -737,10 +805,10 @@ __global__ void __launch_bounds__(256) llda_sweep_kernel(const KParams P)
                     // n_k as this document sees it: +f at the new topic now, and already -f' at the old
                     // topic of the NEXT site (its scalars are in registers), so the cached values are
                     // final long before the next site's scores read them
-                    if (lig == ln) den_update(s_den, s_rcp, sn, tid, P.vbeta, f);
+                    if (lig == ln) den_update(s_nkc, s_rcp, sn, tid, vbeta32, f);
                     if (n + 1 < len) {
                         const int lo2 = zo_c / T;
-                        if (lig == lo2) den_update(s_den, s_rcp, zo_c - lo2 * T, tid, P.vbeta, -f_c);
+                        if (lig == lo2) den_update(s_nkc, s_rcp, zo_c - lo2 * T, tid, vbeta32, -f_c);
                     }
                 }
             }

@@ -114,7 +114,7 @@ class GibbsSampler(object):
         self.n_k = torch.zeros((KP,), dtype=torch.int32, device=dev)
         self.n_kw_delta = torch.zeros((self.V, KP), dtype=torch.int32, device=dev)
         self.n_k_delta = torch.zeros((KP,), dtype=torch.int32, device=dev)
-        self.status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.status = torch.zeros((4,), dtype=torch.int32, device=dev)   # [flags, tier-0 unsure, exact tier, -]
         if counts is None:
             self.backend.count_init(self.doc_off, self.word, self.freq, self.z, self.D, self.K,
                                     self.n_dk, self.n_kw, self.n_k)
@@ -179,7 +179,7 @@ class GibbsSampler(object):
 
     def check_status(self):
         """Raise like the reference would (numpy's multinomial rejects a NaN pvals vector)."""
-        if int(self.status.item()) & 1:
+        if int(self.status[0].item()) & 1:
             raise ValueError("a site had no topic with positive probability (pvals would be NaN)")
 
     # ------------------------------------------------------------------ read-outs

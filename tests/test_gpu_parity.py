@@ -143,7 +143,7 @@ def test_two_tier_draw_equals_exact_tier_on_a_large_dense_workload():
         s.debug_margin = margin
         for _ in range(4):
             s.sweep()
-        runs.append((s.z.clone(), s.n_kw.clone(), s.n_dk.clone(), int(s.status.item())))
+        runs.append((s.z.clone(), s.n_kw.clone(), s.n_dk.clone(), int(s.status[0].item())))
     for r in runs[1:]:
         assert torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) and torch.equal(runs[0][2], r[2])
     assert runs[1][3] & 2 and not (runs[0][3] & 1)
