@@ -577,9 +577,14 @@ __device__ __noinline__ int cold_tiers(const int *ndk, const int *x, const int (
     // ---- tier 1: unnormalised fp64 prefix sums, margin 2^-40 of the total ----
     {
         double run = 0.0;
-#pragma unroll 1
+#pragma unroll 4
         for (int s = 0; s < T; ++s) {
-            const double ws = ((double)ndk[s] + alpha) * (((double)x[s] + beta) * (1.0 / ((double)s_nkc[s][tid] + vbeta)));
+            // 1/den to within 2^-50: hardware estimate + two Newton steps (tier 1 only needs a few 2^-53)
+            const double den = (double)s_nkc[s][tid] + vbeta;
+            double y = __builtin_amdgcn_rcp(den);
+            y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+            y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+            const double ws = ((double)ndk[s] + alpha) * (((double)x[s] + beta) * y);
             run = run + (((lmask >> s) & 1u) ? ws : 0.0);
             w[s] = run;
         }
@@ -589,7 +594,7 @@ __device__ __noinline__ int cold_tiers(const int *ndk, const int *x, const int (
         const double tg = u * tot - (lig ? prev : 0.0);
         const double margin = tot * P->margin_rel;
         int cnt_lo = 0, cnt_hi = 0;
-#pragma unroll 1
+#pragma unroll 4
         for (int s = 0; s < T; ++s) {
             cnt_lo += (w[s] <= tg - margin) ? 1 : 0;
             cnt_hi += (w[s] <= tg + margin) ? 1 : 0;
@@ -661,6 +666,9 @@ __device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, 
 // FAST: alpha, beta >= 1e-6, so every label-allowed topic has a strictly positive probability and the
 // "p > 0" tests of the draw can be read off the label mask (host-checked in llda_sweep).
 // DENSE (implies FAST, K == KP): every document allows every topic, the label mask is not applied.
+#ifndef LLDA_MARGIN0
+#define LLDA_MARGIN0 0x1p-16f   // tier-0 (fp32) decision margin relative to the total score
+#endif
 #ifndef LLDA_WAVES
 #define LLDA_WAVES 3          // waves per SIMD the register allocator must leave room for (164 VGPRs, no spill)
 #endif
@@ -1391,7 +1399,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     const bool dense = fast && a->dense_mask != 0 && L.K == L.KP;
     // debug_margin: 0 = production margin 2^-40; n > 0 = 2^-n (wider: more fallbacks); < 0 = always exact tier
     P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
-    P.margin0_rel = a->debug_margin == 0 ? 0x1p-16f : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
+    P.margin0_rel = a->debug_margin == 0 ? LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
     switch (L.G) {
     case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, fast, dense, blocks, st);
     case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, fast, dense, blocks, st);
