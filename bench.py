@@ -35,6 +35,10 @@ WORKLOADS = {
                "(BASELINE configs[3])"),
     "synth1": (100000, 200, 50000, 128,
                "synthetic 100k docs x 200 tokens, K=128 dense mask, V=50k (BASELINE configs[2])"),
+    # real corpus: tokenised abstracts_data.csv, depth 3 (tests/golden/abstracts_d3.npz); sizes read from the file
+    "abstracts": (4171, 0, 0, 392,
+                  "Labeled LDA on abstracts_data.csv, depth 3, K=392 sparse label masks (BASELINE configs[0]/[1]); "
+                  "replicated per GPU"),
 }
 
 
@@ -43,7 +47,7 @@ def algorithmic_bytes(sites, docs, A):
     return sites * (4 * A + 32) + docs * (12 * A + 16)
 
 
-def cpu_baseline(sampler, doc_off, word, freq, n_docs_py, n_docs_c):
+def cpu_baseline(sampler, doc_off, word, freq, n_docs_py, n_docs_c, labs=None):
     """Reference CPU path restated (oracle/) on a bounded sample of the SAME workload, timed on this
     host.  'port' = numpy per-site loop issuing the op sequence of LabeledLDA.py:108-125 on one core
     (the reference is single-threaded python/numpy)."""
@@ -60,7 +64,8 @@ def cpu_baseline(sampler, doc_off, word, freq, n_docs_py, n_docs_c):
     off = doc_off[:n_docs_py + 1]
     docs = [word[off[d]:off[d + 1]].tolist() for d in range(n_docs_py)]
     freqs = [freq[off[d]:off[d + 1]].tolist() for d in range(n_docs_py)]
-    st = orc.State(docs, freqs, np.ones((n_docs_py, K)), V, sampler.alpha, sampler.beta,
+    labs = np.ones((max(n_docs_py, n_docs_c), K), dtype=np.uint8) if labs is None else labs
+    st = orc.State(docs, freqs, labs[:n_docs_py].astype(np.float64), V, sampler.alpha, sampler.beta,
                    [z[off[d]:off[d + 1]] for d in range(n_docs_py)])
     st.n_k_v, st.n_zk, st.n_d_k = n_k_v.copy(), n_zk.copy(), n_d_k[:n_docs_py].copy()
     np.random.seed(1)
@@ -74,7 +79,7 @@ def cpu_baseline(sampler, doc_off, word, freq, n_docs_py, n_docs_c):
     offc = doc_off[:n_docs_c + 1]
     nc = int(offc[-1])
     for label, threads in (("c_1thread", 1), ("c_allcores", cores)):
-        cs = c_oracle.CState(offc, word[:nc], freq[:nc], z[:nc], np.ones((n_docs_c, K), dtype=np.uint8),
+        cs = c_oracle.CState(offc, word[:nc], freq[:nc], z[:nc], labs[:n_docs_c],
                              n_d_k[:n_docs_c], n_k_v, n_zk, V, sampler.alpha, sampler.beta)
         t0 = time.perf_counter()
         cs.sweep(1, sampler.seed, 0, threads=threads)
@@ -112,10 +117,24 @@ def main():
     if args.docs:
         Dg = args.docs
     alpha, beta = 0.1, 0.01
-    doc_off, word, freq, z = synthetic_corpus(Dg, N, V, K, seed=1234 + rank, device=dev)
-    sampler = GibbsSampler(doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=42,
-                           doc_base=rank * Dg, device=dev, docs_per_group=args.docs_per_group)
-    del z
+    live_topics = K
+    if args.workload == "abstracts":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "abstracts_d3.npz"))
+        Dg, V, K = int(g["D"]), int(g["V"]), int(g["K"])
+        doc_off = torch.from_numpy(g["doc_off"]).to(dev)
+        word = torch.from_numpy(g["word"].astype(np.int32)).to(dev)
+        freq = torch.from_numpy(g["freq"].astype(np.int32)).to(dev)
+        N = int(g["doc_off"][-1]) // Dg
+        live_topics = float(len(g["lab_idx"])) / Dg
+        # every rank samples its own replica of the corpus (independent chains: sharded=False)
+        sampler = GibbsSampler(doc_off, word, freq, g["z_init"].astype(np.int64), K, V, alpha, beta,
+                               labs=(g["lab_off"], g["lab_idx"].astype(np.int64)), counts=None, seed=42 + rank,
+                               device=dev, docs_per_group=args.docs_per_group, sharded=False)
+    else:
+        doc_off, word, freq, z = synthetic_corpus(Dg, N, V, K, seed=1234 + rank, device=dev)
+        sampler = GibbsSampler(doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=42,
+                               doc_base=rank * Dg, device=dev, docs_per_group=args.docs_per_group)
+        del z
     sites_local = sampler.S
     torch.cuda.synchronize()
 
@@ -148,7 +167,7 @@ def main():
         ms = dt / args.steps * 1e3
         value = total_sites * args.steps / dt / 1e6
         kavg = float(np.mean(kern_ms)) if kern_ms else float("nan")
-        alg = algorithmic_bytes(sites_local, Dg, K)
+        alg = algorithmic_bytes(sites_local, Dg, live_topics)
         achieved = alg / (kavg * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -159,9 +178,12 @@ def main():
             "metric": "million tokens resampled/sec (Gibbs sweep)",
             "value": value, "unit": "Mtokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if args.workload != "abstracts" else "tokenised abstracts_data.csv (fixture)",
             "config": {"workload": desc, "docs_per_gpu": Dg, "sites_per_doc": N, "K": K, "V": V,
-                       "alpha": alpha, "beta": beta, "label_mask": "dense", "sites_per_sweep": total_sites,
+                       "alpha": alpha, "beta": beta,
+                       "label_mask": "dense" if args.workload != "abstracts" else "sparse (%.2f live topics per doc)" % live_topics,
+                       "sites_per_sweep": total_sites,
                        "exchange": "RCCL all-reduce of int32 n_kw/n_k deltas per sweep" if world > 1 else "none",
                        "semantics": "per-document snapshot (bit-exact vs the reference under O3)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -174,9 +196,14 @@ def main():
         if world == 1 and not args.no_cpu:
             h_off = doc_off.cpu().numpy()
             n_py, n_c = min(Dg, 400), min(Dg, 1000)
+            labs_h = None
+            if args.workload == "abstracts":          # the whole corpus: one sweep of the numpy loop is ~4 s
+                n_py = n_c = Dg
+                labs_h = np.zeros((Dg, K), dtype=np.uint8)
+                labs_h[np.repeat(np.arange(Dg), np.diff(g["lab_off"])), g["lab_idx"]] = 1
             nmax = int(h_off[max(n_py, n_c)])
             base, cores = cpu_baseline(sampler, h_off, word[:nmax].cpu().numpy(), freq[:nmax].cpu().numpy(),
-                                       n_py, n_c)
+                                       n_py, n_c, labs_h)
             line["cpu_baseline"] = {
                 "value": base["numpy"]["value"], "unit": "Mtokens/s", "cores": 1, "kind": "port",
                 "sample": "first %d docs (%d sites) of the same workload, 1 sweep, numpy per-site loop "
