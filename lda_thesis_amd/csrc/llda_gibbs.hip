@@ -168,38 +168,6 @@ __device__ __forceinline__ double div_by(double a, double b, double y)
     return __builtin_fma(r1, y, q1);
 }
 
-// Scores of the cold fp64 tiers of the FAST kernels: n_k as this document sees it is cached per
-// (slot, thread) in LDS (s_nkc); den_b and num_b / den_b are evaluated exactly as the reference does.
-// DENSE: every topic allowed, no mask to apply.
-template <int T, bool DENSE, int S = 0>
-__device__ __forceinline__ void scores_cold(double (&w)[T], const int (&ndk)[T], const int (&x)[T],
-                                            const int (*s_nkc)[256], int tid, uint32_t mask, double alpha,
-                                            double beta, double vbeta)
-{
-    if constexpr (S < T) {
-        const double a = (double)ndk[S] + alpha;
-        const double num_b = (double)x[S] + beta;
-        const double den_b = (double)s_nkc[S][tid] + vbeta;
-        const double ws = a * (num_b / den_b);
-        if constexpr (DENSE) {
-            w[S] = ws;
-        } else {
-            const long long m = (long long)onehot_bit<S>(mask);
-            w[S] = __longlong_as_double(__double_as_longlong(ws) & m);
-        }
-        scores_cold<T, DENSE, S + 1>(w, ndk, x, s_nkc, tid, mask, alpha, beta, vbeta);
-    }
-}
-
-// n_k of one topic changes by df: refresh the cached count and the fp32 reciprocal of den = n_k + V*beta
-// used by the tier-0 decision (any fp32 value within a few 2^-24 of 1/den will do there)
-__device__ __forceinline__ void den_update(int (*s_nkc)[256], float (*s_rcp)[256], int slot, int tid, float vbeta32, int df)
-{
-    const int nk = s_nkc[slot][tid] + df;
-    s_nkc[slot][tid] = nk;
-    s_rcp[slot][tid] = __builtin_amdgcn_rcpf((float)nk + vbeta32);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Cross-lane moves of doubles without an LDS round trip (DPP / permlane), gfx950.
 // ---------------------------------------------------------------------------------------------
@@ -406,55 +374,6 @@ __device__ __forceinline__ int draw_position(const double (&w)[T], double u, uin
 // with them the chosen position -- are those of the exact pipeline.  Otherwise (probability ~1e-9 per
 // site) the group falls back to the exact tier.  Returns false when the group must fall back.
 // ---------------------------------------------------------------------------------------------
-template <int T, bool DENSE, int S = 0>
-__device__ __forceinline__ void prefix_scores_fast(double (&qw)[T], const int (&ndk)[T], const int (&x)[T],
-                                                   const int (*s_nkc)[256], int tid, uint32_t mask,
-                                                   double alpha, double beta, double vbeta)
-{
-    if constexpr (S < T) {
-        const double a = (double)ndk[S] + alpha;
-        const double num_b = (double)x[S] + beta;
-        double ws = a * (num_b * (1.0 / ((double)s_nkc[S][tid] + vbeta)));
-        if constexpr (!DENSE) {
-            const long long m = (long long)onehot_bit<S>(mask);
-            ws = __longlong_as_double(__double_as_longlong(ws) & m);
-        }
-        if constexpr (S == 0) qw[0] = ws;
-        else qw[S] = qw[S - 1] + ws;
-        prefix_scores_fast<T, DENSE, S + 1>(qw, ndk, x, s_nkc, tid, mask, alpha, beta, vbeta);
-    }
-}
-
-template <int G, int T>
-__device__ __forceinline__ bool draw_fast(const double (&qw)[T], double u, uint32_t mask, double margin_rel,
-                                          int lig, int lane, int &zn)
-{
-    const int gbase = lane & ~(G - 1);
-    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
-    const double X = group_scan<G>(qw[T - 1], lig);
-    const double tot = bcast_last<G>(X, lane);
-    const double prev = dpp_f64<DPP_WAVE_SHR1>(X);
-    const double tg = u * tot - (lig ? prev : 0.0);
-    const double margin = tot * margin_rel;
-    const double lo = tg - margin, hi = tg + margin;
-    int cnt_lo = 0, cnt_hi = 0;
-#pragma unroll
-    for (int s = 0; s < T; ++s) {
-        cnt_lo += (qw[s] <= lo) ? 1 : 0;
-        cnt_hi += (qw[s] <= hi) ? 1 : 0;
-    }
-    const bool unsure = (cnt_lo != cnt_hi) || !(tot > 0.0) || !(margin < tot);
-    if (((__ballot(unsure) >> gbase) & gmask) != 0) return false;
-    const uint32_t fm = mask & (0xFFFFu << cnt_lo);
-    const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
-    const uint64_t gp = (__ballot(mask != 0) >> gbase) & gmask;
-    const bool hit = gf != 0;
-    const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)(gp | 1ull));
-    const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
-    zn = sl * T + __shfl(my, sl, G);
-    return true;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Tier 0: the same decision in fp32.  Every quantity is within 91 * 2^-24 (< 2^-17.4) of the total of its
 // real-number value, the exact pipeline within 2^-44; with a margin of 2^-16 of
@@ -468,18 +387,18 @@ __device__ __forceinline__ float dpp_f32(float x)
 }
 
 template <int T, bool DENSE, int S = 0>
-__device__ __forceinline__ void prefix_scores_f32(float (&qw)[T], const int (&ndk)[T], const int (&x)[T],
+__device__ __forceinline__ void prefix_scores_f32(float (&qw)[T], const int (*s_ndk)[256], const int (&x)[T],
                                                   const float (*s_rcp)[256], int tid, uint32_t mask,
                                                   float alpha, float beta)
 {
     if constexpr (S < T) {
-        const float a = (float)ndk[S] + alpha;
+        const float a = (float)s_ndk[S][tid] + alpha;
         const float num_b = (float)x[S] + beta;
         float ws = a * (num_b * s_rcp[S][tid]);
         if constexpr (!DENSE) ws = __int_as_float(__float_as_int(ws) & onehot_bit<S>(mask));
         if constexpr (S == 0) qw[0] = ws;
         else qw[S] = qw[S - 1] + ws;
-        prefix_scores_f32<T, DENSE, S + 1>(qw, ndk, x, s_rcp, tid, mask, alpha, beta);
+        prefix_scores_f32<T, DENSE, S + 1>(qw, s_ndk, x, s_rcp, tid, mask, alpha, beta);
     }
 }
 
@@ -563,7 +482,7 @@ __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uin
 //           quotient; llda_selftest_div checks it against the hardware division), keyed draw.
 // Returns the chosen device position or -1.
 template <int G, int T, bool HAS_TAIL, bool DENSE>
-__device__ __noinline__ int cold_tiers(const int *ndk, const int *x, const int (*s_nkc)[256], int tid,
+__device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, const int (*s_nkc)[256], int tid,
                                        uint32_t mask, double u, int lig, int lane, const KParams *P)
 {
     // Written as rolled loops over scratch arrays on purpose: few registers, so that this rarely taken
@@ -584,7 +503,7 @@ __device__ __noinline__ int cold_tiers(const int *ndk, const int *x, const int (
             double y = __builtin_amdgcn_rcp(den);
             y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
             y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
-            const double ws = ((double)ndk[s] + alpha) * (((double)x[s] + beta) * y);
+            const double ws = ((double)s_ndk[s][tid] + alpha) * (((double)x[s] + beta) * y);
             run = run + (((lmask >> s) & 1u) ? ws : 0.0);
             w[s] = run;
         }
@@ -617,7 +536,7 @@ __device__ __noinline__ int cold_tiers(const int *ndk, const int *x, const int (
 #pragma unroll 1
     for (int s = 0; s < T; ++s) {
         // prob = lab * a * (num_b / den_b)   (LabeledLDA.py:113-116)
-        const double ws = ((double)ndk[s] + alpha) * (((double)x[s] + beta) / ((double)s_nkc[s][tid] + vbeta));
+        const double ws = ((double)s_ndk[s][tid] + alpha) * (((double)x[s] + beta) / ((double)s_nkc[s][tid] + vbeta));
         const double v = ((lmask >> s) & 1u) ? ws : 0.0;
         w[s] = v;
         if (HAS_TAIL && s == P->tail_row && leaf == P->last_leaf) tv = v;
@@ -663,33 +582,39 @@ __device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, 
 // ---------------------------------------------------------------------------------------------
 // The sweep kernel
 // ---------------------------------------------------------------------------------------------
-// FAST: alpha, beta >= 1e-6, so every label-allowed topic has a strictly positive probability and the
-// "p > 0" tests of the draw can be read off the label mask (host-checked in llda_sweep).
-// DENSE (implies FAST, K == KP): every document allows every topic, the label mask is not applied.
-#ifndef LLDA_MARGIN0
-#define LLDA_MARGIN0 0x1p-16f   // tier-0 (fp32) decision margin relative to the total score (DESIGN.md 4.3)
-#endif
-#ifndef LLDA_WAVES
-#define LLDA_WAVES 3          // waves per SIMD the register allocator must leave room for (164 VGPRs, no spill)
-#endif
-template <int G, int T, bool HAS_TAIL, bool FAST, bool DENSE>
-__global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KParams P)
+// Per-site pieces shared by the two sweep kernels ------------------------------------------------
+// keyed uniform of site n: one Philox block serves sites 2b and 2b+1; the G lanes of the group compute G
+// consecutive blocks at once (every 2G sites) and hand them out by shuffle
+template <int G>
+__device__ __forceinline__ double site_uniform(const KParams &P, int n, uint32_t gdoc, int lig, uint32_t &r0,
+                                               uint32_t &r1, uint32_t &r2, uint32_t &r3)
+{
+    if ((n & (2 * G - 1)) == 0) {
+        r0 = (uint32_t)(n >> 1) + (uint32_t)lig; r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
+        philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
+    }
+    const int holder = (n >> 1) & (G - 1);
+    const uint32_t ra = (uint32_t)__shfl((int)((n & 1) ? r2 : r0), holder, G);
+    const uint32_t rb = (uint32_t)__shfl((int)((n & 1) ? r3 : r1), holder, G);
+    return ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sweep kernel, general form: every site through the reference's fp64 pipeline, inline.  Used when the
+// tiered kernel's preconditions do not hold (alpha or beta < 1e-6, V*beta >= 2^40).
+// ---------------------------------------------------------------------------------------------
+template <int G, int T, bool HAS_TAIL>
+__global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
 {
     constexpr int KP = G * T;
     constexpr int GPB = 256 / G;              // lane groups (documents in flight) per workgroup
     __shared__ int s_nk[KP];                  // workgroup accumulator of the n_k changes
-    // FAST: [slot][thread] caches (conflict-free 8-byte accesses, dynamic slot index for free)
-    __shared__ int s_nkc[FAST ? T : 1][256];     // n_k as the document sees it
-    __shared__ float s_rcp[FAST ? T : 1][256];   // fp32 reciprocal of n_k + V*beta (tier 0)
-
     const int tid = threadIdx.x;
     for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
     __syncthreads();
-
     const int lane = tid & 63;
     const int lig = tid & (G - 1);            // lane in group
     const int grp = tid / G;
-    const float vbeta32 = (float)P.vbeta;
 
     for (int it = 0; it < P.dpg; ++it) {
         const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
@@ -703,15 +628,141 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         int32_t *ndk_row = P.n_dk + d * KP + lig * T;   // document is nkb + ndk at any time
         load_row<T>(ndk_row, ndk);
         load_row<T>(P.n_k + lig * T, nkb);
-        if constexpr (FAST) {
+#pragma unroll
+        for (int s = 0; s < T; ++s) nkb[s] -= ndk[s];
+        const uint32_t mask = P.lab_mask[d * G + lig];
+        const uint32_t gdoc = (uint32_t)(d + P.doc_base);
+
+        // memory pipeline: see llda_sweep_kernel
+        int v_c = P.word[s0], f_c = P.freq[s0], zo_c = P.z[s0];
+        const int64_t i1 = s0 + (len > 1 ? 1 : 0);
+        int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1];
+        int xn[T];
+        load_row<T>(P.n_kw + (int64_t)v_c * KP + lig * T, xn);
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        int64_t pend_i = -1;
+        int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0;
+
+        for (int n = 0; n < len; ++n) {
+            const int v = v_c, f = f_c, zo = zo_c;
+            int x[T];
+#pragma unroll
+            for (int s = 0; s < T; ++s) x[s] = xn[s];
+            if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
+            load_row<T>(P.n_kw + (int64_t)v_1 * KP + lig * T, xn);
+            v_c = v_1; f_c = f_1; zo_c = zo_1;
+            {
+                const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);
+                v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
+            }
+            const double u = site_uniform<G>(P, n, gdoc, lig, r0, r1, r2, r3);
+
+            // remove the site (LabeledLDA.py:109-111)
+            {
+                const int lo = zo / T, so = zo - lo * T;
+                onehot_add2<T>(ndk, x, (lig == lo) ? (1u << so) : 0u, f);
+            }
+            // scores (LabeledLDA.py:113-116), np.sum, prob /= sum, keyed draw
+            double w[T];
+            scores<T>(w, ndk, nkb, x, mask, P.alpha, P.beta, P.vbeta);
+            const double S = group_sum<G, T, HAS_TAIL>(w, P, lig, lane);
+            const double y = 1.0 / S;
+#pragma unroll
+            for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);
+            int zn = draw_position<G, T, false>(w, u, mask, S > 0.0, lig, lane);
+            if (zn < 0) {
+                zn = zo;
+                if (lig == 0 && P.status) atomicOr(P.status, 1);    // no topic with positive probability
+            }
+            // add the site back (LabeledLDA.py:121-125)
+            {
+                const int ln = zn / T, sn = zn - ln * T;
+                onehot_add1<T>(ndk, (lig == ln) ? (1u << sn) : 0u, -f);
+            }
+            pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn;
+        }
+        if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
+
+        int old[T];
+        load_row<T>(ndk_row, old);
+#pragma unroll
+        for (int s = 0; s < T; ++s) {
+            const int dl = ndk[s] - old[s];
+            if (dl) atomicAdd(&s_nk[lig * T + s], dl);
+        }
+        store_row<T>(ndk_row, ndk);
+    }
+    __syncthreads();
+    for (int i = tid; i < KP; i += 256) {
+        const int dl = s_nk[i];
+        if (dl) atomicAdd(P.n_k_delta + i, dl);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sweep kernel, tiered form (the one that runs in practice).  Preconditions, host-checked in llda_sweep:
+// alpha, beta >= 1e-6 (every label-allowed topic has a strictly positive probability, so the "p > 0" tests
+// of the draw can be read off the label mask) and V*beta < 2^40.  DENSE (K == KP): every document allows
+// every topic and the label mask is not applied.
+// The document's n_dk row, the n_k it sees and an fp32 reciprocal of n_k + V*beta live in LDS as
+// [slot][thread] arrays: conflict-free, and the owning lane updates ONE dynamically indexed slot per
+// change (VGPR arrays would need a 16-deep select chain per update).
+// ---------------------------------------------------------------------------------------------
+#ifndef LLDA_MARGIN0
+#define LLDA_MARGIN0 0x1p-16f   // tier-0 (fp32) decision margin relative to the total score (DESIGN.md 4.3)
+#endif
+#ifndef LLDA_WAVES
+#define LLDA_WAVES 3          // waves per SIMD the register allocator must leave room for
+#endif
+
+// a topic count of this document changes by df: n_dk, the n_k the document sees, and the cached reciprocal
+__device__ __forceinline__ void count_update(int (*s_ndk)[256], int (*s_nkc)[256], float (*s_rcp)[256], int slot,
+                                             int tid, float vbeta32, int df)
+{
+    s_ndk[slot][tid] += df;
+    const int nk = s_nkc[slot][tid] + df;
+    s_nkc[slot][tid] = nk;
+    s_rcp[slot][tid] = __builtin_amdgcn_rcpf((float)nk + vbeta32);
+}
+
+template <int G, int T, bool HAS_TAIL, bool DENSE>
+__global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KParams P)
+{
+    constexpr int KP = G * T;
+    constexpr int GPB = 256 / G;              // lane groups (documents in flight) per workgroup
+    __shared__ int s_nk[KP];                  // workgroup accumulator of the n_k changes
+    __shared__ int s_ndk[T][256];             // n_dk row of the document
+    __shared__ int s_nkc[T][256];             // n_k as the document sees it
+    __shared__ float s_rcp[T][256];           // fp32 reciprocal of n_k + V*beta (tier 0)
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int lig = tid & (G - 1);            // lane in group
+    const int grp = tid / G;
+    const float vbeta32 = (float)P.vbeta, alpha32 = (float)P.alpha, beta32 = (float)P.beta;
+
+    for (int it = 0; it < P.dpg; ++it) {
+        const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
+        if (idx >= P.D) break;
+        const int64_t d = P.doc_order ? (int64_t)P.doc_order[idx] : idx;
+        const int64_t s0 = P.doc_off[d];
+        const int len = (int)(P.doc_off[d + 1] - s0);
+        if (len <= 0) continue;
+
+        int32_t *ndk_row = P.n_dk + d * KP + lig * T;
+        {
+            int r[T], k[T];
+            load_row<T>(ndk_row, r);
+            load_row<T>(P.n_k + lig * T, k);
 #pragma unroll
             for (int s = 0; s < T; ++s) {
-                s_nkc[s][tid] = nkb[s];                            // sweep-start n_k
-                s_rcp[s][tid] = __builtin_amdgcn_rcpf((float)nkb[s] + vbeta32);
+                s_ndk[s][tid] = r[s];
+                s_nkc[s][tid] = k[s];                              // sweep-start n_k
+                s_rcp[s][tid] = __builtin_amdgcn_rcpf((float)k[s] + vbeta32);
             }
-        } else {
-#pragma unroll
-            for (int s = 0; s < T; ++s) nkb[s] -= ndk[s];
         }
         const uint32_t mask = P.lab_mask[d * G + lig];
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
@@ -729,9 +780,9 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         int64_t pend_i = -1;
         int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0;
-        if constexpr (FAST) {         // site 0 leaves its topic: n_k[z_old] -= f  (later sites: end of loop body)
+        {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the loop body
             const int lo = zo_c / T;
-            if (lig == lo) den_update(s_nkc, s_rcp, zo_c - lo * T, tid, vbeta32, -f_c);
+            if (lig == lo) count_update(s_ndk, s_nkc, s_rcp, zo_c - lo * T, tid, vbeta32, -f_c);
         }
 
         for (int n = 0; n < len; ++n) {
@@ -753,71 +804,41 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);  // scalars of site n+2 (clamped)
                 v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
             }
+            const double u = site_uniform<G>(P, n, gdoc, lig, r0, r1, r2, r3);
 
-            // keyed uniform: one Philox block serves sites 2b and 2b+1; the G lanes of the group
-            // compute G consecutive blocks at once (every 2G sites) and hand them out by shuffle
-            if ((n & (2 * G - 1)) == 0) {
-                r0 = (uint32_t)(n >> 1) + (uint32_t)lig; r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
-                philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
-            }
-            const int holder = (n >> 1) & (G - 1);
-            const uint32_t ra = (uint32_t)__shfl((int)((n & 1) ? r2 : r0), holder, G);
-            const uint32_t rb = (uint32_t)__shfl((int)((n & 1) ? r3 : r1), holder, G);
-            const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
-
-            // remove the site (LabeledLDA.py:109-111): -f at z_old in n_dk (hence in the n_k this document
-            // sees) and in the fetched n_kw row
+            // the site's own count leaves the fetched n_kw row (n_dk / n_k were updated already)
             {
                 const int lo = zo / T, so = zo - lo * T;
-                const uint32_t oh = (lig == lo) ? (1u << so) : 0u;
-                onehot_add2<T>(ndk, x, oh, f);          // m = -1 at the slot: += (-1) * f
+                onehot_add1<T>(x, (lig == lo) ? (1u << so) : 0u, f);       // m = -1 at the slot: += (-1) * f
             }
 
+            // tiered draw
             int zn = -1;
             bool decided = false;
-            if constexpr (FAST) {
-                if (P.margin0_rel < 1.0f) {       // tier 0: fp32
-                    float qf[T];
-                    prefix_scores_f32<T, DENSE>(qf, ndk, x, s_rcp, tid, mask, (float)P.alpha, (float)P.beta);
-                    decided = draw_fast_f32<G, T>(qf, (float)u, mask, P.margin0_rel, lig, lane, zn);
-                }
+            if (P.margin0_rel < 1.0f) {           // tier 0: fp32
+                float qf[T];
+                prefix_scores_f32<T, DENSE>(qf, s_ndk, x, s_rcp, tid, mask, alpha32, beta32);
+                decided = draw_fast_f32<G, T>(qf, (float)u, mask, P.margin0_rel, lig, lane, zn);
             }
             if (!decided) {
-                if constexpr (FAST) {
-                    int ndk_c[T], x_c[T];
+                int x_c[T];
 #pragma unroll
-                    for (int s = 0; s < T; ++s) { ndk_c[s] = ndk[s]; x_c[s] = x[s]; }
-                    zn = cold_tiers<G, T, HAS_TAIL, DENSE>(ndk_c, x_c, s_nkc, tid, mask, u, lig, lane, &P);
-                } else {
-                    // scores (LabeledLDA.py:113-116): prob = lab * a * (num_b / den_b)
-                    double w[T];
-                    scores<T>(w, ndk, nkb, x, mask, P.alpha, P.beta, P.vbeta);
-                    const double S = group_sum<G, T, HAS_TAIL>(w, P, lig, lane);      // np.sum(prob)
-                    const double y = 1.0 / S;
-#pragma unroll
-                    for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);            // prob /= np.sum(prob)
-                    zn = draw_position<G, T, false>(w, u, mask, S > 0.0, lig, lane);
-                }
+                for (int s = 0; s < T; ++s) x_c[s] = x[s];
+                zn = cold_tiers<G, T, HAS_TAIL, DENSE>(s_ndk, x_c, s_nkc, tid, mask, u, lig, lane, &P);
             }
             if (zn < 0) {
                 zn = zo;
                 if (lig == 0 && P.status) atomicOr(P.status, 1);    // no topic with positive probability
             }
 
-            // add the site back (LabeledLDA.py:121-125)
+            // add the site back (LabeledLDA.py:121-125), and take the NEXT site out of its topic already (its
+            // scalars are in registers): the LDS state is final long before the next site's scores read it
             {
-                const int ln = zn / T, sn = zn - ln * T;
-                const uint32_t oh = (lig == ln) ? (1u << sn) : 0u;
-                onehot_add1<T>(ndk, oh, -f);            // (-1) * (-f) = +f
-                if constexpr (FAST) {
-                    // n_k as this document sees it: +f at the new topic now, and already -f' at the old
-                    // topic of the NEXT site (its scalars are in registers), so the cached values are
-                    // final long before the next site's scores read them
-                    if (lig == ln) den_update(s_nkc, s_rcp, sn, tid, vbeta32, f);
-                    if (n + 1 < len) {
-                        const int lo2 = zo_c / T;
-                        if (lig == lo2) den_update(s_nkc, s_rcp, zo_c - lo2 * T, tid, vbeta32, -f_c);
-                    }
+                const int ln = zn / T;
+                if (lig == ln) count_update(s_ndk, s_nkc, s_rcp, zn - ln * T, tid, vbeta32, f);
+                if (n + 1 < len) {
+                    const int lo2 = zo_c / T;
+                    if (lig == lo2) count_update(s_ndk, s_nkc, s_rcp, zo_c - lo2 * T, tid, vbeta32, -f_c);
                 }
             }
             pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn;
@@ -825,14 +846,15 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
 
         // document done: fold its n_dk change into the workgroup's n_k accumulator, store the row
-        int old[T];
+        int old[T], cur[T];
         load_row<T>(ndk_row, old);
 #pragma unroll
         for (int s = 0; s < T; ++s) {
-            const int dl = ndk[s] - old[s];
+            cur[s] = s_ndk[s][tid];
+            const int dl = cur[s] - old[s];
             if (dl) atomicAdd(&s_nk[lig * T + s], dl);
         }
-        store_row<T>(ndk_row, ndk);
+        store_row<T>(ndk_row, cur);
     }
 
     __syncthreads();
@@ -1196,14 +1218,15 @@ template <int G, int T>
 int launch_sweep(const KParams &P, bool has_tail, bool fast, bool dense, int64_t blocks, hipStream_t st)
 {
     const dim3 grid((unsigned)blocks), block(256);
-    if (dense) {
-        hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true, true>), grid, block, 0, st, P);
+    if (!fast) {
+        if (has_tail) hipLaunchKernelGGL((llda_sweep_exact_kernel<G, T, true>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((llda_sweep_exact_kernel<G, T, false>), grid, block, 0, st, P);
+    } else if (dense) {
+        hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true>), grid, block, 0, st, P);
     } else if (has_tail) {
-        if (fast) hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, true, false>), grid, block, 0, st, P);
-        else hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, false, false>), grid, block, 0, st, P);
+        hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, false>), grid, block, 0, st, P);
     } else {
-        if (fast) hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true, false>), grid, block, 0, st, P);
-        else hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, false, false>), grid, block, 0, st, P);
+        hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, false>), grid, block, 0, st, P);
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
@@ -1399,7 +1422,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     const bool dense = fast && a->dense_mask != 0 && L.K == L.KP;
     // debug_margin: 0 = production margin 2^-40; n > 0 = 2^-n (wider: more fallbacks); < 0 = always exact tier
     P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
-    P.margin0_rel = a->debug_margin == 0 ? LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
+    P.margin0_rel = a->debug_margin == 0 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
     switch (L.G) {
     case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, fast, dense, blocks, st);
     case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, fast, dense, blocks, st);
