@@ -1381,13 +1381,14 @@ int llda_layout_init(int32_t K, llda_layout *L)
 
 int llda_sweep(const llda_sweep_args *a, void *stream)
 {
-    if (!a || !a->doc_off || !a->word || !a->freq || !a->z || !a->lab_mask || !a->n_dk || !a->n_kw ||
-        !a->n_kw_delta || !a->n_k || !a->n_k_delta || a->D < 0 || a->V < 1)
-        return LLDA_E_BAD_ARG;
+    if (!a || a->D < 0 || a->V < 1) return LLDA_E_BAD_ARG;
     llda_layout L;
     const int rc = llda_layout_init(a->K, &L);
     if (rc) return rc;
-    if (a->D == 0) return LLDA_OK;
+    if (a->D == 0) return LLDA_OK;            // an empty shard: nothing to do, array pointers may be NULL
+    if (!a->doc_off || !a->word || !a->freq || !a->z || !a->lab_mask || !a->n_dk || !a->n_kw || !a->n_kw_delta ||
+        !a->n_k || !a->n_k_delta)
+        return LLDA_E_BAD_ARG;
 
     KParams P;
     memset(&P, 0, sizeof P);
@@ -1450,11 +1451,12 @@ int llda_apply_delta(int32_t *counts, int32_t *delta, int64_t n, void *stream)
 int llda_count_init(const int64_t *doc_off, const int32_t *word, const int32_t *freq, const int32_t *z,
                     int64_t D, int32_t K, int32_t *n_dk, int32_t *n_kw, int32_t *n_k, void *stream)
 {
-    if (!doc_off || !word || !freq || !z || !n_dk || !n_kw || !n_k || D < 0) return LLDA_E_BAD_ARG;
+    if (D < 0) return LLDA_E_BAD_ARG;
     llda_layout L;
     const int rc = llda_layout_init(K, &L);
     if (rc) return rc;
     if (D == 0) return LLDA_OK;
+    if (!doc_off || !word || !freq || !z || !n_dk || !n_kw || !n_k) return LLDA_E_BAD_ARG;
     const int64_t blocks = (D + 3) / 4;
     if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
     hipLaunchKernelGGL(llda_count_init_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
@@ -1467,12 +1469,12 @@ int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab
                 const int32_t *n_kw, const int32_t *n_k, int64_t D, int64_t V, int32_t K, double alpha,
                 double beta, double *out_doc, void *stream)
 {
-    if (!doc_off || !word || !lab_mask || !n_dk || !n_kw || !n_k || !out_doc || D < 0 || V < 1)
-        return LLDA_E_BAD_ARG;
+    if (D < 0 || V < 1) return LLDA_E_BAD_ARG;
     llda_layout L;
     const int rc = llda_layout_init(K, &L);
     if (rc) return rc;
     if (D == 0) return LLDA_OK;
+    if (!doc_off || !word || !lab_mask || !n_dk || !n_kw || !n_k || !out_doc) return LLDA_E_BAD_ARG;
     LParams P;
     P.doc_off = doc_off; P.word = word; P.lab_mask = lab_mask; P.n_dk = n_dk; P.n_kw = n_kw; P.n_k = n_k;
     P.out_doc = out_doc; P.D = D; P.alpha = alpha; P.beta = beta; P.vbeta = (double)V * beta;

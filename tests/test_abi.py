@@ -77,8 +77,15 @@ def test_device_entry_points_validate_arguments():
     L = _native.lib()
     assert L.llda_sweep(None, None) == -2
     a = _native.LldaSweepArgs()
+    a.D, a.V, a.K = 3, 10, 8
     assert L.llda_sweep(ctypes.byref(a), None) == -2                          # NULL pointers
+    a.K = 0
+    assert L.llda_sweep(ctypes.byref(a), None) == -1                          # bad K
+    a.D, a.K = 0, 8
+    assert L.llda_sweep(ctypes.byref(a), None) == 0                           # empty shard: nothing to do
     assert L.llda_apply_delta(None, None, 4, None) == -2
     assert L.llda_count_init(None, None, None, None, 1, 8, None, None, None, None) == -2
+    assert L.llda_count_init(None, None, None, None, 0, 8, None, None, None, None) == 0
     assert L.llda_loglik(None, None, None, None, None, None, 1, 1, 8, 0.1, 0.1, None, None) == -2
+    assert L.llda_foldin(None, None) == -2
     assert b"argument" in L.llda_strerror(-2)

@@ -161,3 +161,78 @@ def test_two_tier_draw_equals_exact_tier_on_a_large_dense_workload():
             s.sweep()
         runs.append((s.z.clone(), s.n_kw.clone()))
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
+def _run_vs_c(c_oracle, doc_off, word, freq, labs, z, K, V, alpha=0.1, beta=0.01, sweeps=2, **kw):
+    from lda_thesis_amd.sampler import GibbsSampler
+    s = GibbsSampler(doc_off, word, freq, z, K, V, alpha, beta, labs=labs, seed=7, **kw)
+    cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, alpha, beta)
+    for i in range(sweeps):
+        s.sweep()
+        cs.sweep(1, 7, i, doc_base=kw.get("doc_base", 0), threads=2)
+    np.testing.assert_array_equal(s.z_topics(), cs.z)
+    np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+    np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+    np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
+    s.check_status()
+    return s
+
+
+def test_edge_empty_shard_and_empty_documents(c_oracle):
+    from lda_thesis_amd.sampler import GibbsSampler
+    # a shard without documents: sweep is a no-op
+    s = GibbsSampler(np.array([0]), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int64), 9, 5, 0.1, 0.01,
+                     labs=np.zeros((0, 9), dtype=np.uint8))
+    s.sweep()
+    assert s.n_k_v().sum() == 0 and s.D == 0
+    # ragged: empty documents between one-site and long documents
+    rng = np.random.default_rng(1)
+    lens = np.array([0, 1, 0, 0, 130, 1, 2, 0, 77, 0])
+    off = np.concatenate([[0], np.cumsum(lens)])
+    word = np.concatenate([np.sort(rng.choice(200, size=n, replace=False)) for n in lens]).astype(np.int32)
+    freq = rng.integers(1, 5, size=off[-1]).astype(np.int32)
+    labs = np.ones((10, 24), dtype=np.uint8)
+    _run_vs_c(c_oracle, off, word, freq, labs, rng.integers(0, 24, size=off[-1]), 24, 200)
+
+
+@pytest.mark.parametrize("K", [1, 2, 8, 9, 1024])
+def test_edge_topic_counts(c_oracle, K):
+    rng = np.random.default_rng(K)
+    D, V = (12, 300) if K < 1024 else (6, 120)
+    lens = rng.integers(1, 40, size=D)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    word = np.concatenate([np.sort(rng.choice(V, size=n, replace=False)) for n in lens]).astype(np.int32)
+    freq = rng.integers(1, 3, size=off[-1]).astype(np.int32)
+    labs = np.ones((D, K), dtype=np.uint8)
+    _run_vs_c(c_oracle, off, word, freq, labs, rng.integers(0, K, size=off[-1]), K, V)
+
+
+def test_edge_large_frequencies_last_word_and_root_only_documents(c_oracle):
+    rng = np.random.default_rng(3)
+    D, K, V = 20, 40, 64
+    lens = rng.integers(1, V + 1, size=D)
+    lens[0] = V                                             # a document holding every word id, incl. V-1
+    off = np.concatenate([[0], np.cumsum(lens)])
+    word = np.concatenate([np.sort(rng.choice(V, size=n, replace=False)) for n in lens]).astype(np.int32)
+    freq = rng.integers(1, 100000, size=off[-1]).astype(np.int32)      # frequencies far above 1
+    labs = (rng.random((D, K)) < 0.1).astype(np.uint8)
+    labs[:, 0] = 1
+    labs[3] = 0; labs[3, 0] = 1                             # root is the only allowed topic
+    z = np.concatenate([rng.choice(np.nonzero(labs[d])[0], size=lens[d]) for d in range(D)])
+    s = _run_vs_c(c_oracle, off, word, freq, labs, z, K, V, sweeps=3, doc_base=2 ** 31 - 5)   # doc ids cross 2^31
+    assert (s.z_topics()[off[3]:off[4]] == 0).all()
+
+
+def test_edge_tiny_priors_take_the_exact_kernel(c_oracle):
+    """alpha, beta below 1e-6 are outside the tiered kernel's preconditions: the general kernel runs."""
+    rng = np.random.default_rng(4)
+    D, K, V = 30, 70, 90
+    lens = rng.integers(1, 30, size=D)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    word = np.concatenate([np.sort(rng.choice(V, size=n, replace=False)) for n in lens]).astype(np.int32)
+    freq = np.ones(off[-1], dtype=np.int32)
+    labs = (rng.random((D, K)) < 0.3).astype(np.uint8)
+    labs[:, 0] = 1
+    z = np.concatenate([rng.choice(np.nonzero(labs[d])[0], size=lens[d]) for d in range(D)])
+    _run_vs_c(c_oracle, off, word, freq, labs, z, K, V, alpha=1e-9, beta=1e-8)
+    _run_vs_c(c_oracle, off, word, freq, labs, z, K, V, alpha=0.5, beta=3e10)        # V*beta >= 2^40
