@@ -110,18 +110,21 @@ class GibbsSampler(object):
 
         KP = lay.KP
         self.n_dk = torch.zeros((self.D, KP), dtype=torch.int32, device=dev)
-        self.n_kw = torch.zeros((self.V, KP), dtype=torch.int32, device=dev)
-        self.n_k = torch.zeros((KP,), dtype=torch.int32, device=dev)
-        self.n_kw_delta = torch.zeros((self.V, KP), dtype=torch.int32, device=dev)
-        self.n_k_delta = torch.zeros((KP,), dtype=torch.int32, device=dev)
+        # n_kw and n_k (and their delta buffers) are two views of ONE allocation each, so that the per-sweep
+        # exchange is a single all-reduce and the fold a single launch
+        self._counts = torch.zeros(((self.V + 1) * KP,), dtype=torch.int32, device=dev)
+        self._delta = torch.zeros(((self.V + 1) * KP,), dtype=torch.int32, device=dev)
+        self.n_kw = self._counts[:self.V * KP].view(self.V, KP)
+        self.n_k = self._counts[self.V * KP:]
+        self.n_kw_delta = self._delta[:self.V * KP].view(self.V, KP)
+        self.n_k_delta = self._delta[self.V * KP:]
         self.status = torch.zeros((4,), dtype=torch.int32, device=dev)   # [flags, tier-0 unsure, exact tier, -]
         if counts is None:
             self.backend.count_init(self.doc_off, self.word, self.freq, self.z, self.D, self.K,
                                     self.n_dk, self.n_kw, self.n_k)
             if self.sharded and _dist_active(self.group):
                 import torch.distributed as dist
-                dist.all_reduce(self.n_kw, group=self.group)
-                dist.all_reduce(self.n_k, group=self.group)
+                dist.all_reduce(self._counts, group=self.group)
         else:
             self.n_dk[:, self._topic_pos] = as_dev(counts["n_d_k"], torch.int32)
             self.n_kw[:, self._topic_pos] = as_dev(np.asarray(counts["n_k_v"]).T, torch.int32)
@@ -171,10 +174,8 @@ class GibbsSampler(object):
             self.kernel_events.append(ev)
         if self.sharded and _dist_active(self.group):
             import torch.distributed as dist
-            dist.all_reduce(self.n_kw_delta, group=self.group)      # RCCL over xGMI: SUM int32
-            dist.all_reduce(self.n_k_delta, group=self.group)
-        self.backend.apply_delta(self.n_kw, self.n_kw_delta)
-        self.backend.apply_delta(self.n_k, self.n_k_delta)
+            dist.all_reduce(self._delta, group=self.group)          # RCCL over xGMI: SUM int32, one collective
+        self.backend.apply_delta(self._counts, self._delta)
         self.sweeps_done += 1
 
     def check_status(self):
