@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 2
+#define LLDA_ABI_VERSION 3
 #define LLDA_MAX_K 1024
 #define LLDA_MAX_LEAVES 8
 #define LLDA_MAX_ROUNDS 4
@@ -84,7 +84,8 @@ typedef struct llda_sweep_args {
     int32_t        *n_k_delta;   /* [dev] [KP] += sweep changes                                */
     int32_t        *status;      /* [dev] optional (may be NULL), int32[4]: word 0 bit 0 is set when a site had no
                                     topic with positive probability (the reference would raise);
-                                    bit 1 (informational) when some site took the exact tier;
+                                    bit 1 (informational) when some site took the exact tier; bit 2 when
+                                    the sparse kernel's resume list overflowed (results invalid);
                                     word 1 += sites the fp32 tier was unsure about, word 2 += sites that
                                     reached the exact tier (statistics)                           */
     int64_t  D;                  /* local documents                                            */
@@ -102,6 +103,15 @@ typedef struct llda_sweep_args {
     uint32_t sweep;              /* RNG counter word 3                                         */
     uint32_t stream_id;          /* RNG counter word 2 (sub-problem id for CascadeLDA)         */
     int64_t  doc_base;           /* global id of local document 0 (RNG counter word 1)         */
+    /* optional sparse-label path (all four pointers non-NULL and live_max <= 64): one lane per allowed
+     * topic instead of one lane per 16 topics */
+    const int64_t *live_off;     /* [dev] [D+1] offsets into live_pos                              */
+    const int32_t *live_pos;     /* [dev] device positions of the topics every document allows, ascending */
+    int32_t       *resume;       /* [dev] [resume_cap * 66] scratch: documents handed from the sparse to the
+                                    dense kernel (doc, site, n_dk deltas of the allowed topics)     */
+    int32_t       *resume_count; /* [dev] [1] scratch (zeroed by llda_sweep)                          */
+    int32_t  resume_cap;         /* capacity of `resume` in documents                                */
+    int32_t  live_max;           /* largest number of allowed topics of any document                  */
 } llda_sweep_args;
 
 /* ---- host-only (no device needed) ---- */

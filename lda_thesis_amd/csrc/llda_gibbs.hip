@@ -30,6 +30,8 @@ namespace {
 
 thread_local int g_last_hip_error = 0;
 
+#define LLDA_MAX_LIVE 64   // most allowed topics per document the sparse kernel handles
+
 struct KParams {
     const int64_t *doc_off;
     const int32_t *doc_order;
@@ -54,6 +56,16 @@ struct KParams {
     int32_t xor_tree;       // leaves combine as p^1, p^2, p^4 (balanced recursion, no padded leaves)
     double margin_rel;      // tier-1 decision margin relative to the total score (2^-40; debug: wider / inf)
     float margin0_rel;      // tier-0 (fp32) margin (2^-16; >= 1 disables tier 0)
+    // sparse-label path: per document the device positions of its allowed topics, ascending
+    const int64_t *live_off;
+    const int32_t *live_pos;
+    int32_t KP;             // row length (the sparse kernel is not templated on the layout)
+    // hand-over from the sparse kernel to the dense tiered kernel: documents whose draw the sparse kernel
+    // could not decide within its margin continue there from the recorded site
+    int32_t *resume;        // [cap][2 + LLDA_MAX_LIVE]: doc, site, n_dk delta of the live topics so far
+    int32_t *resume_count;  // [1]
+    int32_t resume_cap;
+    int32_t resume_mode;    // 1: this launch of the dense kernel walks the resume list instead of all documents
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];   // 4 bits per leaf: partner leaf
 };
 
@@ -586,11 +598,11 @@ __device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, 
 // keyed uniform of site n: one Philox block serves sites 2b and 2b+1; the G lanes of the group compute G
 // consecutive blocks at once (every 2G sites) and hand them out by shuffle
 template <int G>
-__device__ __forceinline__ double site_uniform(const KParams &P, int n, uint32_t gdoc, int lig, uint32_t &r0,
-                                               uint32_t &r1, uint32_t &r2, uint32_t &r3)
+__device__ __forceinline__ double site_uniform(const KParams &P, int n, bool first, uint32_t gdoc, int lig,
+                                               uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t &r3)
 {
-    if ((n & (2 * G - 1)) == 0) {
-        r0 = (uint32_t)(n >> 1) + (uint32_t)lig; r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
+    if (first || (n & (2 * G - 1)) == 0) {
+        r0 = (uint32_t)((n >> 1) & ~(G - 1)) + (uint32_t)lig; r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
         philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
     }
     const int holder = (n >> 1) & (G - 1);
@@ -655,7 +667,7 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
                 const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);
                 v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
             }
-            const double u = site_uniform<G>(P, n, gdoc, lig, r0, r1, r2, r3);
+            const double u = site_uniform<G>(P, n, n == 0, gdoc, lig, r0, r1, r2, r3);
 
             // remove the site (LabeledLDA.py:109-111)
             {
@@ -744,13 +756,25 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
     const int grp = tid / G;
     const float vbeta32 = (float)P.vbeta, alpha32 = (float)P.alpha, beta32 = (float)P.beta;
 
-    for (int it = 0; it < P.dpg; ++it) {
-        const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
-        if (idx >= P.D) break;
-        const int64_t d = P.doc_order ? (int64_t)P.doc_order[idx] : idx;
+    const int n_resume = P.resume_mode ? min(*P.resume_count, P.resume_cap) : 0;
+    for (int it = 0; P.resume_mode || it < P.dpg; ++it) {
+        int64_t d;
+        int n0 = 0;                           // first site to sample (resume mode: where the sparse kernel stopped)
+        const int32_t *rec = nullptr;
+        if (P.resume_mode) {
+            const int64_t idx = ((int64_t)it * gridDim.x + blockIdx.x) * GPB + grp;
+            if (idx >= n_resume) break;
+            rec = P.resume + idx * (2 + LLDA_MAX_LIVE);
+            d = rec[0];
+            n0 = rec[1];
+        } else {
+            const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
+            if (idx >= P.D) break;
+            d = P.doc_order ? (int64_t)P.doc_order[idx] : idx;
+        }
         const int64_t s0 = P.doc_off[d];
         const int len = (int)(P.doc_off[d + 1] - s0);
-        if (len <= 0) continue;
+        if (len <= n0) continue;
 
         int32_t *ndk_row = P.n_dk + d * KP + lig * T;
         {
@@ -764,6 +788,19 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 s_rcp[s][tid] = __builtin_amdgcn_rcpf((float)k[s] + vbeta32);
             }
         }
+        if (rec) {
+            // resumed document: the n_k it sees already moved by its own earlier sites (n_dk row holds them)
+            const int64_t l0 = P.live_off[d];
+            const int A = (int)(P.live_off[d + 1] - l0);
+            for (int j = 0; j < A; ++j) {
+                const int pos = P.live_pos[l0 + j], dl = rec[2 + j];
+                if (dl != 0 && lig == pos / T) {
+                    const int nk = s_nkc[pos % T][tid] + dl;
+                    s_nkc[pos % T][tid] = nk;
+                    s_rcp[pos % T][tid] = __builtin_amdgcn_rcpf((float)nk + vbeta32);
+                }
+            }
+        }
         const uint32_t mask = P.lab_mask[d * G + lig];
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
 
@@ -772,8 +809,8 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         // site n+1.  Right after the single s_waitcnt vmcnt(0) of the iteration (first use of xn) the body
         // issues, in this order: the z store + two n_kw_delta atomics of site n-1, the row of site n+1,
         // the scalars of site n+2 -- so nothing the next wait covers is younger than one full site.
-        int v_c = P.word[s0], f_c = P.freq[s0], zo_c = P.z[s0];
-        const int64_t i1 = s0 + (len > 1 ? 1 : 0);
+        int v_c = P.word[s0 + n0], f_c = P.freq[s0 + n0], zo_c = P.z[s0 + n0];
+        const int64_t i1 = s0 + (n0 + 1 < len ? n0 + 1 : n0);
         int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1];
         int xn[T];
         load_row<T>(P.n_kw + (int64_t)v_c * KP + lig * T, xn);
@@ -785,7 +822,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             if (lig == lo) count_update(s_ndk, s_nkc, s_rcp, zo_c - lo * T, tid, vbeta32, -f_c);
         }
 
-        for (int n = 0; n < len; ++n) {
+        for (int n = n0; n < len; ++n) {
             const int v = v_c, f = f_c, zo = zo_c;
             int x[T];
 #pragma unroll
@@ -804,7 +841,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);  // scalars of site n+2 (clamped)
                 v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
             }
-            const double u = site_uniform<G>(P, n, gdoc, lig, r0, r1, r2, r3);
+            const double u = site_uniform<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3);
 
             // the site's own count leaves the fetched n_kw row (n_dk / n_k were updated already)
             {
@@ -857,6 +894,156 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         store_row<T>(ndk_row, cur);
     }
 
+    __syncthreads();
+    for (int i = tid; i < KP; i += 256) {
+        const int dl = s_nk[i];
+        if (dl) atomicAdd(P.n_k_delta + i, dl);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sweep kernel for sparse label sets (Labeled LDA proper: a handful of allowed topics out of hundreds,
+// e.g. 4.6 of 392 on the abstracts corpus).  One lane per ALLOWED topic, GS = 8..64 lanes per document
+// (64/GS documents per wavefront); per site each lane gathers its single n_kw entry, so the traffic is
+// 4*A + 32 bytes instead of a 4*KP-byte row.  All per-topic state (n_dk, the n_k the document sees, the
+// reciprocal of n_k + V*beta) is a scalar register of the owning lane.
+// The draw is the tier-1 decision of DESIGN.md section 4.3 restricted to the live topics: inclusive scan of
+// the unnormalised fp64 scores in device-position order, first lane with Q > u*total, sure when every
+// |Q - u*total| exceeds 2^-40 of the total.  A document with an unsure site (probability ~1e-11 per site)
+// is handed to the dense tiered kernel, which continues from that site (resume list).
+// Preconditions as for llda_sweep_kernel (alpha, beta >= 1e-6, V*beta < 2^40).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_newton(double den)
+{
+    double y = __builtin_amdgcn_rcp(den);                    // hardware estimate, then two Newton steps:
+    y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);    // within a few 2^-53 of 1/den
+    return __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+}
+
+// inclusive scan over the GS lanes of a group, any association order (DPP within 16-lane rows + row carries)
+template <int GS>
+__device__ __forceinline__ double scan_any_f64(double X, int lig)
+{
+    if constexpr (GS == 8) {
+        double y;
+        y = dpp_f64<DPP_ROW_SHR + 1>(X); X = X + ((lig >= 1) ? y : 0.0);
+        y = dpp_f64<DPP_ROW_SHR + 2>(X); X = X + ((lig >= 2) ? y : 0.0);
+        y = dpp_f64<DPP_ROW_SHR + 4>(X); X = X + ((lig >= 4) ? y : 0.0);
+        return X;
+    } else {
+        X = X + dpp_f64<DPP_ROW_SHR + 1>(X);
+        X = X + dpp_f64<DPP_ROW_SHR + 2>(X);
+        X = X + dpp_f64<DPP_ROW_SHR + 4>(X);
+        X = X + dpp_f64<DPP_ROW_SHR + 8>(X);
+        if constexpr (GS >= 32) {           // carry the totals of the 16-lane rows upwards, row by row
+            const double c1 = __shfl(X, 15, GS);
+            X = X + ((lig >= 16 && lig < 32) ? c1 : 0.0);
+        }
+        if constexpr (GS == 64) {
+            const double c2 = __shfl(X, 31, GS);
+            X = X + ((lig >= 32 && lig < 48) ? c2 : 0.0);
+            const double c3 = __shfl(X, 47, GS);
+            X = X + ((lig >= 48) ? c3 : 0.0);
+        }
+        return X;
+    }
+}
+
+template <int GS>
+__global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
+{
+    constexpr int GPB = 256 / GS;
+    __shared__ int s_nk[LLDA_MAX_K];          // workgroup accumulator of the n_k changes
+    const int tid = threadIdx.x;
+    const int KP = P.KP;
+    for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
+    __syncthreads();
+    const int lane = tid & 63;
+    const int lig = tid & (GS - 1);
+    const int grp = tid / GS;
+    const int gbase = lane & ~(GS - 1);
+    const uint64_t gmask = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
+
+    for (int it = 0; it < P.dpg; ++it) {
+        const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
+        if (idx >= P.D) break;
+        const int64_t d = P.doc_order ? (int64_t)P.doc_order[idx] : idx;
+        const int64_t s0 = P.doc_off[d];
+        const int len = (int)(P.doc_off[d + 1] - s0);
+        if (len <= 0) continue;
+        const int64_t l0 = P.live_off[d];
+        const int A = (int)(P.live_off[d + 1] - l0);
+        const bool live = lig < A;
+        const int pos = live ? P.live_pos[l0 + lig] : -1;
+        int32_t *ndk_p = P.n_dk + d * KP + (live ? pos : 0);
+        int ndk = live ? *ndk_p : 0;
+        const int ndk0 = ndk;
+        int nk = live ? P.n_k[pos] : 0;
+        double y = rcp_newton((double)nk + P.vbeta);
+        const uint32_t gdoc = (uint32_t)(d + P.doc_base);
+
+        // memory pipeline as in llda_sweep_kernel; the "row" of a site is one gathered entry per lane
+        int v_c = P.word[s0], f_c = P.freq[s0], zo_c = P.z[s0];
+        const int64_t i1 = s0 + (len > 1 ? 1 : 0);
+        int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1];
+        int xn = live ? P.n_kw[(int64_t)v_c * KP + pos] : 0;
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        int64_t pend_i = -1;
+        int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0;
+        if (pos == zo_c) { ndk -= f_c; nk -= f_c; y = rcp_newton((double)nk + P.vbeta); }   // site 0 leaves its topic
+        int stop_at = -1;
+
+        for (int n = 0; n < len; ++n) {
+            const int v = v_c, f = f_c, zo = zo_c;
+            int x = xn;
+            if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
+            pend_i = -1;
+            xn = live ? P.n_kw[(int64_t)v_1 * KP + pos] : 0;
+            v_c = v_1; f_c = f_1; zo_c = zo_1;
+            {
+                const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);
+                v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
+            }
+            const double u = site_uniform<GS>(P, n, n == 0, gdoc, lig, r0, r1, r2, r3);
+
+            x -= (pos == zo) ? f : 0;                       // the site's own count leaves the gathered entry
+            const double w = live ? ((double)ndk + P.alpha) * (((double)x + P.beta) * y) : 0.0;
+            const double Q = scan_any_f64<GS>(w, lig);
+            const double tot = bcast_last<GS>(Q, lane);
+            const double t = u * tot, margin = tot * P.margin_rel;
+            const bool unsure = (live && !(fabs(Q - t) > margin)) || !(tot > 0.0) || !(margin < tot);
+            if (((__ballot(unsure) >> gbase) & gmask) != 0) { stop_at = n; break; }
+            const uint64_t gf = (__ballot(live && Q > t) >> gbase) & gmask;
+            const int sel = gf ? (int)__ffsll((unsigned long long)gf) - 1 : A - 1;      // none: last allowed topic
+            const int zn = __shfl(pos, sel, GS);
+
+            // add the site back and take the next site out of its topic
+            const int dl = ((pos == zn) ? f : 0) - ((n + 1 < len && pos == zo_c) ? f_c : 0);
+            if (dl != 0) { ndk += dl; nk += dl; y = rcp_newton((double)nk + P.vbeta); }
+            pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn;
+        }
+        if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
+
+        if (stop_at >= 0) {
+            // hand the document over: undo the removal of the undecided site, record (doc, site, deltas so far)
+            const int zo = P.z[s0 + stop_at], f = P.freq[s0 + stop_at];
+            if (pos == zo) ndk += f;
+            int slot = 0;
+            if (lig == 0) slot = atomicAdd(P.resume_count, 1);
+            slot = __shfl(slot, 0, GS);
+            if (slot < P.resume_cap) {
+                int32_t *rec = P.resume + (int64_t)slot * (2 + LLDA_MAX_LIVE);
+                if (lig == 0) { rec[0] = (int32_t)d; rec[1] = stop_at; }
+                if (live) rec[2 + lig] = ndk - ndk0;
+            } else if (lig == 0 && P.status) {
+                atomicOr(P.status, 4);                  // resume list overflow (cannot happen with production margins)
+            }
+        }
+        if (live) {
+            *ndk_p = ndk;
+            if (ndk != ndk0) atomicAdd(&s_nk[pos], ndk - ndk0);
+        }
+    }
     __syncthreads();
     for (int i = tid; i < KP; i += 256) {
         const int dl = s_nk[i];
@@ -1401,7 +1588,24 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     P.key0 = (uint32_t)a->seed; P.key1 = (uint32_t)(a->seed >> 32);
     P.sweep = a->sweep; P.stream_id = a->stream_id;
     fill_schedule(L, P.last_leaf, P.tail, P.tail_row, P.n_rounds, P.xor_tree, P.rounds_pk);
-    const int gpb = 256 / L.G;
+    P.KP = L.KP;
+    const bool has_tail = L.tail != 0;
+    // with alpha, beta >= 1e-6 and int32 counts no label-allowed score can underflow to zero ...
+    // ... and with V*beta < 2^40 the fp32 / fp64 reciprocals of n_k + V*beta stay in range
+    const bool fast = a->alpha >= 1e-6 && a->beta >= 1e-6 && P.vbeta < 1099511627776.0;
+    // all-ones label masks and no padded slots: the mask need not be applied at all
+    const bool dense = fast && a->dense_mask != 0 && L.K == L.KP;
+    // debug_margin: 0 = production margins; n > 0 = 2^-n (wider: more fallbacks); -1 = always exact tier;
+    // -2 = no fp32 tier
+    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
+    P.margin0_rel = a->debug_margin == 0 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
+    hipStream_t st = (hipStream_t)stream;
+
+    // sparse label sets: one lane per allowed topic, undecided documents continue in the dense kernel
+    const bool sparse = fast && !dense && a->live_off && a->live_pos && a->resume && a->resume_count &&
+                        a->resume_cap > 0 && a->live_max >= 1 && a->live_max <= LLDA_MAX_LIVE;
+    const int G = sparse ? (a->live_max <= 8 ? 8 : a->live_max <= 16 ? 16 : a->live_max <= 32 ? 32 : 64) : L.G;
+    const int gpb = 256 / G;
     int dpg = a->docs_per_group;
     if (dpg < 1) {
         // auto: aim for >= 16 workgroups per CU so the hardware dispatcher balances ragged documents
@@ -1414,16 +1618,35 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     const int64_t per_block = (int64_t)gpb * dpg;
     const int64_t blocks = (a->D + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const bool has_tail = L.tail != 0;
-    // with alpha, beta >= 1e-6 and int32 counts no label-allowed score can underflow to zero
-    // ... and with V*beta < 2^40 the integer n_k is recoverable from the cached fl(n_k + V*beta)
-    const bool fast = a->alpha >= 1e-6 && a->beta >= 1e-6 && P.vbeta < 1099511627776.0;
-    // all-ones label masks and no padded slots: the mask need not be applied at all
-    const bool dense = fast && a->dense_mask != 0 && L.K == L.KP;
-    // debug_margin: 0 = production margin 2^-40; n > 0 = 2^-n (wider: more fallbacks); < 0 = always exact tier
-    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
-    P.margin0_rel = a->debug_margin == 0 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
+
+    if (sparse) {
+        P.live_off = a->live_off; P.live_pos = a->live_pos;
+        P.resume = a->resume; P.resume_count = a->resume_count; P.resume_cap = a->resume_cap;
+        hipError_t e = hipMemsetAsync(a->resume_count, 0, sizeof(int32_t), st);
+        if (e != hipSuccess) return hip_fail(e);
+        if (a->debug_margin < 0) P.margin_rel = 2.0;       // test hook: every document is handed to the dense kernel
+        const dim3 grid((unsigned)blocks), block(256);
+        switch (G) {
+        case 8: hipLaunchKernelGGL(llda_sweep_sparse_kernel<8>, grid, block, 0, st, P); break;
+        case 16: hipLaunchKernelGGL(llda_sweep_sparse_kernel<16>, grid, block, 0, st, P); break;
+        case 32: hipLaunchKernelGGL(llda_sweep_sparse_kernel<32>, grid, block, 0, st, P); break;
+        default: hipLaunchKernelGGL(llda_sweep_sparse_kernel<64>, grid, block, 0, st, P); break;
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e);
+        // second launch: the dense tiered kernel walks the (almost always empty) resume list
+        P.resume_mode = 1;
+        P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
+        int64_t rblocks = ((int64_t)a->resume_cap + (256 / L.G) - 1) / (256 / L.G);
+        if (rblocks > 256) rblocks = 256;
+        switch (L.G) {
+        case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, true, false, rblocks, st);
+        case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, true, false, rblocks, st);
+        case 32: return dispatch_sweep_T<32>(L.T, P, has_tail, true, false, rblocks, st);
+        case 64: return dispatch_sweep_T<64>(L.T, P, has_tail, true, false, rblocks, st);
+        }
+        return LLDA_E_BAD_K;
+    }
     switch (L.G) {
     case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, fast, dense, blocks, st);
     case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, fast, dense, blocks, st);

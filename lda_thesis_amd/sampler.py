@@ -57,6 +57,8 @@ class GibbsSampler(object):
                layout for the LOCAL documents / GLOBAL matrices (keeps e.g. SubLDA's phantom columns).
     seed, stream_id, doc_base : RNG key / counter words (doc_base = global id of local doc 0).
     group    : torch.distributed process group (None = default group when initialised).
+    sparse_labels : True (default) = documents that allow few topics run through the sparse kernel when it
+               fits (<= 64 allowed topics, at most a quarter of K); False forces the dense kernel.
     sharded  : True (default) = the local documents are one shard of a corpus spread over the ranks
                of ``group``: deltas are all-reduced every sweep.  False = a self-contained problem
                (e.g. one CascadeLDA sub-problem per GPU): no collective at all.
@@ -66,7 +68,7 @@ class GibbsSampler(object):
 
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
                  stream_id=0, doc_base=0, device=None, group=None, backend=None, sort_docs=True,
-                 docs_per_group=0, sharded=True):
+                 docs_per_group=0, sharded=True, sparse_labels=True):
         self.backend = backend if backend is not None else _native
         if backend is None:
             _native.lib()                                   # fail loudly when the extension is missing
@@ -102,6 +104,12 @@ class GibbsSampler(object):
 
         self.lab_mask = self._make_masks(labs)
         self.dense_mask = labs is None
+        # sparse label sets (Labeled LDA proper): positions of the allowed topics per document, ascending;
+        # the library then runs one lane per ALLOWED topic (llda_sweep_sparse_kernel)
+        self.live_off = self.live_pos = self.resume = self.resume_count = None
+        self.live_max = 0
+        if sparse_labels and labs is not None and self.D > 0:
+            self._make_live()
         lens = (self.doc_off[1:] - self.doc_off[:-1])
         self.doc_order = None
         if sort_docs and self.D > 1 and int(lens.min()) != int(lens.max()):
@@ -154,6 +162,24 @@ class GibbsSampler(object):
         m = torch.where(m >= 32768, m - 65536, m).to(torch.int16).contiguous()
         return m
 
+    def _make_live(self):
+        lay, dev = self.layout, self.device
+        bits = (self.lab_mask.to(torch.int32) & 0xFFFF)                       # (D, G) lane masks
+        shifts = torch.arange(lay.T, device=dev, dtype=torch.int32)
+        allowed = ((bits.unsqueeze(-1) >> shifts) & 1).reshape(self.D, lay.KP)  # device order already
+        counts = allowed.sum(dim=1)
+        live_max = int(counts.max().item())
+        if live_max > 64 or live_max * 4 > self.K:
+            return                                                             # dense kernel is the better fit
+        rows, pos = torch.nonzero(allowed, as_tuple=True)                      # row-major => positions ascending
+        self.live_off = torch.zeros((self.D + 1,), dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=self.live_off[1:])
+        self.live_pos = pos.to(torch.int32).contiguous()
+        self.live_max = live_max
+        cap = min(self.D, 1 << 16)
+        self.resume = torch.zeros((cap, 66), dtype=torch.int32, device=dev)
+        self.resume_count = torch.zeros((1,), dtype=torch.int32, device=dev)
+
     # ------------------------------------------------------------------ the hot path
     def sweep(self):
         """One Gibbs sweep over the local documents + exchange + fold."""
@@ -168,7 +194,8 @@ class GibbsSampler(object):
                            beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
                            stream_id=self.stream_id, doc_base=self.doc_base,
                            docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
-                           debug_margin=self.debug_margin)
+                           debug_margin=self.debug_margin, live_off=self.live_off, live_pos=self.live_pos,
+                           resume=self.resume, resume_count=self.resume_count, live_max=self.live_max)
         if ev is not None:
             ev[1].record()
             self.kernel_events.append(ev)
@@ -180,7 +207,10 @@ class GibbsSampler(object):
 
     def check_status(self):
         """Raise like the reference would (numpy's multinomial rejects a NaN pvals vector)."""
-        if int(self.status[0].item()) & 1:
+        st = int(self.status[0].item())
+        if st & 4:
+            raise _native.NativeError("sparse kernel: resume list overflow")
+        if st & 1:
             raise ValueError("a site had no topic with positive probability (pvals would be NaN)")
 
     # ------------------------------------------------------------------ read-outs

@@ -236,3 +236,54 @@ def test_edge_tiny_priors_take_the_exact_kernel(c_oracle):
     z = np.concatenate([rng.choice(np.nonzero(labs[d])[0], size=lens[d]) for d in range(D)])
     _run_vs_c(c_oracle, off, word, freq, labs, z, K, V, alpha=1e-9, beta=1e-8)
     _run_vs_c(c_oracle, off, word, freq, labs, z, K, V, alpha=0.5, beta=3e10)        # V*beta >= 2^40
+
+
+# ---- sparse-label kernel (one lane per allowed topic) -------------------------------------------------
+@pytest.mark.parametrize("margin", [0, 6, -1])
+@pytest.mark.parametrize("name", ["tiny_k40", "tiny_k392", "tiny_k200", "sublda"])
+def test_sparse_kernel_matches_reference_o3(name, margin):
+    """fixtures whose documents allow few topics run through llda_sweep_sparse_kernel; margin 6 hands many
+    documents over to the dense kernel mid-way, -1 hands over every document at its first site."""
+    g = load_golden(name)
+    s = make_sampler(g)
+    if s.live_off is None:
+        pytest.skip("label sets too dense for the sparse kernel")
+    s.debug_margin = margin
+    for i in range(int(g["sweeps"])):
+        s.sweep()
+        assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics(), name)
+    s.check_status()
+
+
+def test_sparse_and_dense_kernels_agree_on_a_large_sparse_workload(c_oracle):
+    import torch
+    from lda_thesis_amd.corpus import synthetic_corpus
+    from lda_thesis_amd.sampler import GibbsSampler
+    D, N, V = 3000, 120, 5000
+    off, w, f, _ = synthetic_corpus(D, N, V, 8, seed=2, device="cuda")
+    rng = np.random.default_rng(0)
+    for K, nlab in ((392, 7), (512, 15), (100, 20)):
+        labs = np.zeros((D, K), dtype=np.uint8)
+        labs[:, 0] = 1
+        for d in range(D):
+            labs[d, rng.choice(K - 1, size=int(rng.integers(0, nlab + 1)), replace=False) + 1] = 1
+        z = np.concatenate([rng.choice(np.nonzero(labs[d])[0], size=N) for d in range(D)])
+        runs = []
+        for sparse in (True, False):
+            s = GibbsSampler(off, w, f, z, K, V, 0.1, 0.01, labs=labs, seed=11, sparse_labels=sparse)
+            assert (s.live_off is not None) == sparse
+            for _ in range(3):
+                s.sweep()
+            s.check_status()
+            runs.append((s.z.clone(), s.n_kw.clone(), s.n_dk.clone(), s.n_k.clone()))
+        for a, b in zip(*runs):
+            assert torch.equal(a, b)
+    # and against the C oracle for the last configuration
+    cs = c_oracle.CState(off.cpu().numpy(), w.cpu().numpy(), f.cpu().numpy(), z, labs,
+                         np.zeros((D, K), dtype=np.int64), np.zeros((K, V), dtype=np.int64), np.zeros(K, dtype=np.int64),
+                         V, 0.1, 0.01)
+    s0 = GibbsSampler(off, w, f, z, K, V, 0.1, 0.01, labs=labs, seed=11)
+    cs.n_d_k[:], cs.n_k_v[:], cs.n_zk[:] = s0.n_d_k(), s0.n_k_v(), s0.n_zk()
+    for i in range(3):
+        cs.sweep(1, 11, i, threads=8)
+    np.testing.assert_array_equal(s.z_topics(), cs.z)
