@@ -35,6 +35,9 @@ WORKLOADS = {
                "(BASELINE configs[3])"),
     "synth1": (100000, 200, 50000, 128,
                "synthetic 100k docs x 200 tokens, K=128 dense mask, V=50k (BASELINE configs[2])"),
+    "synth2_sparse": (125000, 300, 100000, 512,
+                      "synthetic 1M docs x 300 tokens, K=512, sparse label mask (root + 7 random labels per doc), "
+                      "V=100k, doc-sharded: 125k docs per GPU (secondary variant of BASELINE configs[3])"),
     # real corpus: tokenised abstracts_data.csv, depth 3 (tests/golden/abstracts_d3.npz); sizes read from the file
     "abstracts": (4171, 0, 0, 392,
                   "Labeled LDA on abstracts_data.csv, depth 3, K=392 sparse label masks (BASELINE configs[0]/[1]); "
@@ -130,6 +133,22 @@ def main():
         sampler = GibbsSampler(doc_off, word, freq, g["z_init"].astype(np.int64), K, V, alpha, beta,
                                labs=(g["lab_off"], g["lab_idx"].astype(np.int64)), counts=None, seed=42 + rank,
                                device=dev, docs_per_group=args.docs_per_group, sharded=False)
+    elif args.workload == "synth2_sparse":
+        doc_off, word, freq, _ = synthetic_corpus(Dg, N, V, K, seed=1234 + rank, device=dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(99 + rank)
+        # root + 7 distinct random labels per document: sort 8 draws, bump duplicates (still <= K-1)
+        lab = torch.sort(torch.randint(1, K - 8, (Dg, 7), device=dev, generator=gen), dim=1).values
+        lab = lab + torch.arange(7, device=dev)              # strictly increasing => distinct
+        lab = torch.cat([torch.zeros((Dg, 1), dtype=lab.dtype, device=dev), lab], dim=1)
+        live_topics = 8.0
+        pick = torch.randint(0, 8, (Dg * N,), device=dev, generator=gen)
+        z = lab.repeat_interleave(N, dim=0)[torch.arange(Dg * N, device=dev), pick]
+        lab_off = np.arange(0, 8 * Dg + 1, 8, dtype=np.int64)
+        sampler = GibbsSampler(doc_off, word, freq, z, K, V, alpha, beta, labs=(lab_off, lab.reshape(-1).cpu().numpy()),
+                               counts=None, seed=42, doc_base=rank * Dg, device=dev,
+                               docs_per_group=args.docs_per_group)
+        del z
     else:
         doc_off, word, freq, z = synthetic_corpus(Dg, N, V, K, seed=1234 + rank, device=dev)
         sampler = GibbsSampler(doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=42,
@@ -182,7 +201,8 @@ def main():
             "data": "synthetic" if args.workload != "abstracts" else "tokenised abstracts_data.csv (fixture)",
             "config": {"workload": desc, "docs_per_gpu": Dg, "sites_per_doc": N, "K": K, "V": V,
                        "alpha": alpha, "beta": beta,
-                       "label_mask": "dense" if args.workload != "abstracts" else "sparse (%.2f live topics per doc)" % live_topics,
+                       "label_mask": "dense" if live_topics == K else "sparse (%.2f live topics per doc)" % live_topics,
+                       "kernel": "sparse" if sampler.live_off is not None else "dense",
                        "sites_per_sweep": total_sites,
                        "exchange": "RCCL all-reduce of int32 n_kw/n_k deltas per sweep" if world > 1 else "none",
                        "semantics": "per-document snapshot (bit-exact vs the reference under O3)"},
@@ -197,6 +217,10 @@ def main():
             h_off = doc_off.cpu().numpy()
             n_py, n_c = min(Dg, 400), min(Dg, 1000)
             labs_h = None
+            if args.workload == "synth2_sparse":
+                labs_h = np.zeros((max(n_py, n_c), K), dtype=np.uint8)
+                lh = lab[:max(n_py, n_c)].cpu().numpy()
+                labs_h[np.repeat(np.arange(lh.shape[0]), 8), lh.reshape(-1)] = 1
             if args.workload == "abstracts":          # the whole corpus: one sweep of the numpy loop is ~4 s
                 n_py = n_c = Dg
                 labs_h = np.zeros((Dg, K), dtype=np.uint8)
