@@ -949,6 +949,87 @@ __device__ __forceinline__ double scan_any_f64(double X, int lig)
     }
 }
 
+// value of lane J (J < 8, compile time) of the caller's GS-lane group, in every lane of the group
+template <int GS, int J>
+__device__ __forceinline__ int bcast_lane(int v, int lig)
+{
+    if constexpr (GS <= 16) {
+        constexpr int QP = (J & 3) * 0x55;                                  // quad_perm [j,j,j,j]
+        const int q = __builtin_amdgcn_update_dpp(0, v, QP, 0xF, 0xF, false);
+        int r;
+        if constexpr ((J >> 2) == 0) {                                      // source quad is the lower one of its 8
+            const int up = __builtin_amdgcn_update_dpp(0, q, DPP_ROW_SHR + 4, 0xF, 0xF, false);
+            r = (lig & 4) ? up : q;
+        } else {
+            const int dn = __builtin_amdgcn_update_dpp(0, q, 0x100 + 4, 0xF, 0xF, false);   // row_shl:4
+            r = (lig & 4) ? q : dn;
+        }
+        if constexpr (GS == 16) {                                           // upper 8 lanes take it from the lower 8
+            const int up8 = __builtin_amdgcn_update_dpp(0, r, DPP_ROW_SHR + 8, 0xF, 0xF, false);
+            r = (lig & 8) ? up8 : r;
+        }
+        return r;
+    } else {
+        return __shfl(v, J, GS);
+    }
+}
+
+// sum over the GS lanes of a group in every lane (any association order)
+template <int GS>
+__device__ __forceinline__ double allsum_any_f64(double x, int lane)
+{
+    x = x + dpp_f64<DPP_XOR1>(x);
+    x = x + dpp_f64<DPP_XOR2>(x);
+    x = x + dpp_f64<DPP_HALF_MIRROR>(x);
+    if constexpr (GS >= 16) x = x + dpp_f64<DPP_ROW_ROR + 8>(x);
+    if constexpr (GS >= 32) x = x + xor16_f64(x, lane);
+    if constexpr (GS == 64) x = x + xor32_f64(x, lane);
+    return x;
+}
+
+// OR over the GS lanes of a group in every lane
+template <int GS>
+__device__ __forceinline__ int allor_i32(int x, int lane)
+{
+    x |= __builtin_amdgcn_update_dpp(0, x, DPP_XOR1, 0xF, 0xF, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, DPP_XOR2, 0xF, 0xF, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, DPP_HALF_MIRROR, 0xF, 0xF, false);
+    if constexpr (GS >= 16) x |= __builtin_amdgcn_update_dpp(0, x, DPP_ROW_ROR + 8, 0xF, 0xF, false);
+    if constexpr (GS >= 32) x |= __shfl_xor(x, 16, GS);
+    if constexpr (GS == 64) x |= __shfl_xor(x, 32, GS);
+    return x;
+}
+
+// One site of the sparse kernel (J = index inside the current batch of 8 sites).  Returns false when the
+// draw cannot be decided within the margin (the document is then handed to the dense kernel).
+template <int GS, int J>
+__device__ __forceinline__ bool sparse_site(const KParams &P, int nb, int sv, int sf, int sz, int su_lo, int su_hi,
+                                            const int (&xg)[8], bool live, int pos, int A, int &ndk, int &nk, double &y,
+                                            int &my_zn, int lig, int lane, int gbase, uint64_t gmask)
+{
+    if (J >= nb) return true;
+    const int f = bcast_lane<GS, J>(sf, lig), zo = bcast_lane<GS, J>(sz, lig);
+    const double u = __hiloint2double(bcast_lane<GS, J>(su_hi, lig), bcast_lane<GS, J>(su_lo, lig));
+    if (pos == zo) { ndk -= f; nk -= f; y = rcp_newton((double)nk + P.vbeta); }     // LabeledLDA.py:109-111
+    const int x = xg[J] - ((pos == zo) ? f : 0);
+    const double w = live ? ((double)ndk + P.alpha) * (((double)x + P.beta) * y) : 0.0;
+    const double Q = scan_any_f64<GS>(w, lig);
+    const double tot = allsum_any_f64<GS>(w, lane);
+    const double t = u * tot, margin = tot * P.margin_rel;
+    const bool unsure = (live && !(fabs(Q - t) > margin)) || !(tot > 0.0) || !(margin < tot);
+    if (((__ballot(unsure) >> gbase) & gmask) != 0) {
+        if (pos == zo) { ndk += f; nk += f; }               // undo: the dense kernel starts at this site
+        return false;
+    }
+    const uint64_t gf = (__ballot(live && Q > t) >> gbase) & gmask;
+    const int sel = gf ? (int)__ffsll((unsigned long long)gf) - 1 : A - 1;          // none: last allowed topic
+    const int zn = allor_i32<GS>((lig == sel) ? pos : 0, lane);
+    if (pos == zn) { ndk += f; nk += f; y = rcp_newton((double)nk + P.vbeta); }     // LabeledLDA.py:121-125
+    if (lig == J) my_zn = zn;
+    (void)sv;
+    return true;
+}
+
 template <int GS>
 __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
 {
@@ -981,53 +1062,57 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
         int nk = live ? P.n_k[pos] : 0;
         double y = rcp_newton((double)nk + P.vbeta);
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
-
-        // memory pipeline as in llda_sweep_kernel; the "row" of a site is one gathered entry per lane
-        int v_c = P.word[s0], f_c = P.freq[s0], zo_c = P.z[s0];
-        const int64_t i1 = s0 + (len > 1 ? 1 : 0);
-        int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1];
-        int xn = live ? P.n_kw[(int64_t)v_c * KP + pos] : 0;
-        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        int64_t pend_i = -1;
-        int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0;
-        if (pos == zo_c) { ndk -= f_c; nk -= f_c; y = rcp_newton((double)nk + P.vbeta); }   // site 0 leaves its topic
         int stop_at = -1;
 
-        for (int n = 0; n < len; ++n) {
-            const int v = v_c, f = f_c, zo = zo_c;
-            int x = xn;
-            if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
-            pend_i = -1;
-            xn = live ? P.n_kw[(int64_t)v_1 * KP + pos] : 0;
-            v_c = v_1; f_c = f_1; zo_c = zo_1;
-            {
-                const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);
-                v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
+        // Sites are processed in batches of 8 so that memory latency is paid once per batch: lane j < 8 of
+        // the group loads the scalars of site n0+j and draws its uniform, every lane gathers its own topic's
+        // n_kw entry for all 8 words, then 8 sites run back to back on registers / DPP only, and lane j
+        // commits site n0+j (z store + two atomics) while the next batch loads.
+        for (int n0 = 0; n0 < len && stop_at < 0; n0 += 8) {
+            const int nb = min(8, len - n0);
+            const int jj = lig & 7;
+            const int64_t si = s0 + n0 + (jj < nb ? jj : nb - 1);
+            const int sv = P.word[si], sf = P.freq[si], sz = P.z[si];
+            int su_lo, su_hi;
+            {   // keyed uniform of site n0+jj: Philox block (site >> 1), words (0,1) / (2,3) by parity
+                const int n = n0 + jj;
+                uint32_t c0 = (uint32_t)(n >> 1), c1 = gdoc, c2 = P.stream_id, c3 = P.sweep;
+                philox4x32_10(c0, c1, c2, c3, P.key0, P.key1);
+                const uint32_t ra = (n & 1) ? c2 : c0, rb = (n & 1) ? c3 : c1;
+                const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+                su_lo = __double2loint(u); su_hi = __double2hiint(u);
             }
-            const double u = site_uniform<GS>(P, n, n == 0, gdoc, lig, r0, r1, r2, r3);
+            // (the broadcasts must run in ALL lanes: a DPP read from a lane that is masked off returns 0)
+            const int w0 = bcast_lane<GS, 0>(sv, lig), w1 = bcast_lane<GS, 1>(sv, lig), w2 = bcast_lane<GS, 2>(sv, lig),
+                      w3 = bcast_lane<GS, 3>(sv, lig), w4 = bcast_lane<GS, 4>(sv, lig), w5 = bcast_lane<GS, 5>(sv, lig),
+                      w6 = bcast_lane<GS, 6>(sv, lig), w7 = bcast_lane<GS, 7>(sv, lig);
+            int xg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (live) {
+                const int32_t *col = P.n_kw + pos;
+                xg[0] = col[(int64_t)w0 * KP]; xg[1] = col[(int64_t)w1 * KP]; xg[2] = col[(int64_t)w2 * KP];
+                xg[3] = col[(int64_t)w3 * KP]; xg[4] = col[(int64_t)w4 * KP]; xg[5] = col[(int64_t)w5 * KP];
+                xg[6] = col[(int64_t)w6 * KP]; xg[7] = col[(int64_t)w7 * KP];
+            }
 
-            x -= (pos == zo) ? f : 0;                       // the site's own count leaves the gathered entry
-            const double w = live ? ((double)ndk + P.alpha) * (((double)x + P.beta) * y) : 0.0;
-            const double Q = scan_any_f64<GS>(w, lig);
-            const double tot = bcast_last<GS>(Q, lane);
-            const double t = u * tot, margin = tot * P.margin_rel;
-            const bool unsure = (live && !(fabs(Q - t) > margin)) || !(tot > 0.0) || !(margin < tot);
-            if (((__ballot(unsure) >> gbase) & gmask) != 0) { stop_at = n; break; }
-            const uint64_t gf = (__ballot(live && Q > t) >> gbase) & gmask;
-            const int sel = gf ? (int)__ffsll((unsigned long long)gf) - 1 : A - 1;      // none: last allowed topic
-            const int zn = __shfl(pos, sel, GS);
-
-            // add the site back and take the next site out of its topic
-            const int dl = ((pos == zn) ? f : 0) - ((n + 1 < len && pos == zo_c) ? f_c : 0);
-            if (dl != 0) { ndk += dl; nk += dl; y = rcp_newton((double)nk + P.vbeta); }
-            pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn;
+            int my_zn = sz;
+            bool ok = true;
+            int done = 0;                     // sites of this batch that were decided
+#define LLDA_SPARSE_SITE(J)                                                                                    \
+            if (ok) {                                                                                          \
+                ok = sparse_site<GS, J>(P, nb, sv, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, y, my_zn, \
+                                        lig, lane, gbase, gmask);                                              \
+                if (ok && J < nb) done = J + 1;                                                                \
+            }
+            LLDA_SPARSE_SITE(0) LLDA_SPARSE_SITE(1) LLDA_SPARSE_SITE(2) LLDA_SPARSE_SITE(3)
+            LLDA_SPARSE_SITE(4) LLDA_SPARSE_SITE(5) LLDA_SPARSE_SITE(6) LLDA_SPARSE_SITE(7)
+#undef LLDA_SPARSE_SITE
+            if (!ok) stop_at = n0 + done;
+            // commit the decided sites of the batch: lane j handles site n0+j
+            if (lig < 8 && lig < done) commit_site(P, s0 + n0 + lig, sv, sf, sz, my_zn, KP);
         }
-        if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
 
         if (stop_at >= 0) {
-            // hand the document over: undo the removal of the undecided site, record (doc, site, deltas so far)
-            const int zo = P.z[s0 + stop_at], f = P.freq[s0 + stop_at];
-            if (pos == zo) ndk += f;
+            // hand the document over to the dense kernel: record (doc, site, n_dk deltas so far)
             int slot = 0;
             if (lig == 0) slot = atomicAdd(P.resume_count, 1);
             slot = __shfl(slot, 0, GS);
