@@ -1,0 +1,74 @@
+"""BASELINE.json configs[4]: CascadeLDA on the abstracts corpus -- wall time of go_down_tree(it=4, s=2)
+(the whole ensemble of per-node Labeled-LDA sub-problems) on one MI355X.
+
+The corpus is rebuilt from tests/golden/abstracts_d3.npz (token ids become pseudo-tokens, every depth-3
+label is expanded to its prefixes as CascadeLDA.load_corpus does).  The reference's go_down_tree(4, 2) took
+66.8 s on one core of the survey container; it cannot run on the GPU box.
+
+    python tools/bench_cascade.py [--it 4] [--s 2]
+"""
+import argparse
+import io
+import json
+import os
+import sys
+import time
+from contextlib import redirect_stdout
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from lda_thesis_amd.CascadeLDA import CascadeLDA, partition_label      # noqa: E402
+from lda_thesis_amd.text import Dictionary                              # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--it", type=int, default=4)
+    ap.add_argument("--s", type=int, default=2)
+    args = ap.parse_args()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "abstracts_d3.npz"))
+    off, word, freq = g["doc_off"], g["word"], g["freq"]
+    names = [str(x) for x in g["labelset"]]                 # index 0 is 'root'
+    lab_off, lab_idx = g["lab_off"], g["lab_idx"]
+    docs, labs, seen = [], [], {}
+    for d in range(int(g["D"])):
+        toks = []
+        for v, f in zip(word[off[d]:off[d + 1]], freq[off[d]:off[d + 1]]):
+            toks += ["w%05d" % v] * int(f)
+        docs.append(toks)
+        codes = [names[k] for k in lab_idx[lab_off[d]:lab_off[d + 1]] if k != 0]
+        lab = []
+        for c in codes:
+            for p in partition_label(c, 3):
+                if p not in lab:
+                    lab.append(p)
+        for x in lab:
+            seen.setdefault(x, 1)
+        labs.append(lab)
+    dicti = Dictionary(docs)
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    model = CascadeLDA(docs, labs, list(seen.keys()), dicti, alpha=0.1, beta=0.01, seed=1)
+    tasks = model.enumerate_subproblems()
+    sites = [sum(len(t) for t in task["doc_tups"]) for task in tasks]
+    t1 = time.perf_counter()
+    with redirect_stdout(io.StringIO()):
+        model.go_down_tree(it=args.it, s=args.s)
+    import torch
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    filled = int((np.nan_to_num(model.ph).sum(axis=1) > 0).sum())
+    print(json.dumps({"metric": "CascadeLDA go_down_tree wall time", "value": t2 - t1, "unit": "s", "n_gpus": 1,
+                      "config": {"workload": "CascadeLDA on abstracts_data.csv fixture, it=%d, s=%d" % (args.it, args.s),
+                                 "sub_problems": len(tasks), "sites_per_ensemble_sweep": int(sum(sites)),
+                                 "largest_sub_problem_sites": int(max(sites)), "K": model.K, "V": model.V, "D": model.D},
+                      "model_build_s": t1 - t0, "ph_rows_filled": filled,
+                      "reference_cpu_s": 66.8, "reference_cpu_note": "reference go_down_tree(4, 2), 1 core, survey container "
+                      "(SURVEY.md section 6); not re-measured on this host"}))
+
+
+if __name__ == "__main__":
+    main()
