@@ -387,7 +387,7 @@ __device__ __forceinline__ int draw_position(const double (&w)[T], double u, uin
 // site) the group falls back to the exact tier.  Returns false when the group must fall back.
 // ---------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------
-// Tier 0: the same decision in fp32.  Every quantity is within 91 * 2^-24 (< 2^-17.4) of the total of its
+// Tier 0: the same decision in fp32.  Every quantity is within 103 * 2^-24 (< 2^-17.3) of the total of its
 // real-number value, the exact pipeline within 2^-44; with a margin of 2^-16 of
 // the total a "sure" fp32 decision therefore has the signs of the exact pipeline.  About 1.6 % of the
 // sites (K = 512) are "unsure" and go on to tier 1.
@@ -399,18 +399,15 @@ __device__ __forceinline__ float dpp_f32(float x)
 }
 
 template <int T, bool DENSE, int S = 0>
-__device__ __forceinline__ void prefix_scores_f32(float (&qw)[T], const int (*s_ndk)[256], const int (&x)[T],
-                                                  const float (*s_rcp)[256], int tid, uint32_t mask,
-                                                  float alpha, float beta)
+__device__ __forceinline__ void prefix_scores_f32(float (&qw)[T], const int (&x)[T], const float (*s_pa)[256], int tid,
+                                                  uint32_t mask, float beta)
 {
     if constexpr (S < T) {
-        const float a = (float)s_ndk[S][tid] + alpha;
-        const float num_b = (float)x[S] + beta;
-        float ws = a * (num_b * s_rcp[S][tid]);
+        float ws = ((float)x[S] + beta) * s_pa[S][tid];          // num_b * fl32(a / den_b)
         if constexpr (!DENSE) ws = __int_as_float(__float_as_int(ws) & onehot_bit<S>(mask));
         if constexpr (S == 0) qw[0] = ws;
         else qw[S] = qw[S - 1] + ws;
-        prefix_scores_f32<T, DENSE, S + 1>(qw, s_ndk, x, s_rcp, tid, mask, alpha, beta);
+        prefix_scores_f32<T, DENSE, S + 1>(qw, x, s_pa, tid, mask, beta);
     }
 }
 
@@ -727,14 +724,21 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
 #define LLDA_WAVES 3          // waves per SIMD the register allocator must leave room for
 #endif
 
-// a topic count of this document changes by df: n_dk, the n_k the document sees, and the cached reciprocal
-__device__ __forceinline__ void count_update(int (*s_ndk)[256], int (*s_nkc)[256], float (*s_rcp)[256], int slot,
-                                             int tid, float vbeta32, int df)
+// tier-0 factor of one topic: fl32(a * y) with a = fl32(n_dk + alpha), y = v_rcp_f32(fl32(n_k + V*beta)).
+// n_dk and n_k of a topic always change together, so the product is cached as ONE float per slot.
+__device__ __forceinline__ float tier0_factor(int ndk, int nk, float alpha32, float vbeta32)
 {
-    s_ndk[slot][tid] += df;
-    const int nk = s_nkc[slot][tid] + df;
+    return ((float)ndk + alpha32) * __builtin_amdgcn_rcpf((float)nk + vbeta32);
+}
+
+// a topic count of this document changes by df: n_dk, the n_k the document sees, and the cached tier-0 factor
+__device__ __forceinline__ void count_update(int (*s_ndk)[256], int (*s_nkc)[256], float (*s_pa)[256], int slot,
+                                             int tid, float alpha32, float vbeta32, int df)
+{
+    const int nd = s_ndk[slot][tid] + df, nk = s_nkc[slot][tid] + df;
+    s_ndk[slot][tid] = nd;
     s_nkc[slot][tid] = nk;
-    s_rcp[slot][tid] = __builtin_amdgcn_rcpf((float)nk + vbeta32);
+    s_pa[slot][tid] = tier0_factor(nd, nk, alpha32, vbeta32);
 }
 
 template <int G, int T, bool HAS_TAIL, bool DENSE>
@@ -745,7 +749,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
     __shared__ int s_nk[KP];                  // workgroup accumulator of the n_k changes
     __shared__ int s_ndk[T][256];             // n_dk row of the document
     __shared__ int s_nkc[T][256];             // n_k as the document sees it
-    __shared__ float s_rcp[T][256];           // fp32 reciprocal of n_k + V*beta (tier 0)
+    __shared__ float s_pa[T][256];            // tier-0 factor fl32((n_dk + alpha) / (n_k + V*beta))
 
     const int tid = threadIdx.x;
     for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
@@ -785,7 +789,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             for (int s = 0; s < T; ++s) {
                 s_ndk[s][tid] = r[s];
                 s_nkc[s][tid] = k[s];                              // sweep-start n_k
-                s_rcp[s][tid] = __builtin_amdgcn_rcpf((float)k[s] + vbeta32);
+                s_pa[s][tid] = tier0_factor(r[s], k[s], alpha32, vbeta32);
             }
         }
         if (rec) {
@@ -797,7 +801,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 if (dl != 0 && lig == pos / T) {
                     const int nk = s_nkc[pos % T][tid] + dl;
                     s_nkc[pos % T][tid] = nk;
-                    s_rcp[pos % T][tid] = __builtin_amdgcn_rcpf((float)nk + vbeta32);
+                    s_pa[pos % T][tid] = tier0_factor(s_ndk[pos % T][tid], nk, alpha32, vbeta32);
                 }
             }
         }
@@ -819,7 +823,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0;
         {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the loop body
             const int lo = zo_c / T;
-            if (lig == lo) count_update(s_ndk, s_nkc, s_rcp, zo_c - lo * T, tid, vbeta32, -f_c);
+            if (lig == lo) count_update(s_ndk, s_nkc, s_pa, zo_c - lo * T, tid, alpha32, vbeta32, -f_c);
         }
 
         for (int n = n0; n < len; ++n) {
@@ -854,7 +858,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             bool decided = false;
             if (P.margin0_rel < 1.0f) {           // tier 0: fp32
                 float qf[T];
-                prefix_scores_f32<T, DENSE>(qf, s_ndk, x, s_rcp, tid, mask, alpha32, beta32);
+                prefix_scores_f32<T, DENSE>(qf, x, s_pa, tid, mask, beta32);
                 decided = draw_fast_f32<G, T>(qf, (float)u, mask, P.margin0_rel, lig, lane, zn);
             }
             if (!decided) {
@@ -872,10 +876,10 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             // scalars are in registers): the LDS state is final long before the next site's scores read it
             {
                 const int ln = zn / T;
-                if (lig == ln) count_update(s_ndk, s_nkc, s_rcp, zn - ln * T, tid, vbeta32, f);
+                if (lig == ln) count_update(s_ndk, s_nkc, s_pa, zn - ln * T, tid, alpha32, vbeta32, f);
                 if (n + 1 < len) {
                     const int lo2 = zo_c / T;
-                    if (lig == lo2) count_update(s_ndk, s_nkc, s_rcp, zo_c - lo2 * T, tid, vbeta32, -f_c);
+                    if (lig == lo2) count_update(s_ndk, s_nkc, s_pa, zo_c - lo2 * T, tid, alpha32, vbeta32, -f_c);
                 }
             }
             pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn;
