@@ -280,3 +280,33 @@ def test_cli_harness_cascade_end_to_end(tmp_path, capsys, monkeypatch):
     H.main(["-f", str(tmp_path / "toy.csv"), "-i", "8", "-s", "2", "-d", "3"])
     out = capsys.readouterr().out
     assert out.count("Model:               CascadeLDA") == 3 and out.count("AUC ROC:") == 3
+
+
+def test_integration_md_ctypes_stub_runs_and_matches_reference():
+    """the ctypes stub printed in INTEGRATION.md (what a maintainer of the reference would add) is executed
+    verbatim against a reference-shaped model object and must reproduce the O3 golden."""
+    import os
+    import re
+    import types
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n# llda_gpu.py.*?```", text, flags=re.S).group(0)
+    code = code[len("```python\n"):-3].replace('ctypes.CDLL("lda_thesis_amd/libllda_gibbs.so")',
+                                               'ctypes.CDLL(%r)' % os.path.join(ROOT, "lda_thesis_amd", "libllda_gibbs.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    g = load_golden("tiny_k130")
+    off = g["doc_off"]
+    D = int(g["D"])
+    model = types.SimpleNamespace(
+        K=int(g["K"]), V=int(g["V"]), D=D, alpha=float(g["alpha"]), beta=float(g["beta"]),
+        docs=[g["word"][off[d]:off[d + 1]].tolist() for d in range(D)],
+        freqs=[g["freq"][off[d]:off[d + 1]].tolist() for d in range(D)],
+        z_dn=[g["init_z"][off[d]:off[d + 1]].astype(np.int64) for d in range(D)],
+        labs=g["labs"].astype(np.float64), n_d_k=g["init_n_d_k"].astype(np.int64),
+        n_k_v=g["init_n_k_v"].astype(np.int64), n_zk=g["init_n_zk"].astype(np.int64))
+    ns["attach"](model, seed=int(g["seed"]))
+    for i in range(int(g["sweeps"])):
+        ns["training_iteration"](model)
+        ns["pull"](model)
+        assert_state_equal(g, "o3_s%d" % (i + 1), model.n_k_v, model.n_d_k, model.n_zk, np.concatenate(model.z_dn))
