@@ -274,6 +274,23 @@ __device__ __forceinline__ double group_scan(double X, int lig)
     else return X;
 }
 
+// value held by lane `src` (same for the whole group, but a run-time value) in every lane of the group.
+// 8- and 16-lane groups: OR-butterfly over DPP moves (no LDS round trip); wider groups: ds_bpermute.
+template <int G>
+__device__ __forceinline__ int group_pick(int v, int src, int lig)
+{
+    if constexpr (G <= 16) {
+        int x = (lig == src) ? v : 0;
+        x |= __builtin_amdgcn_update_dpp(0, x, DPP_XOR1, 0xF, 0xF, false);
+        x |= __builtin_amdgcn_update_dpp(0, x, DPP_XOR2, 0xF, 0xF, false);
+        x |= __builtin_amdgcn_update_dpp(0, x, DPP_HALF_MIRROR, 0xF, 0xF, false);
+        if constexpr (G == 16) x |= __builtin_amdgcn_update_dpp(0, x, DPP_ROW_ROR + 8, 0xF, 0xF, false);
+        return x;
+    } else {
+        return __shfl(v, src, G);
+    }
+}
+
 // Sum of the group's K scores in numpy's pairwise order.  Every lane of the group returns S.
 //   chain : per-lane sequential sum over its slots (one of numpy's 8 accumulators)
 //   xor butterfly 1,2,4 : ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))   (fp add is commutative)
@@ -448,7 +465,7 @@ __device__ __forceinline__ float bcast_last_f32(float x, int lane)
         const float ab = (lane & 16) ? b : a, cd = (lane & 16) ? d : c;
         return (lane & 32) ? cd : ab;
     } else {
-        return __shfl(x, G - 1, G);
+        return __int_as_float(group_pick<G>(__float_as_int(x), G - 1, lane & (G - 1)));
     }
 }
 
@@ -478,7 +495,7 @@ __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uin
     const bool hit = gf != 0;
     const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)(gp | 1ull));
     const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
-    zn = sl * T + __shfl(my, sl, G);
+    zn = sl * T + group_pick<G>(my, sl, lig);
     return true;
 }
 
@@ -603,8 +620,8 @@ __device__ __forceinline__ double site_uniform(const KParams &P, int n, bool fir
         philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
     }
     const int holder = (n >> 1) & (G - 1);
-    const uint32_t ra = (uint32_t)__shfl((int)((n & 1) ? r2 : r0), holder, G);
-    const uint32_t rb = (uint32_t)__shfl((int)((n & 1) ? r3 : r1), holder, G);
+    const uint32_t ra = (uint32_t)group_pick<G>((int)((n & 1) ? r2 : r0), holder, lig);
+    const uint32_t rb = (uint32_t)group_pick<G>((int)((n & 1) ? r3 : r1), holder, lig);
     return ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
 }
 
