@@ -470,8 +470,8 @@ __device__ __forceinline__ float bcast_last_f32(float x, int lane)
 }
 
 template <int G, int T>
-__device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uint32_t mask, float margin_rel,
-                                              int lig, int lane, int &zn)
+__device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uint32_t mask, uint64_t gp,
+                                              float margin_rel, int lig, int lane, int &zn)
 {
     const int gbase = lane & ~(G - 1);
     const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
@@ -491,7 +491,6 @@ __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uin
     if (((__ballot(unsure) >> gbase) & gmask) != 0) return false;
     const uint32_t fm = mask & (0xFFFFu << cnt_lo);
     const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
-    const uint64_t gp = (__ballot(mask != 0) >> gbase) & gmask;
     const bool hit = gf != 0;
     const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)(gp | 1ull));
     const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
@@ -609,20 +608,35 @@ __device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, 
 // The sweep kernel
 // ---------------------------------------------------------------------------------------------
 // Per-site pieces shared by the two sweep kernels ------------------------------------------------
-// keyed uniform of site n: one Philox block serves sites 2b and 2b+1; the G lanes of the group compute G
-// consecutive blocks at once (every 2G sites) and hand them out by shuffle
+// random bits of site n: one Philox block serves sites 2b and 2b+1; the G lanes of the group compute G
+// consecutive blocks at once (every 2G sites, or at the first site of a resumed document) and hand them out
 template <int G>
-__device__ __forceinline__ double site_uniform(const KParams &P, int n, bool first, uint32_t gdoc, int lig,
-                                               uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t &r3)
+__device__ __forceinline__ void site_random_bits(const KParams &P, int n, bool first, uint32_t gdoc, int lig,
+                                                 uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t &r3,
+                                                 uint32_t &ra, uint32_t &rb)
 {
     if (first || (n & (2 * G - 1)) == 0) {
         r0 = (uint32_t)((n >> 1) & ~(G - 1)) + (uint32_t)lig; r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
         philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
     }
     const int holder = (n >> 1) & (G - 1);
-    const uint32_t ra = (uint32_t)group_pick<G>((int)((n & 1) ? r2 : r0), holder, lig);
-    const uint32_t rb = (uint32_t)group_pick<G>((int)((n & 1) ? r3 : r1), holder, lig);
+    ra = (uint32_t)group_pick<G>((int)((n & 1) ? r2 : r0), holder, lig);
+    rb = (uint32_t)group_pick<G>((int)((n & 1) ? r3 : r1), holder, lig);
+}
+
+// the 53-bit keyed uniform u = ((a >> 5) * 2^26 + (b >> 6)) / 2^53 (every operation exact)
+__device__ __forceinline__ double uniform53(uint32_t ra, uint32_t rb)
+{
     return ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+template <int G>
+__device__ __forceinline__ double site_uniform(const KParams &P, int n, bool first, uint32_t gdoc, int lig,
+                                               uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t &r3)
+{
+    uint32_t ra, rb;
+    site_random_bits<G>(P, n, first, gdoc, lig, r0, r1, r2, r3, ra, rb);
+    return uniform53(ra, rb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -824,6 +838,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         }
         const uint32_t mask = P.lab_mask[d * G + lig];
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
+        const uint64_t gp_doc = (__ballot(mask != 0) >> (lane & ~(G - 1))) & ((G == 64) ? ~0ull : ((1ull << G) - 1ull));   // lanes with an allowed topic
 
         // Software pipeline of the memory operations: at the top of iteration n the registers hold the
         // scalars (word, freq, z) of site n, the row of site n is in flight (xn) and so are the scalars of
@@ -862,7 +877,8 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);  // scalars of site n+2 (clamped)
                 v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
             }
-            const double u = site_uniform<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3);
+            uint32_t ra, rb;
+            site_random_bits<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3, ra, rb);
 
             // the site's own count leaves the fetched n_kw row (n_dk / n_k were updated already)
             {
@@ -876,13 +892,15 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             if (P.margin0_rel < 1.0f) {           // tier 0: fp32
                 float qf[T];
                 prefix_scores_f32<T, DENSE>(qf, x, s_pa, tid, mask, beta32);
-                decided = draw_fast_f32<G, T>(qf, (float)u, mask, P.margin0_rel, lig, lane, zn);
+                // fp32 image of the uniform: the top 27 bits (within 2^-24 relative + 2^-27 absolute of u)
+                const float u32 = (float)(ra >> 5) * 0x1p-27f;
+                decided = draw_fast_f32<G, T>(qf, u32, mask, gp_doc, P.margin0_rel, lig, lane, zn);
             }
             if (!decided) {
                 int x_c[T];
 #pragma unroll
                 for (int s = 0; s < T; ++s) x_c[s] = x[s];
-                zn = cold_tiers<G, T, HAS_TAIL, DENSE>(s_ndk, x_c, s_nkc, tid, mask, u, lig, lane, &P);
+                zn = cold_tiers<G, T, HAS_TAIL, DENSE>(s_ndk, x_c, s_nkc, tid, mask, uniform53(ra, rb), lig, lane, &P);
             }
             if (zn < 0) {
                 zn = zo;
