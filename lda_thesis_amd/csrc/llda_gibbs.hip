@@ -908,14 +908,18 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             }
 
             // add the site back (LabeledLDA.py:121-125), and take the NEXT site out of its topic already (its
-            // scalars are in registers): the LDS state is final long before the next site's scores read it
+            // scalars are in registers): the LDS state is final long before the next site's scores read it.
+            // Both updates usually belong to different lanes and are done in ONE masked pass; a second pass runs
+            // only for groups where the same lane owns both.
             {
                 const int ln = zn / T;
-                if (lig == ln) count_update(s_ndk, s_nkc, s_pa, zn - ln * T, tid, alpha32, vbeta32, f);
-                if (n + 1 < len) {
-                    const int lo2 = zo_c / T;
-                    if (lig == lo2) count_update(s_ndk, s_nkc, s_pa, zo_c - lo2 * T, tid, alpha32, vbeta32, -f_c);
-                }
+                const bool more = n + 1 < len;
+                const int lo2 = more ? zo_c / T : -1;
+                const bool own_new = lig == ln, own_old = lig == lo2;
+                if (own_new || own_old)
+                    count_update(s_ndk, s_nkc, s_pa, own_new ? zn - ln * T : zo_c - lo2 * T, tid, alpha32, vbeta32,
+                                 own_new ? f : -f_c);
+                if (own_new && own_old) count_update(s_ndk, s_nkc, s_pa, zo_c - lo2 * T, tid, alpha32, vbeta32, -f_c);
             }
             pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn;
         }
