@@ -3,20 +3,28 @@
 // Hot path replaced: LabeledLDA.training_iteration (/root/reference/LabeledLDA.py:101-125) ==
 // SubLDA.training_iteration (/root/reference/CascadeLDA.py:397-421).  C ABI: include/llda_gibbs.h.
 //
-// Execution model:
-//   * one lane GROUP of G = 8..64 lanes per document (64/G documents per wavefront), T topic slots
-//     per lane; topic k lives at (lane, slot) chosen so that numpy's pairwise summation order
-//     (np.sum at LabeledLDA.py:117) is lane-local: one accumulator chain = one lane walking its
-//     slots, the 8 accumulators of a 128-topic leaf = 8 neighbouring lanes;
-//   * n_dk row, n_k (as seen by this document) and the label mask of the document stay in VGPRs for
-//     the whole document; the n_kw row of the current word is one contiguous KP*4-byte read
-//     (word-major layout), prefetched one site ahead;
-//   * categorical draw = per-lane prefix over the slots + Hillis-Steele scan over the G lanes +
-//     one keyed Philox4x32-10 uniform;
-//   * count updates: int32 atomics into n_kw_delta (HBM/L2) and, through an LDS accumulator per
-//     workgroup, into n_k_delta.  Snapshot semantics + integer atomics => bit-deterministic.
-// No MFMA (gather/scan, not a contraction).  fp64 throughout; FMA contraction is OFF because the
-// reference rounds after every numpy ufunc.
+// Execution model (DESIGN.md sections 3-4):
+//   * group layout: one lane GROUP of G = 8..64 lanes per document (64/G documents per wavefront), T topic
+//     slots per lane; topic k lives at (lane, slot) chosen so that numpy's pairwise summation order (np.sum at
+//     LabeledLDA.py:117) is lane-local: one accumulator chain = one lane walking its slots, the 8 accumulators
+//     of a 128-topic leaf = 8 neighbouring lanes;
+//   * the n_kw row of the current word is one contiguous KP*4-byte read (word-major layout), prefetched one
+//     site ahead; count updates are int32 atomics into n_kw_delta and, through an LDS accumulator per workgroup,
+//     into n_k_delta.  Snapshot semantics + integer atomics => bit-deterministic;
+//   * the draw is TIERED: an fp32 decision with a proven margin, an fp64 decision, and the
+//     reference's fp64 pipeline bit for bit (IEEE division, numpy-ordered sum, keyed Philox4x32-10 draw) for
+//     the sites the cheaper tiers cannot decide -- the chosen topic is always the exact pipeline's.
+// No MFMA (gather/scan, not a contraction).  FMA contraction is OFF: the reference rounds after every ufunc.
+//
+// Contents
+//   1. helpers: Philox, row loads, one-hot updates, exact division, DPP / permlane cross-lane moves
+//   2. numpy-ordered group sum, keyed categorical draw (exact), tier-0 (fp32) decision, cold tiers (fp64)
+//   3. llda_sweep_exact_kernel   general kernel, every site through the exact pipeline
+//      llda_sweep_kernel         tiered kernel, per-document state in LDS (the one that runs in practice)
+//      llda_sweep_sparse_kernel  one lane per ALLOWED topic for sparse label sets; hands undecided documents
+//                                to llda_sweep_kernel (resume list)
+//   4. llda_loglik_kernel, llda_foldin_kernel (test-time sampler), llda_apply_delta, llda_count_init, self test
+//   5. host side: layout (llda_layout_init), dispatch, C entry points
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
