@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 3
+#define LLDA_ABI_VERSION 4
 #define LLDA_MAX_K 1024
 #define LLDA_MAX_LEAVES 8
 #define LLDA_MAX_ROUNDS 4
@@ -143,6 +143,30 @@ int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab
                 const int32_t *n_dk, const int32_t *n_kw, const int32_t *n_k,
                 int64_t D, int64_t V, int32_t K, double alpha, double beta,
                 double *out_doc, void *stream);
+
+/* Thinning read-outs with their running means, on the device (LabeledLDA.py:131-153, 231-239;
+ * CascadeLDA.py:394-395, 423-434).  Outputs are in the REFERENCE's layout (row-major (K, V) and (D, K)
+ * doubles), not the device permutation, so they can be handed to the caller as they are.
+ *
+ * llda_readout_phi:   cur[k][v] = (n_kw[v][k] + beta) / den[k]
+ *     den == NULL: den[k] = n_k[k] + V*beta           -> get_phi   (LabeledLDA.py:231-234)
+ *     den != NULL: double[KP] in device order, beta=0 -> SubLDA.get_ph with den = row sums of n_k_v
+ *                                                        (CascadeLDA.py:394-395; 0/0 gives NaN as numpy does)
+ * llda_readout_theta: num = n_dk[d] + labs[d]*alpha; cur[d] = num / np.sum(num)   (LabeledLDA.py:236-239;
+ *     the row sum in numpy's pairwise order, bit for bit)
+ * Both: mode 0: out = cur; mode 1: out = keep*out + share*cur, each product and the sum rounded
+ * separately, as `factor*self.ph_hat + (1/s * cur_ph)` (LabeledLDA.py:144-145) and
+ * `m * self.ph + (1-m) * cur_ph` (CascadeLDA.py:432) round -- the caller passes the two coefficients.
+ * flags (dev int32[1], OR-ed, may be NULL; phi only) report the guards of LabeledLDA.py:146-153 on `out`:
+ *   bit 0 an entry < 0, bit 1 a NaN, bit 2 a word whose column is all zero. */
+#define LLDA_READOUT_NEGATIVE 1
+#define LLDA_READOUT_NAN      2
+#define LLDA_READOUT_NO_LOAD  4
+int llda_readout_phi(const int32_t *n_kw, const int32_t *n_k, const double *den, int64_t V, int32_t K,
+                     double beta, int32_t mode, double keep, double share, double *out, int32_t *flags,
+                     void *stream);
+int llda_readout_theta(const int32_t *n_dk, const uint16_t *lab_mask, int64_t D, int32_t K, double alpha,
+                       int32_t mode, double keep, double share, double *out, void *stream);
 
 /* Test-time fold-in sampler for held-out documents: one lane group per document, the topic-word
  * loadings are fixed and only the document's n_dk moves.  Covers

@@ -18,7 +18,7 @@ import numpy as np
 
 from . import text as _text
 from .corpus import csr_from_doc_tups
-from .sampler import GibbsSampler
+from .sampler import GibbsSampler, HostOrDevice
 
 __all__ = ["np", "re", "load_corpus", "partition_label", "CascadeLDA", "SubLDA", "split_data",
            "prune_dict", "train_it"]
@@ -79,7 +79,7 @@ class SubLDA(object):
         self.doc_tups = docs
         self.V = len(dicti)
         self.D = len(docs)
-        self.ph = np.zeros((self.K, self.V), dtype=float)
+        self._ph = HostOrDevice(np.zeros((self.K, self.V), dtype=float))
 
         self.docs, self.freqs, z0 = [], [], []
         for doc, lab in zip(self.doc_tups, self.labs):
@@ -147,10 +147,20 @@ class SubLDA(object):
             vec[self.labelmap[x]] = 1.0
         return vec
 
+    # running mean of get_ph(): a numpy array when read (reference CascadeLDA.py:372), on the device between
+    # the read-outs of run_training
+    @property
+    def ph(self):
+        return self._ph.get()
+
+    @ph.setter
+    def ph(self, value):
+        self._ph.set(value)
+
     def get_ph(self):
-        """row-normalised n_k_v without smoothing (phantom columns included): CascadeLDA.py:394-395."""
-        n_k_v = self.n_k_v
-        return n_k_v / n_k_v.sum(axis=1, keepdims=True)
+        """row-normalised n_k_v without smoothing (phantom columns included): CascadeLDA.py:394-395
+        (llda_readout_phi with the integer row sums as denominators)."""
+        return self._upload().ph_rows().cpu().numpy()
 
     def training_iteration(self):
         """One Gibbs sweep: reference CascadeLDA.py:397-421 (same body as LabeledLDA.py:101-125)."""
@@ -163,16 +173,16 @@ class SubLDA(object):
             s = (i + 1) / thinning
             if s == int(s):
                 print("Training iteration #", i + 1)
-                self._sampler.check_status()
-                cur_ph = self.get_ph()
-                if s > 1:
-                    m = (s - 1) / s
-                    self.ph = m * self.ph + (1 - m) * cur_ph
-                else:
-                    self.ph = cur_ph
+                sm = self._sampler
+                sm.check_status()
+                first = not s > 1
+                m = (s - 1) / s
+                sm.ph_rows(self._ph.on_device(sm.device, (self.K, self.V), fresh=first),
+                           None if first else m, None if first else 1 - m)
 
     def release(self):
         """drop the device state (the ensemble driver keeps only ph)."""
+        self.ph                                   # a running mean still on the device moves to the host
         self._sampler = None
 
 

@@ -20,7 +20,8 @@ import numpy as np
 
 from . import text as _text
 from .corpus import csr_from_doc_tups
-from .sampler import GibbsSampler, shard_documents
+from . import _native
+from .sampler import GibbsSampler, HostOrDevice, shard_documents
 
 __all__ = ["np", "load_corpus", "LabeledLDA", "split_data", "prune_dict", "train_it", "test_it"]
 
@@ -101,8 +102,8 @@ class LabeledLDA(object):
         self.doc_tups = [dicti.doc2bow(x) for x in docs]
         self.D = len(docs)
         self.V = len(self.vocab)
-        self.ph_hat = np.zeros((self.K, self.V), dtype=float)
-        self.th_hat = np.zeros((self.D, self.K), dtype=float)
+        self._ph_hat = HostOrDevice(np.zeros((self.K, self.V), dtype=float))
+        self._th_hat = HostOrDevice(np.zeros((self.D, self.K), dtype=float))
         self.cur_perplx = []
 
         # initial assignments: one np.random.choice per document over its allowed topics
@@ -148,6 +149,24 @@ class LabeledLDA(object):
         z = _gather_rows(self._sampler.z_topics())
         return [z[self._doc_off[d]:self._doc_off[d + 1]].copy() for d in range(self.D)]
 
+    # running means of phi / theta: numpy arrays when read (reference LabeledLDA.py:65-66); between the
+    # thinning read-outs of run_training they stay on the device
+    @property
+    def ph_hat(self):
+        return self._ph_hat.get()
+
+    @ph_hat.setter
+    def ph_hat(self, value):
+        self._ph_hat.set(value)
+
+    @property
+    def th_hat(self):
+        return self._th_hat.get(_gather_rows)
+
+    @th_hat.setter
+    def th_hat(self, value):
+        self._th_hat.set(value)
+
     def set_label(self, label):
         vec = np.zeros(len(self.labelmap))
         vec[0] = 1.0
@@ -161,38 +180,40 @@ class LabeledLDA(object):
         self._sampler.sweep()
 
     def run_training(self, iters, thinning):
-        """Sweep loop with thinning read-outs and running means: reference LabeledLDA.py:127-153."""
+        """Sweep loop with thinning read-outs and running means: reference LabeledLDA.py:127-153.  phi, theta,
+        their running means and the three guards are evaluated on the device (llda_readout_phi / _theta)."""
+        import torch
+        sm = self._sampler
+        lo, hi = self._bounds[_rank()], self._bounds[_rank() + 1]
         for n in range(iters):
             self.training_iteration()
             print('Running iteration # %d ' % (n + 1))
             if (n + 1) % thinning != 0:
                 continue
-            self._sampler.check_status()
-            cur_ph, cur_th = self.get_phi(), self.get_theta()
+            sm.check_status()
             self.cur_perplx.append(self.perplexity())
             s = (n + 1) / thinning
-            if s == 1:
-                self.ph_hat, self.th_hat = cur_ph, cur_th
-            elif s > 1:
-                keep = (s - 1) / s
-                self.ph_hat = keep * self.ph_hat + (1 / s * cur_ph)
-                self.th_hat = keep * self.th_hat + (1 / s * cur_th)
-            if (self.ph_hat < 0).any():
+            first = s == 1
+            keep, share = (None, None) if first else ((s - 1) / s, 1 / s)
+            flags = torch.zeros((1,), dtype=torch.int32, device=sm.device)
+            sm.phi(self._ph_hat.on_device(sm.device, (self.K, self.V), fresh=first), keep, share, flags)
+            sm.theta(self._th_hat.on_device(sm.device, (sm.D, self.K), fresh=first, rows=(lo, hi)), keep, share)
+            bad = int(flags.item())
+            if bad & _native.READOUT_NEGATIVE:
                 raise ValueError('A negative value occurred in self.ph_hat while saving iteration %d ' % n)
-            if np.isnan(self.ph_hat).any():
+            if bad & _native.READOUT_NAN:
                 raise ValueError('A nan has creeped into ph_hat')
-            if (self.ph_hat.sum(axis=0) == 0).any():
+            if bad & _native.READOUT_NO_LOAD:
                 raise ValueError('A word in dictionary has no z-value')
 
     # ---- read-outs ----
     def get_phi(self):
-        """(n_k_v + beta) / (n_zk + V*beta): reference LabeledLDA.py:231-234."""
-        return (self.n_k_v + self.beta) / (self.n_zk[:, np.newaxis] + self.V * self.beta)
+        """(n_k_v + beta) / (n_zk + V*beta): reference LabeledLDA.py:231-234 (llda_readout_phi)."""
+        return self._sampler.phi().cpu().numpy()
 
     def get_theta(self):
-        """(n_d_k + labs*alpha) / row sums: reference LabeledLDA.py:236-239."""
-        num = self.n_d_k + self.labs * self.alpha
-        return num / num.sum(axis=1)[:, np.newaxis]
+        """(n_d_k + labs*alpha) / row sums: reference LabeledLDA.py:236-239 (llda_readout_theta)."""
+        return _gather_rows(self._sampler.theta().cpu().numpy())
 
     def perplexity(self):
         """exp(-sum_sites log(phi[:, w] . theta_d) / #sites), sites unweighted by frequency
@@ -236,6 +257,7 @@ class LabeledLDA(object):
 
     # ---- pickling: pull the device state to the host (evaluate_LabeledLDA.py:142-145 pickles the model)
     def __getstate__(self):
+        self.ph_hat, self.th_hat                      # bring the running means to the host
         state = {k: v for k, v in self.__dict__.items() if k != "_sampler"}
         state["_host_state"] = dict(n_zk=self.n_zk, n_d_k=self.n_d_k, n_k_v=self.n_k_v,
                                     z=_gather_rows(self._sampler.z_topics()),

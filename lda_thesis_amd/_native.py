@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libllda_gibbs.so")
 MAX_K = 1024
 MAX_LEAVES = 8
 MAX_ROUNDS = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -94,6 +94,10 @@ def lib():
                               _c_p, _c_p]
     L.llda_foldin.restype = ctypes.c_int
     L.llda_foldin.argtypes = [ctypes.POINTER(LldaFoldinArgs), _c_p]
+    L.llda_readout_phi.restype = ctypes.c_int
+    L.llda_readout_phi.argtypes = [_c_p, _c_p, _c_p, _c_i64, _c_i32, _c_d, _c_i32, _c_d, _c_d, _c_p, _c_p, _c_p]
+    L.llda_readout_theta.restype = ctypes.c_int
+    L.llda_readout_theta.argtypes = [_c_p, _c_p, _c_i64, _c_i32, _c_d, _c_i32, _c_d, _c_d, _c_p, _c_p]
     L.llda_selftest_div.restype = ctypes.c_int
     L.llda_selftest_div.argtypes = [_c_u64, _c_i64, _c_p, _c_p]
     if L.llda_abi_version() != ABI_VERSION:
@@ -159,6 +163,26 @@ def loglik(doc_off, word, lab_mask, n_dk, n_kw, n_k, D, V, K, alpha, beta, out_d
     check(lib().llda_loglik(_ptr(doc_off), _ptr(word), _ptr(lab_mask), _ptr(n_dk), _ptr(n_kw), _ptr(n_k),
                             int(D), int(V), int(K), float(alpha), float(beta), _ptr(out_doc), _stream()),
           "llda_loglik")
+
+
+READOUT_NEGATIVE, READOUT_NAN, READOUT_NO_LOAD = 1, 2, 4
+
+
+def readout_phi(n_kw, n_k, den, V, K, beta, out, flags=None, keep=None, share=None):
+    """llda_readout_phi: out (K, V) float64 = phi of the counts, or keep*out + share*phi when the two
+    coefficients are given."""
+    mode = 0 if keep is None else 1
+    check(lib().llda_readout_phi(_ptr(n_kw), _ptr(n_k), _ptr(den), int(V), int(K), float(beta), mode,
+                                 float(keep or 0.0), float(share or 0.0), _ptr(out), _ptr(flags), _stream()),
+          "llda_readout_phi")
+
+
+def readout_theta(n_dk, lab_mask, D, K, alpha, out, keep=None, share=None):
+    """llda_readout_theta: out (D, K) float64 = theta of the counts, or its running mean (as readout_phi)."""
+    mode = 0 if keep is None else 1
+    check(lib().llda_readout_theta(_ptr(n_dk), _ptr(lab_mask), int(D), int(K), float(alpha), mode,
+                                   float(keep or 0.0), float(share or 0.0), _ptr(out), _stream()),
+          "llda_readout_theta")
 
 
 def selftest_div(n, seed=1):

@@ -23,7 +23,8 @@
 //      llda_sweep_kernel         tiered kernel, per-document state in LDS (the one that runs in practice)
 //      llda_sweep_sparse_kernel  one lane per ALLOWED topic for sparse label sets; hands undecided documents
 //                                to llda_sweep_kernel (resume list)
-//   4. llda_loglik_kernel, llda_foldin_kernel (test-time sampler), llda_apply_delta, llda_count_init, self test
+//   4. llda_loglik_kernel, llda_foldin_kernel (test-time sampler), llda_readout_phi / _theta (thinning
+//      read-outs), llda_apply_delta, llda_count_init, self test
 //   5. host side: layout (llda_layout_init), dispatch, C entry points
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -1417,6 +1418,105 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Thinning read-outs (LabeledLDA.py:131-153, 231-239; CascadeLDA.py:394-395, 423-434): phi / theta of
+// the current counts and their running means, written in the reference's (K, V) / (D, K) layout.
+// ---------------------------------------------------------------------------------------------
+struct RParams {
+    const int32_t *n_kw, *n_k, *n_dk;
+    const double *den;
+    const uint16_t *lab_mask;
+    double *out;
+    int32_t *flags;
+    int64_t V, D;
+    int32_t K, KP, T, mode;
+    double alpha, beta, vbeta, keep, share;
+    int32_t leaf_start[LLDA_MAX_LEAVES], leaf_len[LLDA_MAX_LEAVES];
+    int32_t last_leaf, tail, tail_row, n_rounds, xor_tree;
+    uint32_t rounds_pk[LLDA_MAX_ROUNDS];
+};
+
+// topic held by a device position, -1 for padding (inverse of llda_layout.topic_pos)
+__device__ __forceinline__ int topic_of_position(const RParams &P, int pos)
+{
+    const int g = pos / P.T, slot = pos - g * P.T;
+    const int leaf = g >> 3, rel = (g & 7) + 8 * slot;
+    return rel < P.leaf_len[leaf] ? P.leaf_start[leaf] + rel : -1;
+}
+
+__device__ __forceinline__ double running_mean(const RParams &P, double old, double cur)
+{
+    if (P.mode == 0) return cur;
+    const double a = P.keep * old, b = P.share * cur;      // two roundings, then the sum (no FMA)
+    return a + b;
+}
+
+// One workgroup per 64 words: 64 x 64 (word, position) tiles of n_kw go through LDS so that both the
+// word-major reads and the topic-major writes are contiguous.
+__global__ void __launch_bounds__(256) llda_readout_phi_kernel(const RParams P)
+{
+    __shared__ int s_tile[64][65];
+    __shared__ int s_seen[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t v0 = (int64_t)blockIdx.x * 64;
+    if (tid < 64) s_seen[tid] = 0;
+    int bad = 0, seen = 0;
+    const int64_t v = v0 + lane;
+    for (int c0 = 0; c0 < P.KP; c0 += 64) {
+        __syncthreads();
+        for (int r = w; r < 64; r += 4)
+            if (v0 + r < P.V && c0 + lane < P.KP) s_tile[r][lane] = P.n_kw[(v0 + r) * P.KP + c0 + lane];
+        __syncthreads();
+        for (int j = w; j < 64 && c0 + j < P.KP; j += 4) {
+            const int k = topic_of_position(P, c0 + j);
+            if (k < 0 || v >= P.V) continue;
+            const double den = P.den ? P.den[c0 + j] : (double)P.n_k[c0 + j] + P.vbeta;
+            const double cur = ((double)s_tile[lane][j] + P.beta) / den;
+            double *o = P.out + (int64_t)k * P.V + v;
+            const double val = running_mean(P, P.mode ? *o : 0.0, cur);
+            *o = val;
+            if (val < 0.0) bad |= LLDA_READOUT_NEGATIVE;
+            if (val != val) bad |= LLDA_READOUT_NAN;
+            if (val != 0.0) seen = 1;
+        }
+    }
+    if (seen) atomicOr(&s_seen[lane], 1);
+    __syncthreads();
+    if (tid < 64 && v0 + tid < P.V && !s_seen[tid]) bad |= LLDA_READOUT_NO_LOAD;
+    if (bad && P.flags) atomicOr(P.flags, bad);
+}
+
+template <int G, int T, bool HAS_TAIL>
+__global__ void __launch_bounds__(256) llda_readout_theta_kernel(const RParams P)
+{
+    constexpr int KP = G * T;
+    constexpr int GPB = 256 / G;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int lig = tid & (G - 1);
+    const int64_t d = (int64_t)blockIdx.x * GPB + tid / G;
+    if (d >= P.D) return;
+    KParams K;                                     // the summation schedule group_sum() reads
+    K.last_leaf = P.last_leaf; K.tail = P.tail; K.tail_row = P.tail_row; K.n_rounds = P.n_rounds;
+    K.xor_tree = P.xor_tree;
+#pragma unroll
+    for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) K.rounds_pk[r] = P.rounds_pk[r];
+    int ndk[T];
+    load_row<T>(P.n_dk + d * KP + lig * T, ndk);
+    const uint32_t mask = P.lab_mask[d * G + lig];
+    double num[T];
+#pragma unroll
+    for (int s = 0; s < T; ++s) num[s] = (double)ndk[s] + (((mask >> s) & 1u) ? P.alpha : 0.0);   // n_d_k + labs*alpha
+    const double rs = group_sum<G, T, HAS_TAIL>(num, K, lig, lane);                              // np.sum, axis 1
+#pragma unroll
+    for (int s = 0; s < T; ++s) {
+        const int k = topic_of_position(P, lig * T + s);
+        if (k < 0) continue;
+        double *o = P.out + d * P.K + k;
+        *o = running_mean(P, P.mode ? *o : 0.0, num[s] / rs);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // self test: div_by (reciprocal + two corrections) against the hardware IEEE division
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) llda_selftest_div_kernel(uint64_t seed, int iters, unsigned long long *bad)
@@ -1624,6 +1724,34 @@ int dispatch_foldin_T(int T, const FParams &P, bool has_tail, hipStream_t st)
     switch (T) {
     case 12: return launch_foldin<G, 12>(P, has_tail, st);
     case 16: return launch_foldin<G, 16>(P, has_tail, st);
+    }
+    return LLDA_E_BAD_K;
+}
+
+template <int G, int T>
+int launch_theta(const RParams &P, bool has_tail, hipStream_t st)
+{
+    const int64_t blocks = (P.D + (256 / G) - 1) / (256 / G);
+    if (has_tail) hipLaunchKernelGGL((llda_readout_theta_kernel<G, T, true>), dim3((unsigned)blocks), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((llda_readout_theta_kernel<G, T, false>), dim3((unsigned)blocks), dim3(256), 0, st, P);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
+}
+
+template <int G>
+int dispatch_theta_T(int T, const RParams &P, bool has_tail, hipStream_t st)
+{
+    if constexpr (G == 8) {
+        switch (T) {
+        case 1: return launch_theta<8, 1>(P, has_tail, st);
+        case 2: return launch_theta<8, 2>(P, has_tail, st);
+        case 4: return launch_theta<8, 4>(P, has_tail, st);
+        case 8: return launch_theta<8, 8>(P, has_tail, st);
+        }
+    }
+    switch (T) {
+    case 12: return launch_theta<G, 12>(P, has_tail, st);
+    case 16: return launch_theta<G, 16>(P, has_tail, st);
     }
     return LLDA_E_BAD_K;
 }
@@ -1843,6 +1971,55 @@ int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab
     case 16: return dispatch_loglik_T<16>(L.T, P, st);
     case 32: return dispatch_loglik_T<32>(L.T, P, st);
     case 64: return dispatch_loglik_T<64>(L.T, P, st);
+    }
+    return LLDA_E_BAD_K;
+}
+
+static void readout_layout(const llda_layout &L, RParams &P)
+{
+    P.K = L.K; P.KP = L.KP; P.T = L.T;
+    for (int p = 0; p < LLDA_MAX_LEAVES; ++p) { P.leaf_start[p] = L.leaf_start[p]; P.leaf_len[p] = L.leaf_len[p]; }
+    fill_schedule(L, P.last_leaf, P.tail, P.tail_row, P.n_rounds, P.xor_tree, P.rounds_pk);
+}
+
+int llda_readout_phi(const int32_t *n_kw, const int32_t *n_k, const double *den, int64_t V, int32_t K, double beta,
+                     int32_t mode, double keep, double share, double *out, int32_t *flags, void *stream)
+{
+    if (V < 1 || (mode != 0 && mode != 1) || !n_kw || (!n_k && !den) || !out) return LLDA_E_BAD_ARG;
+    llda_layout L;
+    const int rc = llda_layout_init(K, &L);
+    if (rc) return rc;
+    RParams P;
+    memset(&P, 0, sizeof P);
+    readout_layout(L, P);
+    P.n_kw = n_kw; P.n_k = n_k; P.den = den; P.out = out; P.flags = flags; P.V = V; P.mode = mode;
+    P.beta = beta; P.vbeta = (double)V * beta; P.keep = keep; P.share = share;
+    hipLaunchKernelGGL(llda_readout_phi_kernel, dim3((unsigned)((V + 63) / 64)), dim3(256), 0, (hipStream_t)stream, P);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
+}
+
+int llda_readout_theta(const int32_t *n_dk, const uint16_t *lab_mask, int64_t D, int32_t K, double alpha, int32_t mode,
+                       double keep, double share, double *out, void *stream)
+{
+    if (D < 0 || (mode != 0 && mode != 1)) return LLDA_E_BAD_ARG;
+    llda_layout L;
+    const int rc = llda_layout_init(K, &L);
+    if (rc) return rc;
+    if (D == 0) return LLDA_OK;
+    if (!n_dk || !lab_mask || !out) return LLDA_E_BAD_ARG;
+    RParams P;
+    memset(&P, 0, sizeof P);
+    readout_layout(L, P);
+    P.n_dk = n_dk; P.lab_mask = lab_mask; P.out = out; P.D = D; P.mode = mode; P.alpha = alpha;
+    P.keep = keep; P.share = share;
+    hipStream_t st = (hipStream_t)stream;
+    const bool has_tail = L.tail != 0;
+    switch (L.G) {
+    case 8: return dispatch_theta_T<8>(L.T, P, has_tail, st);
+    case 16: return dispatch_theta_T<16>(L.T, P, has_tail, st);
+    case 32: return dispatch_theta_T<32>(L.T, P, has_tail, st);
+    case 64: return dispatch_theta_T<64>(L.T, P, has_tail, st);
     }
     return LLDA_E_BAD_K;
 }

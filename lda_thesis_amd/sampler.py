@@ -230,6 +230,32 @@ class GibbsSampler(object):
             total, sites = float(t[0]), float(t[1])
         return float(np.exp(total / sites))
 
+    # ------------------------------------------------------------------ thinning read-outs on the device
+    # (K, V) / (D, K) float64 tensors in the REFERENCE's layout.  With ``out`` and the two coefficients the
+    # call updates a running mean in place: out = keep*out + share*current.
+    def phi(self, out=None, keep=None, share=None, flags=None):
+        """get_phi: (n_k_v + beta) / (n_zk[:, None] + V*beta), reference LabeledLDA.py:231-234."""
+        if out is None:
+            out = torch.empty((self.K, self.V), dtype=torch.float64, device=self.device)
+        self.backend.readout_phi(self.n_kw, self.n_k, None, self.V, self.K, self.beta, out, flags, keep, share)
+        return out
+
+    def ph_rows(self, out=None, keep=None, share=None):
+        """SubLDA.get_ph: n_k_v / n_k_v.sum(axis=1) without smoothing (reference CascadeLDA.py:394-395); the
+        row sums are exact integers."""
+        if out is None:
+            out = torch.empty((self.K, self.V), dtype=torch.float64, device=self.device)
+        den = self.n_kw.sum(dim=0, dtype=torch.int64).to(torch.float64)
+        self.backend.readout_phi(self.n_kw, None, den, self.V, self.K, 0.0, out, None, keep, share)
+        return out
+
+    def theta(self, out=None, keep=None, share=None):
+        """get_theta of the LOCAL documents: (n_d_k + labs*alpha) / row sums, reference LabeledLDA.py:236-239."""
+        if out is None:
+            out = torch.empty((self.D, self.K), dtype=torch.float64, device=self.device)
+        self.backend.readout_theta(self.n_dk, self.lab_mask, self.D, self.K, self.alpha, out, keep, share)
+        return out
+
     # ------------------------------------------------------------------ reference-layout views
     def n_d_k(self):
         return self.n_dk[:, self._topic_pos].cpu().numpy().astype(np.int64)
@@ -248,3 +274,31 @@ class GibbsSampler(object):
         z = self.z_topics()
         off = self.doc_off.cpu().numpy()
         return [z[off[d]:off[d + 1]].copy() for d in range(self.D)]
+
+
+class HostOrDevice(object):
+    """A float64 matrix that is either on the host (numpy, what the reference's attributes are) or on the
+    device (while the thinning read-outs accumulate into it); never both, so neither copy can go stale."""
+
+    def __init__(self, host):
+        self.host, self.dev = host, None
+
+    def get(self, gather=None):
+        if self.host is None:
+            local = self.dev.cpu().numpy()
+            self.host, self.dev = (gather(local) if gather is not None else local), None
+        return self.host
+
+    def set(self, value):
+        self.host, self.dev = value, None
+
+    def on_device(self, device, shape, fresh=False, rows=None):
+        """the device copy (uploading the host one, or its ``rows`` slice, unless ``fresh``)."""
+        if self.dev is None:
+            if fresh:
+                self.dev = torch.empty(shape, dtype=torch.float64, device=device)
+            else:
+                h = self.host if rows is None else self.host[rows[0]:rows[1]]
+                self.dev = torch.from_numpy(np.ascontiguousarray(h, dtype=np.float64)).to(device)
+            self.host = None
+        return self.dev

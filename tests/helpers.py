@@ -93,5 +93,39 @@ class OracleBackend(object):
         counts += delta
         delta.zero_()
 
-    def loglik(self, *a, **k):
-        raise NotImplementedError
+    def loglik(self, doc_off, word, lab_mask, n_dk, n_kw, n_k, D, V, K, alpha, beta, out_doc):
+        """out_doc[d] = sum over the sites of -log(phi[:, w] . theta_d)  (reference LabeledLDA.py:256-265)"""
+        import torch
+        ph = torch.empty((K, V), dtype=torch.float64)
+        th = torch.empty((D, K), dtype=torch.float64)
+        self.readout_phi(n_kw, n_k, None, V, K, beta, ph)
+        self.readout_theta(n_dk, lab_mask, D, K, alpha, th)
+        ph, th, off, w = ph.numpy(), th.numpy(), doc_off.numpy(), word.numpy()
+        o = out_doc.numpy()
+        for d in range(D):
+            o[d] = -sum(np.log(np.inner(ph[:, v], th[d])) for v in w[off[d]:off[d + 1]])
+
+    # numpy statements of the read-out entry points (reference LabeledLDA.py:231-239, CascadeLDA.py:394-395)
+    def readout_phi(self, n_kw, n_k, den, V, K, beta, out, flags=None, keep=None, share=None):
+        tp = self._lay(K).topic_pos.astype(np.int64)
+        n_k_v = n_kw.numpy()[:, tp].T.astype(np.int64)
+        if den is None:
+            cur = (n_k_v + beta) / (n_k.numpy()[tp].astype(np.int64)[:, np.newaxis] + V * beta)
+        else:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                cur = (n_k_v + beta) / den.numpy()[tp][:, np.newaxis]
+        o = out.numpy()
+        o[...] = cur if keep is None else keep * o + (share * cur)
+        if flags is not None:
+            bad = (1 if (o < 0).any() else 0) | (2 if np.isnan(o).any() else 0) | (4 if (~(o != 0).any(axis=0)).any() else 0)
+            flags |= bad
+
+    def readout_theta(self, n_dk, lab_mask, D, K, alpha, out, keep=None, share=None):
+        lay = self._lay(K)
+        tp = lay.topic_pos.astype(np.int64)
+        bits = lab_mask.numpy().astype(np.int64) & 0xFFFF
+        labs = ((bits[:, :, None] >> np.arange(lay.T)) & 1).reshape(D, lay.KP)[:, tp].astype(np.float64)
+        num = np.ascontiguousarray(n_dk.numpy()[:, tp].astype(np.int64) + labs * alpha)   # C order: np.sum is pairwise per row
+        cur = num / num.sum(axis=1)[:, np.newaxis]
+        o = out.numpy()
+        o[...] = cur if keep is None else keep * o + (share * cur)

@@ -164,6 +164,14 @@ def _llda_worker(rank, world, port, q):
         ok &= np.array_equal(m.n_k_v, g[key + "n_k_v"]) and np.array_equal(m.n_d_k, g[key + "n_d_k"])
         ok &= np.array_equal(m.n_zk, g[key + "n_zk"]) and np.array_equal(np.concatenate(m.z_dn), g[key + "z"])
     ok &= bool(np.array_equal(m.get_phi(), g["o3_phi"]) and np.array_equal(m.get_theta(), g["o3_theta"]))
+    # run_training: thinning read-outs and running means accumulate on each rank's slice, th_hat is gathered
+    g = load_golden("runtraining_k12")
+    docs, labs, labelset, alpha, beta, sweeps, npseed = tiny_corpus("k12")
+    np.random.seed(npseed)
+    m = L.LabeledLDA(docs, labs, list(labelset), Dictionary(docs), alpha, beta, seed=int(g["seed"]))
+    m.run_training(int(g["iters"]), int(g["thinning"]))
+    ok &= bool(np.array_equal(m.ph_hat, g["ph_hat"]) and np.array_equal(m.th_hat, g["th_hat"]))
+    ok &= bool(np.allclose(np.array(m.cur_perplx), g["cur_perplx"], rtol=1e-9, atol=0))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
