@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 4
+#define LLDA_ABI_VERSION 5
 #define LLDA_MAX_K 1024
 #define LLDA_MAX_LEAVES 8
 #define LLDA_MAX_ROUNDS 4
@@ -112,6 +112,13 @@ typedef struct llda_sweep_args {
     int32_t       *resume_count; /* [dev] [1] scratch (zeroed by llda_sweep)                          */
     int32_t  resume_cap;         /* capacity of `resume` in documents                                */
     int32_t  live_max;           /* largest number of allowed topics of any document                  */
+    /* optional commit log (both non-NULL): instead of two int32 atomics on n_kw_delta per changed site the
+     * kernels store ONE word (old position | new position << 16) at the site's place in WORD-major order;
+     * llda_commit_log then folds the log into the counts word by word without global atomics.  (No-return
+     * global atomics saturate at ~27 G/s on MI355X, scattered 4-byte stores at ~88 G/s: tools/atomic_ubench.hip.)
+     * n_kw_delta is not touched in this mode. */
+    const int32_t *csc_pos;      /* [dev] [S] index of every site in word-major (stable) order        */
+    uint32_t      *commit_log;   /* [dev] [S] out, word-major                                         */
 } llda_sweep_args;
 
 /* ---- host-only (no device needed) ---- */
@@ -127,6 +134,18 @@ int llda_sweep(const llda_sweep_args *args, void *stream);
 
 /* n_kw[i] += delta[i]; delta[i] = 0  for i < n   (end-of-sweep fold, after the all-reduce of delta). */
 int llda_apply_delta(int32_t *counts, int32_t *delta, int64_t n, void *stream);
+
+/* Fold a commit log into word-major counts (the deferred `+= f` / `-= f` of LabeledLDA.py:109-111,123-125).
+ * The log is cut into ITEMS of consecutive entries of ONE word: item i covers log[item_begin[i] ..
+ * item_begin[i] + item_len[i]) and belongs to word item_word[i] & 0x7fffffff; bit 31 of item_word is set when
+ * the word is spread over several items (their rows are then combined with atomics, all others with plain
+ * read-modify-writes).  One wavefront per item accumulates a KP-entry histogram in LDS and adds it to
+ * target[word*KP ..].  target = n_kw (single device: counts updated in place) or n_kw_delta (zeroed; then
+ * all-reduced and applied).  If n_k is not NULL the call also folds n_k += n_k_delta; n_k_delta = 0.
+ * freq_csc[j] is the frequency of the site logged at j. */
+int llda_commit_log(const int64_t *item_begin, const int32_t *item_len, const int32_t *item_word, int64_t n_items,
+                    const uint32_t *commit_log, const int32_t *freq_csc, int32_t K, int32_t *target,
+                    int32_t *n_k, int32_t *n_k_delta, void *stream);
 
 /* Count initialisation from assignments: LabeledLDA.py:89-92.  n_dk, n_kw, n_k must be zeroed by the
  * caller; z holds device positions.  (The SubLDA phantom-column quirk, CascadeLDA.py:382-385, is a

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libllda_gibbs.so")
 MAX_K = 1024
 MAX_LEAVES = 8
 MAX_ROUNDS = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -48,11 +48,12 @@ class LldaSweepArgs(ctypes.Structure):
                 ("dense_mask", _c_i32), ("debug_margin", _c_i32), ("alpha", _c_d), ("beta", _c_d), ("seed", _c_u64), ("sweep", _c_u32),
                 ("stream_id", _c_u32), ("doc_base", _c_i64),
                 ("live_off", _c_p), ("live_pos", _c_p), ("resume", _c_p), ("resume_count", _c_p),
-                ("resume_cap", _c_i32), ("live_max", _c_i32)]
+                ("resume_cap", _c_i32), ("live_max", _c_i32), ("csc_pos", _c_p), ("commit_log", _c_p)]
 
 
 EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_layout_init",
-           "llda_sweep", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin", "llda_selftest_div")
+           "llda_sweep", "llda_commit_log", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
+           "llda_readout_phi", "llda_readout_theta", "llda_selftest_div")
 
 _LIB = None
 
@@ -85,6 +86,8 @@ def lib():
     L.llda_layout_init.argtypes = [_c_i32, ctypes.POINTER(LldaLayout)]
     L.llda_sweep.restype = ctypes.c_int
     L.llda_sweep.argtypes = [ctypes.POINTER(LldaSweepArgs), _c_p]
+    L.llda_commit_log.restype = ctypes.c_int
+    L.llda_commit_log.argtypes = [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i32, _c_p, _c_p, _c_p, _c_p]
     L.llda_apply_delta.restype = ctypes.c_int
     L.llda_apply_delta.argtypes = [_c_p, _c_p, _c_i64, _c_p]
     L.llda_count_init.restype = ctypes.c_int
@@ -138,7 +141,7 @@ def _stream():
 def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
           status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
           dense_mask=False, debug_margin=0, live_off=None, live_pos=None, resume=None, resume_count=None,
-          live_max=0):
+          live_max=0, csc_pos=None, commit_log=None):
     """llda_sweep on the current torch stream.  All array arguments are torch CUDA tensors."""
     a = LldaSweepArgs(_ptr(doc_off), _ptr(doc_order), _ptr(word), _ptr(freq), _ptr(z), _ptr(lab_mask),
                       _ptr(n_dk), _ptr(n_kw), _ptr(n_kw_delta), _ptr(n_k), _ptr(n_k_delta), _ptr(status),
@@ -146,8 +149,16 @@ def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta
                       float(alpha), float(beta),
                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(sweep) & 0xFFFFFFFF,
                       int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), _ptr(resume),
-                      _ptr(resume_count), 0 if resume is None else int(resume.shape[0]), int(live_max))
+                      _ptr(resume_count), 0 if resume is None else int(resume.shape[0]), int(live_max),
+                      _ptr(csc_pos), _ptr(commit_log))
     check(lib().llda_sweep(ctypes.byref(a), _stream()), "llda_sweep")
+
+
+def commit_log(item_begin, item_len, item_word, commit_log, freq_csc, K, target, n_k=None, n_k_delta=None):
+    """llda_commit_log: fold the word-major commit log of a sweep into ``target`` (n_kw or its delta buffer)."""
+    check(lib().llda_commit_log(_ptr(item_begin), _ptr(item_len), _ptr(item_word), int(item_len.numel()),
+                                _ptr(commit_log), _ptr(freq_csc), int(K), _ptr(target), _ptr(n_k), _ptr(n_k_delta),
+                                _stream()), "llda_commit_log")
 
 
 def apply_delta(counts, delta):

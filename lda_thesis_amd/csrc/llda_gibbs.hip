@@ -75,6 +75,9 @@ struct KParams {
     int32_t *resume_count;  // [1]
     int32_t resume_cap;
     int32_t resume_mode;    // 1: this launch of the dense kernel walks the resume list instead of all documents
+    // commit log (both NULL: n_kw_delta atomics): one word per site at its word-major position
+    const int32_t *csc_pos;
+    uint32_t *commit_log;
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];   // 4 bits per leaf: partner leaf
 };
 
@@ -603,10 +606,13 @@ __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, co
 }
 
 // store the new assignment of a site and move its count in n_kw_delta (int32 atomics, no return value)
-__device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, int f, int zo, int zn, int KP)
+// (c = the site's position in the commit log when there is one; v, f are only needed without a log)
+__device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, int f, int zo, int zn, int c, int KP)
 {
     P.z[i] = zn;
-    if (zn != zo) {
+    if (P.commit_log) {
+        P.commit_log[c] = (uint32_t)zo | ((uint32_t)zn << 16);
+    } else if (zn != zo) {
         int32_t *row = P.n_kw_delta + (int64_t)v * KP;
         atomicAdd(row + zo, -f);
         atomicAdd(row + zn, f);
@@ -683,26 +689,27 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
 
         // memory pipeline: see llda_sweep_kernel
-        int v_c = P.word[s0], f_c = P.freq[s0], zo_c = P.z[s0];
+        int v_c = P.word[s0], f_c = P.freq[s0], zo_c = P.z[s0], c_c = P.csc_pos ? P.csc_pos[s0] : 0;
         const int64_t i1 = s0 + (len > 1 ? 1 : 0);
-        int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1];
+        int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1], c_1 = P.csc_pos ? P.csc_pos[i1] : 0;
         int xn[T];
         load_row<T>(P.n_kw + (int64_t)v_c * KP + lig * T, xn);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         int64_t pend_i = -1;
-        int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0;
+        int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0, pend_c = 0;
 
         for (int n = 0; n < len; ++n) {
-            const int v = v_c, f = f_c, zo = zo_c;
+            const int v = v_c, f = f_c, zo = zo_c, c = c_c;
             int x[T];
 #pragma unroll
             for (int s = 0; s < T; ++s) x[s] = xn[s];
-            if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
+            if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
             load_row<T>(P.n_kw + (int64_t)v_1 * KP + lig * T, xn);
-            v_c = v_1; f_c = f_1; zo_c = zo_1;
+            v_c = v_1; f_c = f_1; zo_c = zo_1; c_c = c_1;
             {
                 const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);
                 v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
+                if (P.csc_pos) c_1 = P.csc_pos[i2];
             }
             const double u = site_uniform<G>(P, n, n == 0, gdoc, lig, r0, r1, r2, r3);
 
@@ -728,9 +735,9 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
                 const int ln = zn / T, sn = zn - ln * T;
                 onehot_add1<T>(ndk, (lig == ln) ? (1u << sn) : 0u, -f);
             }
-            pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn;
+            pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn; pend_c = c;
         }
-        if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
+        if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
 
         int old[T];
         load_row<T>(ndk_row, old);
@@ -854,26 +861,26 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         // site n+1.  Right after the single s_waitcnt vmcnt(0) of the iteration (first use of xn) the body
         // issues, in this order: the z store + two n_kw_delta atomics of site n-1, the row of site n+1,
         // the scalars of site n+2 -- so nothing the next wait covers is younger than one full site.
-        int v_c = P.word[s0 + n0], f_c = P.freq[s0 + n0], zo_c = P.z[s0 + n0];
+        int v_c = P.word[s0 + n0], f_c = P.freq[s0 + n0], zo_c = P.z[s0 + n0], c_c = P.csc_pos ? P.csc_pos[s0 + n0] : 0;
         const int64_t i1 = s0 + (n0 + 1 < len ? n0 + 1 : n0);
-        int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1];
+        int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1], c_1 = P.csc_pos ? P.csc_pos[i1] : 0;
         int xn[T];
         load_row<T>(P.n_kw + (int64_t)v_c * KP + lig * T, xn);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         int64_t pend_i = -1;
-        int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0;
+        int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0, pend_c = 0;
         {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the loop body
             const int lo = zo_c / T;
             if (lig == lo) count_update(s_ndk, s_nkc, s_pa, zo_c - lo * T, tid, alpha32, vbeta32, -f_c);
         }
 
         for (int n = n0; n < len; ++n) {
-            const int v = v_c, f = f_c, zo = zo_c;
+            const int v = v_c, f = f_c, zo = zo_c, c = c_c;
             int x[T];
 #pragma unroll
             for (int s = 0; s < T; ++s) x[s] = xn[s];
 #ifndef ABL_NOCOMMIT
-            if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
+            if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
 #endif
 #ifndef ABL_NOLOAD
             load_row<T>(P.n_kw + (int64_t)v_1 * KP + lig * T, xn);        // row of site n+1 (clamped)
@@ -881,10 +888,11 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
 #pragma unroll
             for (int s = 0; s < T; ++s) xn[s] = (v_1 + s) & 7;            // ablation: no n_kw traffic
 #endif
-            v_c = v_1; f_c = f_1; zo_c = zo_1;
+            v_c = v_1; f_c = f_1; zo_c = zo_1; c_c = c_1;
             {
                 const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);  // scalars of site n+2 (clamped)
                 v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
+                if (P.csc_pos) c_1 = P.csc_pos[i2];
             }
             uint32_t ra, rb;
             site_random_bits<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3, ra, rb);
@@ -930,9 +938,9 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                                  own_new ? f : -f_c);
                 if (own_new && own_old) count_update(s_ndk, s_nkc, s_pa, zo_c - lo2 * T, tid, alpha32, vbeta32, -f_c);
             }
-            pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn;
+            pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn; pend_c = c;
         }
-        if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, KP);
+        if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
 
         // document done: fold its n_dk change into the workgroup's n_k accumulator, store the row
         int old[T], cur[T];
@@ -1124,7 +1132,7 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
             const int nb = min(8, len - n0);
             const int jj = lig & 7;
             const int64_t si = s0 + n0 + (jj < nb ? jj : nb - 1);
-            const int sv = P.word[si], sf = P.freq[si], sz = P.z[si];
+            const int sv = P.word[si], sf = P.freq[si], sz = P.z[si], sc = P.csc_pos ? P.csc_pos[si] : 0;
             int su_lo, su_hi;
             {   // keyed uniform of site n0+jj: Philox block (site >> 1), words (0,1) / (2,3) by parity
                 const int n = n0 + jj;
@@ -1160,7 +1168,7 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
 #undef LLDA_SPARSE_SITE
             if (!ok) stop_at = n0 + done;
             // commit the decided sites of the batch: lane j handles site n0+j
-            if (lig < 8 && lig < done) commit_site(P, s0 + n0 + lig, sv, sf, sz, my_zn, KP);
+            if (lig < 8 && lig < done) commit_site(P, s0 + n0 + lig, sv, sf, sz, my_zn, sc, KP);
         }
 
         if (stop_at >= 0) {
@@ -1415,6 +1423,76 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
     store_row<T>(P.n_dk + d * KP + lig * T, ndk);
 #pragma unroll
     for (int s = 0; s < T; ++s) P.th[d * KP + lig * T + s] = avg[s];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fold of the commit log into word-major counts (llda_commit_log, include/llda_gibbs.h): one wavefront per
+// item (a run of log entries of one word), a KP-entry histogram per wavefront in LDS.  The histogram is
+// flushed either by walking the item's entries again (short items: each touched topic is claimed with an LDS
+// exchange) or by scanning all KP entries (long items).
+// ---------------------------------------------------------------------------------------------
+struct CParams {
+    const int64_t *item_begin;
+    const int32_t *item_len, *item_word;
+    int64_t n_items;
+    const uint32_t *log;
+    const int32_t *freq;
+    int32_t *target, *n_k, *n_k_delta;
+    int32_t KP;
+};
+
+__device__ __forceinline__ void add_count(int32_t *p, int a, bool shared_row)
+{
+    if (shared_row) atomicAdd(p, a);
+    else *p += a;
+}
+
+__global__ void __launch_bounds__(256) llda_commit_log_kernel(const CParams P)
+{
+    extern __shared__ int s_hist[];               // [4][KP]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int KP = P.KP;
+    if (blockIdx.x == 0 && P.n_k)
+        for (int p = tid; p < KP; p += 256) {
+            P.n_k[p] += P.n_k_delta[p];
+            P.n_k_delta[p] = 0;
+        }
+    int *hist = s_hist + w * KP;
+    for (int p = lane; p < KP; p += 64) hist[p] = 0;
+    const int64_t item = (int64_t)blockIdx.x * 4 + w;
+    if (item >= P.n_items) return;
+    const int64_t b = P.item_begin[item];
+    const int len = P.item_len[item];
+    const int wv = P.item_word[item];
+    const bool shared_row = wv < 0;
+    int32_t *row = P.target + (int64_t)(wv & 0x7fffffff) * KP;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    for (int j = lane; j < len; j += 64) {
+        const uint32_t e = P.log[b + j];
+        const int zo = (int)(e & 0xFFFFu), zn = (int)(e >> 16);
+        if (zo != zn) {
+            const int f = P.freq[b + j];
+            atomicAdd(&hist[zo], -f);
+            atomicAdd(&hist[zn], f);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (len <= KP) {
+        for (int j = lane; j < len; j += 64) {
+            const uint32_t e = P.log[b + j];
+            const int zo = (int)(e & 0xFFFFu), zn = (int)(e >> 16);
+            if (zo != zn) {
+                const int a = atomicExch(&hist[zo], 0), c = atomicExch(&hist[zn], 0);
+                if (a) add_count(row + zo, a, shared_row);
+                if (c) add_count(row + zn, c, shared_row);
+            }
+        }
+    } else {
+        for (int p = lane; p < KP; p += 64) {
+            const int a = hist[p];
+            if (a) add_count(row + p, a, shared_row);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1837,8 +1915,10 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     const int rc = llda_layout_init(a->K, &L);
     if (rc) return rc;
     if (a->D == 0) return LLDA_OK;            // an empty shard: nothing to do, array pointers may be NULL
-    if (!a->doc_off || !a->word || !a->freq || !a->z || !a->lab_mask || !a->n_dk || !a->n_kw || !a->n_kw_delta ||
-        !a->n_k || !a->n_k_delta)
+    const bool logged = a->csc_pos && a->commit_log;
+    if ((a->csc_pos != nullptr) != (a->commit_log != nullptr)) return LLDA_E_BAD_ARG;
+    if (!a->doc_off || !a->word || !a->freq || !a->z || !a->lab_mask || !a->n_dk || !a->n_kw ||
+        (!a->n_kw_delta && !logged) || !a->n_k || !a->n_k_delta)
         return LLDA_E_BAD_ARG;
 
     KParams P;
@@ -1846,6 +1926,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     P.doc_off = a->doc_off; P.doc_order = a->doc_order; P.word = a->word; P.freq = a->freq; P.z = a->z;
     P.lab_mask = a->lab_mask; P.n_dk = a->n_dk; P.n_kw = a->n_kw; P.n_kw_delta = a->n_kw_delta;
     P.n_k = a->n_k; P.n_k_delta = a->n_k_delta; P.status = a->status;
+    P.csc_pos = a->csc_pos; P.commit_log = a->commit_log;
     P.D = a->D; P.doc_base = a->doc_base;
     P.alpha = a->alpha; P.beta = a->beta;
     P.vbeta = (double)a->V * a->beta;                       // V * beta evaluated first (LabeledLDA.py:115)
@@ -1871,13 +1952,10 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     const int G = sparse ? (a->live_max <= 8 ? 8 : a->live_max <= 16 ? 16 : a->live_max <= 32 ? 32 : 64) : L.G;
     const int gpb = 256 / G;
     int dpg = a->docs_per_group;
-    if (dpg < 1) {
-        // auto: aim for >= 16 workgroups per CU so the hardware dispatcher balances ragged documents
-        const int64_t want_blocks = 256 * 16;
-        dpg = (int)((a->D + want_blocks * gpb - 1) / (want_blocks * gpb));
-        if (dpg < 1) dpg = 1;
-        if (dpg > 8) dpg = 8;
-    }
+    // auto: one pass of documents per workgroup.  Workgroups of equal-length documents finish in lock step, so
+    // the tail of the launch idles for up to one workgroup's run time: the shorter the workgroup the better
+    // (synth2: 3540 M sites/s at 1, 3341 at 4, 3205 at 6 documents per lane group)
+    if (dpg < 1) dpg = 1;
     P.dpg = dpg;
     const int64_t per_block = (int64_t)gpb * dpg;
     const int64_t blocks = (a->D + per_block - 1) / per_block;
@@ -1918,6 +1996,27 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     case 64: return dispatch_sweep_T<64>(L.T, P, has_tail, fast, dense, blocks, st);
     }
     return LLDA_E_BAD_K;
+}
+
+int llda_commit_log(const int64_t *item_begin, const int32_t *item_len, const int32_t *item_word, int64_t n_items,
+                    const uint32_t *commit_log, const int32_t *freq_csc, int32_t K, int32_t *target, int32_t *n_k,
+                    int32_t *n_k_delta, void *stream)
+{
+    if (n_items < 0 || (n_k != nullptr) != (n_k_delta != nullptr)) return LLDA_E_BAD_ARG;
+    llda_layout L;
+    const int rc = llda_layout_init(K, &L);
+    if (rc) return rc;
+    if (n_items > 0 && (!item_begin || !item_len || !item_word || !commit_log || !freq_csc || !target)) return LLDA_E_BAD_ARG;
+    if (n_items == 0 && !n_k) return LLDA_OK;
+    CParams P;
+    P.item_begin = item_begin; P.item_len = item_len; P.item_word = item_word; P.n_items = n_items;
+    P.log = commit_log; P.freq = freq_csc; P.target = target; P.n_k = n_k; P.n_k_delta = n_k_delta; P.KP = L.KP;
+    int64_t blocks = (n_items + 3) / 4;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
+    hipLaunchKernelGGL(llda_commit_log_kernel, dim3((unsigned)blocks), dim3(256), 4 * L.KP * sizeof(int), (hipStream_t)stream, P);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
 }
 
 int llda_apply_delta(int32_t *counts, int32_t *delta, int64_t n, void *stream)

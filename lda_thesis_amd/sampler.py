@@ -62,13 +62,17 @@ class GibbsSampler(object):
     sharded  : True (default) = the local documents are one shard of a corpus spread over the ranks
                of ``group``: deltas are all-reduced every sweep.  False = a self-contained problem
                (e.g. one CascadeLDA sub-problem per GPU): no collective at all.
+    commit_log : True = the sweep kernels log (old, new) topic per site in word-major order and
+               ``llda_commit_log`` folds the log into n_kw without global atomics; False = int32 atomics on the
+               delta buffer from inside the sweep kernels.  Same counts either way.  None (default) = log from
+               2^20 local sites up (below that the extra pass costs more than the atomics it saves).
     backend  : module with the _native entry points (tests inject a CPU checker here; the product
                always uses the HIP library).
     """
 
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
                  stream_id=0, doc_base=0, device=None, group=None, backend=None, sort_docs=True,
-                 docs_per_group=0, sharded=True, sparse_labels=True):
+                 docs_per_group=0, sharded=True, sparse_labels=True, commit_log=None):
         self.backend = backend if backend is not None else _native
         if backend is None:
             _native.lib()                                   # fail loudly when the extension is missing
@@ -110,6 +114,11 @@ class GibbsSampler(object):
         self.live_max = 0
         if sparse_labels and labs is not None and self.D > 0:
             self._make_live()
+        self.csc_pos = self.commit_log = None
+        if commit_log is None:
+            commit_log = self.S >= (1 << 20)
+        if commit_log and self.S > 0:
+            self._make_commit_log()
         lens = (self.doc_off[1:] - self.doc_off[:-1])
         self.doc_order = None
         if sort_docs and self.D > 1 and int(lens.min()) != int(lens.max()):
@@ -180,6 +189,33 @@ class GibbsSampler(object):
         self.resume = torch.zeros((cap, 66), dtype=torch.int32, device=dev)
         self.resume_count = torch.zeros((1,), dtype=torch.int32, device=dev)
 
+    LOG_ITEM = 4096    # most log entries one wavefront of llda_commit_log folds (hot words are cut into items)
+
+    def _make_commit_log(self):
+        """word-major (CSC) view of the sites: position of every site, frequencies in that order, and the work
+        items of llda_commit_log (runs of at most LOG_ITEM entries of one word)."""
+        dev = self.device
+        w64 = self.word.to(torch.int64)
+        order = torch.sort(w64, stable=True).indices
+        self.csc_pos = torch.empty((self.S,), dtype=torch.int32, device=dev)
+        self.csc_pos[order] = torch.arange(self.S, dtype=torch.int32, device=dev)
+        self.freq_csc = self.freq[order].contiguous()
+        del order
+        per_word = torch.bincount(w64, minlength=self.V)
+        word_off = torch.zeros((self.V + 1,), dtype=torch.int64, device=dev)
+        torch.cumsum(per_word, 0, out=word_off[1:])
+        n_items = (per_word + (self.LOG_ITEM - 1)) // self.LOG_ITEM            # 0 for words without a site
+        words = torch.repeat_interleave(torch.arange(self.V, device=dev), n_items)
+        first = torch.zeros((self.V + 1,), dtype=torch.int64, device=dev)
+        torch.cumsum(n_items, 0, out=first[1:])
+        part = torch.arange(words.numel(), device=dev) - first[words]          # index of the item within its word
+        self.item_begin = (word_off[words] + part * self.LOG_ITEM).contiguous()
+        self.item_len = torch.minimum(per_word[words] - part * self.LOG_ITEM,
+                                      torch.full_like(part, self.LOG_ITEM)).to(torch.int32).contiguous()
+        shared = n_items[words] > 1
+        self.item_word = torch.where(shared, words - (1 << 31), words).to(torch.int32).contiguous()
+        self.commit_log = torch.zeros((self.S,), dtype=torch.int32, device=dev)
+
     # ------------------------------------------------------------------ the hot path
     def sweep(self):
         """One Gibbs sweep over the local documents + exchange + fold."""
@@ -187,6 +223,7 @@ class GibbsSampler(object):
         if self.kernel_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()              # same stream the kernel is enqueued on (torch's current stream)
+        logged = self.commit_log is not None
         self.backend.sweep(doc_off=self.doc_off, doc_order=self.doc_order, word=self.word, freq=self.freq,
                            z=self.z, lab_mask=self.lab_mask, n_dk=self.n_dk, n_kw=self.n_kw,
                            n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=self.n_k_delta,
@@ -195,14 +232,24 @@ class GibbsSampler(object):
                            stream_id=self.stream_id, doc_base=self.doc_base,
                            docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
                            debug_margin=self.debug_margin, live_off=self.live_off, live_pos=self.live_pos,
-                           resume=self.resume, resume_count=self.resume_count, live_max=self.live_max)
+                           resume=self.resume, resume_count=self.resume_count, live_max=self.live_max,
+                           csc_pos=self.csc_pos, commit_log=self.commit_log)
         if ev is not None:
             ev[1].record()
             self.kernel_events.append(ev)
-        if self.sharded and _dist_active(self.group):
-            import torch.distributed as dist
-            dist.all_reduce(self._delta, group=self.group)          # RCCL over xGMI: SUM int32, one collective
-        self.backend.apply_delta(self._counts, self._delta)
+        exchange = self.sharded and _dist_active(self.group)
+        if logged and not exchange:
+            # single device: the log is folded straight into n_kw (and n_k += its delta) -- no delta pass
+            self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log, self.freq_csc,
+                                    self.K, self.n_kw, self.n_k, self.n_k_delta)
+        else:
+            if logged:
+                self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
+                                        self.freq_csc, self.K, self.n_kw_delta)
+            if exchange:
+                import torch.distributed as dist
+                dist.all_reduce(self._delta, group=self.group)      # RCCL over xGMI: SUM int32, one collective
+            self.backend.apply_delta(self._counts, self._delta)
         self.sweeps_done += 1
 
     def check_status(self):

@@ -67,7 +67,7 @@ class OracleBackend(object):
     def sweep(self, *, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
               status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
               dense_mask=False, debug_margin=0, live_off=None, live_pos=None, resume=None, resume_count=None,
-              live_max=0):
+              live_max=0, csc_pos=None, commit_log=None):
         import torch
         lay = self._lay(K)
         tp = lay.topic_pos.astype(np.int64)
@@ -79,14 +79,34 @@ class OracleBackend(object):
         cs = self.co.CState(doc_off.numpy(), word.numpy(), freq.numpy(), lay.pos_topic[z.numpy()], labs,
                             n_dk.numpy()[:, tp], old_kv, old_k, V, alpha, beta)
         cs.sweep(1, seed, sweep, stream=stream_id, doc_base=doc_base, threads=2)
+        z_old = z.numpy().astype(np.int64).copy()
         z.copy_(torch.from_numpy(lay.topic_pos[cs.z].astype(np.int32)))
         n_dk[:, torch.from_numpy(tp)] = torch.from_numpy(cs.n_d_k.astype(np.int32))
-        d_kv = np.zeros(tuple(n_kw.shape), dtype=np.int32)
-        d_kv[:, tp] = (cs.n_k_v - old_kv).T
-        n_kw_delta += torch.from_numpy(d_kv)
+        if commit_log is not None:       # word-major log of (old position | new position << 16), as the kernels write it
+            packed = (z_old | (z.numpy().astype(np.int64) << 16)).astype(np.int64)
+            commit_log[csc_pos.to(torch.int64)] = torch.from_numpy(np.where(packed >= 2 ** 31, packed - 2 ** 32, packed).astype(np.int32))
+        else:
+            d_kv = np.zeros(tuple(n_kw.shape), dtype=np.int32)
+            d_kv[:, tp] = (cs.n_k_v - old_kv).T
+            n_kw_delta += torch.from_numpy(d_kv)
         d_k = np.zeros(lay.KP, dtype=np.int32)
         d_k[tp] = cs.n_zk - old_k
         n_k_delta += torch.from_numpy(d_k)
+
+    def commit_log(self, item_begin, item_len, item_word, log, freq_csc, K, target, n_k=None, n_k_delta=None):
+        """numpy statement of llda_commit_log (include/llda_gibbs.h)"""
+        KP = self._lay(K).KP
+        t = target.numpy().reshape(-1, KP)
+        lg = log.numpy().astype(np.int64) & 0xFFFFFFFF
+        f = freq_csc.numpy().astype(np.int64)
+        for b, n, wv in zip(item_begin.tolist(), item_len.tolist(), item_word.tolist()):
+            v = wv & 0x7FFFFFFF
+            e = lg[b:b + n]
+            np.add.at(t[v], e & 0xFFFF, -f[b:b + n])
+            np.add.at(t[v], e >> 16, f[b:b + n])
+        if n_k is not None:
+            n_k += n_k_delta
+            n_k_delta.zero_()
 
     @staticmethod
     def apply_delta(counts, delta):

@@ -44,7 +44,7 @@ def _worker(rank, world, port, name, counts_mode, q):
     s = GibbsSampler(off[lo:hi + 1] - off[lo], g["word"][s0:s1], g["freq"][s0:s1], g["init_z"][s0:s1],
                      int(g["K"]), int(g["V"]), float(g["alpha"]), float(g["beta"]), labs=g["labs"][lo:hi],
                      counts=counts, seed=int(g["seed"]), doc_base=lo, device="cpu",
-                     backend=OracleBackend(c_oracle))
+                     backend=OracleBackend(c_oracle), commit_log=counts_mode == "built")   # both commit paths
     ok = True
     for i in range(int(g["sweeps"])):
         s.sweep()
@@ -81,7 +81,8 @@ def test_single_process_oracle_backend_matches_golden(c_oracle):
     g = load_golden("tiny_k130")
     s = GibbsSampler(g["doc_off"], g["word"], g["freq"], g["init_z"], int(g["K"]), int(g["V"]),
                      float(g["alpha"]), float(g["beta"]), labs=g["labs"], seed=int(g["seed"]), device="cpu",
-                     backend=OracleBackend(c_oracle))
+                     backend=OracleBackend(c_oracle), commit_log=True)
+    assert s.commit_log is not None and int(s.item_len.sum()) == s.S
     np.testing.assert_array_equal(s.n_k_v(), g["init_n_k_v"])
     for i in range(int(g["sweeps"])):
         s.sweep()

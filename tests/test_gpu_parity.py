@@ -35,6 +35,27 @@ def test_sweeps_match_reference_o3(name, margin):
     s.check_status()
 
 
+@pytest.mark.parametrize("commit", ["atomics", "log_items_of_16", "log_items_of_3"])
+@pytest.mark.parametrize("name", TINY + ["sublda"])
+def test_commit_paths_agree(name, commit, monkeypatch):
+    """n_kw is updated either by int32 atomics from inside the sweep kernels or by folding the word-major commit
+    log (llda_commit_log); hot words are cut into several log items whose rows are combined with atomics."""
+    from lda_thesis_amd.sampler import GibbsSampler
+    g = load_golden(name)
+    if commit != "atomics":
+        monkeypatch.setattr(GibbsSampler, "LOG_ITEM", int(commit.rsplit("_", 1)[1]))
+    s = make_sampler(g, commit_log=commit != "atomics")
+    assert (s.commit_log is None) == (commit == "atomics")
+    if commit != "atomics":
+        if commit.endswith("_3"):
+            assert int((s.item_word < 0).sum()) > 0                 # some word is spread over several items
+        assert int(s.item_len.sum()) == s.S and int(s.item_len.max()) <= GibbsSampler.LOG_ITEM
+    for i in range(int(g["sweeps"])):
+        s.sweep()
+        assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics(), name)
+    s.check_status()
+
+
 @pytest.mark.parametrize("name", TINY)
 def test_count_init_matches_reference(name):
     g = load_golden(name)
