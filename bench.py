@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--workload", default="synth2", choices=sorted(WORKLOADS))
     ap.add_argument("--docs", type=int, default=0, help="override documents per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="diagnostic: take the multi-GPU path (delta buffer, all-reduce if a group exists, fold) on one GPU")
     ap.add_argument("--docs-per-group", type=int, default=0)
     args = ap.parse_args()
 
@@ -155,6 +157,7 @@ def main():
                                doc_base=rank * Dg, device=dev, docs_per_group=args.docs_per_group)
         del z
     sites_local = sampler.S
+    sampler.exchange_always = bool(args.force_exchange)
     torch.cuda.synchronize()
 
     def barrier():

@@ -89,6 +89,7 @@ class GibbsSampler(object):
         self.sweeps_done = 0
         self.debug_margin = 0          # test hook of the two-tier draw (include/llda_gibbs.h)
         self.kernel_events = None      # set to [] to record a (start, end) HIP event pair per sweep kernel
+        self.exchange_always = False   # True: take the delta-buffer + all-reduce path even with a single rank
         self.layout = lay = group_layout(self.K)
         dev = self.device
 
@@ -237,7 +238,7 @@ class GibbsSampler(object):
         if ev is not None:
             ev[1].record()
             self.kernel_events.append(ev)
-        exchange = self.sharded and _dist_active(self.group)
+        exchange = self.sharded and (_dist_active(self.group) or self.exchange_always)
         if logged and not exchange:
             # single device: the log is folded straight into n_kw (and n_k += its delta) -- no delta pass
             self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log, self.freq_csc,
@@ -246,8 +247,8 @@ class GibbsSampler(object):
             if logged:
                 self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
                                         self.freq_csc, self.K, self.n_kw_delta)
-            if exchange:
-                import torch.distributed as dist
+            import torch.distributed as dist
+            if exchange and dist.is_available() and dist.is_initialized():
                 dist.all_reduce(self._delta, group=self.group)      # RCCL over xGMI: SUM int32, one collective
             self.backend.apply_delta(self._counts, self._delta)
         self.sweeps_done += 1

@@ -1,0 +1,86 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle cannot run 37.5 M sites
+in test time): count conservation, counts == a recount from the assignments, independence of the work
+schedule and of the commit path, and independence of how the documents are sharded (two half shards with
+their deltas summed by hand == one shard) -- which is what makes 1/2/4/8-GPU runs bit-identical.
+
+configs[2]: 100k docs x 200 sites, K=128, V=50k, dense mask; configs[3]: one GPU's 125k docs x 300 sites of the
+1M-document corpus, K=512, V=100k, dense mask."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {"synth1": (100_000, 200, 50_000, 128), "synth2_shard": (125_000, 300, 100_000, 512)}
+
+
+def corpus(name):
+    from lda_thesis_amd.corpus import synthetic_corpus
+    D, N, V, K = CONFIGS[name]
+    return synthetic_corpus(D, N, V, K, 1234, "cuda") + (K, V)
+
+
+def make(doc_off, word, freq, z, K, V, **kw):
+    from lda_thesis_amd.sampler import GibbsSampler
+    return GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, counts=None, seed=42, **kw)
+
+
+def check_conservation(s):
+    total = int(s.freq.sum(dtype=torch.int64))
+    assert int(s.n_kw.sum(dtype=torch.int64)) == total and int(s.n_k.sum(dtype=torch.int64)) == total
+    assert torch.equal(s.n_kw.sum(dim=0, dtype=torch.int64), s.n_k.to(torch.int64))          # n_k = column sums
+    assert torch.equal(s.n_dk.sum(dim=0, dtype=torch.int64), s.n_k.to(torch.int64))          # ... of n_dk too
+    per_doc = torch.zeros((s.D,), dtype=torch.int64, device=s.device)
+    rows = torch.repeat_interleave(torch.arange(s.D, device=s.device), s.doc_off[1:] - s.doc_off[:-1])
+    per_doc.index_add_(0, rows, s.freq.to(torch.int64))
+    assert torch.equal(s.n_dk.sum(dim=1, dtype=torch.int64), per_doc)
+    assert int(s.n_kw.min()) >= 0 and int(s.n_dk.min()) >= 0
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_full_size_properties(name):
+    doc_off, word, freq, z, K, V = corpus(name)
+    s = make(doc_off, word, freq, z, K, V)
+    assert s.commit_log is not None                        # production path at this size: word-major commit log
+    start = s._counts.clone()
+    z0 = s.z.clone()
+    for _ in range(2):
+        s.sweep()
+    s.check_status()
+    check_conservation(s)
+    assert int((s.z != z0).sum()) > s.S // 2               # the chain really moved
+
+    # counts maintained incrementally == counts rebuilt from the final assignments (llda_count_init)
+    r = make(doc_off, word, freq, s.z_topics(), K, V)
+    assert torch.equal(r.n_kw, s.n_kw) and torch.equal(r.n_dk, s.n_dk) and torch.equal(r.n_k, s.n_k)
+    del r
+
+    # a different schedule (documents per workgroup, document order) and the atomics commit path: same state
+    t = make(doc_off, word, freq, z, K, V, docs_per_group=3, sort_docs=False, commit_log=False)
+    t.doc_order = torch.randperm(t.D, device=t.device, generator=torch.Generator(device=t.device).manual_seed(1)).to(torch.int32)
+    for _ in range(2):
+        t.sweep()
+    assert torch.equal(t.z, s.z) and torch.equal(t.n_kw, s.n_kw) and torch.equal(t.n_dk, s.n_dk) and torch.equal(t.n_k, s.n_k)
+    del t
+
+    # two half shards (as two GPUs would hold them), deltas summed by hand == the single shard
+    from lda_thesis_amd.sampler import shard_documents
+    b = shard_documents(doc_off.cpu().numpy(), 2)
+    off = doc_off.cpu()
+    halves = []
+    for r_ in range(2):
+        lo, hi = b[r_], b[r_ + 1]
+        s0, s1 = int(off[lo]), int(off[hi])
+        h = make(doc_off[lo:hi + 1] - doc_off[lo], word[s0:s1], freq[s0:s1], z[s0:s1], K, V, doc_base=lo)
+        h.exchange_always = True                           # delta-buffer path, no process group: folds its own delta
+        halves.append(h)
+    counts = start.clone()
+    for _ in range(2):
+        deltas = []
+        for h in halves:
+            h._counts.copy_(counts)                        # what the all-reduce + fold would leave on every rank
+            h.sweep()
+            deltas.append(h._counts - counts)
+        counts = counts + deltas[0] + deltas[1]
+    assert torch.equal(counts, s._counts)
+    assert torch.equal(torch.cat([h.z for h in halves]), s.z)
+    assert torch.equal(torch.cat([h.n_dk for h in halves]), s.n_dk)

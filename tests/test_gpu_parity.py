@@ -308,3 +308,29 @@ def test_sparse_and_dense_kernels_agree_on_a_large_sparse_workload(c_oracle):
     for i in range(3):
         cs.sweep(1, 11, i, threads=8)
     np.testing.assert_array_equal(s.z_topics(), cs.z)
+
+
+@pytest.mark.parametrize("commit", [True, False])
+def test_exchange_path_on_one_rank(commit):
+    """the multi-GPU path of sweep() -- commit log folded into the DELTA buffer (or atomics on it), RCCL
+    all-reduce of the fused delta buffer, llda_apply_delta -- driven on one GPU with a 1-rank nccl group."""
+    import os
+    import torch.distributed as dist
+    g = load_golden("tiny_k130")
+    made = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        made = True
+    try:
+        s = make_sampler(g, commit_log=commit)
+        s.exchange_always = True
+        for i in range(int(g["sweeps"])):
+            s.sweep()
+            assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics())
+            assert int(s._delta.abs().sum()) == 0                  # folded and cleared
+        s.check_status()
+    finally:
+        if made:
+            dist.destroy_process_group()
