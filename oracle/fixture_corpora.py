@@ -28,12 +28,14 @@ TINY = [
     ("k12",      60, 120,   11,   4,      (5, 40),   0.1, 0.01, 3),    # one row + tail
     ("k20dense", 50, 100,   19,  19,      (5, 40),   0.5, 0.1,  3),    # Cascade-root sized
     ("k40",      60, 150,   39,   6,      (5, 50),   0.1, 0.01, 3),
+    ("k90",      40, 150,   89,  20,      (10, 50),  0.1, 0.01, 2),    # 12 slots per lane
     ("k128",     40, 200,  127,  30,      (10, 60),  0.1, 0.01, 2),    # exactly one full leaf
     ("k130",     40, 200,  129,  30,      (10, 60),  0.1, 0.01, 2),    # two leaves, tail 2
     ("k200",     30, 150,  199,  40,      (10, 60),  0.001, 0.001, 2),
     ("k392",     30, 150,  391,   7,      (10, 60),  0.1, 0.01, 2),    # abstracts-shaped, 4 leaves
     ("k512",     24, 150,  511, 200,      (10, 60),  0.1, 0.01, 2),    # 4 full leaves
     ("k777",     16, 120,  776, 300,      (10, 50),  0.1, 0.01, 2),    # unbalanced tree
+    ("k1024",    12, 100, 1023, 400,      (10, 40),  0.1, 0.01, 2),    # the largest K: 8 full leaves, 64 lanes x 16 slots
 ]
 
 

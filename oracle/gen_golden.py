@@ -130,8 +130,10 @@ def pack(prefix, states, out):
 
 
 # ------------------------------------------------------------------------------------------
-def gen_tiny():
+def gen_tiny(only=None):
     for (name, D, V, nl, ml, (lo, hi), alpha, beta, sweeps) in TINY:
+        if only and name not in only:
+            continue
         rng = np.random.default_rng(sum(map(ord, name)))
         docs, labs, labelset = synth_corpus(rng, D, V, nl, ml, lo, hi)
         dicti = Dictionary(docs)
@@ -533,6 +535,9 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "sublda"]
     if "tiny" in what:
         gen_tiny()
+    for w in what:                                   # tiny:k90,k1024 -> only those fixtures
+        if w.startswith("tiny:"):
+            gen_tiny(set(w[5:].split(",")))
     if "sublda" in what:
         gen_sublda()
     if "runtraining" in what:
