@@ -1654,15 +1654,36 @@ __global__ void __launch_bounds__(256) llda_count_init_kernel(const int64_t *__r
                                                               const int32_t *__restrict__ z, int64_t D, int KP,
                                                               int32_t *n_dk, int32_t *n_kw, int32_t *n_k)
 {
-    // one wavefront per document; lanes stride over its sites
-    const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (d >= D) return;
-    const int lane = threadIdx.x & 63;
-    for (int64_t i = doc_off[d] + lane; i < doc_off[d + 1]; i += 64) {
-        const int f = freq[i], p = z[i];
-        atomicAdd(n_dk + d * KP + p, f);
-        atomicAdd(n_kw + (int64_t)word[i] * KP + p, f);
-        atomicAdd(n_k + p, f);
+    // one wavefront per document at a time, lanes stride over its sites.  The document's n_dk row and the
+    // workgroup's share of n_k are histograms in LDS (the row is then written with plain stores, n_k with KP
+    // atomics per workgroup); only n_kw takes one global atomic per site.
+    extern __shared__ int s_init[];               // [KP] n_k of the workgroup, then [4][KP] per-wavefront rows
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int *s_nk = s_init, *hist = s_init + (1 + w) * KP;
+    for (int p = tid; p < KP; p += 256) s_nk[p] = 0;
+    for (int p = lane; p < KP; p += 64) hist[p] = 0;
+    __syncthreads();
+    for (int64_t d = (int64_t)blockIdx.x * 4 + w; d < D; d += (int64_t)gridDim.x * 4) {
+        for (int64_t i = doc_off[d] + lane; i < doc_off[d + 1]; i += 64) {
+            const int f = freq[i], p = z[i];
+            atomicAdd(&hist[p], f);
+            atomicAdd(n_kw + (int64_t)word[i] * KP + p, f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        for (int p = lane; p < KP; p += 64) {
+            const int h = hist[p];
+            if (h) {
+                hist[p] = 0;
+                n_dk[d * KP + p] += h;
+                atomicAdd(&s_nk[p], h);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    __syncthreads();
+    for (int p = tid; p < KP; p += 256) {
+        const int h = s_nk[p];
+        if (h) atomicAdd(n_k + p, h);
     }
 }
 
@@ -2043,10 +2064,10 @@ int llda_count_init(const int64_t *doc_off, const int32_t *word, const int32_t *
     if (rc) return rc;
     if (D == 0) return LLDA_OK;
     if (!doc_off || !word || !freq || !z || !n_dk || !n_kw || !n_k) return LLDA_E_BAD_ARG;
-    const int64_t blocks = (D + 3) / 4;
-    if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
-    hipLaunchKernelGGL(llda_count_init_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       doc_off, word, freq, z, D, L.KP, n_dk, n_kw, n_k);
+    int64_t blocks = (D + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(llda_count_init_kernel, dim3((unsigned)blocks), dim3(256), 5 * L.KP * sizeof(int),
+                       (hipStream_t)stream, doc_off, word, freq, z, D, L.KP, n_dk, n_kw, n_k);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
 }
