@@ -1,0 +1,374 @@
+// device_common.hpp -- kernel parameters, Philox, row loads, one-hot updates, exact division, cross-lane moves, numpy-ordered group sum, exact keyed draw
+// Part of the single translation unit llda_gibbs.hip (included in order; see the contents list there).
+#pragma once
+
+namespace {
+
+thread_local int g_last_hip_error = 0;
+
+#define LLDA_MAX_LIVE 64   // most allowed topics per document the sparse kernel handles
+
+struct KParams {
+    const int64_t *doc_off;
+    const int32_t *doc_order;
+    const int32_t *word;
+    const int32_t *freq;
+    int32_t *z;
+    const uint16_t *lab_mask;
+    int32_t *n_dk;
+    const int32_t *n_kw;
+    int32_t *n_kw_delta;
+    const int32_t *n_k;
+    int32_t *n_k_delta;
+    int32_t *status;
+    int64_t D;
+    int64_t doc_base;
+    double alpha, beta, vbeta;
+    uint32_t key0, key1, sweep, stream_id;
+    int32_t dpg;
+    int32_t last_leaf;      // index of the last (tail-carrying) leaf
+    int32_t tail, tail_row;
+    int32_t n_rounds;
+    int32_t xor_tree;       // leaves combine as p^1, p^2, p^4 (balanced recursion, no padded leaves)
+    double margin_rel;      // tier-1 decision margin relative to the total score (2^-40; debug: wider / inf)
+    float margin0_rel;      // tier-0 (fp32) margin (2^-16; >= 1 disables tier 0)
+    // sparse-label path: per document the device positions of its allowed topics, ascending
+    const int64_t *live_off;
+    const int32_t *live_pos;
+    int32_t KP;             // row length (the sparse kernel is not templated on the layout)
+    // hand-over from the sparse kernel to the dense tiered kernel: documents whose draw the sparse kernel
+    // could not decide within its margin continue there from the recorded site
+    int32_t *resume;        // [cap][2 + LLDA_MAX_LIVE]: doc, site, n_dk delta of the live topics so far
+    int32_t *resume_count;  // [1]
+    int32_t resume_cap;
+    int32_t resume_mode;    // 1: this launch of the dense kernel walks the resume list instead of all documents
+    // commit log (both NULL: n_kw_delta atomics): one word per site at its word-major position
+    const int32_t *csc_pos;
+    uint32_t *commit_log;
+    uint32_t rounds_pk[LLDA_MAX_ROUNDS];   // 4 bits per leaf: partner leaf
+};
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11).  Counter (c0..c3), key (k0,k1).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3,
+                                              uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// T contiguous int32 starting at p (p is 4*T-byte aligned when T is a multiple of 4).
+template <int T>
+__device__ __forceinline__ void load_row(const int32_t *__restrict__ p, int (&x)[T])
+{
+    if constexpr (T % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < T / 4; ++i) {
+            const int4 v = reinterpret_cast<const int4 *>(p)[i];
+            x[4 * i + 0] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+        }
+    } else if constexpr (T == 2) {
+        const int2 v = *reinterpret_cast<const int2 *>(p);
+        x[0] = v.x; x[1] = v.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) x[i] = p[i];
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void store_row(int32_t *__restrict__ p, const int (&x)[T])
+{
+    if constexpr (T % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < T / 4; ++i)
+            reinterpret_cast<int4 *>(p)[i] = make_int4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+    } else if constexpr (T == 2) {
+        *reinterpret_cast<int2 *>(p) = make_int2(x[0], x[1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) p[i] = x[i];
+    }
+}
+
+// One-hot slot updates without compares (hipcc turns "(bit) * f" back into v_cmp + v_cndmask and
+// spills the masks): m = v_bfe_i32(onehot, S, 1) is 0 or -1, value += m * g via v_mad_i32_i24
+// (|g| < 2^23: g is a word frequency inside one document).
+template <int S>
+__device__ __forceinline__ int onehot_bit(uint32_t oh)
+{
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(oh), "n"(S));
+    return m;
+}
+__device__ __forceinline__ int mad_i24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// a[S] += m_S * g and b[S] += m_S * g for every slot S (m_S = 0 / -1)
+template <int T, int S = 0>
+__device__ __forceinline__ void onehot_add2(int (&a)[T], int (&b)[T], uint32_t oh, int g)
+{
+    if constexpr (S < T) {
+        const int m = onehot_bit<S>(oh);
+        a[S] = mad_i24(m, g, a[S]);
+        b[S] = mad_i24(m, g, b[S]);
+        onehot_add2<T, S + 1>(a, b, oh, g);
+    }
+}
+template <int T, int S = 0>
+__device__ __forceinline__ void onehot_add1(int (&a)[T], uint32_t oh, int g)
+{
+    if constexpr (S < T) {
+        a[S] = mad_i24(onehot_bit<S>(oh), g, a[S]);
+        onehot_add1<T, S + 1>(a, oh, g);
+    }
+}
+
+template <int T, int S = 0>
+__device__ __forceinline__ void scores(double (&w)[T], const int (&ndk)[T], const int (&nkb)[T], const int (&x)[T],
+                                       uint32_t mask, double alpha, double beta, double vbeta)
+{
+    if constexpr (S < T) {
+        const double a = (double)ndk[S] + alpha;
+        const double num_b = (double)x[S] + beta;
+        const double den_b = (double)(nkb[S] + ndk[S]) + vbeta;
+        const double ws = a * (num_b / den_b);
+        const long long m = (long long)onehot_bit<S>(mask);          // 0 or -1, sign-extended
+        w[S] = __longlong_as_double(__double_as_longlong(ws) & m);
+        scores<T, S + 1>(w, ndk, nkb, x, mask, alpha, beta, vbeta);
+    }
+}
+
+// a / b given y = RN(1/b) (IEEE), correctly rounded: q0 = RN(a y); two exact-residual corrections.
+__device__ __forceinline__ double div_by(double a, double b, double y)
+{
+    const double q0 = a * y;
+    const double r0 = __builtin_fma(-b, q0, a);
+    const double q1 = __builtin_fma(r0, y, q0);
+    const double r1 = __builtin_fma(-b, q1, a);
+    return __builtin_fma(r1, y, q1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross-lane moves of doubles without an LDS round trip (DPP / permlane), gfx950.
+// ---------------------------------------------------------------------------------------------
+// DPP move; lanes whose source lane is outside the row (row_shr) or the wave (wave_shr) receive 0.0.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane j <- lane 7-j of its 8-lane half (an "xor 4" once quads are uniform)
+constexpr int DPP_ROW_SHR = 0x110;      // + n
+constexpr int DPP_ROW_ROR = 0x120;      // + n
+constexpr int DPP_WAVE_SHR1 = 0x138;
+
+// v_permlane16_swap vdst, src: odd 16-lane rows of vdst <-> even rows of src.  With both operands x:
+// r[0] = [R0,R0,R2,R2] (odd rows see the row below), r[1] = [R1,R1,R3,R3] (even rows see the row above).
+__device__ __forceinline__ void rows_swapped(double x, double &below, double &above)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+    below = __hiloint2double((int)hi[0], (int)lo[0]);
+    above = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double xor16_f64(double x, int lane)
+{
+    double below, above;
+    rows_swapped(x, below, above);
+    return (lane & 16) ? below : above;
+}
+// v_permlane32_swap vdst, src: upper half of vdst <-> lower half of src.  r[0] = [lo,lo], r[1] = [hi,hi].
+__device__ __forceinline__ double xor32_f64(double x, int lane)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+    return (lane & 32) ? __hiloint2double((int)hi[0], (int)lo[0]) : __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                            __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+// value of the last lane of the caller's group
+template <int G>
+__device__ __forceinline__ double bcast_last(double x, int lane)
+{
+    if constexpr (G == 64) {
+        return readlane_f64(x, 63);
+    } else if constexpr (G == 32) {
+        const double a = readlane_f64(x, 31), b = readlane_f64(x, 63);
+        return (lane & 32) ? b : a;
+    } else if constexpr (G == 16) {
+        const double a = readlane_f64(x, 15), b = readlane_f64(x, 31), c = readlane_f64(x, 47), d = readlane_f64(x, 63);
+        const double ab = (lane & 16) ? b : a, cd = (lane & 16) ? d : c;
+        return (lane & 32) ? cd : ab;
+    } else {
+        return __shfl(x, G - 1, G);
+    }
+}
+// one Hillis-Steele step of the inclusive scan over the G lanes of a group: X[g] = X[g-D] + X[g], g >= D
+template <int G, int D>
+__device__ __forceinline__ double scan_step(double X, int lig)
+{
+    if constexpr (G == 64) {
+        const double y = __shfl_up(X, D, G);
+        return (lig >= D) ? y + X : X;
+    } else if constexpr (G == 32) {
+        if constexpr (D < 16) {
+            const double y = dpp_f64<DPP_ROW_ROR + D>(X);      // lane i <- lane (i-D) mod 16 of its row
+            double below, above;
+            rows_swapped(y, below, above);                     // odd rows: the same rotation of the row below
+            const double src = ((lig & 15) >= D) ? y : ((lig >= 16) ? below : 0.0);
+            return src + X;
+        } else {
+            double below, above;
+            rows_swapped(X, below, above);
+            return ((lig >= 16) ? below : 0.0) + X;
+        }
+    } else {
+        const double y = dpp_f64<DPP_ROW_SHR + D>(X);          // 0.0 shifted in at the row start
+        if constexpr (G == 16) return y + X;
+        else return ((lig >= D) ? y : 0.0) + X;                // 8-lane groups share a row
+    }
+}
+template <int G, int D = 1>
+__device__ __forceinline__ double group_scan(double X, int lig)
+{
+    if constexpr (D < G) return group_scan<G, D * 2>(scan_step<G, D>(X, lig), lig);
+    else return X;
+}
+
+// value held by lane `src` (same for the whole group, but a run-time value) in every lane of the group.
+// 8- and 16-lane groups: OR-butterfly over DPP moves (no LDS round trip); wider groups: ds_bpermute.
+template <int G>
+__device__ __forceinline__ int group_pick(int v, int src, int lig)
+{
+    if constexpr (G <= 16) {
+        int x = (lig == src) ? v : 0;
+        x |= __builtin_amdgcn_update_dpp(0, x, DPP_XOR1, 0xF, 0xF, false);
+        x |= __builtin_amdgcn_update_dpp(0, x, DPP_XOR2, 0xF, 0xF, false);
+        x |= __builtin_amdgcn_update_dpp(0, x, DPP_HALF_MIRROR, 0xF, 0xF, false);
+        if constexpr (G == 16) x |= __builtin_amdgcn_update_dpp(0, x, DPP_ROW_ROR + 8, 0xF, 0xF, false);
+        return x;
+    } else {
+        return __shfl(v, src, G);
+    }
+}
+
+// Sum of the group's K scores in numpy's pairwise order.  Every lane of the group returns S.
+//   chain : per-lane sequential sum over its slots (one of numpy's 8 accumulators)
+//   xor butterfly 1,2,4 : ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))   (fp add is commutative)
+//   tail  : n % 8 leftovers of the last leaf, added sequentially
+//   leaves: combined along numpy's recursion tree by the partner schedule
+// cross-lane part of the sum: acc = this lane's chain, tv = this lane's tail element
+template <int G, bool HAS_TAIL>
+__device__ __forceinline__ double group_sum_tail(double acc, double tv, const KParams &P, int lig, int lane)
+{
+    const int leaf = lig >> 3;
+    acc = acc + dpp_f64<DPP_XOR1>(acc);
+    acc = acc + dpp_f64<DPP_XOR2>(acc);
+    acc = acc + dpp_f64<DPP_HALF_MIRROR>(acc);
+    if (HAS_TAIL) {
+        for (int t = 0; t < P.tail; ++t) {
+            const double o = __shfl(tv, P.last_leaf * 8 + t, G);
+            if (leaf == P.last_leaf) acc = acc + o;
+        }
+    }
+    if constexpr (G > 8) {
+        if (P.xor_tree) {
+            // balanced recursion (leaf p pairs with p^1, then p^2, p^4): lane xor 8 / 16 / 32
+            acc = acc + dpp_f64<DPP_ROW_ROR + 8>(acc);
+            if constexpr (G > 16) acc = acc + xor16_f64(acc, lane);
+            if constexpr (G > 32) acc = acc + xor32_f64(acc, lane);
+        } else {
+#pragma unroll
+            for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) {
+                if (r < P.n_rounds) {
+                    const int partner = (P.rounds_pk[r] >> (4 * leaf)) & 15;
+                    const double o = __shfl(acc, partner * 8 + (lig & 7), G);
+                    if (partner != leaf) acc = acc + o;
+                }
+            }
+            acc = __shfl(acc, 0, G);
+        }
+    }
+    return acc;
+}
+
+template <int G, int T, bool HAS_TAIL>
+__device__ __forceinline__ double group_sum(const double (&w)[T], const KParams &P, int lig, int lane)
+{
+    const int leaf = lig >> 3;
+    double acc = 0.0, tv = 0.0;
+#pragma unroll
+    for (int s = 0; s < T; ++s) {
+        if (HAS_TAIL && s == P.tail_row && leaf == P.last_leaf) tv = w[s];
+        else acc = acc + w[s];
+    }
+    return group_sum_tail<G, HAS_TAIL>(acc, tv, P, lig, lane);
+}
+
+// Keyed categorical draw over the group's K probabilities p (device order, oracle/llda_oracle.py
+// draw_keyed): q = per-lane prefix over the slots, X = Hillis-Steele scan of the lane totals,
+// t = u * X[G-1]; result = first position with p > 0 and q > t - X[lane-1], else the last position with
+// p > 0; -1 if there is none (or !valid).  FAST: "p > 0" is read off the label mask.
+template <int G, int T, bool FAST>
+__device__ __forceinline__ int draw_position(const double (&w)[T], double u, uint32_t mask, bool valid, int lig, int lane)
+{
+    const int gbase = lane & ~(G - 1);
+    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    double q[T];
+    q[0] = w[0];
+#pragma unroll
+    for (int s = 1; s < T; ++s) q[s] = q[s - 1] + w[s];
+    const double X = group_scan<G>(q[T - 1], lig);
+    const double tot = bcast_last<G>(X, lane);
+    const double t = u * tot;
+    const double prev = dpp_f64<DPP_WAVE_SHR1>(X);
+    const double tg = t - (lig ? prev : 0.0);
+    uint32_t fm = 0, pm = 0;
+    if (FAST) {
+        // q is non-decreasing along the slots, so {s : q[s] > tg} is the suffix starting at
+        // cnt = #{s : q[s] <= tg}; positive-probability slots are the label-mask bits.
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < T; ++s) cnt += (q[s] <= tg) ? 1 : 0;
+        pm = mask;
+        fm = mask & (0xFFFFu << cnt);
+    } else {
+#pragma unroll
+        for (int s = 0; s < T; ++s) {
+            const bool pos = w[s] > 0.0;
+            pm |= (pos ? 1u : 0u) << s;
+            fm |= ((pos && q[s] > tg) ? 1u : 0u) << s;
+        }
+    }
+    const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
+    const uint64_t gp = (__ballot(pm != 0) >> gbase) & gmask;
+    int zn = -1;
+    if (gp != 0 && valid) {
+        const bool hit = gf != 0;
+        const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)gp);
+        const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(pm | 1u));
+        const int ss = __shfl(my, sl, G);
+        zn = sl * T + ss;
+    }
+    return zn;
+}
+
+}  // namespace

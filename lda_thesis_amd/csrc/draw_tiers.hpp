@@ -1,0 +1,257 @@
+// draw_tiers.hpp -- tier-0 (fp32) decision, cold tiers (fp64 decision / exact pipeline), commit of a site, per-site random bits
+// Part of the single translation unit llda_gibbs.hip (included in order; see the contents list there).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Two-tier draw (FAST kernels).  The integer state only depends on WHICH topic the draw picks, i.e. on
+// the signs of  E[g][s] = q[g][s] - (t - X[g-1])  in the exact fp64 pipeline above.  Tier 1 evaluates
+// the same comparison from unnormalised, cheaply rounded scores
+//     w~ = a * (num_b * RN(1/den_b)),   Q~ = prefix(w~),   X~ = scan,   T~ = u * X~[G-1] - X~[g-1]
+// (no division, no pairwise sum, no normalisation).  Relative to the total every quantity differs from
+// its exact counterpart by at most a few hundred units of 2^-53 (DESIGN.md section 4.3 derives
+// |E~ - E| <= 2^-44 of the total), so whenever every |Q~ - T~| exceeds 2^-40 of the total the signs -- and
+// with them the chosen position -- are those of the exact pipeline.  Otherwise (probability ~1e-9 per
+// site) the group falls back to the exact tier.  Returns false when the group must fall back.
+// ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Tier 0: the same decision in fp32.  Every quantity is within 103 * 2^-24 (< 2^-17.3) of the total of its
+// real-number value, the exact pipeline within 2^-44; with a margin of 2^-16 of
+// the total a "sure" fp32 decision therefore has the signs of the exact pipeline.  About 1.6 % of the
+// sites (K = 512) are "unsure" and go on to tier 1.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
+}
+
+template <int T, bool DENSE, int S = 0>
+__device__ __forceinline__ void prefix_scores_f32(float (&qw)[T], const int (&x)[T], const float (*s_pa)[256], int tid,
+                                                  uint32_t mask, float beta)
+{
+    if constexpr (S < T) {
+        float ws = ((float)x[S] + beta) * s_pa[S][tid];          // num_b * fl32(a / den_b)
+        if constexpr (!DENSE) ws = __int_as_float(__float_as_int(ws) & onehot_bit<S>(mask));
+        if constexpr (S == 0) qw[0] = ws;
+        else qw[S] = qw[S - 1] + ws;
+        prefix_scores_f32<T, DENSE, S + 1>(qw, x, s_pa, tid, mask, beta);
+    }
+}
+
+// inclusive scan over the G lanes of a group (any association order will do here)
+template <int G>
+__device__ __forceinline__ float group_scan_f32(float X, int lig)
+{
+    if constexpr (G == 8) {
+        float y;
+        y = dpp_f32<DPP_ROW_SHR + 1>(X); X += (lig >= 1) ? y : 0.0f;
+        y = dpp_f32<DPP_ROW_SHR + 2>(X); X += (lig >= 2) ? y : 0.0f;
+        y = dpp_f32<DPP_ROW_SHR + 4>(X); X += (lig >= 4) ? y : 0.0f;
+    } else {
+        X += dpp_f32<DPP_ROW_SHR + 1>(X);
+        X += dpp_f32<DPP_ROW_SHR + 2>(X);
+        X += dpp_f32<DPP_ROW_SHR + 4>(X);
+        X += dpp_f32<DPP_ROW_SHR + 8>(X);
+        if constexpr (G >= 32) X += dpp_f32<0x142, 0xA>(X);     // row_bcast:15 into rows 1 and 3
+        if constexpr (G == 64) X += dpp_f32<0x143, 0xC>(X);     // row_bcast:31 into rows 2 and 3
+    }
+    return X;
+}
+
+template <int G>
+__device__ __forceinline__ float bcast_last_f32(float x, int lane)
+{
+    if constexpr (G == 64) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+    } else if constexpr (G == 32) {
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 31));
+        const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+        return (lane & 32) ? b : a;
+    } else if constexpr (G == 16) {
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 15));
+        const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 31));
+        const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 47));
+        const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+        const float ab = (lane & 16) ? b : a, cd = (lane & 16) ? d : c;
+        return (lane & 32) ? cd : ab;
+    } else {
+        return __int_as_float(group_pick<G>(__float_as_int(x), G - 1, lane & (G - 1)));
+    }
+}
+
+template <int G, int T>
+__device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uint32_t mask, uint64_t gp,
+                                              float margin_rel, int lig, int lane, int &zn)
+{
+    const int gbase = lane & ~(G - 1);
+    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    const float X = group_scan_f32<G>(qw[T - 1], lig);
+    const float tot = bcast_last_f32<G>(X, lane);
+    const float prev = dpp_f32<DPP_WAVE_SHR1>(X);
+    const float tg = u * tot - (lig ? prev : 0.0f);
+    const float margin = tot * margin_rel;
+    const float lo = tg - margin, hi = tg + margin;
+    int cnt_lo = 0, cnt_hi = 0;
+#pragma unroll
+    for (int s = 0; s < T; ++s) {
+        cnt_lo += (qw[s] <= lo) ? 1 : 0;
+        cnt_hi += (qw[s] <= hi) ? 1 : 0;
+    }
+    const bool unsure = (cnt_lo != cnt_hi) || !(tot > 0.0f) || !(margin < tot) || !(tot < 3.0e38f);
+    if (((__ballot(unsure) >> gbase) & gmask) != 0) return false;
+    const uint32_t fm = mask & (0xFFFFu << cnt_lo);
+    const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
+    const bool hit = gf != 0;
+    const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)(gp | 1ull));
+    const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
+    zn = sl * T + group_pick<G>(my, sl, lig);
+    return true;
+}
+
+// Cold tiers of the FAST kernels, out of line: they run for the ~1.6 % of the sites
+// tier 0 is unsure about and work on scratch copies, so the hot loop's register allocation never sees them.
+//   tier 1: the decision from unnormalised fp64 prefix sums, margin 2^-40 of the total;
+//   exact : the reference's fp64 pipeline bit for bit -- scores, numpy-ordered sum, p = fl(w/S) through
+//           ONE IEEE reciprocal y = RN(1/S) and two residual corrections per slot (Markstein: with y
+//           correctly rounded and q1 faithful, q2 = RN(q1 + (w - S q1) y) is the correctly rounded
+//           quotient; llda_selftest_div checks it against the hardware division), keyed draw.
+// Returns the chosen device position or -1.
+template <int G, int T, bool HAS_TAIL, bool DENSE>
+__device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, const int (*s_nkc)[256], int tid,
+                                       uint32_t mask, double u, int lig, int lane, const KParams *P)
+{
+    // Written as rolled loops over scratch arrays on purpose: few registers, so that this rarely taken
+    // function does not dictate the kernel's register allocation (occupancy of the hot loop).
+    const int gbase = lane & ~(G - 1);
+    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    const double alpha = P->alpha, beta = P->beta, vbeta = P->vbeta;
+    const uint32_t lmask = DENSE ? 0xFFFFu : mask;
+    double w[T];
+    if (lig == 0 && P->status) atomicAdd(P->status + 1, 1);      // statistics: sites tier 0 was unsure about
+    // ---- tier 1: unnormalised fp64 prefix sums, margin 2^-40 of the total ----
+    {
+        double run = 0.0;
+#pragma unroll 4
+        for (int s = 0; s < T; ++s) {
+            // 1/den to within 2^-50: hardware estimate + two Newton steps (tier 1 only needs a few 2^-53)
+            const double den = (double)s_nkc[s][tid] + vbeta;
+            double y = __builtin_amdgcn_rcp(den);
+            y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+            y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+            const double ws = ((double)s_ndk[s][tid] + alpha) * (((double)x[s] + beta) * y);
+            run = run + (((lmask >> s) & 1u) ? ws : 0.0);
+            w[s] = run;
+        }
+        const double X = group_scan<G>(run, lig);
+        const double tot = bcast_last<G>(X, lane);
+        const double prev = dpp_f64<DPP_WAVE_SHR1>(X);
+        const double tg = u * tot - (lig ? prev : 0.0);
+        const double margin = tot * P->margin_rel;
+        int cnt_lo = 0, cnt_hi = 0;
+#pragma unroll 4
+        for (int s = 0; s < T; ++s) {
+            cnt_lo += (w[s] <= tg - margin) ? 1 : 0;
+            cnt_hi += (w[s] <= tg + margin) ? 1 : 0;
+        }
+        const bool unsure = (cnt_lo != cnt_hi) || !(tot > 0.0) || !(margin < tot);
+        if (((__ballot(unsure) >> gbase) & gmask) == 0) {
+            const uint32_t fm = mask & (0xFFFFu << cnt_lo);
+            const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
+            const uint64_t gp = (__ballot(mask != 0) >> gbase) & gmask;
+            const bool hit = gf != 0;
+            const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)(gp | 1ull));
+            const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
+            return sl * T + __shfl(my, sl, G);
+        }
+    }
+    // ---- exact tier: the reference's fp64 pipeline, bit for bit ----
+    if (lig == 0 && P->status) { atomicOr(P->status, 2); atomicAdd(P->status + 2, 1); }   // the exact tier ran
+    const int leaf = lig >> 3;
+    double acc = 0.0, tv = 0.0;
+#pragma unroll 1
+    for (int s = 0; s < T; ++s) {
+        // prob = lab * a * (num_b / den_b)   (LabeledLDA.py:113-116)
+        const double ws = ((double)s_ndk[s][tid] + alpha) * (((double)x[s] + beta) / ((double)s_nkc[s][tid] + vbeta));
+        const double v = ((lmask >> s) & 1u) ? ws : 0.0;
+        w[s] = v;
+        if (HAS_TAIL && s == P->tail_row && leaf == P->last_leaf) tv = v;
+        else acc = acc + v;
+    }
+    const double S = group_sum_tail<G, HAS_TAIL>(acc, tv, *P, lig, lane);      // np.sum(prob), LabeledLDA.py:117
+    const double y = 1.0 / S;
+    // prob /= np.sum(prob); keyed draw: per-lane prefix, Hillis-Steele scan, first slot with p > 0 and q > t - X[g-1]
+    double run = 0.0;
+#pragma unroll 1
+    for (int s = 0; s < T; ++s) {
+        run = (s == 0) ? div_by(w[s], S, y) : run + div_by(w[s], S, y);
+        w[s] = run;
+    }
+    const double X = group_scan<G>(run, lig);
+    const double tot = bcast_last<G>(X, lane);
+    const double prev = dpp_f64<DPP_WAVE_SHR1>(X);
+    const double tg = u * tot - (lig ? prev : 0.0);
+    int cnt = 0;
+#pragma unroll 1
+    for (int s = 0; s < T; ++s) cnt += (w[s] <= tg) ? 1 : 0;
+    const uint32_t fm = mask & (0xFFFFu << cnt);
+    const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
+    const uint64_t gp = (__ballot(mask != 0) >> gbase) & gmask;
+    if (gp == 0 || !(S > 0.0)) return -1;
+    const bool hit = gf != 0;
+    const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)gp);
+    const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
+    return sl * T + __shfl(my, sl, G);
+}
+
+// store the new assignment of a site and move its count in n_kw_delta (int32 atomics, no return value)
+// (c = the site's position in the commit log when there is one; v, f are only needed without a log)
+__device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, int f, int zo, int zn, int c, int KP)
+{
+    P.z[i] = zn;
+    if (P.commit_log) {
+        P.commit_log[c] = (uint32_t)zo | ((uint32_t)zn << 16);
+    } else if (zn != zo) {
+        int32_t *row = P.n_kw_delta + (int64_t)v * KP;
+        atomicAdd(row + zo, -f);
+        atomicAdd(row + zn, f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The sweep kernel
+// ---------------------------------------------------------------------------------------------
+// Per-site pieces shared by the two sweep kernels ------------------------------------------------
+// random bits of site n: one Philox block serves sites 2b and 2b+1; the G lanes of the group compute G
+// consecutive blocks at once (every 2G sites, or at the first site of a resumed document) and hand them out
+template <int G>
+__device__ __forceinline__ void site_random_bits(const KParams &P, int n, bool first, uint32_t gdoc, int lig,
+                                                 uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t &r3,
+                                                 uint32_t &ra, uint32_t &rb)
+{
+    if (first || (n & (2 * G - 1)) == 0) {
+        r0 = (uint32_t)((n >> 1) & ~(G - 1)) + (uint32_t)lig; r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
+        philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
+    }
+    const int holder = (n >> 1) & (G - 1);
+    ra = (uint32_t)group_pick<G>((int)((n & 1) ? r2 : r0), holder, lig);
+    rb = (uint32_t)group_pick<G>((int)((n & 1) ? r3 : r1), holder, lig);
+}
+
+// the 53-bit keyed uniform u = ((a >> 5) * 2^26 + (b >> 6)) / 2^53 (every operation exact)
+__device__ __forceinline__ double uniform53(uint32_t ra, uint32_t rb)
+{
+    return ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+template <int G>
+__device__ __forceinline__ double site_uniform(const KParams &P, int n, bool first, uint32_t gdoc, int lig,
+                                               uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t &r3)
+{
+    uint32_t ra, rb;
+    site_random_bits<G>(P, n, first, gdoc, lig, r0, r1, r2, r3, ra, rb);
+    return uniform53(ra, rb);
+}
+
+}  // namespace

@@ -1,0 +1,170 @@
+// kernel_counts.hpp -- llda_commit_log_kernel, llda_apply_delta_kernel, llda_count_init_kernel, division self test
+// Part of the single translation unit llda_gibbs.hip (included in order; see the contents list there).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Fold of the commit log into word-major counts (llda_commit_log, include/llda_gibbs.h): one wavefront per
+// item (a run of log entries of one word), a KP-entry histogram per wavefront in LDS.  The histogram is
+// flushed either by walking the item's entries again (short items: each touched topic is claimed with an LDS
+// exchange) or by scanning all KP entries (long items).
+// ---------------------------------------------------------------------------------------------
+struct CParams {
+    const int64_t *item_begin;
+    const int32_t *item_len, *item_word;
+    int64_t n_items;
+    const uint32_t *log;
+    const int32_t *freq;
+    int32_t *target, *n_k, *n_k_delta;
+    int32_t KP;
+};
+
+__device__ __forceinline__ void add_count(int32_t *p, int a, bool shared_row)
+{
+    if (shared_row) atomicAdd(p, a);
+    else *p += a;
+}
+
+__global__ void __launch_bounds__(256) llda_commit_log_kernel(const CParams P)
+{
+    extern __shared__ int s_hist[];               // [4][KP]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int KP = P.KP;
+    if (blockIdx.x == 0 && P.n_k)
+        for (int p = tid; p < KP; p += 256) {
+            P.n_k[p] += P.n_k_delta[p];
+            P.n_k_delta[p] = 0;
+        }
+    int *hist = s_hist + w * KP;
+    for (int p = lane; p < KP; p += 64) hist[p] = 0;
+    const int64_t item = (int64_t)blockIdx.x * 4 + w;
+    if (item >= P.n_items) return;
+    const int64_t b = P.item_begin[item];
+    const int len = P.item_len[item];
+    const int wv = P.item_word[item];
+    const bool shared_row = wv < 0;
+    int32_t *row = P.target + (int64_t)(wv & 0x7fffffff) * KP;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    for (int j = lane; j < len; j += 64) {
+        const uint32_t e = P.log[b + j];
+        const int zo = (int)(e & 0xFFFFu), zn = (int)(e >> 16);
+        if (zo != zn) {
+            const int f = P.freq[b + j];
+            atomicAdd(&hist[zo], -f);
+            atomicAdd(&hist[zn], f);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (len <= KP) {
+        for (int j = lane; j < len; j += 64) {
+            const uint32_t e = P.log[b + j];
+            const int zo = (int)(e & 0xFFFFu), zn = (int)(e >> 16);
+            if (zo != zn) {
+                const int a = atomicExch(&hist[zo], 0), c = atomicExch(&hist[zn], 0);
+                if (a) add_count(row + zo, a, shared_row);
+                if (c) add_count(row + zn, c, shared_row);
+            }
+        }
+    } else {
+        for (int p = lane; p < KP; p += 64) {
+            const int a = hist[p];
+            if (a) add_count(row + p, a, shared_row);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// self test: div_by (reciprocal + two corrections) against the hardware IEEE division
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) llda_selftest_div_kernel(uint64_t seed, int iters, unsigned long long *bad)
+{
+    uint32_t mism = 0;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = 0; i < iters; ++i) {
+        uint32_t c0 = tid, c1 = (uint32_t)i, c2 = 0x5e1f7e57u, c3 = 0;
+        philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+        // b: a sum-like positive double with a random 52-bit significand and exponent in [-20, 40];
+        // a: anything from 0 to 2^60 times smaller than b up to a few times b
+        const uint64_t mb = ((uint64_t)(c0 & 0xFFFFFu) << 32) | c1;
+        const uint64_t ma = ((uint64_t)(c2 & 0xFFFFFu) << 32) | c3;
+        const int eb = (int)((c0 >> 20) % 61) - 20;
+        const int ea = eb + 2 - (int)((c2 >> 20) % 64);
+        double b = __longlong_as_double((long long)(((uint64_t)(1023 + eb) << 52) | mb));
+        double a = __longlong_as_double((long long)(((uint64_t)(1023 + ea) << 52) | ma));
+        if ((i & 7) == 7) {            // integer-valued operands, the shape of the count terms
+            b = (double)(c0 >> 4) + 1000.0 * 1.0000000000000002;
+            a = (double)(c2 >> 12) * 0.1;
+        }
+        if ((i & 63) == 63) a = 0.0;
+        const double y = 1.0 / b;
+        if (div_by(a, b, y) != a / b) ++mism;
+    }
+    if (mism) atomicAdd(bad, (unsigned long long)mism);
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers: fold deltas, build counts from assignments
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) llda_apply_delta_kernel(int32_t *__restrict__ counts,
+                                                               int32_t *__restrict__ delta, int64_t n4,
+                                                               int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int4 *c4 = reinterpret_cast<int4 *>(counts);
+    int4 *d4 = reinterpret_cast<int4 *>(delta);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        int4 c = c4[i];
+        const int4 d = d4[i];
+        if (d.x | d.y | d.z | d.w) {
+            c.x += d.x; c.y += d.y; c.z += d.z; c.w += d.w;
+            c4[i] = c;
+            d4[i] = make_int4(0, 0, 0, 0);
+        }
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        counts[i] += delta[i];
+        delta[i] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) llda_count_init_kernel(const int64_t *__restrict__ doc_off,
+                                                              const int32_t *__restrict__ word,
+                                                              const int32_t *__restrict__ freq,
+                                                              const int32_t *__restrict__ z, int64_t D, int KP,
+                                                              int32_t *n_dk, int32_t *n_kw, int32_t *n_k)
+{
+    // one wavefront per document at a time, lanes stride over its sites.  The document's n_dk row and the
+    // workgroup's share of n_k are histograms in LDS (the row is then written with plain stores, n_k with KP
+    // atomics per workgroup); only n_kw takes one global atomic per site.
+    extern __shared__ int s_init[];               // [KP] n_k of the workgroup, then [4][KP] per-wavefront rows
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int *s_nk = s_init, *hist = s_init + (1 + w) * KP;
+    for (int p = tid; p < KP; p += 256) s_nk[p] = 0;
+    for (int p = lane; p < KP; p += 64) hist[p] = 0;
+    __syncthreads();
+    for (int64_t d = (int64_t)blockIdx.x * 4 + w; d < D; d += (int64_t)gridDim.x * 4) {
+        for (int64_t i = doc_off[d] + lane; i < doc_off[d + 1]; i += 64) {
+            const int f = freq[i], p = z[i];
+            atomicAdd(&hist[p], f);
+            atomicAdd(n_kw + (int64_t)word[i] * KP + p, f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        for (int p = lane; p < KP; p += 64) {
+            const int h = hist[p];
+            if (h) {
+                hist[p] = 0;
+                n_dk[d * KP + p] += h;
+                atomicAdd(&s_nk[p], h);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    __syncthreads();
+    for (int p = tid; p < KP; p += 256) {
+        const int h = s_nk[p];
+        if (h) atomicAdd(n_k + p, h);
+    }
+}
+
+}  // namespace

@@ -1,0 +1,176 @@
+// kernel_foldin.hpp -- llda_foldin_kernel: the test-time sampler
+// Part of the single translation unit llda_gibbs.hip (included in order; see the contents list there).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Test-time fold-in sampler: LabeledLDA.prep4test / run_test (LabeledLDA.py:155-212).
+// One lane group per held-out document; topic-word loadings ph_hat are fixed, only the document's n_dk
+// moves.  phn = ph_hat with every word column normalised (prep4test, LabeledLDA.py:162-167, done by
+// the host); both matrices are word-major in device order: (V, KP) doubles.
+// ---------------------------------------------------------------------------------------------
+struct FParams {
+    const int64_t *doc_off;
+    const int32_t *word;
+    const int32_t *init_idx; // row of `phn` holding the initial probabilities of every site
+    const int32_t *freq;
+    int32_t *z;              // [S] out: final assignments (device positions)
+    const double *ph;        // [V*KP]
+    const double *phn;       // [V*KP]
+    int32_t *n_dk;           // [D*KP] out: final counts
+    double *th;              // [D*KP] out: thinned average of n_dk / sum(n_dk)
+    const uint8_t *slot_valid; // [KP] 1 for slots that hold a topic (0 in the padding)
+    int32_t *status;
+    int64_t D;
+    int64_t doc_base;
+    double alpha, beta;
+    double c_init, c_loop;   // the reference's "while prob.sum() > 1: prob /= c" constants
+    uint32_t key0, key1, stream_id;
+    int32_t iters, thinning;
+    int32_t beta_fallback;   // CascadeLDA.cascade_test: prob.sum() == 0 -> prob = num_a * (b + beta)
+    int32_t avg_mode;        // 0: (s-1)/s*avg + (1/s)*cur   1: m*avg + (1-m)*cur with m = (s-1)/s
+    int32_t last_leaf, tail, tail_row, n_rounds, xor_tree;
+    uint32_t rounds_pk[LLDA_MAX_ROUNDS];
+};
+
+template <int T>
+__device__ __forceinline__ void load_row_f64(const double *__restrict__ p, double (&x)[T])
+{
+    if constexpr (T % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < T / 2; ++i) {
+            const double2 v = reinterpret_cast<const double2 *>(p)[i];
+            x[2 * i] = v.x; x[2 * i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) x[i] = p[i];
+    }
+}
+
+// `while prob.sum() > 1: prob /= c`  (LabeledLDA.py:170-171, 192-193); c_rcp = RN(1/c)
+template <int G, int T, bool HAS_TAIL>
+__device__ __forceinline__ void shrink_to_one(double (&p)[T], double c, double c_rcp, const KParams &K, int lig, int lane)
+{
+    for (int guard = 0; guard < (1 << 28); ++guard) {   // the reference loops until the sum is <= 1
+        const double s = group_sum<G, T, HAS_TAIL>(p, K, lig, lane);
+        if (!(s > 1.0)) break;                     // group-uniform: every lane holds the same s
+#pragma unroll
+        for (int k = 0; k < T; ++k) p[k] = div_by(p[k], c, c_rcp);
+    }
+}
+
+template <int G, int T, bool HAS_TAIL>
+__global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
+{
+    constexpr int KP = G * T;
+    constexpr int GPB = 256 / G;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int lig = tid & (G - 1);
+    const int64_t d = (int64_t)blockIdx.x * GPB + tid / G;
+    if (d >= P.D) return;
+    KParams K;                                     // the summation schedule group_sum() reads
+    K.last_leaf = P.last_leaf; K.tail = P.tail; K.tail_row = P.tail_row; K.n_rounds = P.n_rounds;
+    K.xor_tree = P.xor_tree;
+#pragma unroll
+    for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) K.rounds_pk[r] = P.rounds_pk[r];
+
+    const int64_t s0 = P.doc_off[d];
+    const int len = (int)(P.doc_off[d + 1] - s0);
+    const uint32_t gdoc = (uint32_t)(d + P.doc_base);
+    int ndk[T];
+    double avg[T];
+#pragma unroll
+    for (int s = 0; s < T; ++s) { ndk[s] = 0; avg[s] = 0.0; }
+    int ntot = 0;
+    const double c0 = P.c_init, c0r = 1.0 / c0, c1 = P.c_loop, c1r = 1.0 / c1;
+
+    // sweep = -1: prep4test (initial assignments from the normalised loadings), then `iters` sweeps
+    for (int sweep = -1; sweep < P.iters; ++sweep) {
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        for (int n = 0; n < len; ++n) {
+            const int v = P.word[s0 + n], f = P.freq[s0 + n];
+            if ((n & (2 * G - 1)) == 0) {
+                r0 = (uint32_t)(n >> 1) + (uint32_t)lig; r1 = gdoc; r2 = P.stream_id; r3 = (uint32_t)sweep;
+                philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
+            }
+            const int holder = (n >> 1) & (G - 1);
+            const uint32_t ra = (uint32_t)__shfl((int)((n & 1) ? r2 : r0), holder, G);
+            const uint32_t rb = (uint32_t)__shfl((int)((n & 1) ? r3 : r1), holder, G);
+            const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+
+            double w[T];
+            int zo = -1;
+            if (sweep < 0) {
+                load_row_f64<T>(P.phn + (int64_t)P.init_idx[s0 + n] * KP + lig * T, w);
+                shrink_to_one<G, T, HAS_TAIL>(w, c0, c0r, K, lig, lane);
+                ntot += f;
+            } else {
+                zo = P.z[s0 + n];
+                {
+                    const int lo = zo / T, so = zo - lo * T;
+                    onehot_add1<T>(ndk, (lig == lo) ? (1u << so) : 0u, f);       // n_dk[z] -= f
+                }
+                double b[T];
+                load_row_f64<T>(P.ph + (int64_t)v * KP + lig * T, b);
+#pragma unroll
+                for (int s = 0; s < T; ++s) w[s] = ((double)ndk[s] + P.alpha) * b[s];   // num_a * b
+                double S = group_sum<G, T, HAS_TAIL>(w, K, lig, lane);
+                if (P.beta_fallback && S == 0.0) {     // 0/0 raises in the reference (CascadeLDA.py:225-230)
+#pragma unroll
+                    for (int s = 0; s < T; ++s) {
+                        const bool real = P.slot_valid[lig * T + s] != 0;
+                        w[s] = real ? ((double)ndk[s] + P.alpha) * (b[s] + P.beta) : 0.0;
+                    }
+                    S = group_sum<G, T, HAS_TAIL>(w, K, lig, lane);
+                }
+                const double y = 1.0 / S;
+#pragma unroll
+                for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);                  // prob /= prob.sum()
+                shrink_to_one<G, T, HAS_TAIL>(w, c1, c1r, K, lig, lane);
+            }
+            int zn = draw_position<G, T, false>(w, u, 0u, true, lig, lane);
+            if (zn < 0) {                         // all-zero / NaN probabilities: the reference would raise
+                zn = zo < 0 ? 0 : zo;
+                if (lig == 0 && P.status) atomicOr(P.status, 1);
+            }
+            {
+                const int ln = zn / T, sn = zn - ln * T;
+                onehot_add1<T>(ndk, (lig == ln) ? (1u << sn) : 0u, -f);          // n_dk[new_z] += f
+            }
+            if (lig == 0) P.z[s0 + n] = zn;
+        }
+        // thinned running average of the document-topic state (LabeledLDA.py:199-211)
+        if (sweep >= 0 && (sweep + 1) % P.thinning == 0) {
+            const int s2 = (sweep + 1) / P.thinning;
+            const double tot = (double)ntot;
+            if (s2 == 1) {
+#pragma unroll
+                for (int s = 0; s < T; ++s) avg[s] = (double)ndk[s] / tot;
+            } else if (P.avg_mode == 0) {          // LabeledLDA.py:204-209, CascadeLDA.py:240-246
+                const double f_old = (double)(s2 - 1) / (double)s2, f_new = 1.0 / (double)s2;
+#pragma unroll
+                for (int s = 0; s < T; ++s) {
+                    const double old_part = f_old * avg[s];
+                    const double new_part = f_new * ((double)ndk[s] / tot);
+                    avg[s] = old_part + new_part;
+                }
+            } else {                               // CascadeLDA.run_test, CascadeLDA.py:337-341
+                const double m = (double)(s2 - 1) / (double)s2, m1 = 1.0 - m;
+#pragma unroll
+                for (int s = 0; s < T; ++s) {
+                    const double old_part = m * avg[s];
+                    const double new_part = m1 * ((double)ndk[s] / tot);
+                    avg[s] = old_part + new_part;
+                }
+            }
+        }
+    }
+    store_row<T>(P.n_dk + d * KP + lig * T, ndk);
+#pragma unroll
+    for (int s = 0; s < T; ++s) P.th[d * KP + lig * T + s] = avg[s];
+}
+
+}  // namespace

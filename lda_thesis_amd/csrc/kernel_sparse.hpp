@@ -1,0 +1,242 @@
+// kernel_sparse.hpp -- llda_sweep_sparse_kernel: one lane per allowed topic
+// Part of the single translation unit llda_gibbs.hip (included in order; see the contents list there).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Sweep kernel for sparse label sets (Labeled LDA proper: a handful of allowed topics out of hundreds,
+// e.g. 4.6 of 392 on the abstracts corpus).  One lane per ALLOWED topic, GS = 8..64 lanes per document
+// (64/GS documents per wavefront); per site each lane gathers its single n_kw entry, so the traffic is
+// 4*A + 32 bytes instead of a 4*KP-byte row.  All per-topic state (n_dk, the n_k the document sees, the
+// reciprocal of n_k + V*beta) is a scalar register of the owning lane.
+// The draw is the tier-1 decision of DESIGN.md section 4.3 restricted to the live topics: inclusive scan of
+// the unnormalised fp64 scores in device-position order, first lane with Q > u*total, sure when every
+// |Q - u*total| exceeds 2^-40 of the total.  A document with an unsure site (probability ~1e-11 per site)
+// is handed to the dense tiered kernel, which continues from that site (resume list).
+// Preconditions as for llda_sweep_kernel (alpha, beta >= 1e-6, V*beta < 2^40).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_newton(double den)
+{
+    double y = __builtin_amdgcn_rcp(den);                    // hardware estimate, then two Newton steps:
+    y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);    // within a few 2^-53 of 1/den
+    return __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+}
+
+// inclusive scan over the GS lanes of a group, any association order (DPP within 16-lane rows + row carries)
+template <int GS>
+__device__ __forceinline__ double scan_any_f64(double X, int lig)
+{
+    if constexpr (GS == 8) {
+        double y;
+        y = dpp_f64<DPP_ROW_SHR + 1>(X); X = X + ((lig >= 1) ? y : 0.0);
+        y = dpp_f64<DPP_ROW_SHR + 2>(X); X = X + ((lig >= 2) ? y : 0.0);
+        y = dpp_f64<DPP_ROW_SHR + 4>(X); X = X + ((lig >= 4) ? y : 0.0);
+        return X;
+    } else {
+        X = X + dpp_f64<DPP_ROW_SHR + 1>(X);
+        X = X + dpp_f64<DPP_ROW_SHR + 2>(X);
+        X = X + dpp_f64<DPP_ROW_SHR + 4>(X);
+        X = X + dpp_f64<DPP_ROW_SHR + 8>(X);
+        if constexpr (GS >= 32) {           // carry the totals of the 16-lane rows upwards, row by row
+            const double c1 = __shfl(X, 15, GS);
+            X = X + ((lig >= 16 && lig < 32) ? c1 : 0.0);
+        }
+        if constexpr (GS == 64) {
+            const double c2 = __shfl(X, 31, GS);
+            X = X + ((lig >= 32 && lig < 48) ? c2 : 0.0);
+            const double c3 = __shfl(X, 47, GS);
+            X = X + ((lig >= 48) ? c3 : 0.0);
+        }
+        return X;
+    }
+}
+
+// value of lane J (J < 8, compile time) of the caller's GS-lane group, in every lane of the group
+template <int GS, int J>
+__device__ __forceinline__ int bcast_lane(int v, int lig)
+{
+    if constexpr (GS <= 16) {
+        constexpr int QP = (J & 3) * 0x55;                                  // quad_perm [j,j,j,j]
+        const int q = __builtin_amdgcn_update_dpp(0, v, QP, 0xF, 0xF, false);
+        int r;
+        if constexpr ((J >> 2) == 0) {                                      // source quad is the lower one of its 8
+            const int up = __builtin_amdgcn_update_dpp(0, q, DPP_ROW_SHR + 4, 0xF, 0xF, false);
+            r = (lig & 4) ? up : q;
+        } else {
+            const int dn = __builtin_amdgcn_update_dpp(0, q, 0x100 + 4, 0xF, 0xF, false);   // row_shl:4
+            r = (lig & 4) ? q : dn;
+        }
+        if constexpr (GS == 16) {                                           // upper 8 lanes take it from the lower 8
+            const int up8 = __builtin_amdgcn_update_dpp(0, r, DPP_ROW_SHR + 8, 0xF, 0xF, false);
+            r = (lig & 8) ? up8 : r;
+        }
+        return r;
+    } else {
+        return __shfl(v, J, GS);
+    }
+}
+
+// sum over the GS lanes of a group in every lane (any association order)
+template <int GS>
+__device__ __forceinline__ double allsum_any_f64(double x, int lane)
+{
+    x = x + dpp_f64<DPP_XOR1>(x);
+    x = x + dpp_f64<DPP_XOR2>(x);
+    x = x + dpp_f64<DPP_HALF_MIRROR>(x);
+    if constexpr (GS >= 16) x = x + dpp_f64<DPP_ROW_ROR + 8>(x);
+    if constexpr (GS >= 32) x = x + xor16_f64(x, lane);
+    if constexpr (GS == 64) x = x + xor32_f64(x, lane);
+    return x;
+}
+
+// OR over the GS lanes of a group in every lane
+template <int GS>
+__device__ __forceinline__ int allor_i32(int x, int lane)
+{
+    x |= __builtin_amdgcn_update_dpp(0, x, DPP_XOR1, 0xF, 0xF, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, DPP_XOR2, 0xF, 0xF, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, DPP_HALF_MIRROR, 0xF, 0xF, false);
+    if constexpr (GS >= 16) x |= __builtin_amdgcn_update_dpp(0, x, DPP_ROW_ROR + 8, 0xF, 0xF, false);
+    if constexpr (GS >= 32) x |= __shfl_xor(x, 16, GS);
+    if constexpr (GS == 64) x |= __shfl_xor(x, 32, GS);
+    return x;
+}
+
+// One site of the sparse kernel (J = index inside the current batch of 8 sites).  Returns false when the
+// draw cannot be decided within the margin (the document is then handed to the dense kernel).
+template <int GS, int J>
+__device__ __forceinline__ bool sparse_site(const KParams &P, int nb, int sv, int sf, int sz, int su_lo, int su_hi,
+                                            const int (&xg)[8], bool live, int pos, int A, int &ndk, int &nk, double &y,
+                                            int &my_zn, int lig, int lane, int gbase, uint64_t gmask)
+{
+    if (J >= nb) return true;
+    const int f = bcast_lane<GS, J>(sf, lig), zo = bcast_lane<GS, J>(sz, lig);
+    const double u = __hiloint2double(bcast_lane<GS, J>(su_hi, lig), bcast_lane<GS, J>(su_lo, lig));
+    if (pos == zo) { ndk -= f; nk -= f; y = rcp_newton((double)nk + P.vbeta); }     // LabeledLDA.py:109-111
+    const int x = xg[J] - ((pos == zo) ? f : 0);
+    const double w = live ? ((double)ndk + P.alpha) * (((double)x + P.beta) * y) : 0.0;
+    const double Q = scan_any_f64<GS>(w, lig);
+    const double tot = allsum_any_f64<GS>(w, lane);
+    const double t = u * tot, margin = tot * P.margin_rel;
+    const bool unsure = (live && !(fabs(Q - t) > margin)) || !(tot > 0.0) || !(margin < tot);
+    if (((__ballot(unsure) >> gbase) & gmask) != 0) {
+        if (pos == zo) { ndk += f; nk += f; }               // undo: the dense kernel starts at this site
+        return false;
+    }
+    const uint64_t gf = (__ballot(live && Q > t) >> gbase) & gmask;
+    const int sel = gf ? (int)__ffsll((unsigned long long)gf) - 1 : A - 1;          // none: last allowed topic
+    const int zn = allor_i32<GS>((lig == sel) ? pos : 0, lane);
+    if (pos == zn) { ndk += f; nk += f; y = rcp_newton((double)nk + P.vbeta); }     // LabeledLDA.py:121-125
+    if (lig == J) my_zn = zn;
+    (void)sv;
+    return true;
+}
+
+template <int GS>
+__global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
+{
+    constexpr int GPB = 256 / GS;
+    __shared__ int s_nk[LLDA_MAX_K];          // workgroup accumulator of the n_k changes
+    const int tid = threadIdx.x;
+    const int KP = P.KP;
+    for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
+    __syncthreads();
+    const int lane = tid & 63;
+    const int lig = tid & (GS - 1);
+    const int grp = tid / GS;
+    const int gbase = lane & ~(GS - 1);
+    const uint64_t gmask = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
+
+    for (int it = 0; it < P.dpg; ++it) {
+        const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
+        if (idx >= P.D) break;
+        const int64_t d = P.doc_order ? (int64_t)P.doc_order[idx] : idx;
+        const int64_t s0 = P.doc_off[d];
+        const int len = (int)(P.doc_off[d + 1] - s0);
+        if (len <= 0) continue;
+        const int64_t l0 = P.live_off[d];
+        const int A = (int)(P.live_off[d + 1] - l0);
+        const bool live = lig < A;
+        const int pos = live ? P.live_pos[l0 + lig] : -1;
+        int32_t *ndk_p = P.n_dk + d * KP + (live ? pos : 0);
+        int ndk = live ? *ndk_p : 0;
+        const int ndk0 = ndk;
+        int nk = live ? P.n_k[pos] : 0;
+        double y = rcp_newton((double)nk + P.vbeta);
+        const uint32_t gdoc = (uint32_t)(d + P.doc_base);
+        int stop_at = -1;
+
+        // Sites are processed in batches of 8 so that memory latency is paid once per batch: lane j < 8 of
+        // the group loads the scalars of site n0+j and draws its uniform, every lane gathers its own topic's
+        // n_kw entry for all 8 words, then 8 sites run back to back on registers / DPP only, and lane j
+        // commits site n0+j (z store + two atomics) while the next batch loads.
+        for (int n0 = 0; n0 < len && stop_at < 0; n0 += 8) {
+            const int nb = min(8, len - n0);
+            const int jj = lig & 7;
+            const int64_t si = s0 + n0 + (jj < nb ? jj : nb - 1);
+            const int sv = P.word[si], sf = P.freq[si], sz = P.z[si], sc = P.csc_pos ? P.csc_pos[si] : 0;
+            int su_lo, su_hi;
+            {   // keyed uniform of site n0+jj: Philox block (site >> 1), words (0,1) / (2,3) by parity
+                const int n = n0 + jj;
+                uint32_t c0 = (uint32_t)(n >> 1), c1 = gdoc, c2 = P.stream_id, c3 = P.sweep;
+                philox4x32_10(c0, c1, c2, c3, P.key0, P.key1);
+                const uint32_t ra = (n & 1) ? c2 : c0, rb = (n & 1) ? c3 : c1;
+                const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+                su_lo = __double2loint(u); su_hi = __double2hiint(u);
+            }
+            // (the broadcasts must run in ALL lanes: a DPP read from a lane that is masked off returns 0)
+            const int w0 = bcast_lane<GS, 0>(sv, lig), w1 = bcast_lane<GS, 1>(sv, lig), w2 = bcast_lane<GS, 2>(sv, lig),
+                      w3 = bcast_lane<GS, 3>(sv, lig), w4 = bcast_lane<GS, 4>(sv, lig), w5 = bcast_lane<GS, 5>(sv, lig),
+                      w6 = bcast_lane<GS, 6>(sv, lig), w7 = bcast_lane<GS, 7>(sv, lig);
+            int xg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (live) {
+                const int32_t *col = P.n_kw + pos;
+                xg[0] = col[(int64_t)w0 * KP]; xg[1] = col[(int64_t)w1 * KP]; xg[2] = col[(int64_t)w2 * KP];
+                xg[3] = col[(int64_t)w3 * KP]; xg[4] = col[(int64_t)w4 * KP]; xg[5] = col[(int64_t)w5 * KP];
+                xg[6] = col[(int64_t)w6 * KP]; xg[7] = col[(int64_t)w7 * KP];
+            }
+
+            int my_zn = sz;
+            bool ok = true;
+            int done = 0;                     // sites of this batch that were decided
+#define LLDA_SPARSE_SITE(J)                                                                                    \
+            if (ok) {                                                                                          \
+                ok = sparse_site<GS, J>(P, nb, sv, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, y, my_zn, \
+                                        lig, lane, gbase, gmask);                                              \
+                if (ok && J < nb) done = J + 1;                                                                \
+            }
+            LLDA_SPARSE_SITE(0) LLDA_SPARSE_SITE(1) LLDA_SPARSE_SITE(2) LLDA_SPARSE_SITE(3)
+            LLDA_SPARSE_SITE(4) LLDA_SPARSE_SITE(5) LLDA_SPARSE_SITE(6) LLDA_SPARSE_SITE(7)
+#undef LLDA_SPARSE_SITE
+            if (!ok) stop_at = n0 + done;
+            // commit the decided sites of the batch: lane j handles site n0+j
+            if (lig < 8 && lig < done) commit_site(P, s0 + n0 + lig, sv, sf, sz, my_zn, sc, KP);
+        }
+
+        if (stop_at >= 0) {
+            // hand the document over to the dense kernel: record (doc, site, n_dk deltas so far)
+            int slot = 0;
+            if (lig == 0) slot = atomicAdd(P.resume_count, 1);
+            slot = __shfl(slot, 0, GS);
+            if (slot < P.resume_cap) {
+                int32_t *rec = P.resume + (int64_t)slot * (2 + LLDA_MAX_LIVE);
+                if (lig == 0) { rec[0] = (int32_t)d; rec[1] = stop_at; }
+                if (live) rec[2 + lig] = ndk - ndk0;
+            } else if (lig == 0 && P.status) {
+                atomicOr(P.status, 4);                  // resume list overflow (cannot happen with production margins)
+            }
+        }
+        if (live) {
+            *ndk_p = ndk;
+            if (ndk != ndk0) atomicAdd(&s_nk[pos], ndk - ndk0);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < KP; i += 256) {
+        const int dl = s_nk[i];
+        if (dl) atomicAdd(P.n_k_delta + i, dl);
+    }
+}
+
+}  // namespace

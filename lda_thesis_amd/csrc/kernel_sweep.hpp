@@ -1,0 +1,314 @@
+// kernel_sweep.hpp -- llda_sweep_exact_kernel (general) and llda_sweep_kernel (tiered, the hot kernel)
+// Part of the single translation unit llda_gibbs.hip (included in order; see the contents list there).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Sweep kernel, general form: every site through the reference's fp64 pipeline, inline.  Used when the
+// tiered kernel's preconditions do not hold (alpha or beta < 1e-6, V*beta >= 2^40).
+// ---------------------------------------------------------------------------------------------
+template <int G, int T, bool HAS_TAIL>
+__global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
+{
+    constexpr int KP = G * T;
+    constexpr int GPB = 256 / G;              // lane groups (documents in flight) per workgroup
+    __shared__ int s_nk[KP];                  // workgroup accumulator of the n_k changes
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
+    __syncthreads();
+    const int lane = tid & 63;
+    const int lig = tid & (G - 1);            // lane in group
+    const int grp = tid / G;
+
+    for (int it = 0; it < P.dpg; ++it) {
+        const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
+        if (idx >= P.D) break;
+        const int64_t d = P.doc_order ? (int64_t)P.doc_order[idx] : idx;
+        const int64_t s0 = P.doc_off[d];
+        const int len = (int)(P.doc_off[d + 1] - s0);
+        if (len <= 0) continue;
+
+        int ndk[T], nkb[T];           // nkb = n_k(sweep start) - n_dk(sweep start): n_k seen by the
+        int32_t *ndk_row = P.n_dk + d * KP + lig * T;   // document is nkb + ndk at any time
+        load_row<T>(ndk_row, ndk);
+        load_row<T>(P.n_k + lig * T, nkb);
+#pragma unroll
+        for (int s = 0; s < T; ++s) nkb[s] -= ndk[s];
+        const uint32_t mask = P.lab_mask[d * G + lig];
+        const uint32_t gdoc = (uint32_t)(d + P.doc_base);
+
+        // memory pipeline: see llda_sweep_kernel
+        int v_c = P.word[s0], f_c = P.freq[s0], zo_c = P.z[s0], c_c = P.csc_pos ? P.csc_pos[s0] : 0;
+        const int64_t i1 = s0 + (len > 1 ? 1 : 0);
+        int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1], c_1 = P.csc_pos ? P.csc_pos[i1] : 0;
+        int xn[T];
+        load_row<T>(P.n_kw + (int64_t)v_c * KP + lig * T, xn);
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        int64_t pend_i = -1;
+        int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0, pend_c = 0;
+
+        for (int n = 0; n < len; ++n) {
+            const int v = v_c, f = f_c, zo = zo_c, c = c_c;
+            int x[T];
+#pragma unroll
+            for (int s = 0; s < T; ++s) x[s] = xn[s];
+            if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
+            load_row<T>(P.n_kw + (int64_t)v_1 * KP + lig * T, xn);
+            v_c = v_1; f_c = f_1; zo_c = zo_1; c_c = c_1;
+            {
+                const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);
+                v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
+                if (P.csc_pos) c_1 = P.csc_pos[i2];
+            }
+            const double u = site_uniform<G>(P, n, n == 0, gdoc, lig, r0, r1, r2, r3);
+
+            // remove the site (LabeledLDA.py:109-111)
+            {
+                const int lo = zo / T, so = zo - lo * T;
+                onehot_add2<T>(ndk, x, (lig == lo) ? (1u << so) : 0u, f);
+            }
+            // scores (LabeledLDA.py:113-116), np.sum, prob /= sum, keyed draw
+            double w[T];
+            scores<T>(w, ndk, nkb, x, mask, P.alpha, P.beta, P.vbeta);
+            const double S = group_sum<G, T, HAS_TAIL>(w, P, lig, lane);
+            const double y = 1.0 / S;
+#pragma unroll
+            for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);
+            int zn = draw_position<G, T, false>(w, u, mask, S > 0.0, lig, lane);
+            if (zn < 0) {
+                zn = zo;
+                if (lig == 0 && P.status) atomicOr(P.status, 1);    // no topic with positive probability
+            }
+            // add the site back (LabeledLDA.py:121-125)
+            {
+                const int ln = zn / T, sn = zn - ln * T;
+                onehot_add1<T>(ndk, (lig == ln) ? (1u << sn) : 0u, -f);
+            }
+            pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn; pend_c = c;
+        }
+        if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
+
+        int old[T];
+        load_row<T>(ndk_row, old);
+#pragma unroll
+        for (int s = 0; s < T; ++s) {
+            const int dl = ndk[s] - old[s];
+            if (dl) atomicAdd(&s_nk[lig * T + s], dl);
+        }
+        store_row<T>(ndk_row, ndk);
+    }
+    __syncthreads();
+    for (int i = tid; i < KP; i += 256) {
+        const int dl = s_nk[i];
+        if (dl) atomicAdd(P.n_k_delta + i, dl);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sweep kernel, tiered form (the one that runs in practice).  Preconditions, host-checked in llda_sweep:
+// alpha, beta >= 1e-6 (every label-allowed topic has a strictly positive probability, so the "p > 0" tests
+// of the draw can be read off the label mask) and V*beta < 2^40.  DENSE (K == KP): every document allows
+// every topic and the label mask is not applied.
+// The document's n_dk row, the n_k it sees and an fp32 reciprocal of n_k + V*beta live in LDS as
+// [slot][thread] arrays: conflict-free, and the owning lane updates ONE dynamically indexed slot per
+// change (VGPR arrays would need a 16-deep select chain per update).
+// ---------------------------------------------------------------------------------------------
+#ifndef LLDA_MARGIN0
+#define LLDA_MARGIN0 0x1p-16f   // tier-0 (fp32) decision margin relative to the total score
+#endif
+#ifndef LLDA_WAVES
+#define LLDA_WAVES 3          // waves per SIMD the register allocator must leave room for
+#endif
+
+// tier-0 factor of one topic: fl32(a * y) with a = fl32(n_dk + alpha), y = v_rcp_f32(fl32(n_k + V*beta)).
+// n_dk and n_k of a topic always change together, so the product is cached as ONE float per slot.
+__device__ __forceinline__ float tier0_factor(int ndk, int nk, float alpha32, float vbeta32)
+{
+    return ((float)ndk + alpha32) * __builtin_amdgcn_rcpf((float)nk + vbeta32);
+}
+
+// a topic count of this document changes by df: n_dk, the n_k the document sees, and the cached tier-0 factor
+__device__ __forceinline__ void count_update(int (*s_ndk)[256], int (*s_nkc)[256], float (*s_pa)[256], int slot,
+                                             int tid, float alpha32, float vbeta32, int df)
+{
+    const int nd = s_ndk[slot][tid] + df, nk = s_nkc[slot][tid] + df;
+    s_ndk[slot][tid] = nd;
+    s_nkc[slot][tid] = nk;
+    s_pa[slot][tid] = tier0_factor(nd, nk, alpha32, vbeta32);
+}
+
+template <int G, int T, bool HAS_TAIL, bool DENSE>
+__global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KParams P)
+{
+    constexpr int KP = G * T;
+    constexpr int GPB = 256 / G;              // lane groups (documents in flight) per workgroup
+    __shared__ int s_nk[KP];                  // workgroup accumulator of the n_k changes
+    __shared__ int s_ndk[T][256];             // n_dk row of the document
+    __shared__ int s_nkc[T][256];             // n_k as the document sees it
+    __shared__ float s_pa[T][256];            // tier-0 factor fl32((n_dk + alpha) / (n_k + V*beta))
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int lig = tid & (G - 1);            // lane in group
+    const int grp = tid / G;
+    const float vbeta32 = (float)P.vbeta, alpha32 = (float)P.alpha, beta32 = (float)P.beta;
+
+    const int n_resume = P.resume_mode ? min(*P.resume_count, P.resume_cap) : 0;
+    for (int it = 0; P.resume_mode || it < P.dpg; ++it) {
+        int64_t d;
+        int n0 = 0;                           // first site to sample (resume mode: where the sparse kernel stopped)
+        const int32_t *rec = nullptr;
+        if (P.resume_mode) {
+            const int64_t idx = ((int64_t)it * gridDim.x + blockIdx.x) * GPB + grp;
+            if (idx >= n_resume) break;
+            rec = P.resume + idx * (2 + LLDA_MAX_LIVE);
+            d = rec[0];
+            n0 = rec[1];
+        } else {
+            const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
+            if (idx >= P.D) break;
+            d = P.doc_order ? (int64_t)P.doc_order[idx] : idx;
+        }
+        const int64_t s0 = P.doc_off[d];
+        const int len = (int)(P.doc_off[d + 1] - s0);
+        if (len <= n0) continue;
+
+        int32_t *ndk_row = P.n_dk + d * KP + lig * T;
+        {
+            int r[T], k[T];
+            load_row<T>(ndk_row, r);
+            load_row<T>(P.n_k + lig * T, k);
+#pragma unroll
+            for (int s = 0; s < T; ++s) {
+                s_ndk[s][tid] = r[s];
+                s_nkc[s][tid] = k[s];                              // sweep-start n_k
+                s_pa[s][tid] = tier0_factor(r[s], k[s], alpha32, vbeta32);
+            }
+        }
+        if (rec) {
+            // resumed document: the n_k it sees already moved by its own earlier sites (n_dk row holds them)
+            const int64_t l0 = P.live_off[d];
+            const int A = (int)(P.live_off[d + 1] - l0);
+            for (int j = 0; j < A; ++j) {
+                const int pos = P.live_pos[l0 + j], dl = rec[2 + j];
+                if (dl != 0 && lig == pos / T) {
+                    const int nk = s_nkc[pos % T][tid] + dl;
+                    s_nkc[pos % T][tid] = nk;
+                    s_pa[pos % T][tid] = tier0_factor(s_ndk[pos % T][tid], nk, alpha32, vbeta32);
+                }
+            }
+        }
+        const uint32_t mask = P.lab_mask[d * G + lig];
+        const uint32_t gdoc = (uint32_t)(d + P.doc_base);
+        const uint64_t gp_doc = (__ballot(mask != 0) >> (lane & ~(G - 1))) & ((G == 64) ? ~0ull : ((1ull << G) - 1ull));   // lanes with an allowed topic
+
+        // Software pipeline of the memory operations: at the top of iteration n the registers hold the
+        // scalars (word, freq, z) of site n, the row of site n is in flight (xn) and so are the scalars of
+        // site n+1.  Right after the single s_waitcnt vmcnt(0) of the iteration (first use of xn) the body
+        // issues, in this order: the z store + two n_kw_delta atomics of site n-1, the row of site n+1,
+        // the scalars of site n+2 -- so nothing the next wait covers is younger than one full site.
+        int v_c = P.word[s0 + n0], f_c = P.freq[s0 + n0], zo_c = P.z[s0 + n0], c_c = P.csc_pos ? P.csc_pos[s0 + n0] : 0;
+        const int64_t i1 = s0 + (n0 + 1 < len ? n0 + 1 : n0);
+        int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1], c_1 = P.csc_pos ? P.csc_pos[i1] : 0;
+        int xn[T];
+        load_row<T>(P.n_kw + (int64_t)v_c * KP + lig * T, xn);
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        int64_t pend_i = -1;
+        int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0, pend_c = 0;
+        {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the loop body
+            const int lo = zo_c / T;
+            if (lig == lo) count_update(s_ndk, s_nkc, s_pa, zo_c - lo * T, tid, alpha32, vbeta32, -f_c);
+        }
+
+        for (int n = n0; n < len; ++n) {
+            const int v = v_c, f = f_c, zo = zo_c, c = c_c;
+            int x[T];
+#pragma unroll
+            for (int s = 0; s < T; ++s) x[s] = xn[s];
+#ifndef ABL_NOCOMMIT
+            if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
+#endif
+#ifndef ABL_NOLOAD
+            load_row<T>(P.n_kw + (int64_t)v_1 * KP + lig * T, xn);        // row of site n+1 (clamped)
+#else
+#pragma unroll
+            for (int s = 0; s < T; ++s) xn[s] = (v_1 + s) & 7;            // ablation: no n_kw traffic
+#endif
+            v_c = v_1; f_c = f_1; zo_c = zo_1; c_c = c_1;
+            {
+                const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);  // scalars of site n+2 (clamped)
+                v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
+                if (P.csc_pos) c_1 = P.csc_pos[i2];
+            }
+            uint32_t ra, rb;
+            site_random_bits<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3, ra, rb);
+
+            // the site's own count leaves the fetched n_kw row (n_dk / n_k were updated already)
+            {
+                const int lo = zo / T, so = zo - lo * T;
+                onehot_add1<T>(x, (lig == lo) ? (1u << so) : 0u, f);       // m = -1 at the slot: += (-1) * f
+            }
+
+            // tiered draw
+            int zn = -1;
+            bool decided = false;
+            if (P.margin0_rel < 1.0f) {           // tier 0: fp32
+                float qf[T];
+                prefix_scores_f32<T, DENSE>(qf, x, s_pa, tid, mask, beta32);
+                // fp32 image of the uniform: the top 27 bits (within 2^-24 relative + 2^-27 absolute of u)
+                const float u32 = (float)(ra >> 5) * 0x1p-27f;
+                decided = draw_fast_f32<G, T>(qf, u32, mask, gp_doc, P.margin0_rel, lig, lane, zn);
+            }
+            if (!decided) {
+                int x_c[T];
+#pragma unroll
+                for (int s = 0; s < T; ++s) x_c[s] = x[s];
+                zn = cold_tiers<G, T, HAS_TAIL, DENSE>(s_ndk, x_c, s_nkc, tid, mask, uniform53(ra, rb), lig, lane, &P);
+            }
+            if (zn < 0) {
+                zn = zo;
+                if (lig == 0 && P.status) atomicOr(P.status, 1);    // no topic with positive probability
+            }
+
+            // add the site back (LabeledLDA.py:121-125), and take the NEXT site out of its topic already (its
+            // scalars are in registers): the LDS state is final long before the next site's scores read it.
+            // Both updates usually belong to different lanes and are done in ONE masked pass; a second pass runs
+            // only for groups where the same lane owns both.
+            {
+                const int ln = zn / T;
+                const bool more = n + 1 < len;
+                const int lo2 = more ? zo_c / T : -1;
+                const bool own_new = lig == ln, own_old = lig == lo2;
+                if (own_new || own_old)
+                    count_update(s_ndk, s_nkc, s_pa, own_new ? zn - ln * T : zo_c - lo2 * T, tid, alpha32, vbeta32,
+                                 own_new ? f : -f_c);
+                if (own_new && own_old) count_update(s_ndk, s_nkc, s_pa, zo_c - lo2 * T, tid, alpha32, vbeta32, -f_c);
+            }
+            pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn; pend_c = c;
+        }
+        if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
+
+        // document done: fold its n_dk change into the workgroup's n_k accumulator, store the row
+        int old[T], cur[T];
+        load_row<T>(ndk_row, old);
+#pragma unroll
+        for (int s = 0; s < T; ++s) {
+            cur[s] = s_ndk[s][tid];
+            const int dl = cur[s] - old[s];
+            if (dl) atomicAdd(&s_nk[lig * T + s], dl);
+        }
+        store_row<T>(ndk_row, cur);
+    }
+
+    __syncthreads();
+    for (int i = tid; i < KP; i += 256) {
+        const int dl = s_nk[i];
+        if (dl) atomicAdd(P.n_k_delta + i, dl);
+    }
+}
+
+}  // namespace
