@@ -99,6 +99,8 @@ class SubLDA(object):
             self._upload()
 
     def _initial_counts(self):
+        """host statement of the reference's count initialisation incl. the phantom columns (CascadeLDA.py:382-385);
+        the device path of _upload builds the same counts with llda_count_init + add_word_topic_counts."""
         doc_off, word, freq = csr_from_doc_tups(self.doc_tups)
         z = self._z0
         f64 = freq.astype(np.int64)
@@ -118,10 +120,16 @@ class SubLDA(object):
         if self._sampler is None:
             if self.seed is None:
                 self.seed = int(np.random.randint(0, 2 ** 31 - 1))
-            (doc_off, word, freq), counts = self._initial_counts()
+            doc_off, word, freq = csr_from_doc_tups(self.doc_tups)
+            if freq.size and int(freq.max()) >= self.V:
+                raise IndexError("index %d is out of bounds for axis 1 with size %d" % (int(freq.max()), self.V))
+            # counts from the assignments on the device (llda_count_init), then the phantom counts: the
+            # reference's n_k_v[z, (id, f)] += f also bumps column f (once if f == id)
             self._sampler = GibbsSampler(doc_off, word, freq, self._z0, self.K, self.V, self.alpha,
-                                         self.beta, labs=self.labs, counts=counts, seed=self.seed,
+                                         self.beta, labs=self.labs, counts=None, seed=self.seed,
                                          stream_id=self.stream_id, device=self._device, sharded=False)
+            ghost = freq != word
+            self._sampler.add_word_topic_counts(freq[ghost], self._z0[ghost], freq[ghost])
         return self._sampler
 
     @property

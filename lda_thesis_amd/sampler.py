@@ -148,6 +148,17 @@ class GibbsSampler(object):
             self.n_kw[:, self._topic_pos] = as_dev(np.asarray(counts["n_k_v"]).T, torch.int32)
             self.n_k[self._topic_pos] = as_dev(counts["n_zk"], torch.int32)
 
+    def add_word_topic_counts(self, words, topics, amounts):
+        """n_kw[word, topic] += amount for parallel 1-D arrays (host or device); n_k and n_dk are left alone.
+        (SubLDA's phantom columns, reference CascadeLDA.py:382-385, are such counts.)"""
+        dev = self.device
+        w = torch.as_tensor(np.asarray(words), dtype=torch.int64, device=dev)
+        if w.numel() == 0:
+            return
+        pos = self._topic_pos[torch.as_tensor(np.asarray(topics), dtype=torch.int64, device=dev)]
+        self.n_kw.index_put_((w, pos), torch.as_tensor(np.asarray(amounts), dtype=torch.int32, device=dev),
+                             accumulate=True)
+
     # ------------------------------------------------------------------ masks
     def _make_masks(self, labs):
         lay, dev = self.layout, self.device

@@ -88,7 +88,8 @@ def test_sublda_phantom_init_and_run_training(capsys):
 
 
 def test_sublda_golden_phantom_counts():
-    """host-side phantom initialisation == the reference's n_k_v for the sublda fixture."""
+    """phantom initialisation == the reference's n_k_v for the sublda fixture: the host statement and the device
+    path (llda_count_init + add_word_topic_counts) SubLDA actually uses."""
     from lda_thesis_amd.CascadeLDA import SubLDA
     g = load_golden("sublda")
     sub = SubLDA.__new__(SubLDA)
@@ -100,6 +101,11 @@ def test_sublda_golden_phantom_counts():
     np.testing.assert_array_equal(counts["n_k_v"], g["init_n_k_v"])
     np.testing.assert_array_equal(counts["n_d_k"], g["init_n_d_k"])
     np.testing.assert_array_equal(counts["n_zk"], g["init_n_zk"])
+    sub.labs, sub.alpha, sub.beta = g["labs"].astype(float), float(g["alpha"]), float(g["beta"])
+    sub.seed, sub.stream_id, sub._device, sub._sampler = 1, 0, None, None
+    np.testing.assert_array_equal(sub.n_k_v, g["init_n_k_v"])
+    np.testing.assert_array_equal(sub.n_d_k, g["init_n_d_k"])
+    np.testing.assert_array_equal(sub.n_zk, g["init_n_zk"])
 
 
 def test_cascade_go_down_tree_matches_reference(capsys):

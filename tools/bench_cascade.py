@@ -54,10 +54,13 @@ def main():
     model = CascadeLDA(docs, labs, list(seen.keys()), dicti, alpha=0.1, beta=0.01, seed=1)
     tasks = model.enumerate_subproblems()
     sites = [sum(len(t) for t in task["doc_tups"]) for task in tasks]
+    import torch
+    from lda_thesis_amd import _native
+    _native.lib()
+    torch.zeros(1, device="cuda").item()                    # HIP context and library load are not part of the ensemble
     t1 = time.perf_counter()
     with redirect_stdout(io.StringIO()):
         model.go_down_tree(it=args.it, s=args.s)
-    import torch
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     filled = int((np.nan_to_num(model.ph).sum(axis=1) > 0).sum())
