@@ -134,6 +134,16 @@ __device__ __forceinline__ void onehot_add1(int (&a)[T], uint32_t oh, int g)
     }
 }
 
+// out-of-place form: b = a + (-1 at the one-hot slot) * g -- saves the register copy when a must survive
+template <int T, int S = 0>
+__device__ __forceinline__ void onehot_add_to(int (&b)[T], const int (&a)[T], uint32_t oh, int g)
+{
+    if constexpr (S < T) {
+        b[S] = mad_i24(onehot_bit<S>(oh), g, a[S]);
+        onehot_add_to<T, S + 1>(b, a, oh, g);
+    }
+}
+
 template <int T, int S = 0>
 __device__ __forceinline__ void scores(double (&w)[T], const int (&ndk)[T], const int (&nkb)[T], const int (&x)[T],
                                        uint32_t mask, double alpha, double beta, double vbeta)

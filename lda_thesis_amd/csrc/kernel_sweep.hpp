@@ -226,9 +226,13 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
 
         for (int n = n0; n < len; ++n) {
             const int v = v_c, f = f_c, zo = zo_c, c = c_c;
+            // the fetched row minus the site's own count (n_dk / n_k were updated already), written to a second
+            // array so that the next row can be loaded into xn right away
             int x[T];
-#pragma unroll
-            for (int s = 0; s < T; ++s) x[s] = xn[s];
+            {
+                const int lo = zo / T, so = zo - lo * T;
+                onehot_add_to<T>(x, xn, (lig == lo) ? (1u << so) : 0u, f);   // m = -1 at the slot: += (-1) * f
+            }
 #ifndef ABL_NOCOMMIT
             if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
 #endif
@@ -246,12 +250,6 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             }
             uint32_t ra, rb;
             site_random_bits<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3, ra, rb);
-
-            // the site's own count leaves the fetched n_kw row (n_dk / n_k were updated already)
-            {
-                const int lo = zo / T, so = zo - lo * T;
-                onehot_add1<T>(x, (lig == lo) ? (1u << so) : 0u, f);       // m = -1 at the slot: += (-1) * f
-            }
 
             // tiered draw
             int zn = -1;
