@@ -23,6 +23,7 @@ struct KParams {
     int32_t *status;
     int64_t D;
     int64_t doc_base;
+    int64_t site_base;      // llda_sweep_kernel: the site-indexed arrays are addressed relative to this site
     double alpha, beta, vbeta;
     uint32_t key0, key1, sweep, stream_id;
     int32_t dpg;
@@ -61,6 +62,44 @@ __device__ __forceinline__ void philox4x32_10(uint32_t &c0, uint32_t &c1, uint32
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// Global-memory accesses of the hot loop: base pointer (uniform, from the kernel arguments) + 32-bit BYTE
+// offset.  The explicit global address space gives global_load / global_store with the base in SGPRs and the
+// offset in one VGPR -- no 64-bit address arithmetic per access, and no lgkmcnt coupling as with flat_*.
+#define LLDA_GLOBAL __attribute__((address_space(1)))
+// (the empty asm hides how the offset was computed: otherwise loop strength reduction turns base + offset into
+// one 64-bit pointer induction variable per array, i.e. back into 64-bit VALU adds)
+__device__ __forceinline__ uint32_t opaque_u32(uint32_t x)
+{
+    asm("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ int gload_i32(const int32_t *base, uint32_t byte_off)
+{
+    return *(const LLDA_GLOBAL int32_t *)((const LLDA_GLOBAL char *)base + byte_off);
+}
+__device__ __forceinline__ void gstore_i32(int32_t *base, uint32_t byte_off, int v)
+{
+    *(LLDA_GLOBAL int32_t *)((LLDA_GLOBAL char *)base + byte_off) = v;
+}
+// T contiguous int32 at element offset `elem` of a global array
+template <int T>
+__device__ __forceinline__ void gload_row(const int32_t *base, int64_t elem, int (&x)[T])
+{
+    const LLDA_GLOBAL int32_t *q = (const LLDA_GLOBAL int32_t *)base + elem;
+    if constexpr (T % 4 == 0) {
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const LLDA_GLOBAL v4i *p = (const LLDA_GLOBAL v4i *)q;
+#pragma unroll
+        for (int i = 0; i < T / 4; ++i) {
+            const v4i v = p[i];
+            x[4 * i + 0] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) x[i] = q[i];
     }
 }
 

@@ -211,13 +211,19 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         // site n+1.  Right after the single s_waitcnt vmcnt(0) of the iteration (first use of xn) the body
         // issues, in this order: the z store + two n_kw_delta atomics of site n-1, the row of site n+1,
         // the scalars of site n+2 -- so nothing the next wait covers is younger than one full site.
-        int v_c = P.word[s0 + n0], f_c = P.freq[s0 + n0], zo_c = P.z[s0 + n0], c_c = P.csc_pos ? P.csc_pos[s0 + n0] : 0;
-        const int64_t i1 = s0 + (n0 + 1 < len ? n0 + 1 : n0);
-        int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1], c_1 = P.csc_pos ? P.csc_pos[i1] : 0;
+        // (site-indexed arrays are addressed as base + 32-bit byte offset: llda_sweep launches this kernel on
+        // document ranges whose sites span less than 2^30 entries from P.site_base)
+        const uint32_t sb = (uint32_t)(s0 - P.site_base) * 4u;
+        const uint32_t o0 = opaque_u32(sb + (uint32_t)n0 * 4u), o1 = opaque_u32(sb + (uint32_t)(n0 + 1 < len ? n0 + 1 : n0) * 4u);
+        int v_c = gload_i32(P.word, o0), f_c = gload_i32(P.freq, o0), zo_c = gload_i32(P.z, o0),
+            c_c = P.csc_pos ? gload_i32(P.csc_pos, o0) : 0;
+        int v_1 = gload_i32(P.word, o1), f_1 = gload_i32(P.freq, o1), zo_1 = gload_i32(P.z, o1),
+            c_1 = P.csc_pos ? gload_i32(P.csc_pos, o1) : 0;
         int xn[T];
-        load_row<T>(P.n_kw + (int64_t)v_c * KP + lig * T, xn);
+        gload_row<T>(P.n_kw, (int64_t)v_c * KP + lig * T, xn);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        int64_t pend_i = -1;
+        uint32_t pend_o = 0;
+        bool pend = false;
         int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0, pend_c = 0;
         {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the loop body
             const int lo = zo_c / T;
@@ -234,19 +240,19 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 onehot_add_to<T>(x, xn, (lig == lo) ? (1u << so) : 0u, f);   // m = -1 at the slot: += (-1) * f
             }
 #ifndef ABL_NOCOMMIT
-            if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
+            if (lig == 0 && pend) commit_site_off(P, pend_o, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
 #endif
 #ifndef ABL_NOLOAD
-            load_row<T>(P.n_kw + (int64_t)v_1 * KP + lig * T, xn);        // row of site n+1 (clamped)
+            gload_row<T>(P.n_kw, (int64_t)v_1 * KP + lig * T, xn);        // row of site n+1 (clamped)
 #else
 #pragma unroll
             for (int s = 0; s < T; ++s) xn[s] = (v_1 + s) & 7;            // ablation: no n_kw traffic
 #endif
             v_c = v_1; f_c = f_1; zo_c = zo_1; c_c = c_1;
             {
-                const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);  // scalars of site n+2 (clamped)
-                v_1 = P.word[i2]; f_1 = P.freq[i2]; zo_1 = P.z[i2];
-                if (P.csc_pos) c_1 = P.csc_pos[i2];
+                const uint32_t o2 = opaque_u32(sb + (uint32_t)(n + 2 < len ? n + 2 : len - 1) * 4u);   // scalars of site n+2 (clamped)
+                v_1 = gload_i32(P.word, o2); f_1 = gload_i32(P.freq, o2); zo_1 = gload_i32(P.z, o2);
+                if (P.csc_pos) c_1 = gload_i32(P.csc_pos, o2);
             }
             uint32_t ra, rb;
             site_random_bits<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3, ra, rb);
@@ -265,7 +271,10 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 int x_c[T];
 #pragma unroll
                 for (int s = 0; s < T; ++s) x_c[s] = x[s];
-                zn = cold_tiers<G, T, HAS_TAIL, DENSE>(s_ndk, x_c, s_nkc, tid, mask, uniform53(ra, rb), lig, lane, &P);
+                // (the callee reads the parameters from the kernel-argument segment: taking &P would force a scratch
+                // copy of all of P and put its pointers into VGPRs)
+                zn = cold_tiers<G, T, HAS_TAIL, DENSE>(s_ndk, x_c, s_nkc, tid, mask, uniform53(ra, rb), lig, lane,
+                                                       (const KParams *)__builtin_amdgcn_kernarg_segment_ptr());
             }
             if (zn < 0) {
                 zn = zo;
@@ -286,9 +295,9 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                                  own_new ? f : -f_c);
                 if (own_new && own_old) count_update(s_ndk, s_nkc, s_pa, zo_c - lo2 * T, tid, alpha32, vbeta32, -f_c);
             }
-            pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn; pend_c = c;
+            pend = true; pend_o = opaque_u32(sb + (uint32_t)n * 4u); pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn; pend_c = c;
         }
-        if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
+        if (lig == 0 && pend) commit_site_off(P, pend_o, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
 
         // document done: fold its n_dk change into the workgroup's n_k accumulator, store the row
         int old[T], cur[T];
