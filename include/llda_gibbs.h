@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 5
+#define LLDA_ABI_VERSION 6
 #define LLDA_MAX_K 1024
 #define LLDA_MAX_LEAVES 8
 #define LLDA_MAX_ROUNDS 4
@@ -119,6 +119,11 @@ typedef struct llda_sweep_args {
      * n_kw_delta is not touched in this mode. */
     const int32_t *csc_pos;      /* [dev] [S] index of every site in word-major (stable) order        */
     uint32_t      *commit_log;   /* [dev] [S] out, word-major                                         */
+    int64_t  n_sites;            /* doc_off[D] - doc_off[0], the sites this call spans: must be < 2^30 (the hot
+                                    kernel addresses word / freq / z / csc_pos as base + 32-bit byte offset from
+                                    the first document of the call).  Larger shards: one call per document
+                                    range -- pass doc_off + d0, D = d1 - d0, n_dk + d0*KP, lab_mask + d0*G,
+                                    doc_base + d0 (and live_off + d0); every other pointer stays as it is. */
 } llda_sweep_args;
 
 /* ---- host-only (no device needed) ---- */

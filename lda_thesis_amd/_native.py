@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libllda_gibbs.so")
 MAX_K = 1024
 MAX_LEAVES = 8
 MAX_ROUNDS = 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -48,7 +48,8 @@ class LldaSweepArgs(ctypes.Structure):
                 ("dense_mask", _c_i32), ("debug_margin", _c_i32), ("alpha", _c_d), ("beta", _c_d), ("seed", _c_u64), ("sweep", _c_u32),
                 ("stream_id", _c_u32), ("doc_base", _c_i64),
                 ("live_off", _c_p), ("live_pos", _c_p), ("resume", _c_p), ("resume_count", _c_p),
-                ("resume_cap", _c_i32), ("live_max", _c_i32), ("csc_pos", _c_p), ("commit_log", _c_p)]
+                ("resume_cap", _c_i32), ("live_max", _c_i32), ("csc_pos", _c_p), ("commit_log", _c_p),
+                ("n_sites", _c_i64)]
 
 
 EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_layout_init",
@@ -141,8 +142,9 @@ def _stream():
 def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
           status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
           dense_mask=False, debug_margin=0, live_off=None, live_pos=None, resume=None, resume_count=None,
-          live_max=0, csc_pos=None, commit_log=None):
-    """llda_sweep on the current torch stream.  All array arguments are torch CUDA tensors."""
+          live_max=0, csc_pos=None, commit_log=None, n_sites=None):
+    """llda_sweep on the current torch stream.  All array arguments are torch CUDA tensors.  n_sites = the sites
+    the D documents span (default: all of ``word``)."""
     a = LldaSweepArgs(_ptr(doc_off), _ptr(doc_order), _ptr(word), _ptr(freq), _ptr(z), _ptr(lab_mask),
                       _ptr(n_dk), _ptr(n_kw), _ptr(n_kw_delta), _ptr(n_k), _ptr(n_k_delta), _ptr(status),
                       int(D), int(V), int(K), int(docs_per_group), 1 if dense_mask else 0, int(debug_margin),
@@ -150,7 +152,7 @@ def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta
                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(sweep) & 0xFFFFFFFF,
                       int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), _ptr(resume),
                       _ptr(resume_count), 0 if resume is None else int(resume.shape[0]), int(live_max),
-                      _ptr(csc_pos), _ptr(commit_log))
+                      _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites))
     check(lib().llda_sweep(ctypes.byref(a), _stream()), "llda_sweep")
 
 

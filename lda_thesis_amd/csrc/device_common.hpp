@@ -23,7 +23,6 @@ struct KParams {
     int32_t *status;
     int64_t D;
     int64_t doc_base;
-    int64_t site_base;      // llda_sweep_kernel: the site-indexed arrays are addressed relative to this site
     double alpha, beta, vbeta;
     uint32_t key0, key1, sweep, stream_id;
     int32_t dpg;

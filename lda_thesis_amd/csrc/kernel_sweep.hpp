@@ -158,6 +158,10 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
     const float vbeta32 = (float)P.vbeta, alpha32 = (float)P.alpha, beta32 = (float)P.beta;
 
     const int n_resume = P.resume_mode ? min(*P.resume_count, P.resume_cap) : 0;
+    const int64_t site_base = P.doc_off[0];                 // uniform: the bases below stay in SGPRs
+    const int32_t *word_b = P.word + site_base, *freq_b = P.freq + site_base;
+    const int32_t *csc_b = P.csc_pos ? P.csc_pos + site_base : nullptr;
+    int32_t *z_b = P.z + site_base;
     for (int it = 0; P.resume_mode || it < P.dpg; ++it) {
         int64_t d;
         int n0 = 0;                           // first site to sample (resume mode: where the sparse kernel stopped)
@@ -211,14 +215,14 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         // site n+1.  Right after the single s_waitcnt vmcnt(0) of the iteration (first use of xn) the body
         // issues, in this order: the z store + two n_kw_delta atomics of site n-1, the row of site n+1,
         // the scalars of site n+2 -- so nothing the next wait covers is younger than one full site.
-        // (site-indexed arrays are addressed as base + 32-bit byte offset: llda_sweep launches this kernel on
-        // document ranges whose sites span less than 2^30 entries from P.site_base)
-        const uint32_t sb = (uint32_t)(s0 - P.site_base) * 4u;
+        // (site-indexed arrays are addressed as base + 32-bit byte offset from the first document of the call;
+        // llda_sweep refuses calls that span 2^30 sites or more)
+        const uint32_t sb = (uint32_t)(s0 - site_base) * 4u;
         const uint32_t o0 = opaque_u32(sb + (uint32_t)n0 * 4u), o1 = opaque_u32(sb + (uint32_t)(n0 + 1 < len ? n0 + 1 : n0) * 4u);
-        int v_c = gload_i32(P.word, o0), f_c = gload_i32(P.freq, o0), zo_c = gload_i32(P.z, o0),
-            c_c = P.csc_pos ? gload_i32(P.csc_pos, o0) : 0;
-        int v_1 = gload_i32(P.word, o1), f_1 = gload_i32(P.freq, o1), zo_1 = gload_i32(P.z, o1),
-            c_1 = P.csc_pos ? gload_i32(P.csc_pos, o1) : 0;
+        int v_c = gload_i32(word_b, o0), f_c = gload_i32(freq_b, o0), zo_c = gload_i32(z_b, o0),
+            c_c = P.csc_pos ? gload_i32(csc_b, o0) : 0;
+        int v_1 = gload_i32(word_b, o1), f_1 = gload_i32(freq_b, o1), zo_1 = gload_i32(z_b, o1),
+            c_1 = P.csc_pos ? gload_i32(csc_b, o1) : 0;
         int xn[T];
         gload_row<T>(P.n_kw, (int64_t)v_c * KP + lig * T, xn);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
@@ -240,7 +244,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 onehot_add_to<T>(x, xn, (lig == lo) ? (1u << so) : 0u, f);   // m = -1 at the slot: += (-1) * f
             }
 #ifndef ABL_NOCOMMIT
-            if (lig == 0 && pend) commit_site_off(P, pend_o, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
+            if (lig == 0 && pend) commit_site_off(P, z_b, pend_o, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
 #endif
 #ifndef ABL_NOLOAD
             gload_row<T>(P.n_kw, (int64_t)v_1 * KP + lig * T, xn);        // row of site n+1 (clamped)
@@ -251,8 +255,8 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             v_c = v_1; f_c = f_1; zo_c = zo_1; c_c = c_1;
             {
                 const uint32_t o2 = opaque_u32(sb + (uint32_t)(n + 2 < len ? n + 2 : len - 1) * 4u);   // scalars of site n+2 (clamped)
-                v_1 = gload_i32(P.word, o2); f_1 = gload_i32(P.freq, o2); zo_1 = gload_i32(P.z, o2);
-                if (P.csc_pos) c_1 = gload_i32(P.csc_pos, o2);
+                v_1 = gload_i32(word_b, o2); f_1 = gload_i32(freq_b, o2); zo_1 = gload_i32(z_b, o2);
+                if (P.csc_pos) c_1 = gload_i32(csc_b, o2);
             }
             uint32_t ra, rb;
             site_random_bits<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3, ra, rb);
@@ -297,7 +301,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             }
             pend = true; pend_o = opaque_u32(sb + (uint32_t)n * 4u); pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn; pend_c = c;
         }
-        if (lig == 0 && pend) commit_site_off(P, pend_o, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
+        if (lig == 0 && pend) commit_site_off(P, z_b, pend_o, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
 
         // document done: fold its n_dk change into the workgroup's n_k accumulator, store the row
         int old[T], cur[T];

@@ -296,6 +296,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     const int rc = llda_layout_init(a->K, &L);
     if (rc) return rc;
     if (a->D == 0) return LLDA_OK;            // an empty shard: nothing to do, array pointers may be NULL
+    if (a->n_sites < 0 || a->n_sites >= (1LL << 30)) return LLDA_E_BAD_ARG;   // split the shard (llda_gibbs.h)
     const bool logged = a->csc_pos && a->commit_log;
     if ((a->csc_pos != nullptr) != (a->commit_log != nullptr)) return LLDA_E_BAD_ARG;
     if (!a->doc_off || !a->word || !a->freq || !a->z || !a->lab_mask || !a->n_dk || !a->n_kw ||

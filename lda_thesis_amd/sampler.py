@@ -120,11 +120,10 @@ class GibbsSampler(object):
             commit_log = self.S >= (1 << 20)
         if commit_log and self.S > 0:
             self._make_commit_log()
-        lens = (self.doc_off[1:] - self.doc_off[:-1])
-        self.doc_order = None
-        if sort_docs and self.D > 1 and int(lens.min()) != int(lens.max()):
-            # longest documents first, neighbours in a wavefront get similar lengths
-            self.doc_order = torch.sort(lens, descending=True, stable=True).indices.to(torch.int32)
+        self._sort_docs = bool(sort_docs)
+        self._off_host = self.doc_off.cpu().numpy() if self.S > self.MAX_CALL_SITES else None
+        self._calls = self._make_calls(self.doc_off[1:] - self.doc_off[:-1])
+        self.doc_order = self._calls[0][2]       # (order of the first -- normally the only -- call)
 
         KP = lay.KP
         self.n_dk = torch.zeros((self.D, KP), dtype=torch.int32, device=dev)
@@ -202,6 +201,28 @@ class GibbsSampler(object):
         self.resume_count = torch.zeros((1,), dtype=torch.int32, device=dev)
 
     LOG_ITEM = 4096    # most log entries one wavefront of llda_commit_log folds (hot words are cut into items)
+    MAX_CALL_SITES = (1 << 30) - 1   # llda_sweep addresses the sites of one call with 32-bit byte offsets
+
+    def _make_calls(self, lens):
+        """document ranges of the llda_sweep calls of one sweep (one range unless the shard spans 2^30 sites),
+        each with its processing order: longest documents first, neighbours in a wavefront of similar length."""
+        def order(lo, hi):
+            ln = lens[lo:hi]
+            if not self._sort_docs or hi - lo < 2 or int(ln.min()) == int(ln.max()):
+                return None
+            return torch.sort(ln, descending=True, stable=True).indices.to(torch.int32)
+        if self.S <= self.MAX_CALL_SITES:
+            return [(0, self.D, order(0, self.D))]
+        off = self._off_host
+        if int(np.diff(off).max()) > self.MAX_CALL_SITES:
+            raise ValueError("a document has more than %d sites" % self.MAX_CALL_SITES)
+        calls, lo = [], 0
+        while lo < self.D:
+            hi = int(np.searchsorted(off, off[lo] + self.MAX_CALL_SITES, side="right")) - 1
+            hi = max(min(hi, self.D), lo + 1)
+            calls.append((lo, hi, order(lo, hi)))
+            lo = hi
+        return calls
 
     def _make_commit_log(self):
         """word-major (CSC) view of the sites: position of every site, frequencies in that order, and the work
@@ -236,16 +257,23 @@ class GibbsSampler(object):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()              # same stream the kernel is enqueued on (torch's current stream)
         logged = self.commit_log is not None
-        self.backend.sweep(doc_off=self.doc_off, doc_order=self.doc_order, word=self.word, freq=self.freq,
-                           z=self.z, lab_mask=self.lab_mask, n_dk=self.n_dk, n_kw=self.n_kw,
-                           n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=self.n_k_delta,
-                           status=self.status, D=self.D, V=self.V, K=self.K, alpha=self.alpha,
-                           beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
-                           stream_id=self.stream_id, doc_base=self.doc_base,
-                           docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
-                           debug_margin=self.debug_margin, live_off=self.live_off, live_pos=self.live_pos,
-                           resume=self.resume, resume_count=self.resume_count, live_max=self.live_max,
-                           csc_pos=self.csc_pos, commit_log=self.commit_log)
+        if len(self._calls) == 1:
+            self._calls[0] = (0, self.D, self.doc_order)
+        for lo, hi, order in self._calls:
+            s0 = 0 if len(self._calls) == 1 else int(self._off_host[lo])
+            s1 = self.S if len(self._calls) == 1 else int(self._off_host[hi])
+            self.backend.sweep(doc_off=self.doc_off[lo:hi + 1], doc_order=order, word=self.word, freq=self.freq,
+                               z=self.z, lab_mask=self.lab_mask[lo:hi], n_dk=self.n_dk[lo:hi], n_kw=self.n_kw,
+                               n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=self.n_k_delta,
+                               status=self.status, D=hi - lo, V=self.V, K=self.K, alpha=self.alpha,
+                               beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
+                               stream_id=self.stream_id, doc_base=self.doc_base + lo,
+                               docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
+                               debug_margin=self.debug_margin,
+                               live_off=None if self.live_off is None else self.live_off[lo:hi + 1],
+                               live_pos=self.live_pos, resume=self.resume, resume_count=self.resume_count,
+                               live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
+                               n_sites=s1 - s0)
         if ev is not None:
             ev[1].record()
             self.kernel_events.append(ev)

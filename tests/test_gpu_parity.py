@@ -56,6 +56,34 @@ def test_commit_paths_agree(name, commit, monkeypatch):
     s.check_status()
 
 
+@pytest.mark.parametrize("name", ["tiny_k40", "tiny_k130", "tiny_k392", "tiny_k512", "sublda"])
+def test_shard_split_into_several_calls(name, monkeypatch):
+    """llda_sweep addresses the sites of one call with 32-bit offsets from its first document, so a shard that
+    spans 2^30 sites is walked in several calls over document ranges; here the limit is lowered to 150 sites."""
+    from lda_thesis_amd.sampler import GibbsSampler
+    g = load_golden(name)
+    monkeypatch.setattr(GibbsSampler, "MAX_CALL_SITES", 150)
+    for commit in (False, True):
+        s = make_sampler(g, commit_log=commit)
+        assert len(s._calls) > 2 and s._calls[0][0] == 0 and s._calls[-1][1] == s.D
+        assert all(a[1] == b[0] for a, b in zip(s._calls, s._calls[1:]))
+        for i in range(int(g["sweeps"])):
+            s.sweep()
+            assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics(), name)
+        s.check_status()
+
+
+def test_call_spanning_too_many_sites_is_refused():
+    from lda_thesis_amd import _native
+    g = load_golden("tiny_k40")
+    s = make_sampler(g)
+    kw = dict(doc_off=s.doc_off, doc_order=None, word=s.word, freq=s.freq, z=s.z, lab_mask=s.lab_mask, n_dk=s.n_dk,
+              n_kw=s.n_kw, n_kw_delta=s.n_kw_delta, n_k=s.n_k, n_k_delta=s.n_k_delta, status=s.status, D=s.D, V=s.V,
+              K=s.K, alpha=s.alpha, beta=s.beta, seed=1, sweep=0)
+    with pytest.raises(_native.NativeError):
+        _native.sweep(n_sites=1 << 30, **kw)
+
+
 @pytest.mark.parametrize("name", TINY)
 def test_count_init_matches_reference(name):
     g = load_golden(name)
