@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         bool pend = false;
         int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0, pend_c = 0;
         {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the loop body
-            const int lo = zo_c / T;
+            const int lo = (int)((unsigned)zo_c / (unsigned)T);   // positions are never negative: unsigned division
             if (lig == lo) count_update(s_ndk, s_nkc, s_pa, zo_c - lo * T, tid, alpha32, vbeta32, -f_c);
         }
 
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             // array so that the next row can be loaded into xn right away
             int x[T];
             {
-                const int lo = zo / T, so = zo - lo * T;
+                const int lo = (int)((unsigned)zo / (unsigned)T), so = zo - lo * T;
                 onehot_add_to<T>(x, xn, (lig == lo) ? (1u << so) : 0u, f);   // m = -1 at the slot: += (-1) * f
             }
 #ifndef ABL_NOCOMMIT
@@ -290,9 +290,9 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             // Both updates usually belong to different lanes and are done in ONE masked pass; a second pass runs
             // only for groups where the same lane owns both.
             {
-                const int ln = zn / T;
+                const int ln = (int)((unsigned)zn / (unsigned)T);
                 const bool more = n + 1 < len;
-                const int lo2 = more ? zo_c / T : -1;
+                const int lo2 = more ? (int)((unsigned)zo_c / (unsigned)T) : -1;
                 const bool own_new = lig == ln, own_old = lig == lo2;
                 if (own_new || own_old)
                     count_update(s_ndk, s_nkc, s_pa, own_new ? zn - ln * T : zo_c - lo2 * T, tid, alpha32, vbeta32,
