@@ -103,34 +103,41 @@ __device__ __forceinline__ int allor_i32(int x, int lane)
     return x;
 }
 
-// One site of the sparse kernel (J = index inside the current batch of 8 sites).  Returns false when the
-// draw cannot be decided within the margin (the document is then handed to the dense kernel).
+// One site of the sparse kernel (J = index inside the current batch of 8 sites), branch free: every lane of the
+// wavefront executes every instruction and the per-group conditions (is site J part of this batch? has an
+// earlier site of the batch been undecidable?) are data -- divergent branches here cost more in exec-mask
+// bookkeeping (SGPR spills) than the arithmetic they skip.
+// `ok` = no site of this batch has been undecidable so far; `done` counts the decided sites.  The reciprocal y of
+// n_k + V*beta is recomputed ONCE per site, after the removal (it then also covers the previous site's add-back).
 template <int GS, int J>
-__device__ __forceinline__ bool sparse_site(const KParams &P, int nb, int sv, int sf, int sz, int su_lo, int su_hi,
-                                            const int (&xg)[8], bool live, int pos, int A, int &ndk, int &nk, double &y,
-                                            int &my_zn, int lig, int lane, int gbase, uint64_t gmask)
+__device__ __forceinline__ void sparse_site(const KParams &P, int nb, int sf, int sz, int su_lo, int su_hi,
+                                            const int (&xg)[8], bool live, int pos, int A, int &ndk, int &nk,
+                                            int &my_zn, int &ok, int &done, int lig, int lane, int gbase, uint64_t gmask)
 {
-    if (J >= nb) return true;
+    // (the per-group flags are 0 / -1 integers in VGPRs: as `bool`s they would each occupy an SGPR pair)
     const int f = bcast_lane<GS, J>(sf, lig), zo = bcast_lane<GS, J>(sz, lig);
     const double u = __hiloint2double(bcast_lane<GS, J>(su_hi, lig), bcast_lane<GS, J>(su_lo, lig));
-    if (pos == zo) { ndk -= f; nk -= f; y = rcp_newton((double)nk + P.vbeta); }     // LabeledLDA.py:109-111
-    const int x = xg[J] - ((pos == zo) ? f : 0);
-    const double w = live ? ((double)ndk + P.alpha) * (((double)x + P.beta) * y) : 0.0;
+    const int active = ok & ((J < nb) ? -1 : 0);
+    const int rm = f & active & ((pos == zo) ? -1 : 0);                             // LabeledLDA.py:109-111
+    ndk -= rm; nk -= rm;
+    const double y = rcp_newton((double)nk + P.vbeta);
+    const double w = live ? ((double)ndk + P.alpha) * (((double)(xg[J] - rm) + P.beta) * y) : 0.0;
     const double Q = scan_any_f64<GS>(w, lig);
     const double tot = allsum_any_f64<GS>(w, lane);
     const double t = u * tot, margin = tot * P.margin_rel;
-    const bool unsure = (live && !(fabs(Q - t) > margin)) || !(tot > 0.0) || !(margin < tot);
-    if (((__ballot(unsure) >> gbase) & gmask) != 0) {
-        if (pos == zo) { ndk += f; nk += f; }               // undo: the dense kernel starts at this site
-        return false;
-    }
+    const bool unsure = active && ((live && !(fabs(Q - t) > margin)) || !(tot > 0.0) || !(margin < tot));
+    const int bad = (((__ballot(unsure) >> gbase) & gmask) != 0) ? -1 : 0;         // group-uniform
     const uint64_t gf = (__ballot(live && Q > t) >> gbase) & gmask;
     const int sel = gf ? (int)__ffsll((unsigned long long)gf) - 1 : A - 1;          // none: last allowed topic
     const int zn = allor_i32<GS>((lig == sel) ? pos : 0, lane);
-    if (pos == zn) { ndk += f; nk += f; y = rcp_newton((double)nk + P.vbeta); }     // LabeledLDA.py:121-125
-    if (lig == J) my_zn = zn;
-    (void)sv;
-    return true;
+    const int commit = active & ~bad;
+    // decided: add the site back (LabeledLDA.py:121-125); undecidable: undo the removal, the dense kernel
+    // starts at this site
+    const int back = (commit & f & ((pos == zn) ? -1 : 0)) | (~commit & rm);
+    ndk += back; nk += back;
+    my_zn = (commit & ((lig == J) ? -1 : 0)) ? zn : my_zn;
+    done -= commit;                                                                 // commit is 0 or -1
+    ok &= ~bad;
 }
 
 template <int GS>
@@ -163,7 +170,6 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
         int ndk = live ? *ndk_p : 0;
         const int ndk0 = ndk;
         int nk = live ? P.n_k[pos] : 0;
-        double y = rcp_newton((double)nk + P.vbeta);
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
         int stop_at = -1;
 
@@ -198,14 +204,11 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
             }
 
             int my_zn = sz;
-            bool ok = true;
+            int ok = -1;                      // 0 once a site of this batch was undecidable
             int done = 0;                     // sites of this batch that were decided
 #define LLDA_SPARSE_SITE(J)                                                                                    \
-            if (ok) {                                                                                          \
-                ok = sparse_site<GS, J>(P, nb, sv, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, y, my_zn, \
-                                        lig, lane, gbase, gmask);                                              \
-                if (ok && J < nb) done = J + 1;                                                                \
-            }
+            sparse_site<GS, J>(P, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, ok, done, lig, lane, \
+                               gbase, gmask);
             LLDA_SPARSE_SITE(0) LLDA_SPARSE_SITE(1) LLDA_SPARSE_SITE(2) LLDA_SPARSE_SITE(3)
             LLDA_SPARSE_SITE(4) LLDA_SPARSE_SITE(5) LLDA_SPARSE_SITE(6) LLDA_SPARSE_SITE(7)
 #undef LLDA_SPARSE_SITE
