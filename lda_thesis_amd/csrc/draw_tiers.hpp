@@ -91,6 +91,44 @@ __device__ __forceinline__ float bcast_last_f32(float x, int lane)
     }
 }
 
+// q[0..T-1] is non-decreasing (prefix sums of non-negative terms): cnt = #{s : q[s] <= lo} and whether NO q[s]
+// lies in (lo, hi].  T == 16: a branch-free binary search (5 compares) that also tracks the smallest element
+// found above lo -- that element is q[cnt], and the gap is clean iff it is above hi too; 30 instructions
+// instead of 64 for two linear counts.
+template <int T>
+__device__ __forceinline__ void count_sorted_f32(const float (&q)[T], float lo, float hi, int &cnt, bool &clean)
+{
+    if constexpr (T == 16) {
+        const bool c5 = q[15] <= lo;                                   // then every element is
+        float ub = c5 ? __int_as_float(0x7f800000) : q[15];            // smallest element known to be > lo
+        const bool c1 = q[7] <= lo;
+        ub = c1 ? ub : q[7];
+        const float m2 = c1 ? q[11] : q[3];                            // the later probes, pre-selected by c1
+        const float a1 = c1 ? q[9] : q[1], a5 = c1 ? q[13] : q[5];
+        const float e0 = c1 ? q[8] : q[0], e2 = c1 ? q[10] : q[2], e4 = c1 ? q[12] : q[4], e6 = c1 ? q[14] : q[6];
+        const bool c2 = m2 <= lo;
+        ub = c2 ? ub : m2;
+        const float m3 = c2 ? a5 : a1;
+        const float g0 = c2 ? e4 : e0, g2 = c2 ? e6 : e2;
+        const bool c3 = m3 <= lo;
+        ub = c3 ? ub : m3;
+        const float m4 = c3 ? g2 : g0;
+        const bool c4 = m4 <= lo;
+        ub = c4 ? ub : m4;
+        cnt = c5 ? 16 : ((c1 ? 8 : 0) | (c2 ? 4 : 0) | (c3 ? 2 : 0) | (c4 ? 1 : 0));
+        clean = ub > hi;
+    } else {
+        int cnt_lo = 0, cnt_hi = 0;
+#pragma unroll
+        for (int s = 0; s < T; ++s) {
+            cnt_lo += (q[s] <= lo) ? 1 : 0;
+            cnt_hi += (q[s] <= hi) ? 1 : 0;
+        }
+        cnt = cnt_lo;
+        clean = cnt_lo == cnt_hi;
+    }
+}
+
 template <int G, int T>
 __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uint32_t mask, uint64_t gp,
                                               float margin_rel, int lig, int lane, int &zn)
@@ -103,13 +141,10 @@ __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uin
     const float tg = u * tot - (lig ? prev : 0.0f);
     const float margin = tot * margin_rel;
     const float lo = tg - margin, hi = tg + margin;
-    int cnt_lo = 0, cnt_hi = 0;
-#pragma unroll
-    for (int s = 0; s < T; ++s) {
-        cnt_lo += (qw[s] <= lo) ? 1 : 0;
-        cnt_hi += (qw[s] <= hi) ? 1 : 0;
-    }
-    const bool unsure = (cnt_lo != cnt_hi) || !(tot > 0.0f) || !(margin < tot) || !(tot < 3.0e38f);
+    int cnt_lo;
+    bool clean;
+    count_sorted_f32<T>(qw, lo, hi, cnt_lo, clean);
+    const bool unsure = !clean || !(tot > 0.0f) || !(margin < tot) || !(tot < 3.0e38f);
     if (((__ballot(unsure) >> gbase) & gmask) != 0) return false;
     const uint32_t fm = mask & (0xFFFFu << cnt_lo);
     const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
