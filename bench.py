@@ -154,10 +154,10 @@ def main():
     else:
         doc_off, word, freq, z = synthetic_corpus(Dg, N, V, K, seed=1234 + rank, device=dev)
         sampler = GibbsSampler(doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=42,
-                               doc_base=rank * Dg, device=dev, docs_per_group=args.docs_per_group)
+                               doc_base=rank * Dg, device=dev, docs_per_group=args.docs_per_group,
+                               exchange_always=bool(args.force_exchange))
         del z
     sites_local = sampler.S
-    sampler.exchange_always = bool(args.force_exchange)
     torch.cuda.synchronize()
 
     def barrier():
@@ -207,7 +207,8 @@ def main():
                        "label_mask": "dense" if live_topics == K else "sparse (%.2f live topics per doc)" % live_topics,
                        "kernel": "sparse" if sampler.live_off is not None else "dense",
                        "sites_per_sweep": total_sites,
-                       "exchange": "RCCL all-reduce of int32 n_kw/n_k deltas per sweep" if world > 1 else "none",
+                       "exchange": ("one RCCL int32 SUM all-reduce of the n_kw/n_k deltas per sweep; rows of words with a global "
+                                    "frequency mass <= 32767 travel as int16 pairs") if world > 1 else "none",
                        "semantics": "per-document snapshot (bit-exact vs the reference under O3)",
                        "draw": "tiered: fp32 decision with a proven margin, fp64 / exact fp64 pipeline otherwise; "
                                "the result is the exact fp64 pipeline's"},

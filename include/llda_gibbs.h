@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 6
+#define LLDA_ABI_VERSION 7
 #define LLDA_MAX_K 1024
 #define LLDA_MAX_LEAVES 8
 #define LLDA_MAX_ROUNDS 4
@@ -149,8 +149,18 @@ int llda_apply_delta(int32_t *counts, int32_t *delta, int64_t n, void *stream);
  * all-reduced and applied).  If n_k is not NULL the call also folds n_k += n_k_delta; n_k_delta = 0.
  * freq_csc[j] is the frequency of the site logged at j. */
 int llda_commit_log(const int64_t *item_begin, const int32_t *item_len, const int32_t *item_word, int64_t n_items,
-                    const uint32_t *commit_log, const int32_t *freq_csc, int32_t K, int32_t *target,
-                    int32_t *n_k, int32_t *n_k_delta, void *stream);
+                    const uint32_t *commit_log, const int32_t *freq_csc, int32_t K, const int64_t *row_off,
+                    int32_t *target, int32_t *n_k, int32_t *n_k_delta, void *stream);
+/* row_off (dev, may be NULL = row v at target + v*KP): where the row of every word lives in `target`, for the
+ * exchange between ranks.  row_off[v] >= 0: KP int32 at target + row_off[v].  row_off[v] < 0: KP/2 int32 at
+ * target + ~row_off[v], each holding the counts of positions 2j (low half) and 2j+1 (high half) as int16 PAIRS;
+ * counts are added as f * 65536^(p & 1), so words of several ranks can be summed with a plain int32 all-reduce
+ * and decoded afterwards -- exact when the frequency mass of the word over ALL ranks and sites is <= 32767 (the
+ * caller decides per word from that static bound; hot words stay int32).  Halves the bytes of the all-reduce.
+ *
+ * llda_apply_rows: counts[r*KP ..] += row r (pairs decoded), row zeroed, for r < n_rows.  With n_rows = V + 1
+ * and counts = the fused [n_kw | n_k] buffer, row V is the n_k delta the sweep kernels wrote. */
+int llda_apply_rows(const int64_t *row_off, int32_t *rows, int64_t n_rows, int32_t K, int32_t *counts, void *stream);
 
 /* Count initialisation from assignments: LabeledLDA.py:89-92.  n_dk, n_kw, n_k must be zeroed by the
  * caller; z holds device positions.  (The SubLDA phantom-column quirk, CascadeLDA.py:382-385, is a

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libllda_gibbs.so")
 MAX_K = 1024
 MAX_LEAVES = 8
 MAX_ROUNDS = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -53,7 +53,7 @@ class LldaSweepArgs(ctypes.Structure):
 
 
 EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_layout_init",
-           "llda_sweep", "llda_commit_log", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
+           "llda_sweep", "llda_commit_log", "llda_apply_rows", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
            "llda_readout_phi", "llda_readout_theta", "llda_selftest_div")
 
 _LIB = None
@@ -88,7 +88,9 @@ def lib():
     L.llda_sweep.restype = ctypes.c_int
     L.llda_sweep.argtypes = [ctypes.POINTER(LldaSweepArgs), _c_p]
     L.llda_commit_log.restype = ctypes.c_int
-    L.llda_commit_log.argtypes = [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i32, _c_p, _c_p, _c_p, _c_p]
+    L.llda_commit_log.argtypes = [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i32, _c_p, _c_p, _c_p, _c_p, _c_p]
+    L.llda_apply_rows.restype = ctypes.c_int
+    L.llda_apply_rows.argtypes = [_c_p, _c_p, _c_i64, _c_i32, _c_p, _c_p]
     L.llda_apply_delta.restype = ctypes.c_int
     L.llda_apply_delta.argtypes = [_c_p, _c_p, _c_i64, _c_p]
     L.llda_count_init.restype = ctypes.c_int
@@ -156,11 +158,19 @@ def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta
     check(lib().llda_sweep(ctypes.byref(a), _stream()), "llda_sweep")
 
 
-def commit_log(item_begin, item_len, item_word, commit_log, freq_csc, K, target, n_k=None, n_k_delta=None):
-    """llda_commit_log: fold the word-major commit log of a sweep into ``target`` (n_kw or its delta buffer)."""
+def commit_log(item_begin, item_len, item_word, commit_log, freq_csc, K, target, n_k=None, n_k_delta=None,
+               row_off=None):
+    """llda_commit_log: fold the word-major commit log of a sweep into ``target`` (n_kw, its delta buffer, or --
+    with ``row_off`` -- the exchange rows, int16 pairs where the offset is negative)."""
     check(lib().llda_commit_log(_ptr(item_begin), _ptr(item_len), _ptr(item_word), int(item_len.numel()),
-                                _ptr(commit_log), _ptr(freq_csc), int(K), _ptr(target), _ptr(n_k), _ptr(n_k_delta),
-                                _stream()), "llda_commit_log")
+                                _ptr(commit_log), _ptr(freq_csc), int(K), _ptr(row_off), _ptr(target), _ptr(n_k),
+                                _ptr(n_k_delta), _stream()), "llda_commit_log")
+
+
+def apply_rows(row_off, rows, K, counts):
+    """llda_apply_rows: counts[r] += row r of the exchange rows (pairs decoded), rows cleared."""
+    check(lib().llda_apply_rows(_ptr(row_off), _ptr(rows), int(row_off.numel()), int(K), _ptr(counts), _stream()),
+          "llda_apply_rows")
 
 
 def apply_delta(counts, delta):

@@ -6,9 +6,13 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------
 // Fold of the commit log into word-major counts (llda_commit_log, include/llda_gibbs.h): one wavefront per
-// item (a run of log entries of one word), a KP-entry histogram per wavefront in LDS.  The histogram is
-// flushed either by walking the item's entries again (short items: each touched topic is claimed with an LDS
-// exchange) or by scanning all KP entries (long items).
+// item (a run of log entries of one word), a histogram of the word's row per wavefront in LDS.  The histogram
+// is flushed either by walking the item's entries again (short items: each touched entry is claimed with an LDS
+// exchange, so every entry has exactly one writer) or by scanning the whole row (long items).
+// With a row table the rows live at row_off[v] in `target`, and a NEGATIVE offset marks a row of int16 PAIRS:
+// position p is the low (p even) or high (p odd) half of word ~row_off[v] + p/2, and counts are added as
+// f * 65536^(p & 1) -- plain int32 adds of such words are exact as long as every half stays inside int16
+// (llda_apply_rows decodes them), which is what lets the per-sweep all-reduce move half the bytes.
 // ---------------------------------------------------------------------------------------------
 struct CParams {
     const int64_t *item_begin;
@@ -16,6 +20,7 @@ struct CParams {
     int64_t n_items;
     const uint32_t *log;
     const int32_t *freq;
+    const int64_t *row_off;
     int32_t *target, *n_k, *n_k_delta;
     int32_t KP;
 };
@@ -44,32 +49,68 @@ __global__ void __launch_bounds__(256) llda_commit_log_kernel(const CParams P)
     const int len = P.item_len[item];
     const int wv = P.item_word[item];
     const bool shared_row = wv < 0;
-    int32_t *row = P.target + (int64_t)(wv & 0x7fffffff) * KP;
+    const int64_t v = wv & 0x7fffffff;
+    const int64_t ro = P.row_off ? P.row_off[v] : v * KP;
+    const bool pairs = ro < 0;                    // int16 pairs: entry p -> word p >> 1, weight 65536^(p & 1)
+    int32_t *row = P.target + (pairs ? ~ro : ro);
+    const int sh = pairs ? 1 : 0, n_words = KP >> sh;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     for (int j = lane; j < len; j += 64) {
         const uint32_t e = P.log[b + j];
         const int zo = (int)(e & 0xFFFFu), zn = (int)(e >> 16);
         if (zo != zn) {
-            const int f = P.freq[b + j];
-            atomicAdd(&hist[zo], -f);
-            atomicAdd(&hist[zn], f);
+            const uint32_t f = (uint32_t)P.freq[b + j];
+            atomicAdd(&hist[zo >> sh], -(int)(f << ((zo & sh) * 16)));
+            atomicAdd(&hist[zn >> sh], (int)(f << ((zn & sh) * 16)));
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    if (len <= KP) {
+    if (len <= n_words) {
         for (int j = lane; j < len; j += 64) {
             const uint32_t e = P.log[b + j];
             const int zo = (int)(e & 0xFFFFu), zn = (int)(e >> 16);
             if (zo != zn) {
-                const int a = atomicExch(&hist[zo], 0), c = atomicExch(&hist[zn], 0);
-                if (a) add_count(row + zo, a, shared_row);
-                if (c) add_count(row + zn, c, shared_row);
+                const int a = atomicExch(&hist[zo >> sh], 0), c = atomicExch(&hist[zn >> sh], 0);
+                if (a) add_count(row + (zo >> sh), a, shared_row);
+                if (c) add_count(row + (zn >> sh), c, shared_row);
             }
         }
     } else {
-        for (int p = lane; p < KP; p += 64) {
+        for (int p = lane; p < n_words; p += 64) {
             const int a = hist[p];
             if (a) add_count(row + p, a, shared_row);
+        }
+    }
+}
+
+// counts[r][:] += row r of `rows` (decoding int16 pairs), row cleared: one wavefront per row (llda_apply_rows)
+__global__ void __launch_bounds__(256) llda_apply_rows_kernel(const int64_t *__restrict__ row_off, int32_t *rows,
+                                                             int64_t n_rows, int KP, int32_t *counts)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int64_t ro = row_off[r];
+    int32_t *dst = counts + r * KP;
+    if (ro < 0) {
+        int32_t *src = rows + ~ro;
+        for (int j = lane; j < KP / 2; j += 64) {
+            const int32_t s = src[j];
+            if (s) {
+                const int lo = (int)(int16_t)(s & 0xFFFF);
+                const int hi = (int)(((int64_t)s - lo) >> 16);
+                src[j] = 0;
+                int2 *d2 = reinterpret_cast<int2 *>(dst) + j;
+                int2 c = *d2;
+                c.x += lo; c.y += hi;
+                *d2 = c;
+            }
+        }
+    } else {
+        int32_t *src = rows + ro;
+        for (int p = lane; p < KP; p += 64) {
+            const int32_t s = src[p];
+            if (s) { src[p] = 0; dst[p] += s; }
         }
     }
 }

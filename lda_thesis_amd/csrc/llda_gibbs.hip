@@ -381,8 +381,8 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
 }
 
 int llda_commit_log(const int64_t *item_begin, const int32_t *item_len, const int32_t *item_word, int64_t n_items,
-                    const uint32_t *commit_log, const int32_t *freq_csc, int32_t K, int32_t *target, int32_t *n_k,
-                    int32_t *n_k_delta, void *stream)
+                    const uint32_t *commit_log, const int32_t *freq_csc, int32_t K, const int64_t *row_off,
+                    int32_t *target, int32_t *n_k, int32_t *n_k_delta, void *stream)
 {
     if (n_items < 0 || (n_k != nullptr) != (n_k_delta != nullptr)) return LLDA_E_BAD_ARG;
     llda_layout L;
@@ -392,11 +392,28 @@ int llda_commit_log(const int64_t *item_begin, const int32_t *item_len, const in
     if (n_items == 0 && !n_k) return LLDA_OK;
     CParams P;
     P.item_begin = item_begin; P.item_len = item_len; P.item_word = item_word; P.n_items = n_items;
-    P.log = commit_log; P.freq = freq_csc; P.target = target; P.n_k = n_k; P.n_k_delta = n_k_delta; P.KP = L.KP;
+    P.log = commit_log; P.freq = freq_csc; P.row_off = row_off; P.target = target; P.n_k = n_k; P.n_k_delta = n_k_delta;
+    P.KP = L.KP;
     int64_t blocks = (n_items + 3) / 4;
     if (blocks < 1) blocks = 1;
     if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
     hipLaunchKernelGGL(llda_commit_log_kernel, dim3((unsigned)blocks), dim3(256), 4 * L.KP * sizeof(int), (hipStream_t)stream, P);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
+}
+
+int llda_apply_rows(const int64_t *row_off, int32_t *rows, int64_t n_rows, int32_t K, int32_t *counts, void *stream)
+{
+    if (n_rows < 0) return LLDA_E_BAD_ARG;
+    llda_layout L;
+    const int rc = llda_layout_init(K, &L);
+    if (rc) return rc;
+    if (n_rows == 0) return LLDA_OK;
+    if (!row_off || !rows || !counts) return LLDA_E_BAD_ARG;
+    const int64_t blocks = (n_rows + 3) / 4;
+    if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
+    hipLaunchKernelGGL(llda_apply_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, row_off, rows,
+                       n_rows, L.KP, counts);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
 }

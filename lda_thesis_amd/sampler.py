@@ -72,7 +72,7 @@ class GibbsSampler(object):
 
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
                  stream_id=0, doc_base=0, device=None, group=None, backend=None, sort_docs=True,
-                 docs_per_group=0, sharded=True, sparse_labels=True, commit_log=None):
+                 docs_per_group=0, sharded=True, sparse_labels=True, commit_log=None, exchange_always=False):
         self.backend = backend if backend is not None else _native
         if backend is None:
             _native.lib()                                   # fail loudly when the extension is missing
@@ -89,7 +89,7 @@ class GibbsSampler(object):
         self.sweeps_done = 0
         self.debug_margin = 0          # test hook of the two-tier draw (include/llda_gibbs.h)
         self.kernel_events = None      # set to [] to record a (start, end) HIP event pair per sweep kernel
-        self.exchange_always = False   # True: take the delta-buffer + all-reduce path even with a single rank
+        self.exchange_always = bool(exchange_always)   # take the exchange path even with a single rank (tests)
         self.layout = lay = group_layout(self.K)
         dev = self.device
 
@@ -146,6 +146,39 @@ class GibbsSampler(object):
             self.n_dk[:, self._topic_pos] = as_dev(counts["n_d_k"], torch.int32)
             self.n_kw[:, self._topic_pos] = as_dev(np.asarray(counts["n_k_v"]).T, torch.int32)
             self.n_k[self._topic_pos] = as_dev(counts["n_zk"], torch.int32)
+        self.row_off = self.rows = None
+        if self.sharded and (_dist_active(self.group) or exchange_always):
+            self._make_exchange_rows()
+
+    PAIR_LIMIT = 32767   # largest frequency mass of a word (all ranks) whose row is exchanged as int16 pairs
+
+    def _make_exchange_rows(self):
+        """Exchange layout of the per-sweep count deltas when every rank folds a commit log: one row per word plus
+        the n_k row.  |delta[v][k]| can never exceed the frequency mass M_v of word v over ALL ranks (a static
+        property of the corpus), so rows with M_v <= 32767 travel as int16 pairs packed in int32 words -- a plain
+        int32 SUM all-reduce stays exact -- and only the hot words keep int32 rows: about half the bytes."""
+        import torch.distributed as dist
+        dev, KP = self.device, self.layout.KP
+        mass = torch.zeros((self.V,), dtype=torch.int64, device=dev)
+        if self.S:
+            mass.index_add_(0, self.word.to(torch.int64), self.freq.to(torch.int64))
+        everyone = torch.tensor([1 if (self.commit_log is not None or self.S == 0) else 0], device=dev)
+        if _dist_active(self.group):
+            dist.all_reduce(mass, group=self.group)
+            dist.all_reduce(everyone, op=dist.ReduceOp.MIN, group=self.group)
+        if int(everyone.item()) == 0:
+            return                                   # some rank commits with atomics: int32 delta buffer for all
+        pairs = mass <= self.PAIR_LIMIT
+        size = torch.where(pairs, KP // 2, KP)
+        size = torch.cat([size, torch.tensor([KP], device=dev)])          # row V: the n_k delta, int32
+        off = torch.cumsum(size, 0) - size
+        self.row_off = torch.where(torch.cat([pairs, torch.tensor([False], device=dev)]), ~off, off).contiguous()
+        total = int(off[-1].item()) + KP
+        self.rows = torch.zeros((total,), dtype=torch.int32, device=dev)
+        # the sweep kernels add the n_k changes straight into row V; the int32 delta buffer is not needed
+        self.n_k_delta = self.rows[total - KP:]
+        self.n_kw_delta = None
+        self._delta = self.rows
 
     def add_word_topic_counts(self, words, topics, amounts):
         """n_kw[word, topic] += amount for parallel 1-D arrays (host or device); n_k and n_dk are left alone.
@@ -278,16 +311,29 @@ class GibbsSampler(object):
             ev[1].record()
             self.kernel_events.append(ev)
         exchange = self.sharded and (_dist_active(self.group) or self.exchange_always)
-        if logged and not exchange:
-            # single device: the log is folded straight into n_kw (and n_k += its delta) -- no delta pass
-            self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log, self.freq_csc,
-                                    self.K, self.n_kw, self.n_k, self.n_k_delta)
+        import torch.distributed as dist
+        have_group = dist.is_available() and dist.is_initialized()
+        if not exchange:
+            if logged:
+                # single device: the log is folded straight into n_kw (and n_k += its delta) -- no delta pass
+                self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
+                                        self.freq_csc, self.K, self.n_kw, self.n_k, self.n_k_delta)
+            else:
+                self.backend.apply_delta(self._counts, self._delta)
+        elif self.rows is not None:
+            # every rank folds its log into the exchange rows (int16 pairs for all but the hot words), ONE int32
+            # all-reduce over xGMI, then the rows are decoded into [n_kw | n_k]
+            if logged:
+                self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
+                                        self.freq_csc, self.K, self.rows, row_off=self.row_off)
+            if have_group:
+                dist.all_reduce(self.rows, group=self.group)
+            self.backend.apply_rows(self.row_off, self.rows, self.K, self._counts)
         else:
             if logged:
                 self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
                                         self.freq_csc, self.K, self.n_kw_delta)
-            import torch.distributed as dist
-            if exchange and dist.is_available() and dist.is_initialized():
+            if have_group:
                 dist.all_reduce(self._delta, group=self.group)      # RCCL over xGMI: SUM int32, one collective
             self.backend.apply_delta(self._counts, self._delta)
         self.sweeps_done += 1

@@ -93,20 +93,47 @@ class OracleBackend(object):
         d_k[tp] = cs.n_zk - old_k
         n_k_delta += torch.from_numpy(d_k)
 
-    def commit_log(self, item_begin, item_len, item_word, log, freq_csc, K, target, n_k=None, n_k_delta=None):
-        """numpy statement of llda_commit_log (include/llda_gibbs.h)"""
+    def commit_log(self, item_begin, item_len, item_word, log, freq_csc, K, target, n_k=None, n_k_delta=None,
+                   row_off=None):
+        """numpy statement of llda_commit_log (include/llda_gibbs.h), int16-pair rows included"""
         KP = self._lay(K).KP
-        t = target.numpy().reshape(-1, KP)
+        t = target.numpy().reshape(-1)
         lg = log.numpy().astype(np.int64) & 0xFFFFFFFF
         f = freq_csc.numpy().astype(np.int64)
+        ro = None if row_off is None else row_off.numpy()
         for b, n, wv in zip(item_begin.tolist(), item_len.tolist(), item_word.tolist()):
             v = wv & 0x7FFFFFFF
             e = lg[b:b + n]
-            np.add.at(t[v], e & 0xFFFF, -f[b:b + n])
-            np.add.at(t[v], e >> 16, f[b:b + n])
+            zo, zn, ff = e & 0xFFFF, e >> 16, f[b:b + n]
+            off = v * KP if ro is None else int(ro[v])
+            if off >= 0:
+                row = t[off:off + KP]
+                np.add.at(row, zo, -ff)
+                np.add.at(row, zn, ff)
+            else:
+                row = t[~off:~off + KP // 2]
+                acc = np.zeros(KP // 2, dtype=np.int64)
+                np.add.at(acc, zo >> 1, -ff * np.where(zo & 1, 65536, 1))
+                np.add.at(acc, zn >> 1, ff * np.where(zn & 1, 65536, 1))
+                row += acc.astype(np.int32)
         if n_k is not None:
             n_k += n_k_delta
             n_k_delta.zero_()
+
+    def apply_rows(self, row_off, rows, K, counts):
+        """numpy statement of llda_apply_rows"""
+        KP = self._lay(K).KP
+        r, c = rows.numpy(), counts.numpy().reshape(-1, KP)
+        for i, off in enumerate(row_off.numpy().tolist()):
+            if off >= 0:
+                c[i] += r[off:off + KP]
+                r[off:off + KP] = 0
+            else:
+                s = r[~off:~off + KP // 2].astype(np.int64)
+                lo = ((s & 0xFFFF) ^ 0x8000) - 0x8000
+                c[i, 0::2] += lo.astype(np.int32)
+                c[i, 1::2] += ((s - lo) >> 16).astype(np.int32)
+                r[~off:~off + KP // 2] = 0
 
     @staticmethod
     def apply_delta(counts, delta):

@@ -34,6 +34,8 @@ def _worker(rank, world, port, name, counts_mode, q):
     from helpers import OracleBackend
     from lda_thesis_amd.sampler import GibbsSampler, shard_documents
     g = load_golden(name)
+    if name == "tiny_k12":
+        GibbsSampler.PAIR_LIMIT = 20        # mix of int16-pair rows and int32 rows (hot words) in the exchange
     off = g["doc_off"]
     b = shard_documents(off, world)
     lo, hi = b[rank], b[rank + 1]
@@ -45,7 +47,9 @@ def _worker(rank, world, port, name, counts_mode, q):
                      int(g["K"]), int(g["V"]), float(g["alpha"]), float(g["beta"]), labs=g["labs"][lo:hi],
                      counts=counts, seed=int(g["seed"]), doc_base=lo, device="cpu",
                      backend=OracleBackend(c_oracle), commit_log=counts_mode == "built")   # both commit paths
-    ok = True
+    ok = (s.rows is not None) == (counts_mode == "built")       # every rank logs -> packed exchange rows
+    if name == "tiny_k12":
+        ok &= 0 < int((s.row_off < 0).sum()) < s.V
     for i in range(int(g["sweeps"])):
         s.sweep()
         key = "o3_s%d_" % (i + 1)

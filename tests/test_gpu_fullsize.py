@@ -70,8 +70,10 @@ def test_full_size_properties(name):
     for r_ in range(2):
         lo, hi = b[r_], b[r_ + 1]
         s0, s1 = int(off[lo]), int(off[hi])
-        h = make(doc_off[lo:hi + 1] - doc_off[lo], word[s0:s1], freq[s0:s1], z[s0:s1], K, V, doc_base=lo)
-        h.exchange_always = True                           # delta-buffer path, no process group: folds its own delta
+        # exchange path without a process group: every half folds its own rows (int16 pairs for all but the hot words)
+        h = make(doc_off[lo:hi + 1] - doc_off[lo], word[s0:s1], freq[s0:s1], z[s0:s1], K, V, doc_base=lo,
+                 exchange_always=True)
+        assert h.rows is not None and int((h.row_off < 0).sum()) > V // 2
         halves.append(h)
     counts = start.clone()
     for _ in range(2):

@@ -338,13 +338,16 @@ def test_sparse_and_dense_kernels_agree_on_a_large_sparse_workload(c_oracle):
     np.testing.assert_array_equal(s.z_topics(), cs.z)
 
 
-@pytest.mark.parametrize("commit", [True, False])
-def test_exchange_path_on_one_rank(commit):
+@pytest.mark.parametrize("commit", [True, False, "mixed rows"])
+def test_exchange_path_on_one_rank(commit, monkeypatch):
     """the multi-GPU path of sweep() -- commit log folded into the DELTA buffer (or atomics on it), RCCL
     all-reduce of the fused delta buffer, llda_apply_delta -- driven on one GPU with a 1-rank nccl group."""
     import os
     import torch.distributed as dist
     g = load_golden("tiny_k130")
+    if commit == "mixed rows":              # words with a frequency mass above 12 keep int32 rows, the others int16 pairs
+        from lda_thesis_amd.sampler import GibbsSampler
+        monkeypatch.setattr(GibbsSampler, "PAIR_LIMIT", 12)
     made = False
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -352,8 +355,10 @@ def test_exchange_path_on_one_rank(commit):
         dist.init_process_group("nccl", rank=0, world_size=1)
         made = True
     try:
-        s = make_sampler(g, commit_log=commit)
-        s.exchange_always = True
+        s = make_sampler(g, commit_log=bool(commit), exchange_always=True)
+        assert (s.rows is not None) == bool(commit)    # int16-pair exchange rows whenever every rank folds a log
+        if commit == "mixed rows":
+            assert 0 < int((s.row_off < 0).sum()) < s.V
         for i in range(int(g["sweeps"])):
             s.sweep()
             assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics())
