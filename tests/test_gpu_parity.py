@@ -146,7 +146,13 @@ def synth(rng, D, V, K, n_lo, n_hi, dense, fmax=3):
 
 @pytest.mark.parametrize("K,dense,D,V", [(7, True, 300, 200), (64, True, 400, 500), (128, True, 300, 1000),
                                          (392, False, 300, 800), (512, True, 96, 2000), (1024, True, 40, 600),
-                                         (300, True, 64, 500), (100, False, 1000, 300)])
+                                         (300, True, 64, 500), (100, False, 1000, 300),
+                                         # every (lanes per document, slots per lane, tail) shape of the layout
+                                         (3, True, 200, 100), (15, False, 200, 150), (17, True, 150, 200),
+                                         (33, True, 150, 200), (60, True, 120, 300), (90, True, 120, 300),
+                                         (96, True, 100, 300), (129, True, 100, 300), (190, False, 100, 400),
+                                         (256, True, 80, 400), (257, True, 80, 400), (640, True, 50, 500),
+                                         (777, True, 40, 500), (900, True, 40, 500), (968, True, 32, 500)])
 def test_seeded_inputs_vs_c_oracle(c_oracle, K, dense, D, V):
     """larger seeded inputs: HIP == C oracle (snapshot mode) after 3 sweeps, every integer."""
     from lda_thesis_amd.sampler import GibbsSampler
