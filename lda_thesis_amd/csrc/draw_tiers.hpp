@@ -178,7 +178,7 @@ __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, co
     // ---- tier 1: unnormalised fp64 prefix sums, margin 2^-40 of the total ----
     {
         double run = 0.0;
-#pragma unroll 4
+#pragma unroll
         for (int s = 0; s < T; ++s) {
             // 1/den to within 2^-50: hardware estimate + two Newton steps (tier 1 only needs a few 2^-53)
             const double den = (double)s_nkc[s][tid] + vbeta;
@@ -195,7 +195,7 @@ __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, co
         const double tg = u * tot - (lig ? prev : 0.0);
         const double margin = tot * P->margin_rel;
         int cnt_lo = 0, cnt_hi = 0;
-#pragma unroll 4
+#pragma unroll
         for (int s = 0; s < T; ++s) {
             cnt_lo += (w[s] <= tg - margin) ? 1 : 0;
             cnt_hi += (w[s] <= tg + margin) ? 1 : 0;
