@@ -16,9 +16,9 @@ namespace {
 // site) the group falls back to the exact tier.  Returns false when the group must fall back.
 // ---------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------
-// Tier 0: the same decision in fp32.  Every quantity is within 103 * 2^-24 (< 2^-17.3) of the total of its
-// real-number value, the exact pipeline within 2^-44; with a margin of 2^-16 of
-// the total a "sure" fp32 decision therefore has the signs of the exact pipeline.  About 1.6 % of the
+// Tier 0: the same decision in fp32.  Every compared quantity is within 105 * 2^-24 (< 2^-17.2) of the total of
+// its real-number value, the exact pipeline within 2^-44; with a margin of 2^-17 = 128 *
+// 2^-24 of the total a "sure" fp32 decision therefore has the signs of the exact pipeline.  About 0.6 % of the
 // sites (K = 512) are "unsure" and go on to tier 1.
 // ---------------------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xF>

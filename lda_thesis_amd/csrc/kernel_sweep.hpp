@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
 // change (VGPR arrays would need a 16-deep select chain per update).
 // ---------------------------------------------------------------------------------------------
 #ifndef LLDA_MARGIN0
-#define LLDA_MARGIN0 0x1p-16f   // tier-0 (fp32) decision margin relative to the total score
+#define LLDA_MARGIN0 0x1p-17f   // tier-0 (fp32) decision margin relative to the total score: 128 * 2^-24, the
+                                // worst-case error bound of DESIGN.md section 4.3 is 105 * 2^-24
 #endif
 #ifndef LLDA_WAVES
 #define LLDA_WAVES 3          // waves per SIMD the register allocator must leave room for
