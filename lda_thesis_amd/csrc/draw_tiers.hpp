@@ -155,7 +155,7 @@ __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uin
     return true;
 }
 
-// Cold tiers of the FAST kernels, out of line: they run for the ~1.6 % of the sites
+// Cold tiers of the FAST kernels, out of line: they run for the ~0.65 % of the sites
 // tier 0 is unsure about and work on scratch copies, so the hot loop's register allocation never sees them.
 //   tier 1: the decision from unnormalised fp64 prefix sums, margin 2^-40 of the total;
 //   exact : the reference's fp64 pipeline bit for bit -- scores, numpy-ordered sum, p = fl(w/S) through
@@ -167,8 +167,9 @@ template <int G, int T, bool HAS_TAIL, bool DENSE>
 __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, const int (*s_nkc)[256], int tid,
                                        uint32_t mask, double u, int lig, int lane, const KParams *P)
 {
-    // Written as rolled loops over scratch arrays on purpose: few registers, so that this rarely taken
-    // function does not dictate the kernel's register allocation (occupancy of the hot loop).
+    // Tier 1 is unrolled and lives in registers (the kernel is LDS-limited to 3 waves per SIMD, which leaves 168
+    // VGPRs: scratch round trips here stalled the whole wave); the exact tier, ~1e-9 per site, stays rolled over
+    // a scratch array.
     const int gbase = lane & ~(G - 1);
     const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
     const double alpha = P->alpha, beta = P->beta, vbeta = P->vbeta;

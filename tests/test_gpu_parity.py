@@ -20,7 +20,7 @@ def make_sampler(g, counts=True, **kw):
                         seed=int(g["seed"]), stream_id=int(g["stream"]) if "stream" in g else 0, **kw)
 
 
-# debug_margin: 0 = production tiered draw (fp32 decision when |Q - T| > 2^-16 of the total, else fp64
+# debug_margin: 0 = production tiered draw (fp32 decision when |Q - T| > 2^-17 of the total, else fp64
 # decision when > 2^-40, else the exact fp64 pipeline); -1 = every site through the exact tier; -2 = no fp32
 # tier; 6 = both margins 2^-6, i.e. many sites fall through, mixing all tiers inside one wavefront
 @pytest.mark.parametrize("margin", [0, -1, -2, 6])
