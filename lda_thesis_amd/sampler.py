@@ -118,6 +118,8 @@ class GibbsSampler(object):
         self.csc_pos = self.commit_log = None
         if commit_log is None:
             commit_log = self.S >= (1 << 20)
+        if self.S >= (1 << 31):
+            commit_log = False                      # log positions are int32
         if commit_log and self.S > 0:
             self._make_commit_log()
         self._sort_docs = bool(sort_docs)
