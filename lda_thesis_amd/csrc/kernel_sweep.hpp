@@ -219,24 +219,30 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         // (site-indexed arrays are addressed as base + 32-bit byte offset from the first document of the call;
         // llda_sweep refuses calls that span 2^30 sites or more)
         const uint32_t sb = (uint32_t)(s0 - site_base) * 4u;
+        // The scalars of three consecutive sites live in three register sets whose roles (previous / current /
+        // next site) rotate with the site index, and the site loop is unrolled by three: no register-to-register
+        // moves for the pipeline (a rolled loop spends 17 v_mov per site on them; the compiler cannot unroll it
+        // itself because the body contains convergent cross-lane operations).
+        struct SiteRegs { int v, f, zo, c, zn; };
         const uint32_t o0 = opaque_u32(sb + (uint32_t)n0 * 4u), o1 = opaque_u32(sb + (uint32_t)(n0 + 1 < len ? n0 + 1 : n0) * 4u);
-        int v_c = gload_i32(word_b, o0), f_c = gload_i32(freq_b, o0), zo_c = gload_i32(z_b, o0),
-            c_c = P.csc_pos ? gload_i32(csc_b, o0) : 0;
-        int v_1 = gload_i32(word_b, o1), f_1 = gload_i32(freq_b, o1), zo_1 = gload_i32(z_b, o1),
-            c_1 = P.csc_pos ? gload_i32(csc_b, o1) : 0;
+        SiteRegs R0, R1, R2;
+        R0.v = gload_i32(word_b, o0); R0.f = gload_i32(freq_b, o0); R0.zo = gload_i32(z_b, o0);
+        R0.c = P.csc_pos ? gload_i32(csc_b, o0) : 0; R0.zn = 0;
+        R1.v = gload_i32(word_b, o1); R1.f = gload_i32(freq_b, o1); R1.zo = gload_i32(z_b, o1);
+        R1.c = P.csc_pos ? gload_i32(csc_b, o1) : 0; R1.zn = 0;
+        R2.v = R2.f = R2.zo = R2.c = R2.zn = 0;
         int xn[T];
-        gload_row<T>(P.n_kw, (int64_t)v_c * KP + lig * T, xn);
+        gload_row<T>(P.n_kw, (int64_t)R0.v * KP + lig * T, xn);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        uint32_t pend_o = 0;
-        bool pend = false;
-        int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0, pend_c = 0;
-        {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the loop body
-            const int lo = (int)((unsigned)zo_c / (unsigned)T);   // positions are never negative: unsigned division
-            if (lig == lo) count_update(s_ndk, s_nkc, s_pa, zo_c - lo * T, tid, alpha32, vbeta32, -f_c);
+        {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the previous site
+            const int lo = (int)((unsigned)R0.zo / (unsigned)T);   // positions are never negative: unsigned division
+            if (lig == lo) count_update(s_ndk, s_nkc, s_pa, R0.zo - lo * T, tid, alpha32, vbeta32, -R0.f);
         }
 
-        for (int n = n0; n < len; ++n) {
-            const int v = v_c, f = f_c, zo = zo_c, c = c_c;
+        // one site: `cur` holds its scalars, `nxt` those of site n+1, `prv` those of site n-1 (committed here, then
+        // reloaded with the scalars of site n+2)
+        auto site = [&](const int n, SiteRegs &cur, SiteRegs &nxt, SiteRegs &prv) {
+            const int f = cur.f, zo = cur.zo;
             // the fetched row minus the site's own count (n_dk / n_k were updated already), written to a second
             // array so that the next row can be loaded into xn right away
             int x[T];
@@ -245,19 +251,19 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 onehot_add_to<T>(x, xn, (lig == lo) ? (1u << so) : 0u, f);   // m = -1 at the slot: += (-1) * f
             }
 #ifndef ABL_NOCOMMIT
-            if (lig == 0 && pend) commit_site_off(P, z_b, pend_o, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
+            if (lig == 0 && n > n0)
+                commit_site_off(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn, prv.c, KP);
 #endif
 #ifndef ABL_NOLOAD
-            gload_row<T>(P.n_kw, (int64_t)v_1 * KP + lig * T, xn);        // row of site n+1 (clamped)
+            gload_row<T>(P.n_kw, (int64_t)nxt.v * KP + lig * T, xn);      // row of site n+1 (clamped)
 #else
 #pragma unroll
-            for (int s = 0; s < T; ++s) xn[s] = (v_1 + s) & 7;            // ablation: no n_kw traffic
+            for (int s = 0; s < T; ++s) xn[s] = (nxt.v + s) & 7;          // ablation: no n_kw traffic
 #endif
-            v_c = v_1; f_c = f_1; zo_c = zo_1; c_c = c_1;
             {
                 const uint32_t o2 = opaque_u32(sb + (uint32_t)(n + 2 < len ? n + 2 : len - 1) * 4u);   // scalars of site n+2 (clamped)
-                v_1 = gload_i32(word_b, o2); f_1 = gload_i32(freq_b, o2); zo_1 = gload_i32(z_b, o2);
-                if (P.csc_pos) c_1 = gload_i32(csc_b, o2);
+                prv.v = gload_i32(word_b, o2); prv.f = gload_i32(freq_b, o2); prv.zo = gload_i32(z_b, o2);
+                if (P.csc_pos) prv.c = gload_i32(csc_b, o2);
             }
             uint32_t ra, rb;
             site_random_bits<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3, ra, rb);
@@ -285,6 +291,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 zn = zo;
                 if (lig == 0 && P.status) atomicOr(P.status, 1);    // no topic with positive probability
             }
+            cur.zn = zn;
 
             // add the site back (LabeledLDA.py:121-125), and take the NEXT site out of its topic already (its
             // scalars are in registers): the LDS state is final long before the next site's scores read it.
@@ -293,16 +300,24 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             {
                 const int ln = (int)((unsigned)zn / (unsigned)T);
                 const bool more = n + 1 < len;
-                const int lo2 = more ? (int)((unsigned)zo_c / (unsigned)T) : -1;
+                const int lo2 = more ? (int)((unsigned)nxt.zo / (unsigned)T) : -1;
                 const bool own_new = lig == ln, own_old = lig == lo2;
                 if (own_new || own_old)
-                    count_update(s_ndk, s_nkc, s_pa, own_new ? zn - ln * T : zo_c - lo2 * T, tid, alpha32, vbeta32,
-                                 own_new ? f : -f_c);
-                if (own_new && own_old) count_update(s_ndk, s_nkc, s_pa, zo_c - lo2 * T, tid, alpha32, vbeta32, -f_c);
+                    count_update(s_ndk, s_nkc, s_pa, own_new ? zn - ln * T : nxt.zo - lo2 * T, tid, alpha32, vbeta32,
+                                 own_new ? f : -nxt.f);
+                if (own_new && own_old) count_update(s_ndk, s_nkc, s_pa, nxt.zo - lo2 * T, tid, alpha32, vbeta32, -nxt.f);
             }
-            pend = true; pend_o = opaque_u32(sb + (uint32_t)n * 4u); pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn; pend_c = c;
+#ifndef ABL_NOCOMMIT
+            // the last site of the document is committed right away
+            if (lig == 0 && n + 1 == len)
+                commit_site_off(P, z_b, opaque_u32(sb + (uint32_t)n * 4u), cur.v, cur.f, cur.zo, cur.zn, cur.c, KP);
+#endif
+        };
+        for (int n = n0; n < len; n += 3) {
+            site(n, R0, R1, R2);
+            if (n + 1 < len) site(n + 1, R1, R2, R0);
+            if (n + 2 < len) site(n + 2, R2, R0, R1);
         }
-        if (lig == 0 && pend) commit_site_off(P, z_b, pend_o, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
 
         // document done: fold its n_dk change into the workgroup's n_k accumulator, store the row
         int old[T], cur[T];
