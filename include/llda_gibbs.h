@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 7
+#define LLDA_ABI_VERSION 8
 #define LLDA_MAX_K 1024
 #define LLDA_MAX_LEAVES 8
 #define LLDA_MAX_ROUNDS 4
@@ -234,6 +234,8 @@ typedef struct llda_foldin_args {
     double alpha, beta, c_init, c_loop;
     uint64_t seed;
     uint32_t stream_id, reserved2;
+    const int64_t *doc_ids;     /* [dev] [D] optional: RNG counter word 1 of every document (its low 32 bits);
+                                   NULL = doc_base + d.  Lets documents with unrelated ids share one launch. */
 } llda_foldin_args;
 
 int llda_foldin(const llda_foldin_args *args, void *stream);

@@ -330,6 +330,68 @@ class CascadeLDA(object):
                 level_3.append(list(zip(keep3, loads3)))
         return level_1, level_2, level_3
 
+    def cascade_test_batch(self, docs, it, thinning, labels, seed=None, doc_ids=None):
+        """cascade_test for several documents against the SAME label subset: one llda_foldin launch, one lane
+        group per document.  Row d equals cascade_test(docs[d], ...) -- the RNG is keyed by the document, not by
+        its place in the batch."""
+        from .foldin import cascade_fold_in, doc_key
+        ids = [self.labelmap[x] for x in labels]
+        tups = [self.dicti.doc2bow(doc) for doc in docs]
+        keys = [doc_key(t) for t in tups] if doc_ids is None else list(doc_ids)
+        r = cascade_fold_in(self.ph[ids, :], self.alpha, self.beta, tups, it, thinning, self._seed(seed),
+                            self._test_stream(labels), keys, device=self._device)
+        return r["th_hat"]
+
+    def test_down_tree_batch(self, docs, it, thinning, threshold, seed=None):
+        """test_down_tree for a list of documents, level by level: all documents that reach the same node of the
+        label tree are sampled in one launch (at most one launch per node instead of several per document).
+        Returns [test_down_tree(doc, ...) for doc in docs]."""
+        docs = list(docs)
+        children = lambda parent: [parent] + list(filter(re.compile("^" + parent + "[0-9]{1}$").match, self.lablist))
+        out = [[None, [], []] for _ in docs]
+        # level 1: every document against the one-character labels
+        labels = self.lablist_l1
+        th = self.cascade_test_batch(docs, it, thinning, labels, seed=seed)
+        todo2 = {}                                      # parent -> documents that kept it, in visiting order
+        for d in range(len(docs)):
+            keep, loads = self._head(th[d], labels, threshold)
+            out[d][0] = list(zip(keep, loads))
+            if "root" in keep:
+                keep.remove("root")
+            for parent in keep:
+                todo2.setdefault(parent, []).append(d)
+        # level 2, then level 3: one launch per node that some document reached
+        res2, todo3 = {}, {}
+        for parent, members in todo2.items():
+            labels = children(parent)
+            th = self.cascade_test_batch([docs[d] for d in members], it, thinning, labels, seed=seed)
+            for row, d in zip(th, members):
+                keep2, loads2 = self._head(row, labels, threshold)
+                res2[(d, parent)] = list(zip(keep2, loads2))
+                if parent in keep2:
+                    keep2.remove(parent)
+                for parent2 in keep2:
+                    todo3.setdefault(parent2, []).append(d)
+        res3 = {}
+        for parent2, members in todo3.items():
+            labels = children(parent2)
+            th = self.cascade_test_batch([docs[d] for d in members], it, thinning, labels, seed=seed)
+            for row, d in zip(th, members):
+                keep3, loads3 = self._head(row, labels, threshold)
+                res3.setdefault((d, parent2), []).append(list(zip(keep3, loads3)))
+        # assemble in the order test_down_tree visits the nodes
+        for d in range(len(docs)):
+            for parent, _ in out[d][0]:
+                if parent == "root":
+                    continue
+                lvl2 = res2[(d, parent)]
+                out[d][1].append(lvl2)
+                for parent2, _ in lvl2:
+                    if parent2 == parent:
+                        continue
+                    out[d][2].append(res3[(d, parent2)].pop(0))
+        return [tuple(x) for x in out]
+
     def run_test(self, docs, it, thinning, depth="all", seed=None):
         """flat test over all labels (or the labels of one depth): CascadeLDA.py:299-344."""
         from .foldin import CASCADE_STREAM, cascade_fold_in

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libllda_gibbs.so")
 MAX_K = 1024
 MAX_LEAVES = 8
 MAX_ROUNDS = 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -36,7 +36,7 @@ class LldaFoldinArgs(ctypes.Structure):
                 ("status", _c_p), ("D", _c_i64), ("doc_base", _c_i64), ("K", _c_i32), ("iters", _c_i32),
                 ("thinning", _c_i32), ("beta_fallback", _c_i32), ("avg_mode", _c_i32), ("reserved", _c_i32),
                 ("alpha", _c_d), ("beta", _c_d), ("c_init", _c_d), ("c_loop", _c_d), ("seed", _c_u64),
-                ("stream_id", _c_u32), ("reserved2", _c_u32)]
+                ("stream_id", _c_u32), ("reserved2", _c_u32), ("doc_ids", _c_p)]
 
 
 class LldaSweepArgs(ctypes.Structure):
@@ -218,10 +218,10 @@ def selftest_div(n, seed=1):
 
 
 def foldin(*, doc_off, word, init_idx, freq, ph, init_rows, slot_valid, z, n_dk, th, status, D, K, iters, thinning,
-           alpha, beta, c_init, c_loop, seed, stream_id, doc_base=0, beta_fallback=False, avg_mode=0):
+           alpha, beta, c_init, c_loop, seed, stream_id, doc_base=0, beta_fallback=False, avg_mode=0, doc_ids=None):
     a = LldaFoldinArgs(_ptr(doc_off), _ptr(word), _ptr(init_idx), _ptr(freq), _ptr(ph), _ptr(init_rows),
                        _ptr(slot_valid), _ptr(z), _ptr(n_dk), _ptr(th), _ptr(status), int(D), int(doc_base), int(K),
                        int(iters), int(thinning), 1 if beta_fallback else 0, int(avg_mode), 0, float(alpha),
                        float(beta), float(c_init), float(c_loop), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                       int(stream_id) & 0xFFFFFFFF, 0)
+                       int(stream_id) & 0xFFFFFFFF, 0, _ptr(doc_ids))
     check(lib().llda_foldin(ctypes.byref(a), _stream()), "llda_foldin")

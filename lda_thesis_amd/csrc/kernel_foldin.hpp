@@ -24,6 +24,7 @@ struct FParams {
     int32_t *status;
     int64_t D;
     int64_t doc_base;
+    const int64_t *doc_ids;  // optional per-document RNG ids (else doc_base + d)
     double alpha, beta;
     double c_init, c_loop;   // the reference's "while prob.sum() > 1: prob /= c" constants
     uint32_t key0, key1, stream_id;
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
 
     const int64_t s0 = P.doc_off[d];
     const int len = (int)(P.doc_off[d + 1] - s0);
-    const uint32_t gdoc = (uint32_t)(d + P.doc_base);
+    const uint32_t gdoc = P.doc_ids ? (uint32_t)P.doc_ids[d] : (uint32_t)(d + P.doc_base);
     int ndk[T];
     double avg[T];
 #pragma unroll

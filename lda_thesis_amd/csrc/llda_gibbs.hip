@@ -535,7 +535,7 @@ int llda_foldin(const llda_foldin_args *a, void *stream)
     memset(&P, 0, sizeof P);
     P.doc_off = a->doc_off; P.word = a->word; P.init_idx = a->init_idx; P.freq = a->freq; P.z = a->z;
     P.ph = a->ph; P.phn = a->init_rows; P.n_dk = a->n_dk; P.th = a->th; P.slot_valid = a->slot_valid;
-    P.status = a->status; P.D = a->D; P.doc_base = a->doc_base; P.alpha = a->alpha; P.beta = a->beta;
+    P.status = a->status; P.D = a->D; P.doc_base = a->doc_base; P.doc_ids = a->doc_ids; P.alpha = a->alpha; P.beta = a->beta;
     P.c_init = a->c_init; P.c_loop = a->c_loop;
     P.key0 = (uint32_t)a->seed; P.key1 = (uint32_t)(a->seed >> 32); P.stream_id = a->stream_id;
     P.iters = a->iters; P.thinning = a->thinning; P.beta_fallback = a->beta_fallback; P.avg_mode = a->avg_mode;

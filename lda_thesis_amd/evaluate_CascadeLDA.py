@@ -52,7 +52,9 @@ def main(argv=None):
     train, test = split_data(f=opt.file)            # the depth flag only limits the report, as in the reference
     model = train_it(train, it=opt.it, s=opt.thinning, l=opt.lower, u=opt.upper, al=opt.alpha, be=opt.beta)
     print("Testing test data, this may take a while")
-    l1, l2, l3 = zip(*[model.test_down_tree(x, it=opt.it, thinning=opt.thinning, threshold=0.95) for x in test[0]])
+    # (the reference calls test_down_tree document by document; the batch form returns the same lists with one
+    # launch per node of the label tree)
+    l1, l2, l3 = zip(*model.test_down_tree_batch(test[0], it=opt.it, thinning=opt.thinning, threshold=0.95))
     if opt.pickle:
         for name, obj in (("Cascade_model.pkl", model), ("Cascade_testset.pkl", test), ("Cascade_d1_pred.pkl", l1), ("Cascade_d2_pred.pkl", l2),
                           ("Cascade_d3_pred.pkl", l3)):

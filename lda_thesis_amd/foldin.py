@@ -33,8 +33,8 @@ def doc_key(doc_tup):
 
 def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, seed, stream_id, doc_ids, c_init,
             c_loop, beta_fallback, avg_mode, device=None):
-    """ph (K, V) float64; init_rows (R, K) float64; init_idx[S] row per site.  doc_ids: RNG id per doc
-    (consecutive ids run as one launch with doc_base; arbitrary ids run one launch per document)."""
+    """ph (K, V) float64; init_rows (R, K) float64; init_idx[S] row per site.  doc_ids: RNG id per document (any
+    values: the whole batch is one launch)."""
     _native.lib()
     if not torch.cuda.is_available():
         raise _native.NativeError("no HIP device visible: the fold-in sampler has no CPU fallback")
@@ -61,13 +61,9 @@ def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, see
     common = dict(word=d_word, init_idx=d_idx, freq=d_freq, ph=d_ph, init_rows=d_init, slot_valid=valid, z=z,
                   status=status, K=K, iters=it, thinning=thinning, alpha=alpha, beta=beta, c_init=c_init,
                   c_loop=c_loop, seed=seed, stream_id=stream_id, beta_fallback=beta_fallback, avg_mode=avg_mode)
-    doc_ids = np.asarray(doc_ids, dtype=np.int64)
-    if D and (np.diff(doc_ids) == 1).all():
-        _native.foldin(doc_off=d_off, n_dk=n_dk, th=th, D=D, doc_base=int(doc_ids[0]), **common)
-    else:
-        for d in range(D):                    # unrelated RNG ids: one document per launch (views, no copies)
-            _native.foldin(doc_off=d_off[d:d + 2], n_dk=n_dk[d:d + 1], th=th[d:d + 1], D=1,
-                           doc_base=int(doc_ids[d]), **common)
+    # one launch for the whole batch: every document carries its own RNG id
+    d_ids = t(np.asarray(doc_ids, dtype=np.int64), torch.int64)
+    _native.foldin(doc_off=d_off, n_dk=n_dk, th=th, D=D, doc_ids=d_ids, **common)
     if int(status.item()) != 0:
         raise ValueError("pvals < 0, pvals > 1 or pvals contains NaNs")     # numpy.random.multinomial's complaint
     tp = torch.from_numpy(lay.topic_pos.astype(np.int64)).to(dev)

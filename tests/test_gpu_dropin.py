@@ -205,6 +205,13 @@ def test_cascade_test_down_tree_matches_reference():
         assert [[(a, float(b)) for a, b in grp] for grp in l2] == [[tuple(x) for x in grp] for grp in w[1]]
         assert [[(a, float(b)) for a, b in grp] for grp in l3] == [[tuple(x) for x in grp] for grp in w[2]]
     np.testing.assert_array_equal(c.cascade_test(docs[0], 4, 1, ["A", "A1", "A2"]), g["single_A"])
+    # the batch form (one launch per node of the label tree, all documents that reach it) returns the same trees
+    got = c.test_down_tree_batch(docs, int(g["it"]), int(g["thinning"]), float(g["threshold"]))
+    assert len(got) == len(docs)
+    for (l1, l2, l3), w in zip(got, want):
+        assert [(a, float(b)) for a, b in l1] == [tuple(x) for x in w[0]]
+        assert [[(a, float(b)) for a, b in grp] for grp in l2] == [[tuple(x) for x in grp] for grp in w[1]]
+        assert [[(a, float(b)) for a, b in grp] for grp in l3] == [[tuple(x) for x in grp] for grp in w[2]]
 
 
 def test_cascade_flat_run_test_matches_reference(capsys):
