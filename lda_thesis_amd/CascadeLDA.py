@@ -330,28 +330,48 @@ class CascadeLDA(object):
                 level_3.append(list(zip(keep3, loads3)))
         return level_1, level_2, level_3
 
-    def cascade_test_batch(self, docs, it, thinning, labels, seed=None, doc_ids=None):
+    def cascade_test_batch(self, docs, it, thinning, labels, seed=None, doc_ids=None, stream=None, defer=False,
+                           bows=None):
         """cascade_test for several documents against the SAME label subset: one llda_foldin launch, one lane
         group per document.  Row d equals cascade_test(docs[d], ...) -- the RNG is keyed by the document, not by
-        its place in the batch."""
+        its place in the batch.  defer=True: enqueue on ``stream`` and return the pending launch."""
         from .foldin import cascade_fold_in, doc_key
         ids = [self.labelmap[x] for x in labels]
-        tups = [self.dicti.doc2bow(doc) for doc in docs]
+        tups = [self.dicti.doc2bow(doc) for doc in docs] if bows is None else bows     # (bows: doc2bow done by the caller)
         keys = [doc_key(t) for t in tups] if doc_ids is None else list(doc_ids)
         r = cascade_fold_in(self.ph[ids, :], self.alpha, self.beta, tups, it, thinning, self._seed(seed),
-                            self._test_stream(labels), keys, device=self._device)
-        return r["th_hat"]
+                            self._test_stream(labels), keys, device=self._device, stream=stream, defer=defer)
+        return r if defer else r["th_hat"]
 
-    def test_down_tree_batch(self, docs, it, thinning, threshold, seed=None):
+    def test_down_tree_batch(self, docs, it, thinning, threshold, seed=None, streams=32):
         """test_down_tree for a list of documents, level by level: all documents that reach the same node of the
-        label tree are sampled in one launch (at most one launch per node instead of several per document).
-        Returns [test_down_tree(doc, ...) for doc in docs]."""
+        label tree are sampled in one launch (at most one launch per node instead of several per document), and
+        the launches of one level -- each a latency-bound chain on a few compute units -- run concurrently on
+        ``streams`` HIP streams.  Returns [test_down_tree(doc, ...) for doc in docs]."""
+        import torch
         docs = list(docs)
         children = lambda parent: [parent] + list(filter(re.compile("^" + parent + "[0-9]{1}$").match, self.lablist))
         out = [[None, [], []] for _ in docs]
+        pool = [torch.cuda.Stream() for _ in range(max(1, streams))] if torch.cuda.is_available() else [None]
+        bows = [self.dicti.doc2bow(doc) for doc in docs]
+        keys = None
+        if bows:
+            from .foldin import doc_key
+            keys = [doc_key(b) if b else 0 for b in bows]
+
+        def level(todo):
+            """todo: parent -> documents.  Enqueue every node, then collect: parent -> (labels, th rows)."""
+            pending = []
+            for i, (parent, members) in enumerate(todo.items()):
+                labels = children(parent)
+                pending.append((parent, labels, self.cascade_test_batch(
+                    None, it, thinning, labels, seed=seed, stream=pool[i % len(pool)], defer=True,
+                    bows=[bows[d] for d in members], doc_ids=[keys[d] for d in members])))
+            return {parent: (labels, p.result()["th_hat"]) for parent, labels, p in pending}
+
         # level 1: every document against the one-character labels
         labels = self.lablist_l1
-        th = self.cascade_test_batch(docs, it, thinning, labels, seed=seed)
+        th = self.cascade_test_batch(None, it, thinning, labels, seed=seed, bows=bows, doc_ids=keys)
         todo2 = {}                                      # parent -> documents that kept it, in visiting order
         for d in range(len(docs)):
             keep, loads = self._head(th[d], labels, threshold)
@@ -362,10 +382,8 @@ class CascadeLDA(object):
                 todo2.setdefault(parent, []).append(d)
         # level 2, then level 3: one launch per node that some document reached
         res2, todo3 = {}, {}
-        for parent, members in todo2.items():
-            labels = children(parent)
-            th = self.cascade_test_batch([docs[d] for d in members], it, thinning, labels, seed=seed)
-            for row, d in zip(th, members):
+        for parent, (labels, th) in level(todo2).items():
+            for row, d in zip(th, todo2[parent]):
                 keep2, loads2 = self._head(row, labels, threshold)
                 res2[(d, parent)] = list(zip(keep2, loads2))
                 if parent in keep2:
@@ -373,12 +391,10 @@ class CascadeLDA(object):
                 for parent2 in keep2:
                     todo3.setdefault(parent2, []).append(d)
         res3 = {}
-        for parent2, members in todo3.items():
-            labels = children(parent2)
-            th = self.cascade_test_batch([docs[d] for d in members], it, thinning, labels, seed=seed)
-            for row, d in zip(th, members):
+        for parent2, (labels, th) in level(todo3).items():
+            for row, d in zip(th, todo3[parent2]):
                 keep3, loads3 = self._head(row, labels, threshold)
-                res3.setdefault((d, parent2), []).append(list(zip(keep3, loads3)))
+                res3[(d, parent2)] = list(zip(keep3, loads3))
         # assemble in the order test_down_tree visits the nodes
         for d in range(len(docs)):
             for parent, _ in out[d][0]:
@@ -387,9 +403,8 @@ class CascadeLDA(object):
                 lvl2 = res2[(d, parent)]
                 out[d][1].append(lvl2)
                 for parent2, _ in lvl2:
-                    if parent2 == parent:
-                        continue
-                    out[d][2].append(res3[(d, parent2)].pop(0))
+                    if parent2 != parent:
+                        out[d][2].append(res3[(d, parent2)])
         return [tuple(x) for x in out]
 
     def run_test(self, docs, it, thinning, depth="all", seed=None):

@@ -31,14 +31,36 @@ def doc_key(doc_tup):
     return zlib.crc32(np.asarray(list(ids) + list(freqs), dtype=np.int32).tobytes())
 
 
+class Pending(object):
+    """An enqueued llda_foldin launch; ``result()`` waits for it (on its stream) and brings the outputs to the host."""
+
+    def __init__(self, stream, lay, doc_off, z, n_dk, th, status, keep):
+        self.stream, self.lay, self.doc_off = stream, lay, doc_off
+        self.z, self.n_dk, self.th, self.status = z, n_dk, th, status
+        self._keep = keep                          # inputs of the launch stay alive until it has run
+
+    def result(self):
+        with torch.cuda.stream(self.stream):
+            if int(self.status.item()) != 0:       # (synchronises with the launch)
+                raise ValueError("pvals < 0, pvals > 1 or pvals contains NaNs")     # numpy.random.multinomial's complaint
+            lay, dev, doc_off = self.lay, self.th.device, self.doc_off
+            tp = torch.from_numpy(lay.topic_pos.astype(np.int64)).to(dev)
+            zt = torch.from_numpy(lay.pos_topic.astype(np.int64)).to(dev)[self.z.to(torch.int64)].cpu().numpy()
+            out = dict(th_hat=self.th[:, tp].cpu().numpy(), n_dk=self.n_dk[:, tp].cpu().numpy().astype(np.int64),
+                       z=[zt[doc_off[d]:doc_off[d + 1]] for d in range(len(doc_off) - 1)])
+        self._keep = None
+        return out
+
+
 def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, seed, stream_id, doc_ids, c_init,
-            c_loop, beta_fallback, avg_mode, device=None):
+            c_loop, beta_fallback, avg_mode, device=None, stream=None):
     """ph (K, V) float64; init_rows (R, K) float64; init_idx[S] row per site.  doc_ids: RNG id per document (any
-    values: the whole batch is one launch)."""
+    values: the whole batch is one launch).  Enqueues on ``stream`` (default: the current one), returns Pending."""
     _native.lib()
     if not torch.cuda.is_available():
         raise _native.NativeError("no HIP device visible: the fold-in sampler has no CPU fallback")
     dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+    stream = stream if stream is not None else torch.cuda.current_stream(dev)
     K, V = ph.shape
     lay = group_layout(K)
     doc_off, word, freq = csr_from_doc_tups(doc_tups)
@@ -50,6 +72,8 @@ def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, see
         return torch.from_numpy(out).to(dev)
 
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)
+    # uploads and zero fills go through the CURRENT stream (they never queue behind an earlier fold-in kernel);
+    # only the kernel runs on ``stream``, after an event on the current stream
     d_off, d_word, d_freq = t(doc_off, torch.int64), t(word, torch.int32), t(freq, torch.int32)
     d_idx = t(np.asarray(init_idx, dtype=np.int32), torch.int32)
     d_ph, d_init = rows_to_dev(np.ascontiguousarray(ph.T)), rows_to_dev(init_rows)
@@ -58,18 +82,14 @@ def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, see
     n_dk = torch.zeros((D, lay.KP), dtype=torch.int32, device=dev)
     th = torch.zeros((D, lay.KP), dtype=torch.float64, device=dev)
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
-    common = dict(word=d_word, init_idx=d_idx, freq=d_freq, ph=d_ph, init_rows=d_init, slot_valid=valid, z=z,
-                  status=status, K=K, iters=it, thinning=thinning, alpha=alpha, beta=beta, c_init=c_init,
-                  c_loop=c_loop, seed=seed, stream_id=stream_id, beta_fallback=beta_fallback, avg_mode=avg_mode)
-    # one launch for the whole batch: every document carries its own RNG id
-    d_ids = t(np.asarray(doc_ids, dtype=np.int64), torch.int64)
-    _native.foldin(doc_off=d_off, n_dk=n_dk, th=th, D=D, doc_ids=d_ids, **common)
-    if int(status.item()) != 0:
-        raise ValueError("pvals < 0, pvals > 1 or pvals contains NaNs")     # numpy.random.multinomial's complaint
-    tp = torch.from_numpy(lay.topic_pos.astype(np.int64)).to(dev)
-    zt = torch.from_numpy(lay.pos_topic.astype(np.int64)).to(dev)[z.to(torch.int64)].cpu().numpy()
-    return dict(th_hat=th[:, tp].cpu().numpy(), n_dk=n_dk[:, tp].cpu().numpy().astype(np.int64),
-                z=[zt[doc_off[d]:doc_off[d + 1]] for d in range(D)])
+    d_ids = t(np.asarray(doc_ids, dtype=np.int64), torch.int64)   # every document carries its own RNG id
+    stream.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(stream):
+        _native.foldin(doc_off=d_off, n_dk=n_dk, th=th, D=D, doc_ids=d_ids, word=d_word, init_idx=d_idx, freq=d_freq,
+                       ph=d_ph, init_rows=d_init, slot_valid=valid, z=z, status=status, K=K, iters=it,
+                       thinning=thinning, alpha=alpha, beta=beta, c_init=c_init, c_loop=c_loop, seed=seed,
+                       stream_id=stream_id, beta_fallback=beta_fallback, avg_mode=avg_mode)
+    return Pending(stream, lay, doc_off, z, n_dk, th, status, (d_off, d_word, d_freq, d_idx, d_ph, d_init, valid, d_ids))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -99,7 +119,7 @@ def fold_in(ph_hat, alpha, doc_tups, it, thinning, seed, stream_id=TEST_STREAM, 
         init_idx = np.where(doc_bad[site_doc], V, word)
     return _launch(ph_hat, rows, init_idx, doc_tups, alpha=alpha, beta=0.0, it=it, thinning=thinning, seed=seed,
                    stream_id=stream_id, doc_ids=np.arange(len(doc_tups)) + doc_base, c_init=1.0000000005,
-                   c_loop=1.0000005, beta_fallback=False, avg_mode=0, device=device)
+                   c_loop=1.0000005, beta_fallback=False, avg_mode=0, device=device).result()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -120,14 +140,17 @@ def cascade_init_rows(ph, beta, doc_tups):
     return rows, np.arange(rows.shape[0])
 
 
-def cascade_fold_in(ph, alpha, beta, doc_tups, it, thinning, seed, stream_id, doc_ids, flat=False, device=None):
+def cascade_fold_in(ph, alpha, beta, doc_tups, it, thinning, seed, stream_id, doc_ids, flat=False, device=None,
+                    stream=None, defer=False):
     """CascadeLDA.cascade_test (flat=False) / CascadeLDA.run_test (flat=True) for a batch of documents
-    against the label subset whose loadings are ``ph`` (K_sub, V)."""
+    against the label subset whose loadings are ``ph`` (K_sub, V).  defer=True: enqueue on ``stream`` and return
+    the Pending launch (``.result()`` gives the dict) so that launches of different label subsets overlap."""
     ph = np.ascontiguousarray(ph, dtype=np.float64)
     for doc in doc_tups:
         if not doc:
             raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
     rows, idx = cascade_init_rows(ph, beta, doc_tups)
-    return _launch(ph, rows, idx, doc_tups, alpha=alpha, beta=beta, it=it, thinning=thinning, seed=seed,
-                   stream_id=stream_id, doc_ids=doc_ids, c_init=1.0000005, c_loop=1.000005,
-                   beta_fallback=not flat, avg_mode=1 if flat else 0, device=device)
+    pending = _launch(ph, rows, idx, doc_tups, alpha=alpha, beta=beta, it=it, thinning=thinning, seed=seed,
+                      stream_id=stream_id, doc_ids=doc_ids, c_init=1.0000005, c_loop=1.000005,
+                      beta_fallback=not flat, avg_mode=1 if flat else 0, device=device, stream=stream)
+    return pending if defer else pending.result()

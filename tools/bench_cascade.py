@@ -28,6 +28,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--it", type=int, default=4)
     ap.add_argument("--s", type=int, default=2)
+    ap.add_argument("--test-it", type=int, default=0,
+                    help="also time test_down_tree over the fixture's held-out documents with this many iterations")
     args = ap.parse_args()
     g = np.load(os.path.join(ROOT, "tests", "golden", "abstracts_d3.npz"))
     off, word, freq = g["doc_off"], g["word"], g["freq"]
@@ -64,11 +66,32 @@ def main():
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     filled = int((np.nan_to_num(model.ph).sum(axis=1) > 0).sum())
+    test = None
+    if args.test_it:
+        toff, tw, tf = g["test_doc_off"], g["test_word"], g["test_freq"]
+        held = []
+        for d in range(len(toff) - 1):
+            toks = []
+            for v, f in zip(tw[toff[d]:toff[d + 1]], tf[toff[d]:toff[d + 1]]):
+                toks += ["w%05d" % v] * int(f)
+            if toks:
+                held.append(toks)
+        model.ph = np.nan_to_num(model.ph)               # (the never-trained '' row)
+        thin = max(1, args.test_it // 6)
+        t3 = time.perf_counter()
+        trees = model.test_down_tree_batch(held, args.test_it, thin, 0.95)
+        t4 = time.perf_counter()
+        some = held[:20]
+        one_by_one = [model.test_down_tree(x, args.test_it, thin, 0.95) for x in some]
+        t5 = time.perf_counter()
+        same = all(str(a) == str(b) for a, b in zip(trees[:20], one_by_one))
+        test = {"held_out_documents": len(held), "iterations": args.test_it, "batch_s": t4 - t3,
+                "one_by_one_s_per_document": (t5 - t4) / len(some), "identical_trees": same}
     print(json.dumps({"metric": "CascadeLDA go_down_tree wall time", "value": t2 - t1, "unit": "s", "n_gpus": 1,
                       "config": {"workload": "CascadeLDA on abstracts_data.csv fixture, it=%d, s=%d" % (args.it, args.s),
                                  "sub_problems": len(tasks), "sites_per_ensemble_sweep": int(sum(sites)),
                                  "largest_sub_problem_sites": int(max(sites)), "K": model.K, "V": model.V, "D": model.D},
-                      "model_build_s": t1 - t0, "ph_rows_filled": filled,
+                      "model_build_s": t1 - t0, "ph_rows_filled": filled, "test_down_tree": test,
                       "reference_cpu_s": 66.8, "reference_cpu_note": "reference go_down_tree(4, 2), 1 core, survey container "
                       "(SURVEY.md section 6); not re-measured on this host"}))
 
