@@ -1,20 +1,40 @@
 """bench.py -- Gibbs-sweep throughput of the HIP sampler on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload synth2|synth1|abstracts]
+    python bench.py --gpus N --steps K --warmup W [--workload synth2|synth1|synth2_hostile|synth2_sparse|abstracts]
 
-A "step" is one full Gibbs sweep (every site of every local document resampled once + the per-sweep
-exchange/fold).  Default workload (weak scaling): every GPU holds 125 000 synthetic documents x 300
-sites, K = 512 dense label mask, V = 100 000 -- the per-GPU shard of BASELINE.json configs[3]
-(1M docs over 8 GPUs); at --gpus 8 the job IS that config.  Inputs are resident in HBM before the
-timed region.  One JSON line is printed by rank 0.
+A "step" is one full Gibbs sweep: every site of every local document resampled once, plus the per-sweep
+exchange (RCCL all-reduce of the n_kw / n_k deltas when N > 1) and the fold of the deltas into the counts.
 
-Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-                   --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Default workload = BASELINE.json configs[3], the configuration the metric is quoted on: ONE synthetic corpus of
+1 000 000 documents x 300 sites, K = 512 dense label mask, V = 100 000 (Zipf word frequencies).  It fits one GPU
+(16 GB of state), so N = 1 samples the whole corpus and N GPUs hold 1 000 000 / N documents each: STRONG scaling,
+the corpus (generated in 64 seeded blocks) and therefore the state after every sweep are identical for every N.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks
+(python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>).
+
+At N = 1 the same JSON line also carries (key "extra"):
+  * "synth1"          BASELINE configs[2] (100k docs x 200 sites, K = 128): the roofline case BASELINE names;
+  * "hbm_bound"       a cache-hostile variant (uniform words, V = 500 000: n_kw = 1 GB > the 256 MB Infinity Cache)
+                      that shows the genuinely HBM-bound regime of the same kernel;
+  * "abstracts"       Labeled LDA on the tokenised abstracts_data.csv fixture (configs[0]/[1]) with its own
+                      cpu_baseline -- the >= 50x target of BASELINE.json's north_star.
+and the roofline of the dominant kernel from HBM-side PMC counters collected IN THIS RUN: the script re-runs itself
+for a few sweeps under `rocprofv3 --kernel-trace --pmc ...` (separate passes for FETCH_SIZE, WRITE_SIZE and the SQ
+group; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction of MI355X_MICROARCH.md).
 """
 import argparse
+import collections
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -23,26 +43,34 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from lda_thesis_amd.corpus import synthetic_corpus          # noqa: E402
+from lda_thesis_amd.corpus import synthetic_corpus_blocks    # noqa: E402
 from lda_thesis_amd.sampler import GibbsSampler              # noqa: E402
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+N_SIMD = 1024                # 256 CUs x 4 SIMDs
+N_XCD = 8                    # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (1.16e9 per 63 ms launch = 8 x 2.3 GHz)
+MAX_CLOCK_HZ = 2.4e9         # MI355X_MICROARCH.md: max clock
+VALU_CYCLES_PER_INST = 4     # SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.01 quad-cycles on this kernel (profiles/)
 
 WORKLOADS = {
-    # name: (docs per GPU, sites per doc, V, K, description)
-    "synth2": (125000, 300, 100000, 512,
-               "synthetic 1M docs x 300 tokens, K=512 dense mask, V=100k, doc-sharded: 125k docs per GPU "
+    # name: (documents in the corpus, sites per doc, V, K, zipf exponent, generator block, description)
+    "synth2": (1000000, 300, 100000, 512, 1.0, 15625,
+               "synthetic 1M docs x 300 tokens, K=512 dense mask, V=100k, doc-sharded over the GPUs of the job "
                "(BASELINE configs[3])"),
-    "synth1": (100000, 200, 50000, 128,
+    "synth1": (100000, 200, 50000, 128, 1.0, 12500,
                "synthetic 100k docs x 200 tokens, K=128 dense mask, V=50k (BASELINE configs[2])"),
-    "synth2_sparse": (125000, 300, 100000, 512,
-                      "synthetic 1M docs x 300 tokens, K=512, sparse label mask (root + 7 random labels per doc), "
-                      "V=100k, doc-sharded: 125k docs per GPU (secondary variant of BASELINE configs[3])"),
+    "synth2_hostile": (125000, 300, 500000, 512, 0.0, 15625,
+                       "cache-hostile variant of configs[3]: 125k docs x 300 tokens, K=512 dense mask, UNIFORM words over "
+                       "V=500k -- n_kw is 1.02 GB, four times the Infinity Cache, every site reads a cold 2 KB row"),
+    "synth2_sparse": (125000, 300, 100000, 512, 1.0, 15625,
+                      "synthetic 125k docs x 300 tokens, K=512, sparse label mask (root + 7 random labels per doc), "
+                      "V=100k (secondary variant of BASELINE configs[3])"),
     # real corpus: tokenised abstracts_data.csv, depth 3 (tests/golden/abstracts_d3.npz); sizes read from the file
-    "abstracts": (4171, 0, 0, 392,
+    "abstracts": (4171, 0, 0, 392, 0.0, 0,
                   "Labeled LDA on abstracts_data.csv, depth 3, K=392 sparse label masks (BASELINE configs[0]/[1]); "
                   "replicated per GPU"),
 }
+ALPHA, BETA = 0.1, 0.01
 
 
 def algorithmic_bytes(sites, docs, A):
@@ -50,6 +78,83 @@ def algorithmic_bytes(sites, docs, A):
     return sites * (4 * A + 32) + docs * (12 * A + 16)
 
 
+# ------------------------------------------------------------------------------------------------ workloads
+def build_sampler(name, dev, rank, world, dist_on, docs_total=0, docs_per_group=0, force_exchange=False,
+                  overlap=None):
+    """-> (sampler, info dict).  Inputs are generated on the device."""
+    Dt, N, V, K, zs, block, desc = WORKLOADS[name]
+    if docs_total:
+        Dt = docs_total
+    info = dict(desc=desc, K=K, V=V, N=N, live_topics=float(K), docs_total=Dt)
+    kw = {} if overlap is None else dict(overlap_ranges=overlap)
+    if name == "abstracts":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "abstracts_d3.npz"))
+        Dg, V, K = int(g["D"]), int(g["V"]), int(g["K"])
+        # every rank samples its own replica of the corpus (independent chains: sharded=False)
+        s = GibbsSampler(g["doc_off"], g["word"].astype(np.int32), g["freq"].astype(np.int32),
+                         g["z_init"].astype(np.int64), K, V, ALPHA, BETA,
+                         labs=(g["lab_off"], g["lab_idx"].astype(np.int64)), counts=None, seed=42 + rank,
+                         device=dev, docs_per_group=docs_per_group, sharded=False)
+        info.update(K=K, V=V, N=int(g["doc_off"][-1]) // Dg, live_topics=float(len(g["lab_idx"])) / Dg,
+                    docs_total=Dg, docs_local=Dg, fixture=g)
+        return s, info
+    if Dt % (block * world):
+        block = Dt // world if Dt % world == 0 else None
+        if block is None:
+            raise SystemExit("%d documents do not split over %d GPUs" % (Dt, world))
+    lo, hi = Dt // world * rank, Dt // world * (rank + 1)
+    doc_off, word, freq, z = synthetic_corpus_blocks(lo, hi, N, V, K, 1234, dev, zipf_s=zs, block=block)
+    Dg = hi - lo
+    info["docs_local"] = Dg
+    if name == "synth2_sparse":
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(99 + rank)
+        # root + 7 distinct random labels per document: sort 7 draws, bump duplicates (still <= K-1)
+        lab = torch.sort(torch.randint(1, K - 8, (Dg, 7), device=dev, generator=gen), dim=1).values
+        lab = lab + torch.arange(7, device=dev)              # strictly increasing => distinct
+        lab = torch.cat([torch.zeros((Dg, 1), dtype=lab.dtype, device=dev), lab], dim=1)
+        pick = torch.randint(0, 8, (Dg * N,), device=dev, generator=gen)
+        z = lab.repeat_interleave(N, dim=0)[torch.arange(Dg * N, device=dev), pick]
+        lab_off = np.arange(0, 8 * Dg + 1, 8, dtype=np.int64)
+        s = GibbsSampler(doc_off, word, freq, z, K, V, ALPHA, BETA, labs=(lab_off, lab.reshape(-1).cpu().numpy()),
+                         counts=None, seed=42, doc_base=lo, device=dev, docs_per_group=docs_per_group, **kw)
+        info.update(live_topics=8.0, lab=lab)
+    else:
+        s = GibbsSampler(doc_off, word, freq, z, K, V, ALPHA, BETA, labs=None, counts=None, seed=42,
+                         doc_base=lo, device=dev, docs_per_group=docs_per_group,
+                         exchange_always=bool(force_exchange), **kw)
+    info.update(doc_off=doc_off, word=word, freq=freq)
+    return s, info
+
+
+def time_sweeps(sampler, steps, warmup, dist=None, dev=None):
+    """warmup untimed sweeps, then exactly `steps` sweeps between barrier + synchronize; MAX over ranks.
+    -> (seconds, mean sweep-kernel ms from HIP events on the launch stream, tier counters)"""
+    for _ in range(warmup):
+        sampler.sweep()
+    sampler.kernel_events = []
+    sampler.comm_events = [] if hasattr(sampler, "comm_events") else None
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sampler.sweep()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    sampler.check_status()
+    kern_ms = [a.elapsed_time(b) for a, b in sampler.kernel_events]
+    sampler.kernel_events = None
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, (float(np.mean(kern_ms)) if kern_ms else float("nan"))
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(sampler, doc_off, word, freq, n_docs_py, n_docs_c, labs=None):
     """Reference CPU path restated (oracle/) on a bounded sample of the SAME workload, timed on this
     host.  'port' = numpy per-site loop issuing the op sequence of LabeledLDA.py:108-125 on one core
@@ -60,14 +165,15 @@ def cpu_baseline(sampler, doc_off, word, freq, n_docs_py, n_docs_c, labs=None):
     K, V = sampler.K, sampler.V
     n_k_v = sampler.n_k_v()
     n_zk = sampler.n_zk()
-    n_d_k = sampler.n_dk[:max(n_docs_py, n_docs_c), sampler._topic_pos].cpu().numpy().astype(np.int64)
-    z = sampler._pos_topic[sampler.z[:int(doc_off[max(n_docs_py, n_docs_c)])].to(torch.int64)].cpu().numpy()
+    nmax = max(n_docs_py, n_docs_c)
+    n_d_k = sampler.n_dk[:nmax, sampler._topic_pos].cpu().numpy().astype(np.int64)
+    z = sampler._pos_topic[sampler.z[:int(doc_off[nmax])].to(torch.int64)].cpu().numpy()
     out = {}
     # --- numpy loop (like-for-like with the reference) ---
     off = doc_off[:n_docs_py + 1]
     docs = [word[off[d]:off[d + 1]].tolist() for d in range(n_docs_py)]
     freqs = [freq[off[d]:off[d + 1]].tolist() for d in range(n_docs_py)]
-    labs = np.ones((max(n_docs_py, n_docs_c), K), dtype=np.uint8) if labs is None else labs
+    labs = np.ones((nmax, K), dtype=np.uint8) if labs is None else labs
     st = orc.State(docs, freqs, labs[:n_docs_py].astype(np.float64), V, sampler.alpha, sampler.beta,
                    [z[off[d]:off[d + 1]] for d in range(n_docs_py)])
     st.n_k_v, st.n_zk, st.n_d_k = n_k_v.copy(), n_zk.copy(), n_d_k[:n_docs_py].copy()
@@ -91,165 +197,293 @@ def cpu_baseline(sampler, doc_off, word, freq, n_docs_py, n_docs_c, labs=None):
     return out, cores
 
 
+def cpu_baseline_json(sampler, info, name, value):
+    K = sampler.K
+    Dg = info["docs_local"]
+    n_py = n_c = min(Dg, 3000)                         # ~10 s of single-core numpy work at K=512
+    labs_h = None
+    if name == "synth2_sparse":
+        labs_h = np.zeros((n_py, K), dtype=np.uint8)
+        lh = info["lab"][:n_py].cpu().numpy()
+        labs_h[np.repeat(np.arange(lh.shape[0]), 8), lh.reshape(-1)] = 1
+    if name == "abstracts":                            # the whole corpus: one sweep of the numpy loop is ~2 s
+        g = info["fixture"]
+        n_py = n_c = Dg
+        labs_h = np.zeros((Dg, K), dtype=np.uint8)
+        labs_h[np.repeat(np.arange(Dg), np.diff(g["lab_off"])), g["lab_idx"]] = 1
+        h_off, h_word, h_freq = g["doc_off"], g["word"].astype(np.int32), g["freq"].astype(np.int32)
+    else:
+        h_off = info["doc_off"][:n_py + 1].cpu().numpy()
+        nmax = int(h_off[n_py])
+        h_word, h_freq = info["word"][:nmax].cpu().numpy(), info["freq"][:nmax].cpu().numpy()
+    base, cores = cpu_baseline(sampler, h_off, h_word, h_freq, n_py, n_c, labs_h)
+    return {
+        "value": base["numpy"]["value"], "unit": "Mtokens/s", "cores": 1, "kind": "port",
+        "sample": "first %d docs (%d sites) of the same workload, 1 sweep, numpy per-site loop "
+                  "restating LabeledLDA.py:108-125 (oracle/llda_oracle.py sweep_sequential), %.1f s"
+                  % (n_py, base["numpy"]["sites"], base["numpy"]["seconds"]),
+        "c_port_1thread_Mtokens_s": base["c_1thread"]["value"],
+        "c_port_allcores_Mtokens_s": base["c_allcores"]["value"],
+        "c_port_sample": "first %d docs (%d sites), oracle/llda_oracle.c snapshot mode" %
+                         (n_c, base["c_1thread"]["sites"]),
+        "host_cores": cores,
+        "port_vs_reference": "the port runs within 10 % of the unmodified reference loop and leaves identical "
+                             "counts (measured in the build container: profiles/port_calibration.json)",
+    }, value / base["numpy"]["value"]
+
+
+# ------------------------------------------------------------------------------------------------ PMC passes
+PMC_WORKLOADS = ("synth2", "synth1", "synth2_hostile")     # dense kernels, in the order the inner run sweeps them
+PMC_SWEEPS = 3                                              # per workload in the inner run (all are measured)
+PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+              ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]))
+
+
+def pmc_inner(dev, workloads):
+    """the process rocprofv3 wraps: PMC_SWEEPS sweeps of each dense workload, nothing else."""
+    for name in workloads:
+        s, info = build_sampler(name, dev, 0, 1, False)
+        for _ in range(PMC_SWEEPS):
+            s.sweep()
+        torch.cuda.synchronize()
+        del s, info
+        torch.cuda.empty_cache()
+
+
+def pmc_collect(workloads, keep_dir=None, timeout=600):
+    """Run this script under rocprofv3, one --pmc group per pass (kernel trace only, as the guide prescribes), and
+    return {workload: {counter: mean per sweep-kernel launch}}.  Any failure returns {} (traffic is then null)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found"
+    out = {w: {} for w in workloads}
+    tmp = tempfile.mkdtemp(prefix="llda_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        for tag, counters in PMC_PASSES:
+            d = os.path.join(tmp, tag)
+            cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                                                                 sys.executable, os.path.join(ROOT, "bench.py"),
+                                                                 "--pmc-inner", ",".join(workloads)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {}, "rocprofv3 pass %s failed (rc %d): %s" % (tag, r.returncode, r.stdout.decode(errors="replace")[-300:])
+            rows = []
+            for r_ in csv.DictReader(open(files[0])):
+                nm = r_["Kernel_Name"]
+                if "llda_sweep_kernel" in nm or "llda_sweep_exact_kernel" in nm:
+                    rows.append((int(r_["Dispatch_Id"]), r_["Counter_Name"], float(r_["Counter_Value"])))
+                    if r_["Counter_Name"] == counters[0]:      # the launch's duration under this pass
+                        rows.append((int(r_["Dispatch_Id"]), tag + "_pass_kernel_ns",
+                                     float(int(r_["End_Timestamp"]) - int(r_["Start_Timestamp"]))))
+            disp = sorted(set(x[0] for x in rows))
+            if len(disp) != PMC_SWEEPS * len(workloads):
+                return {}, "unexpected number of sweep-kernel dispatches in pass %s: %d" % (tag, len(disp))
+            which = {d_: workloads[i // PMC_SWEEPS] for i, d_ in enumerate(disp)}
+            agg = collections.defaultdict(list)
+            for d_, c, v in rows:
+                agg[(which[d_], c)].append(v)
+            for (w, c), v in agg.items():
+                out[w][c] = sum(v) / PMC_SWEEPS          # a counter may be reported in several rows per dispatch
+            if keep_dir:
+                os.makedirs(keep_dir, exist_ok=True)
+                shutil.copy(files[0], os.path.join(keep_dir, "pmc_%s_counter_collection.csv" % tag))
+    except Exception as e:                                # noqa: BLE001 -- the bench line must survive a profiler problem
+        return {}, "pmc collection failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, "in-run rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group), %d launches each" % PMC_SWEEPS
+
+
+def roofline_json(kernel_ms, sites, docs, live_topics, pmc, source, stored_key=None):
+    """roofline of the sweep kernel.  `hbm`: HBM-side bytes from the PMC counters over the kernel's mean duration
+    (HIP events in the timed region) against 8 TB/s.  `valu_issue`: VALU instructions issued x 4 cycles against
+    1024 SIMDs x clock.  Algorithmic bytes are reported separately: hot n_kw rows are served by the
+    L2s / Infinity Cache, so algorithmic bytes over time is NOT an HBM rate."""
+    alg = algorithmic_bytes(sites, docs, live_topics)
+    ks = kernel_ms * 1e-3
+    traffic = None
+    if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+    elif stored_key:
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            per_site = json.load(open(tpath)).get(stored_key)
+            if per_site:
+                traffic = per_site * sites
+                source = "stored PMC figure (profiles/pmc_traffic.json: %.1f HBM bytes per site) x local sites" % per_site
+    r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "llda_sweep_kernel", "kernel_ms": kernel_ms,
+         "algorithmic_bytes_per_launch": alg, "algorithmic_GBps": alg / ks / 1e9,
+         "algorithmic_note": "SURVEY 8(d) bytes / kernel time; includes rows served by L2 / Infinity Cache, so it may "
+                             "exceed the HBM peak and is not the roofline fraction"}
+    if traffic is not None:
+        r.update(achieved=traffic / ks / 1e9, frac=traffic / ks / 1e9 / HBM_PEAK_GBS, traffic=traffic,
+                 traffic_source=source, traffic_over_algorithmic=traffic / alg)
+    else:
+        r.update(achieved=None, frac=None, traffic=None, traffic_source=source)
+    if pmc and "SQ_INSTS_VALU" in pmc:
+        insts = pmc["SQ_INSTS_VALU"]
+        peak_ips = N_SIMD * MAX_CLOCK_HZ / VALU_CYCLES_PER_INST
+        v = {"achieved": insts / ks, "peak": peak_ips, "unit": "wave64 VALU instructions/s",
+             "frac": insts / ks / peak_ips, "valu_insts_per_site": insts / sites,
+             "model": "SQ_INSTS_VALU x %d cycles / (%d SIMDs x %.1f GHz)" % (VALU_CYCLES_PER_INST, N_SIMD, MAX_CLOCK_HZ / 1e9)}
+        if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("SQ_ACTIVE_INST_VALU"):
+            cycles = pmc["GRBM_GUI_ACTIVE"] / N_XCD                       # shader cycles of the profiled launch
+            v["valu_busy_frac"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * N_SIMD)
+            v["valu_busy_note"] = ("SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share "
+                                   "of the profiled launch's own cycles in which a SIMD issues VALU")
+            if pmc.get("sq_pass_kernel_ns"):
+                v["effective_clock_GHz"] = cycles / pmc["sq_pass_kernel_ns"]
+        r["valu_issue"] = v
+        if traffic is not None:
+            r["binding_roof"] = "valu_issue" if v["frac"] > r["frac"] else "hbm"
+    return r
+
+
+# ------------------------------------------------------------------------------------------------ main
+def self_launch(args):
+    """--gpus N > 1 without torch.distributed.run around us: start N ranks of this script."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="synth2", choices=sorted(WORKLOADS))
-    ap.add_argument("--docs", type=int, default=0, help="override documents per GPU")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--docs", type=int, default=0, help="override the number of documents of the corpus (all GPUs)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads of the N = 1 line")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
+    ap.add_argument("--pmc-keep", default="", help="directory to keep the raw counter CSVs of the in-run passes in")
+    ap.add_argument("--pmc-inner", default="", help=argparse.SUPPRESS)
     ap.add_argument("--force-exchange", action="store_true",
-                    help="diagnostic: take the multi-GPU path (delta buffer, all-reduce if a group exists, fold) on one GPU")
+                    help="diagnostic: take the multi-GPU path (exchange rows, all-reduce if a group exists) on one GPU")
+    ap.add_argument("--overlap", type=int, default=-1, help="document ranges per sweep for the overlapped exchange")
     ap.add_argument("--docs-per-group", type=int, default=0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.pmc_inner:
+        pmc_inner(dev, args.pmc_inner.split(","))
+        return
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    Dg, N, V, K, desc = WORKLOADS[args.workload]
-    if args.docs:
-        Dg = args.docs
-    alpha, beta = 0.1, 0.01
-    live_topics = K
-    if args.workload == "abstracts":
-        g = np.load(os.path.join(ROOT, "tests", "golden", "abstracts_d3.npz"))
-        Dg, V, K = int(g["D"]), int(g["V"]), int(g["K"])
-        doc_off = torch.from_numpy(g["doc_off"]).to(dev)
-        word = torch.from_numpy(g["word"].astype(np.int32)).to(dev)
-        freq = torch.from_numpy(g["freq"].astype(np.int32)).to(dev)
-        N = int(g["doc_off"][-1]) // Dg
-        live_topics = float(len(g["lab_idx"])) / Dg
-        # every rank samples its own replica of the corpus (independent chains: sharded=False)
-        sampler = GibbsSampler(doc_off, word, freq, g["z_init"].astype(np.int64), K, V, alpha, beta,
-                               labs=(g["lab_off"], g["lab_idx"].astype(np.int64)), counts=None, seed=42 + rank,
-                               device=dev, docs_per_group=args.docs_per_group, sharded=False)
-    elif args.workload == "synth2_sparse":
-        doc_off, word, freq, _ = synthetic_corpus(Dg, N, V, K, seed=1234 + rank, device=dev)
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(99 + rank)
-        # root + 7 distinct random labels per document: sort 8 draws, bump duplicates (still <= K-1)
-        lab = torch.sort(torch.randint(1, K - 8, (Dg, 7), device=dev, generator=gen), dim=1).values
-        lab = lab + torch.arange(7, device=dev)              # strictly increasing => distinct
-        lab = torch.cat([torch.zeros((Dg, 1), dtype=lab.dtype, device=dev), lab], dim=1)
-        live_topics = 8.0
-        pick = torch.randint(0, 8, (Dg * N,), device=dev, generator=gen)
-        z = lab.repeat_interleave(N, dim=0)[torch.arange(Dg * N, device=dev), pick]
-        lab_off = np.arange(0, 8 * Dg + 1, 8, dtype=np.int64)
-        sampler = GibbsSampler(doc_off, word, freq, z, K, V, alpha, beta, labs=(lab_off, lab.reshape(-1).cpu().numpy()),
-                               counts=None, seed=42, doc_base=rank * Dg, device=dev,
-                               docs_per_group=args.docs_per_group)
-        del z
-    else:
-        doc_off, word, freq, z = synthetic_corpus(Dg, N, V, K, seed=1234 + rank, device=dev)
-        sampler = GibbsSampler(doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=42,
-                               doc_base=rank * Dg, device=dev, docs_per_group=args.docs_per_group,
-                               exchange_always=bool(args.force_exchange))
-        del z
+    name = args.workload
+    sampler, info = build_sampler(name, dev, rank, world, dist is not None, docs_total=args.docs,
+                                  docs_per_group=args.docs_per_group, force_exchange=args.force_exchange,
+                                  overlap=None if args.overlap < 0 else args.overlap)
     sites_local = sampler.S
     torch.cuda.synchronize()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        sampler.sweep()
-    sampler.kernel_events = []
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sampler.sweep()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    sampler.check_status()
+    dt, kavg = time_sweeps(sampler, args.steps, args.warmup, dist, dev)
     tier = sampler.status.cpu().numpy().astype(np.int64)
-    kern_ms = [a.elapsed_time(b) for a, b in sampler.kernel_events]
-    sampler.kernel_events = None
+    total_sites = sites_local
+    checksum = int(sampler.n_k.to(torch.int64).mul(torch.arange(1, sampler.n_k.numel() + 1, device=dev)).sum().item())
+    comm = sampler.comm_stats() if hasattr(sampler, "comm_stats") else None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([sites_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        total_sites = int(t.item())
 
     if rank == 0:
-        total_sites = sites_local * world
+        K, V, N = info["K"], info["V"], info["N"]
+        live = info["live_topics"]
         ms = dt / args.steps * 1e3
         value = total_sites * args.steps / dt / 1e6
-        kavg = float(np.mean(kern_ms)) if kern_ms else float("nan")
-        alg = algorithmic_bytes(sites_local, Dg, live_topics)
-        achieved = alg / (kavg * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get("%s:%d" % (args.workload, Dg))
+        do_pmc = world == 1 and not args.no_pmc and name in PMC_WORKLOADS
+        extras_on = world == 1 and not args.no_extras and name == "synth2" and not args.docs
+        pmc_names = [w for w in PMC_WORKLOADS if w == name or extras_on] if do_pmc else []
         line = {
             "metric": "million tokens resampled/sec (Gibbs sweep)",
             "value": value, "unit": "Mtokens/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong" if name != "abstracts" else "weak",
             "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic" if args.workload != "abstracts" else "tokenised abstracts_data.csv (fixture)",
-            "config": {"workload": desc, "docs_per_gpu": Dg, "sites_per_doc": N, "K": K, "V": V,
-                       "alpha": alpha, "beta": beta,
-                       "label_mask": "dense" if live_topics == K else "sparse (%.2f live topics per doc)" % live_topics,
+            "data": "synthetic" if name != "abstracts" else "tokenised abstracts_data.csv (fixture)",
+            "config": {"workload": info["desc"], "docs_total": info["docs_total"], "docs_per_gpu": info["docs_local"],
+                       "sites_per_doc": N, "K": K, "V": V, "alpha": ALPHA, "beta": BETA,
+                       "label_mask": "dense" if live == K else "sparse (%.2f live topics per doc)" % live,
                        "kernel": "sparse" if sampler.live_off is not None else "dense",
-                       "sites_per_sweep": total_sites,
-                       "exchange": ("one RCCL int32 SUM all-reduce of the n_kw/n_k deltas per sweep; rows of words with a global "
-                                    "frequency mass <= 32767 travel as int16 pairs") if world > 1 else "none",
+                       "sites_per_sweep": total_sites, "timed_seconds": dt,
+                       "exchange": sampler.exchange_description() if world > 1 else "none (single GPU: the commit log is "
+                                   "folded straight into n_kw)",
                        "semantics": "per-document snapshot (bit-exact vs the reference under O3)",
                        "draw": "tiered: fp32 decision with a proven margin, fp64 / exact fp64 pipeline otherwise; "
-                               "the result is the exact fp64 pipeline's"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "llda_sweep_kernel", "kernel_ms": kavg,
-                         "algorithmic_bytes_per_launch": alg},
+                               "the result is the exact fp64 pipeline's",
+                       "state_checksum_n_k": checksum},
             "draw_tiers": {"sites": int(sites_local) * (args.steps + args.warmup),
                            "fp32_tier_unsure": int(tier[1]), "exact_tier": int(tier[2])},
         }
+        if comm is not None:
+            line["exchange_ms"] = comm
+        # ---- extras (N = 1, default workload): the other configurations, timed in this run ----
+        extra = {}
+        measured = {name: dict(kernel_ms=kavg, sites=sites_local, docs=info["docs_local"], live=live)}
         if world == 1 and not args.no_cpu:
-            h_off = doc_off.cpu().numpy()
-            n_py, n_c = min(Dg, 3000), min(Dg, 3000)       # ~10 s of single-core numpy work at K=512
-            labs_h = None
-            if args.workload == "synth2_sparse":
-                labs_h = np.zeros((max(n_py, n_c), K), dtype=np.uint8)
-                lh = lab[:max(n_py, n_c)].cpu().numpy()
-                labs_h[np.repeat(np.arange(lh.shape[0]), 8), lh.reshape(-1)] = 1
-            if args.workload == "abstracts":          # the whole corpus: one sweep of the numpy loop is ~4 s
-                n_py = n_c = Dg
-                labs_h = np.zeros((Dg, K), dtype=np.uint8)
-                labs_h[np.repeat(np.arange(Dg), np.diff(g["lab_off"])), g["lab_idx"]] = 1
-            nmax = int(h_off[max(n_py, n_c)])
-            base, cores = cpu_baseline(sampler, h_off, word[:nmax].cpu().numpy(), freq[:nmax].cpu().numpy(),
-                                       n_py, n_c, labs_h)
-            line["cpu_baseline"] = {
-                "value": base["numpy"]["value"], "unit": "Mtokens/s", "cores": 1, "kind": "port",
-                "sample": "first %d docs (%d sites) of the same workload, 1 sweep, numpy per-site loop "
-                          "restating LabeledLDA.py:108-125 (oracle/llda_oracle.py sweep_sequential), %.1f s"
-                          % (n_py, base["numpy"]["sites"], base["numpy"]["seconds"]),
-                "c_port_1thread_Mtokens_s": base["c_1thread"]["value"],
-                "c_port_allcores_Mtokens_s": base["c_allcores"]["value"],
-                "c_port_sample": "first %d docs (%d sites), oracle/llda_oracle.c snapshot mode" %
-                                 (n_c, base["c_1thread"]["sites"]),
-                "host_cores": cores,
-                "port_vs_reference": "the port runs within 10 % of the unmodified reference loop and leaves identical "
-                                     "counts (measured in the build container: profiles/port_calibration.json)",
-            }
-            line["speedup_vs_cpu_port"] = value / base["numpy"]["value"]
+            line["cpu_baseline"], line["speedup_vs_cpu_port"] = cpu_baseline_json(sampler, info, name, value)
+        del sampler, info
+        torch.cuda.empty_cache()
+        if extras_on:
+            for key, wname, st, wu in (("synth1", "synth1", 200, 5), ("hbm_bound", "synth2_hostile", 40, 3),
+                                       ("abstracts", "abstracts", 3000, 20)):
+                s2, i2 = build_sampler(wname, dev, 0, 1, False)
+                torch.cuda.synchronize()
+                dt2, k2 = time_sweeps(s2, st, wu)
+                v2 = s2.S * st / dt2 / 1e6
+                e = {"workload": i2["desc"], "value": v2, "unit": "Mtokens/s", "steps": st, "warmup": wu,
+                     "ms_per_step": dt2 / st * 1e3, "timed_seconds": dt2, "docs": i2["docs_local"], "sites_per_sweep": s2.S,
+                     "K": i2["K"], "V": i2["V"], "kernel": "sparse" if s2.live_off is not None else "dense",
+                     "kernel_ms": k2}
+                measured[wname] = dict(kernel_ms=k2, sites=s2.S, docs=i2["docs_local"], live=i2["live_topics"])
+                if wname == "abstracts":
+                    e["live_topics_per_doc"] = i2["live_topics"]
+                    e["algorithmic_GBps"] = algorithmic_bytes(s2.S, i2["docs_local"], i2["live_topics"]) / (k2 * 1e-3) / 1e9
+                    e["note"] = "latency bound (one 48-site document chain per lane group), not bandwidth bound"
+                    if not args.no_cpu:
+                        e["cpu_baseline"], e["speedup_vs_cpu_port"] = cpu_baseline_json(s2, i2, wname, v2)
+                        e["target_speedup"] = 50.0
+                extra[key] = e
+                del s2, i2
+                torch.cuda.empty_cache()
+        # ---- roofline: HBM-side counters collected in this run (separate rocprofv3 passes) ----
+        pmc, source = ({}, "not collected (N > 1 or --no-pmc)")
+        if pmc_names:
+            pmc, source = pmc_collect(pmc_names, keep_dir=args.pmc_keep or None)
+        m = measured[name]
+        line["roofline"] = roofline_json(m["kernel_ms"], m["sites"], m["docs"], m["live"], pmc.get(name), source,
+                                         stored_key=name)
+        for key, wname in (("synth1", "synth1"), ("hbm_bound", "synth2_hostile")):
+            if key in extra:
+                m = measured[wname]
+                extra[key]["roofline"] = roofline_json(m["kernel_ms"], m["sites"], m["docs"], m["live"], pmc.get(wname),
+                                                       source, stored_key=wname)
+        if extra:
+            line["extra"] = extra
         print(json.dumps(line))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -27,9 +27,9 @@ def zipf_cdf(V, s=1.0, device="cpu"):
     return cdf / cdf[-1].clone()
 
 
-def synthetic_corpus(D, N, V, K, seed, device, chunk=32768, oversample=3):
+def synthetic_corpus(D, N, V, K, seed, device, chunk=32768, oversample=3, zipf_s=1.0):
     """D documents of exactly N distinct word ids each (ascending, f = 1): successive sampling
-    WITHOUT replacement from Zipf(s=1) over V words; initial topics uniform over K.
+    WITHOUT replacement from Zipf(s=zipf_s) over V words (zipf_s = 0: uniform); initial topics uniform over K.
     Generated on ``device`` with a torch.Generator seeded by ``seed``.
     Returns (doc_off int64 (D+1), word int32 (D*N), freq int32, z int64 topic ids)."""
     if N > V:
@@ -37,7 +37,7 @@ def synthetic_corpus(D, N, V, K, seed, device, chunk=32768, oversample=3):
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
     gen.manual_seed(int(seed))
-    cdf = zipf_cdf(V, 1.0, dev)
+    cdf = zipf_cdf(V, float(zipf_s), dev)
     M = min(max(oversample * N, N + 64), 64 * N)
     words = torch.empty((D, N), dtype=torch.int32, device=dev)
     for lo in range(0, D, chunk):
@@ -70,3 +70,25 @@ def synthetic_corpus(D, N, V, K, seed, device, chunk=32768, oversample=3):
     freq = torch.ones_like(word)
     z = torch.randint(0, K, (D * N,), dtype=torch.int64, device=dev, generator=gen)
     return doc_off, word, freq, z
+
+
+BLOCK_DOCS = 15625      # 1 000 000 / 64: the unit in which synthetic_corpus_blocks seeds its generator
+
+
+def synthetic_corpus_blocks(doc_lo, doc_hi, N, V, K, seed, device, zipf_s=1.0, block=BLOCK_DOCS):
+    """Documents [doc_lo, doc_hi) of a corpus that is generated in fixed blocks of ``block`` documents, block b
+    from seed + b -- so the corpus (and the initial topics) are the same whichever way the documents are later
+    split over GPUs, as long as the split points are multiples of ``block``.  Returns the local CSR as
+    synthetic_corpus does."""
+    if doc_lo % block or doc_hi % block:
+        raise ValueError("shard bounds must be multiples of %d documents" % block)
+    words, zs = [], []
+    for lo in range(doc_lo, doc_hi, block):
+        n = block
+        _, w, _, z = synthetic_corpus(n, N, V, K, seed + lo // block, device, zipf_s=zipf_s)
+        words.append(w)
+        zs.append(z)
+    word = torch.cat(words)
+    D = doc_hi - doc_lo
+    doc_off = torch.arange(0, D + 1, dtype=torch.int64, device=word.device) * N
+    return doc_off, word, torch.ones_like(word), torch.cat(zs)

@@ -340,6 +340,15 @@ class GibbsSampler(object):
             self.backend.apply_delta(self._counts, self._delta)
         self.sweeps_done += 1
 
+    def exchange_description(self):
+        """what travels between the GPUs per sweep (for reports)."""
+        if self.rows is not None:
+            pairs = int((self.row_off[:-1] < 0).sum().item())
+            return ("one RCCL int32 SUM all-reduce per sweep of the n_kw / n_k deltas as exchange rows: %d of %d word rows "
+                    "as int16 pairs (frequency mass <= %d), %.1f MB" % (pairs, self.V, self.PAIR_LIMIT,
+                                                                          self.rows.numel() * 4 / 1e6))
+        return "one RCCL int32 SUM all-reduce per sweep of the n_kw / n_k delta buffer, %.1f MB" % (self._delta.numel() * 4 / 1e6)
+
     def check_status(self):
         """Raise like the reference would (numpy's multinomial rejects a NaN pvals vector)."""
         st = int(self.status[0].item())

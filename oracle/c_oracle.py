@@ -34,6 +34,10 @@ def lib():
                                         P, P, P, P, P, P, P, P,
                                         ctypes.c_double, ctypes.c_double, ctypes.c_uint64,
                                         ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int64, ctypes.c_int]
+        L.llda_oracle_sweep_docs.restype = ctypes.c_int
+        L.llda_oracle_sweep_docs.argtypes = [ctypes.c_int64, P, ctypes.c_int, ctypes.c_int64, P, P, P, P, P, P, P, P,
+                                             ctypes.c_double, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint32,
+                                             ctypes.c_uint32, ctypes.c_int]
         L.llda_oracle_pairwise_sum.restype = ctypes.c_double
         L.llda_oracle_pairwise_sum.argtypes = [P, ctypes.c_int64]
         L.llda_oracle_uniform.restype = ctypes.c_double
@@ -97,3 +101,29 @@ class CState(object):
                                      seed, sweep, stream, doc_base, threads)
         if rc != 0:
             raise RuntimeError("llda_oracle_sweep failed: %d" % rc)
+
+
+def sweep_docs(doc_ids, doc_off, word, freq, z, labs, n_d_k, n_k_v, n_zk, V, alpha, beta, seed, sweep, stream=0,
+               threads=1):
+    """llda_oracle_sweep_docs: snapshot sweep (O3) of a SELECTION of documents of a larger corpus against the
+    sweep-start counts n_k_v (K, V) int64 / n_zk (K) int64, which are left untouched.  doc_ids = global document
+    ids (RNG key); doc_off / word / freq / z = CSR of the selected documents only; labs = (n_sel, K) 0/1 or None
+    (dense); n_d_k = (n_sel, K) int64 rows.  Returns (z_new int32, n_d_k_new int64)."""
+    doc_ids = np.ascontiguousarray(doc_ids, dtype=np.int64)
+    doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
+    word = np.ascontiguousarray(word, dtype=np.int32)
+    freq = np.ascontiguousarray(freq, dtype=np.int32)
+    z = np.array(z, dtype=np.int32)
+    n_d_k = np.array(n_d_k, dtype=np.int64, order="C")
+    assert n_k_v.dtype == np.int64 and n_k_v.flags.c_contiguous and n_zk.dtype == np.int64
+    K = n_k_v.shape[0]
+    lab_p = None
+    if labs is not None:
+        labs = np.ascontiguousarray(np.asarray(labs) != 0, dtype=np.uint8)
+        lab_p = _p(labs)
+    rc = lib().llda_oracle_sweep_docs(doc_ids.shape[0], _p(doc_ids), K, int(V), _p(doc_off), _p(word), _p(freq), _p(z),
+                                      lab_p, _p(n_d_k), _p(n_k_v), _p(n_zk), float(alpha), float(beta), int(seed),
+                                      int(sweep), int(stream), int(threads))
+    if rc != 0:
+        raise RuntimeError("llda_oracle_sweep_docs failed: %d" % rc)
+    return z, n_d_k

@@ -272,3 +272,46 @@ int llda_oracle_sweep(int mode, int64_t D, int K, int64_t V,
     free(z_old);
     return err;
 }
+
+/* Snapshot sweep (O3) of a SELECTION of documents of a larger corpus -- the checker of the full-size parity
+ * tests.  Under snapshot semantics a document depends only on the sweep-start n_k_v / n_zk and on itself, so
+ * n_sel documents picked at random can be checked without sweeping the rest: local document d (CSR doc_off /
+ * word / freq / z, rows labs[d] and n_d_k[d]) has the global id doc_ids[d] for the RNG key.  z and n_d_k are
+ * updated; n_k_v and n_zk are the sweep-start counts and are NOT modified (the deltas of the other documents
+ * are not known here).  labs == NULL: every topic allowed. */
+int llda_oracle_sweep_docs(int64_t n_sel, const int64_t *doc_ids, int K, int64_t V,
+                           const int64_t *doc_off, const int32_t *word, const int32_t *freq, int32_t *z,
+                           const uint8_t *labs, int64_t *n_d_k, const int64_t *n_k_v, const int64_t *n_zk,
+                           double alpha, double beta, uint64_t seed, uint32_t sweep, uint32_t stream, int threads)
+{
+    layout_t L;
+    if (make_layout(&L, K)) return -1;
+    uint8_t *ones = NULL;
+    if (!labs) {
+        ones = (uint8_t *)malloc((size_t)K);
+        if (!ones) return -4;
+        memset(ones, 1, (size_t)K);
+    }
+    int err = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        double prob[MAX_KP];
+        int64_t *work = (int64_t *)malloc(sizeof(int64_t) * (size_t)K);
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t d = 0; d < n_sel; d++) {
+            memcpy(work, n_zk, sizeof(int64_t) * (size_t)K);
+            /* do_doc indexes labs by d: hand it a base that makes row d the all-ones row when labs is absent */
+            const uint8_t *lab_base = labs ? labs : ones - d * K;
+            int rc = do_doc(&L, 1, d, K, V, doc_off, word, freq, z, lab_base, n_d_k, (int64_t *)n_k_v, work,
+                            alpha, beta, seed, sweep, stream, doc_ids[d] - d, prob);
+            if (rc) {
+#pragma omp atomic write
+                err = rc;
+            }
+        }
+        free(work);
+    }
+    free(ones);
+    return err;
+}

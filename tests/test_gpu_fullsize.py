@@ -4,7 +4,18 @@ schedule and of the commit path, and independence of how the documents are shard
 their deltas summed by hand == one shard) -- which is what makes 1/2/4/8-GPU runs bit-identical.
 
 configs[2]: 100k docs x 200 sites, K=128, V=50k, dense mask; configs[3]: one GPU's 125k docs x 300 sites of the
-1M-document corpus, K=512, V=100k, dense mask."""
+1M-document corpus, K=512, V=100k, dense mask -- and the WHOLE 1M-document corpus on one GPU (what bench.py times
+at N = 1).
+
+On top of the properties, the oracle itself is applied at full size BY SAMPLING: under per-document snapshot
+semantics a document depends only on the sweep-start n_kw / n_k and on itself, so a few thousand documents picked
+at random are swept by oracle/llda_oracle.c (llda_oracle_sweep_docs, reference LabeledLDA.py:106-125 restated)
+against the sweep-start counts and compared bit for bit with what the HIP sweep of the whole corpus left for
+them; and the production draw tiers are compared with the fp32 tier switched off (debug_margin = -2) on the full
+sweep."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -14,9 +25,41 @@ CONFIGS = {"synth1": (100_000, 200, 50_000, 128), "synth2_shard": (125_000, 300,
 
 
 def corpus(name):
-    from lda_thesis_amd.corpus import synthetic_corpus
+    from lda_thesis_amd.corpus import synthetic_corpus, synthetic_corpus_blocks
+    if name == "synth2_1M":                                 # bench.py's default workload, generated the same way
+        return synthetic_corpus_blocks(0, 1_000_000, 300, 100_000, 512, 1234, "cuda") + (512, 100_000)
     D, N, V, K = CONFIGS[name]
     return synthetic_corpus(D, N, V, K, 1234, "cuda") + (K, V)
+
+
+def sample_documents(s, n_docs, rng):
+    """random documents of the sampler: (ids, local CSR offsets, site indices on the device)."""
+    sel = np.sort(rng.choice(s.D, size=n_docs, replace=False))
+    sel_t = torch.from_numpy(sel).to(s.device)
+    lens = s.doc_off[sel_t + 1] - s.doc_off[sel_t]
+    loc_off = torch.zeros(n_docs + 1, dtype=torch.int64, device=s.device)
+    torch.cumsum(lens, 0, out=loc_off[1:])
+    idx = torch.repeat_interleave(s.doc_off[sel_t] - loc_off[:-1], lens) + torch.arange(int(loc_off[-1]), device=s.device)
+    return sel, sel_t, loc_off.cpu().numpy(), idx
+
+
+def sweep_and_check_sample(s, c_oracle, n_docs, rng):
+    """one HIP sweep of everything; the sampled documents must come out exactly as the C oracle leaves them."""
+    sel, sel_t, loc_off, idx = sample_documents(s, n_docs, rng)
+    n_k_v, n_zk = s.n_k_v(), s.n_zk()                       # sweep-start counts, reference layout
+    word, freq = s.word[idx].cpu().numpy(), s.freq[idx].cpu().numpy()
+    z0 = s._pos_topic[s.z[idx].to(torch.int64)].cpu().numpy()
+    ndk0 = s.n_dk[sel_t][:, s._topic_pos].cpu().numpy().astype(np.int64)
+    sweep = s.sweeps_done
+    s.sweep()
+    z_want, ndk_want = c_oracle.sweep_docs(sel + s.doc_base, loc_off, word, freq, z0, None, ndk0, n_k_v, n_zk, s.V,
+                                           s.alpha, s.beta, s.seed, sweep, stream=s.stream_id,
+                                           threads=min(32, os.cpu_count() or 1))
+    z_got = s._pos_topic[s.z[idx].to(torch.int64)].cpu().numpy()
+    ndk_got = s.n_dk[sel_t][:, s._topic_pos].cpu().numpy().astype(np.int64)
+    np.testing.assert_array_equal(z_got, z_want)
+    np.testing.assert_array_equal(ndk_got, ndk_want)
+    assert int((z_got != z0).sum()) > z0.size // 2          # the sampled sites really moved
 
 
 def make(doc_off, word, freq, z, K, V, **kw):
@@ -86,3 +129,35 @@ def test_full_size_properties(name):
     assert torch.equal(counts, s._counts)
     assert torch.equal(torch.cat([h.z for h in halves]), s.z)
     assert torch.equal(torch.cat([h.n_dk for h in halves]), s.n_dk)
+
+
+@pytest.mark.parametrize("name,n_docs", [("synth1", 3000), ("synth2_shard", 2000), ("synth2_1M", 2000)])
+def test_full_size_sampled_documents_vs_c_oracle(c_oracle, name, n_docs):
+    """the oracle at full size, by sampling (see the module docstring): two sweeps, a fresh sample each."""
+    doc_off, word, freq, z, K, V = corpus(name)
+    s = make(doc_off, word, freq, z, K, V)
+    del z
+    assert s.commit_log is not None and s.debug_margin == 0     # production path: tiers + word-major commit log
+    rng = np.random.default_rng(2024)
+    for _ in range(2):
+        sweep_and_check_sample(s, c_oracle, n_docs, rng)
+    s.check_status()
+    check_conservation(s)
+
+
+@pytest.mark.parametrize("name", ["synth1", "synth2_shard"])
+def test_full_size_production_margins_vs_no_fp32_tier(name):
+    """every site of the full-size sweep: the production tiers (fp32 decision first) pick the topic the fp64 tiers
+    pick with the fp32 tier switched off (debug_margin = -2), two sweeps."""
+    doc_off, word, freq, z, K, V = corpus(name)
+    a = make(doc_off, word, freq, z, K, V)
+    b = make(doc_off, word, freq, z, K, V)
+    b.debug_margin = -2
+    for _ in range(2):
+        a.sweep()
+        b.sweep()
+        assert torch.equal(a.z, b.z)
+    assert torch.equal(a._counts, b._counts) and torch.equal(a.n_dk, b.n_dk)
+    st = a.status.cpu().numpy()
+    assert 0 < int(st[1]) < a.S // 20                      # the fp32 tier was unsure about some sites, but few
+    assert int(b.status[1]) == 2 * b.S                     # ... and b sent every site to the fp64 tiers

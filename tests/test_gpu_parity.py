@@ -373,3 +373,38 @@ def test_exchange_path_on_one_rank(commit, monkeypatch):
     finally:
         if made:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K,dense", [(1024, True), (512, True), (128, True), (777, False), (257, False), (40, False)])
+def test_adversarial_near_ties_for_the_fp32_tier(c_oracle, K, dense):
+    """tests/neartie.py: the last site of every document has its keyed threshold within 2^-24 of a prefix-sum
+    boundary (far below fp32 resolution), all other sites are at least 2^-14 away.  The fp32 tier (margin 2^-17,
+    proven error bound 105 * 2^-24) must call exactly the tuned sites undecidable -- were its
+    rounding error ever above the margin it would decide some of them itself, wrongly half of the time -- and the
+    sweep must leave what the exact pipeline (debug_margin = -1) and the C oracle leave
+    (/root/reference/LabeledLDA.py:113-119)."""
+    import neartie
+    from lda_thesis_amd.sampler import GibbsSampler
+    st = neartie.make_neartie_state(K, 1500, dense, seed=4242, rng=np.random.default_rng(K), doc_base=7)
+    assert st["tuned_gap_max"] < 2.0 ** -23 and st["safe_gap_min"] > 2.0 ** -14.5
+    counts = dict(n_d_k=st["n_d_k"], n_k_v=st["n_k_v"], n_zk=st["n_zk"])
+    labs = None if dense else st["labs"]
+    runs = {}
+    for margin in (0, -1):
+        s = GibbsSampler(st["doc_off"], st["word"], st["freq"], st["z"], K, st["V"], st["alpha"], st["beta"],
+                         labs=labs, counts=counts, seed=4242, doc_base=7, sparse_labels=False)
+        s.debug_margin = margin
+        s.sweep()
+        s.check_status()
+        runs[margin] = (s.z_topics(), s.n_d_k(), s.n_k_v(), s.n_zk(), s.status.cpu().numpy())
+    cs = c_oracle.CState(st["doc_off"], st["word"], st["freq"], st["z"], st["labs"], st["n_d_k"], st["n_k_v"],
+                         st["n_zk"], st["V"], st["alpha"], st["beta"])
+    cs.sweep(1, 4242, 0, doc_base=7, threads=4)
+    for margin in (0, -1):
+        z, ndk, nkv, nzk, _ = runs[margin]
+        np.testing.assert_array_equal(z, cs.z)
+        np.testing.assert_array_equal(ndk, cs.n_d_k)
+        np.testing.assert_array_equal(nkv, cs.n_k_v)
+        np.testing.assert_array_equal(nzk, cs.n_zk)
+    # production run: the fp32 tier gave up on every tuned site and on no other
+    assert int(runs[0][4][1]) == st["n_tuned"]

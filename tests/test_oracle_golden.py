@@ -81,3 +81,26 @@ def test_sublda_phantom_and_get_ph():
     np.testing.assert_array_equal(rebuilt.n_k_v, g["init_n_k_v"])
     st = oracle_state(g, prefix="o3_s%d_" % int(g["sweeps"]))
     np.testing.assert_array_equal(orc.get_ph(st), g["o3_ph"])
+
+
+@pytest.mark.parametrize("name", ["tiny_k12", "tiny_k392", "tiny_k512", "tiny_k777"])
+def test_c_oracle_selected_documents(c_oracle, name):
+    """llda_oracle_sweep_docs (the checker of the full-size parity tests): a random selection of documents swept
+    against the sweep-start counts gives exactly those documents' rows of the reference's O3 sweep."""
+    g = load_golden(name)
+    off, D, K, V = g["doc_off"], int(g["D"]), int(g["K"]), int(g["V"])
+    rng = np.random.default_rng(5)
+    sel = np.sort(rng.choice(D, size=max(1, D // 3), replace=False))
+    prev = "init_"
+    for s in range(int(g["sweeps"])):
+        z0, ndk0 = g[prev + "z"], g[prev + "n_d_k"]
+        idx = np.concatenate([np.arange(off[d], off[d + 1]) for d in sel])
+        loc_off = np.concatenate(([0], np.cumsum(off[sel + 1] - off[sel])))
+        labs = None if (g["labs"] != 0).all() and s % 2 == 0 else g["labs"][sel]
+        z, ndk = c_oracle.sweep_docs(sel, loc_off, g["word"][idx], g["freq"][idx], z0[idx], labs, ndk0[sel],
+                                     np.ascontiguousarray(g[prev + "n_k_v"], dtype=np.int64),
+                                     np.ascontiguousarray(g[prev + "n_zk"], dtype=np.int64), V, float(g["alpha"]),
+                                     float(g["beta"]), int(g["seed"]), s, threads=2)
+        prev = "o3_s%d_" % (s + 1)
+        np.testing.assert_array_equal(z, g[prev + "z"][idx])
+        np.testing.assert_array_equal(ndk, g[prev + "n_d_k"][sel])
