@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 8
+#define LLDA_ABI_VERSION 9
 #define LLDA_MAX_K 1024
 #define LLDA_MAX_LEAVES 8
 #define LLDA_MAX_ROUNDS 4
@@ -136,6 +136,48 @@ int         llda_layout_init(int32_t K, llda_layout *out);
 /* ---- device entry points (enqueue on `stream`) ---- */
 /* One Gibbs sweep over the shard: LabeledLDA.py:101-125 / CascadeLDA.py:397-421. */
 int llda_sweep(const llda_sweep_args *args, void *stream);
+
+/* One Gibbs sweep over MANY independent small problems in ONE launch: the ensemble of per-node sub-problems of
+ * CascadeLDA.go_down_tree (/root/reference/CascadeLDA.py:135-184; each is SubLDA.training_iteration,
+ * CascadeLDA.py:397-421).  A "document instance" is a document as a member of one sub-problem.  All problems
+ * share the vocabulary (V) and the priors; problem p keeps its fused [n_kw (V x KP_p) | n_k (KP_p)] counts at
+ * counts + kw_off[p] / counts + nk_off[p], and its changes are added (int32 atomics) at the same offsets of
+ * `delta`; the caller folds with llda_apply_delta(counts, delta, total) after the launch(es) of a sweep.
+ * The draw key is (seed; sweep, stream = prob_stream[inst_prob[i]], doc = inst_doc[i], site) -- what llda_sweep uses
+ * with that stream_id and doc_base = 0 on the problem alone, so both paths leave identical states.
+ * Arithmetic: one lane per ALLOWED topic (every instance of a launch has <= `lanes` allowed topics, lanes in
+ * {8, 16, 32, 64}); the draw is decided from unnormalised fp64 prefix sums with a 2^-40 margin (it then equals the
+ * reference pipeline's choice).  If some site cannot be decided (~1e-11 per site) status bit 3
+ * (value 8) is set and the results of this sweep are INVALID: restore the state and run the problems through
+ * llda_sweep.  Needs alpha, beta >= 1e-6 and V*beta < 2^40 (LLDA_E_BAD_ARG otherwise). */
+typedef struct llda_batch_args {
+    const int64_t *inst_off;     /* [dev] [I+1] site offsets of all document instances               */
+    const int32_t *order;        /* [dev] [n_inst] the instances this launch samples                  */
+    int64_t        n_inst;
+    const int32_t *word;         /* [dev] [S] word id per instance site                               */
+    const int32_t *freq;         /* [dev] [S]                                                         */
+    int32_t       *z;            /* [dev] [S] in/out device positions (layout of the instance's problem) */
+    const int32_t *inst_prob;    /* [dev] [I] problem of every instance                               */
+    const int32_t *inst_doc;     /* [dev] [I] index of the document inside its problem (RNG word 1)   */
+    const int64_t *live_off;     /* [dev] [I+1] offsets into live_pos                                 */
+    const int32_t *live_pos;     /* [dev] allowed device positions of every instance, ascending       */
+    const int64_t *ndk_off;      /* [dev] [I] offset of the instance's n_dk row (KP_p entries) in n_dk */
+    int32_t       *n_dk;         /* [dev] in/out                                                      */
+    const int64_t *kw_off;       /* [dev] [P] offset of problem p's n_kw in counts / delta            */
+    const int64_t *nk_off;       /* [dev] [P] offset of problem p's n_k                               */
+    const int32_t *kp;           /* [dev] [P] KP_p                                                    */
+    const int32_t *prob_stream;  /* [dev] [P] RNG counter word 2 of problem p                         */
+    const int32_t *counts;       /* [dev] sweep-start snapshot (read only)                            */
+    int32_t       *delta;        /* [dev] += sweep changes                                            */
+    int32_t       *status;       /* [dev] optional int32[4] as in llda_sweep_args; bit 3 = undecidable site */
+    int64_t  V;
+    int32_t  lanes;              /* lanes per instance: 8, 16, 32 or 64                               */
+    int32_t  debug_margin;       /* 0 in production; n > 0 widens the margin to 2^-n; < 0: every site undecidable */
+    double   alpha, beta;
+    uint64_t seed;
+    uint32_t sweep, reserved;
+} llda_batch_args;
+int llda_sweep_batch(const llda_batch_args *args, void *stream);
 
 /* n_kw[i] += delta[i]; delta[i] = 0  for i < n   (end-of-sweep fold, after the all-reduce of delta). */
 int llda_apply_delta(int32_t *counts, int32_t *delta, int64_t n, void *stream);

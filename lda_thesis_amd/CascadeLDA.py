@@ -232,6 +232,10 @@ class CascadeLDA(object):
         self.seed = seed
         self._device = device
         self._group = group
+        self._ensemble = None          # go_down_tree(keep_state=True): the trained batched ensemble
+        self._batch_debug_margin = 0   # test hook of llda_sweep_batch (include/llda_gibbs.h)
+        self._keep_subs = None         # tests: set to [] to keep the SubLDA objects of the sequential path
+        self._owned_rows = np.zeros(0, dtype=np.int64)
 
     def set_label(self, label):
         vec = np.zeros(len(self.labelmap))
@@ -442,15 +446,133 @@ class CascadeLDA(object):
                 tasks.append(dict(parent=l2, doc_tups=doc_tups, labs=labs, labset=labset))
         return tasks
 
-    def go_down_tree(self, it, s):
+    def plan_subproblems(self):
+        """Every sub-problem of go_down_tree in the reference's visiting order (CascadeLDA.py:135-184) as index
+        arrays -- what enumerate_subproblems + SubLDA.__init__ build as python lists, without touching the corpus:
+        dict(parent, labset (children, 'root' NOT yet inserted), K, docs (member document ids, ascending),
+        allowed ((D_p, A_max) local topic ids of every member, ascending, -1 padded; topic 0 = the sub-problem's
+        'root'), n_allowed)."""
+        members, kids = {}, {}
+        for d, lab in enumerate(self.rawlabs):
+            for x in set(lab):
+                members.setdefault(x, []).append(d)                 # `parent in lab` (sub_corpus)
+        for level, lists in ((1, self.l2), (2, self.l3)):
+            for d, lab in enumerate(lists):
+                for x in lab:
+                    kids.setdefault(x[:level], []).append((d, x))
+        order = ["root"]
+        for l in [x for x in self.lablist_l1 if x != "root"]:
+            order.append(l)
+            order += [x for x in self.lablist_l2 if x[0] == l]
+        plans = []
+        for parent in order:
+            if parent == "root":
+                docs = np.arange(self.D, dtype=np.int64)
+                labset = [x for x in self.lablist_l1 if x != "root"]
+                pairs = [(d, x) for d, lab in enumerate(self.l1) for x in lab]
+            else:
+                docs = np.asarray(members.get(parent, []), dtype=np.int64)
+                inside = set(members.get(parent, []))
+                pairs = [(d, x) for d, x in kids.get(parent, []) if d in inside]
+                labset = sorted(set(x for _, x in pairs))
+            local = {x: i + 1 for i, x in enumerate(labset)}
+            K = 1 + len(labset)
+            flags = np.zeros((len(docs), K), dtype=bool)
+            flags[:, 0] = True
+            if pairs:
+                pd = np.searchsorted(docs, np.fromiter((d for d, _ in pairs), dtype=np.int64, count=len(pairs)))
+                pk = np.fromiter((local[x] for _, x in pairs), dtype=np.int64, count=len(pairs))
+                flags[pd, pk] = True
+            n_allowed = flags.sum(axis=1)
+            a_max = int(n_allowed.max()) if len(docs) else 1
+            # ascending local topic ids, -1 padded: argsort of ~flags is stable, allowed topics come first
+            idx = np.argsort(~flags, axis=1, kind="stable")[:, :a_max]
+            allowed = np.where(np.arange(a_max)[None, :] < n_allowed[:, None], idx, -1)
+            plans.append(dict(parent=parent, labset=labset, K=K, docs=docs, allowed=allowed, n_allowed=n_allowed))
+        return plans
+
+    def go_down_tree(self, it, s, batched=True, keep_state=False):
         """Train every sub-problem and scatter its topic-word rows into ``self.ph``
-        (reference CascadeLDA.py:135-184).  Sub-problem i uses RNG stream id i."""
+        (reference CascadeLDA.py:135-184).  Sub-problem i (visiting order) uses RNG stream id i.
+
+        batched=True: all sub-problems of this rank are trained TOGETHER (lda_thesis_amd/ensemble.py: a sweep of
+        the whole ensemble is a handful of launches); should the batched arithmetic meet a site it cannot decide
+        (~1e-11 per site) -- or priors it does not cover -- the sub-problems are trained one after another instead,
+        which gives the same result.  keep_state=True keeps the trained ensemble in ``self._ensemble`` (tests)."""
         import torch.distributed as dist
         world, rank = 1, 0
         if dist.is_available() and dist.is_initialized():
             world, rank = dist.get_world_size(self._group), dist.get_rank(self._group)
         if self.seed is None:
             self.seed = int(np.random.randint(0, 2 ** 31 - 1))
+        rng_state = np.random.get_state()
+        done = False
+        owner = None
+        if batched and self.alpha >= 1e-6 and self.beta >= 1e-6 and self.V * self.beta < 2.0 ** 40:
+            owner, done = self._go_down_tree_batched(it, s, world, rank, keep_state)
+        if not done:
+            np.random.set_state(rng_state)                  # the batched attempt consumed the same stream
+            owner = self._go_down_tree_sequential(it, s, world, rank)
+        if world > 1:
+            import torch
+            dev = self._device if self._device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+            # all-reduce a buffer that holds ONLY the rows this rank trained (rows are disjoint: sum = union);
+            # rows left by an earlier call must not be summed world times
+            mine = np.zeros_like(self.ph)
+            rows = self._owned_rows
+            mine[rows] = self.ph[rows]
+            buf = torch.from_numpy(mine).to(dev)
+            dist.all_reduce(buf, group=self._group)
+            self.ph = buf.cpu().numpy()
+        return owner
+
+    def _label_rows(self, i, plan):
+        """rows of self.ph the topics of sub-problem i fill (-1: not kept): the root problem keeps all its rows,
+        every other one drops its local 'root' (CascadeLDA.py:143-144, 162-165, 181-184)."""
+        rows = [self.labelmap[x] for x in plan["labset"]]
+        return [self.labelmap["root"] if i == 0 else -1] + rows
+
+    def _go_down_tree_batched(self, it, s, world, rank, keep_state):
+        import torch
+        from .ensemble import Ensemble, draw_initial_topics
+        plans = self.plan_subproblems()
+        doc_off, word, freq = csr_from_doc_tups(self.doc_tups)
+        lens = np.diff(doc_off)
+        # initial assignments of EVERY sub-problem, in visiting order, from numpy's global stream -- exactly the
+        # uniforms the reference's per-document np.random.choice calls consume (CascadeLDA.py:373-381)
+        z_local = []
+        for pl in plans:
+            n_sites = lens[pl["docs"]]
+            u = np.random.random_sample(int(n_sites.sum()))
+            inst = np.repeat(np.arange(len(pl["docs"])), n_sites)
+            z_local.append(draw_initial_topics(pl["allowed"], pl["n_allowed"], inst, u) if len(u) else
+                           np.zeros(0, dtype=np.int64))
+        sites = [int(lens[pl["docs"]].sum()) for pl in plans]
+        owner = lpt_assign(sites, world)
+        mine = [i for i in range(len(plans)) if owner[i] == rank]
+        ens = Ensemble([plans[i] for i in mine], [z_local[i] for i in mine], doc_off, word, freq,
+                       self.V, self.alpha, self.beta, self.seed, device=self._device, streams=mine)
+        ens.debug_margin = self._batch_debug_margin
+        for i in mine:
+            if i > 0:
+                print(" --- ")
+                print("Working on parent node", plans[i]["parent"])
+        for i in range(it):
+            ens.sweep()
+            if (i + 1) % s == 0:
+                print("Training iteration #", i + 1)
+        if ens.undecided():
+            return owner, False
+        ph_dev = torch.zeros((self.K, self.V), dtype=torch.float64, device=ens.device)
+        label_rows = [self._label_rows(i, plans[i]) for i in mine]
+        ens.scatter_ph(ph_dev, label_rows)
+        rows = sorted(r for lr in label_rows for r in lr if r >= 0)
+        self._owned_rows = np.asarray(rows, dtype=np.int64)
+        self.ph[self._owned_rows] = ph_dev[torch.from_numpy(self._owned_rows).to(ens.device)].cpu().numpy()
+        self._ensemble = ens if keep_state else None
+        return owner, True
+
+    def _go_down_tree_sequential(self, it, s, world, rank):
         tasks = self.enumerate_subproblems()
         # host initialisation of every sub-problem, in visiting order, on every rank (identical
         # consumption of numpy's global stream); device state only for the ones trained here
@@ -459,6 +581,7 @@ class CascadeLDA(object):
             subs.append(SubLDA(t["doc_tups"], t["labs"], t["labset"], self.dicti, alpha=self.alpha,
                                beta=self.beta, seed=self.seed, stream_id=i, device=self._device, defer=True))
         owner = lpt_assign([sub.n_sites for sub in subs], world)
+        owned = []
         for i, (t, sub) in enumerate(zip(tasks, subs)):
             labset = t["labset"]                  # 'root' was inserted at position 0 by SubLDA
             if owner[i] == rank:
@@ -467,20 +590,19 @@ class CascadeLDA(object):
                     print("Working on parent node", t["parent"])
                 sub.run_training(it=it, thinning=s)
                 sub_ph = sub.get_ph()             # final state, as get_sub_ph returns (CascadeLDA.py:129-133)
-                sub.release()
+                if self._keep_subs is not None:
+                    self._keep_subs.append((i, sub))
+                else:
+                    sub.release()
                 if i == 0:
                     ids = [self.labelmap[x] for x in labset]          # root problem keeps its 'root' row
                     self.ph[ids, :] = sub_ph
                 else:
                     ids = [self.labelmap[x] for x in labset[1:]]
                     self.ph[ids, :] = sub_ph[1:, :]
+                owned += ids
             labset.remove("root")
-        if world > 1:
-            import torch
-            dev = self._device if self._device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
-            buf = torch.from_numpy(self.ph).to(dev)
-            dist.all_reduce(buf, group=self._group)                   # rows are disjoint: sum = union
-            self.ph = buf.cpu().numpy()
+        self._owned_rows = np.asarray(sorted(owned), dtype=np.int64)
         return owner
 
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libllda_gibbs.so")
 MAX_K = 1024
 MAX_LEAVES = 8
 MAX_ROUNDS = 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -52,8 +52,18 @@ class LldaSweepArgs(ctypes.Structure):
                 ("n_sites", _c_i64)]
 
 
+class LldaBatchArgs(ctypes.Structure):
+    """struct llda_batch_args (include/llda_gibbs.h)."""
+    _fields_ = [("inst_off", _c_p), ("order", _c_p), ("n_inst", _c_i64), ("word", _c_p), ("freq", _c_p), ("z", _c_p),
+                ("inst_prob", _c_p), ("inst_doc", _c_p), ("live_off", _c_p), ("live_pos", _c_p), ("ndk_off", _c_p),
+                ("n_dk", _c_p), ("kw_off", _c_p), ("nk_off", _c_p), ("kp", _c_p), ("prob_stream", _c_p), ("counts", _c_p),
+                ("delta", _c_p),
+                ("status", _c_p), ("V", _c_i64), ("lanes", _c_i32), ("debug_margin", _c_i32), ("alpha", _c_d),
+                ("beta", _c_d), ("seed", _c_u64), ("sweep", _c_u32), ("reserved", _c_u32)]
+
+
 EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_layout_init",
-           "llda_sweep", "llda_commit_log", "llda_apply_rows", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
+           "llda_sweep", "llda_sweep_batch", "llda_commit_log", "llda_apply_rows", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
            "llda_readout_phi", "llda_readout_theta", "llda_selftest_div")
 
 _LIB = None
@@ -87,6 +97,8 @@ def lib():
     L.llda_layout_init.argtypes = [_c_i32, ctypes.POINTER(LldaLayout)]
     L.llda_sweep.restype = ctypes.c_int
     L.llda_sweep.argtypes = [ctypes.POINTER(LldaSweepArgs), _c_p]
+    L.llda_sweep_batch.restype = ctypes.c_int
+    L.llda_sweep_batch.argtypes = [ctypes.POINTER(LldaBatchArgs), _c_p]
     L.llda_commit_log.restype = ctypes.c_int
     L.llda_commit_log.argtypes = [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i32, _c_p, _c_p, _c_p, _c_p, _c_p]
     L.llda_apply_rows.restype = ctypes.c_int
@@ -136,9 +148,14 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def _stream():
+def _launch(ref, fn, what, *args):
+    """call the enqueue-only entry point ``fn(*args, stream)`` on the device that holds the tensor ``ref``: that
+    device is made current for the call and the stream is torch's current stream OF THAT DEVICE (not of whichever
+    device happens to be current), so the kernels are ordered with the torch ops on the tensors they touch."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dev = ref.device
+    with torch.cuda.device(dev):
+        check(fn(*args, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), what)
 
 
 def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
@@ -155,37 +172,48 @@ def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta
                       int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), _ptr(resume),
                       _ptr(resume_count), 0 if resume is None else int(resume.shape[0]), int(live_max),
                       _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites))
-    check(lib().llda_sweep(ctypes.byref(a), _stream()), "llda_sweep")
+    _launch(z, lib().llda_sweep, "llda_sweep", ctypes.byref(a))
+
+
+def sweep_batch(*, inst_off, order, word, freq, z, inst_prob, inst_doc, live_off, live_pos, ndk_off, n_dk, kw_off,
+                nk_off, kp, prob_stream, counts, delta, status, V, lanes, alpha, beta, seed, sweep, debug_margin=0):
+    """llda_sweep_batch on the current torch stream: one sweep of the instances in ``order`` (each with at most
+    ``lanes`` allowed topics) of an ensemble of small problems."""
+    a = LldaBatchArgs(_ptr(inst_off), _ptr(order), int(order.numel()), _ptr(word), _ptr(freq), _ptr(z),
+                      _ptr(inst_prob), _ptr(inst_doc), _ptr(live_off), _ptr(live_pos), _ptr(ndk_off), _ptr(n_dk),
+                      _ptr(kw_off), _ptr(nk_off), _ptr(kp), _ptr(prob_stream), _ptr(counts), _ptr(delta), _ptr(status), int(V),
+                      int(lanes), int(debug_margin), float(alpha), float(beta), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                      int(sweep) & 0xFFFFFFFF, 0)
+    _launch(z, lib().llda_sweep_batch, "llda_sweep_batch", ctypes.byref(a))
 
 
 def commit_log(item_begin, item_len, item_word, commit_log, freq_csc, K, target, n_k=None, n_k_delta=None,
                row_off=None):
     """llda_commit_log: fold the word-major commit log of a sweep into ``target`` (n_kw, its delta buffer, or --
     with ``row_off`` -- the exchange rows, int16 pairs where the offset is negative)."""
-    check(lib().llda_commit_log(_ptr(item_begin), _ptr(item_len), _ptr(item_word), int(item_len.numel()),
-                                _ptr(commit_log), _ptr(freq_csc), int(K), _ptr(row_off), _ptr(target), _ptr(n_k),
-                                _ptr(n_k_delta), _stream()), "llda_commit_log")
+    _launch(target, lib().llda_commit_log, "llda_commit_log", _ptr(item_begin), _ptr(item_len), _ptr(item_word),
+            int(item_len.numel()), _ptr(commit_log), _ptr(freq_csc), int(K), _ptr(row_off), _ptr(target), _ptr(n_k),
+            _ptr(n_k_delta))
 
 
 def apply_rows(row_off, rows, K, counts):
     """llda_apply_rows: counts[r] += row r of the exchange rows (pairs decoded), rows cleared."""
-    check(lib().llda_apply_rows(_ptr(row_off), _ptr(rows), int(row_off.numel()), int(K), _ptr(counts), _stream()),
-          "llda_apply_rows")
+    _launch(rows, lib().llda_apply_rows, "llda_apply_rows", _ptr(row_off), _ptr(rows), int(row_off.numel()), int(K),
+            _ptr(counts))
 
 
 def apply_delta(counts, delta):
-    check(lib().llda_apply_delta(_ptr(counts), _ptr(delta), counts.numel(), _stream()), "llda_apply_delta")
+    _launch(counts, lib().llda_apply_delta, "llda_apply_delta", _ptr(counts), _ptr(delta), counts.numel())
 
 
 def count_init(doc_off, word, freq, z, D, K, n_dk, n_kw, n_k):
-    check(lib().llda_count_init(_ptr(doc_off), _ptr(word), _ptr(freq), _ptr(z), int(D), int(K),
-                                _ptr(n_dk), _ptr(n_kw), _ptr(n_k), _stream()), "llda_count_init")
+    _launch(n_kw, lib().llda_count_init, "llda_count_init", _ptr(doc_off), _ptr(word), _ptr(freq), _ptr(z), int(D), int(K),
+            _ptr(n_dk), _ptr(n_kw), _ptr(n_k))
 
 
 def loglik(doc_off, word, lab_mask, n_dk, n_kw, n_k, D, V, K, alpha, beta, out_doc):
-    check(lib().llda_loglik(_ptr(doc_off), _ptr(word), _ptr(lab_mask), _ptr(n_dk), _ptr(n_kw), _ptr(n_k),
-                            int(D), int(V), int(K), float(alpha), float(beta), _ptr(out_doc), _stream()),
-          "llda_loglik")
+    _launch(out_doc, lib().llda_loglik, "llda_loglik", _ptr(doc_off), _ptr(word), _ptr(lab_mask), _ptr(n_dk), _ptr(n_kw),
+            _ptr(n_k), int(D), int(V), int(K), float(alpha), float(beta), _ptr(out_doc))
 
 
 READOUT_NEGATIVE, READOUT_NAN, READOUT_NO_LOAD = 1, 2, 4
@@ -195,17 +223,15 @@ def readout_phi(n_kw, n_k, den, V, K, beta, out, flags=None, keep=None, share=No
     """llda_readout_phi: out (K, V) float64 = phi of the counts, or keep*out + share*phi when the two
     coefficients are given."""
     mode = 0 if keep is None else 1
-    check(lib().llda_readout_phi(_ptr(n_kw), _ptr(n_k), _ptr(den), int(V), int(K), float(beta), mode,
-                                 float(keep or 0.0), float(share or 0.0), _ptr(out), _ptr(flags), _stream()),
-          "llda_readout_phi")
+    _launch(out, lib().llda_readout_phi, "llda_readout_phi", _ptr(n_kw), _ptr(n_k), _ptr(den), int(V), int(K), float(beta),
+            mode, float(keep or 0.0), float(share or 0.0), _ptr(out), _ptr(flags))
 
 
 def readout_theta(n_dk, lab_mask, D, K, alpha, out, keep=None, share=None):
     """llda_readout_theta: out (D, K) float64 = theta of the counts, or its running mean (as readout_phi)."""
     mode = 0 if keep is None else 1
-    check(lib().llda_readout_theta(_ptr(n_dk), _ptr(lab_mask), int(D), int(K), float(alpha), mode,
-                                   float(keep or 0.0), float(share or 0.0), _ptr(out), _stream()),
-          "llda_readout_theta")
+    _launch(out, lib().llda_readout_theta, "llda_readout_theta", _ptr(n_dk), _ptr(lab_mask), int(D), int(K), float(alpha),
+            mode, float(keep or 0.0), float(share or 0.0), _ptr(out))
 
 
 def selftest_div(n, seed=1):
@@ -213,7 +239,7 @@ def selftest_div(n, seed=1):
     division differs from the hardware IEEE division.  Must be 0."""
     import torch
     bad = torch.zeros((1,), dtype=torch.int64, device="cuda")
-    check(lib().llda_selftest_div(int(seed), int(n), _ptr(bad), _stream()), "llda_selftest_div")
+    _launch(bad, lib().llda_selftest_div, "llda_selftest_div", int(seed), int(n), _ptr(bad))
     return int(bad.item())
 
 
@@ -224,4 +250,4 @@ def foldin(*, doc_off, word, init_idx, freq, ph, init_rows, slot_valid, z, n_dk,
                        int(iters), int(thinning), 1 if beta_fallback else 0, int(avg_mode), 0, float(alpha),
                        float(beta), float(c_init), float(c_loop), int(seed) & 0xFFFFFFFFFFFFFFFF,
                        int(stream_id) & 0xFFFFFFFF, 0, _ptr(doc_ids))
-    check(lib().llda_foldin(ctypes.byref(a), _stream()), "llda_foldin")
+    _launch(z, lib().llda_foldin, "llda_foldin", ctypes.byref(a))

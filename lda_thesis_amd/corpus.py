@@ -21,6 +21,30 @@ def csr_from_doc_tups(doc_tups):
     return doc_off, pairs[:, 0].astype(np.int32), pairs[:, 1].astype(np.int32)
 
 
+def cascade_corpus_from_csr(doc_off, word, freq, lab_off, lab_idx, names, depth=3):
+    """Token lists and prefix-expanded label lists (what CascadeLDA.load_corpus returns, reference
+    CascadeLDA.py:8-49) rebuilt from a tokenised corpus in CSR form: word id v with frequency f becomes f copies of
+    the pseudo-token 'w%05d' % v, every label code (names[k], k != 0 = 'root') is expanded to its prefixes up to
+    ``depth`` in first-seen order.  -> (docs, labs, labelset)."""
+    docs, labs, seen = [], [], {}
+    for d in range(len(doc_off) - 1):
+        toks = []
+        for v, f in zip(word[doc_off[d]:doc_off[d + 1]], freq[doc_off[d]:doc_off[d + 1]]):
+            toks += ["w%05d" % v] * int(f)
+        docs.append(toks)
+        lab = []
+        for k in lab_idx[lab_off[d]:lab_off[d + 1]]:
+            if k != 0:
+                for i in range(depth):
+                    p = names[k][:i + 1]
+                    if p not in lab:
+                        lab.append(p)
+        for x in lab:
+            seen.setdefault(x, 1)
+        labs.append(lab)
+    return docs, labs, list(seen.keys())
+
+
 def zipf_cdf(V, s=1.0, device="cpu"):
     w = 1.0 / torch.arange(1, V + 1, dtype=torch.float64, device=device) ** s
     cdf = torch.cumsum(w, 0)

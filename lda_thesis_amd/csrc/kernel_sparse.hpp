@@ -109,8 +109,8 @@ __device__ __forceinline__ int allor_i32(int x, int lane)
 // bookkeeping (SGPR spills) than the arithmetic they skip.
 // `ok` = no site of this batch has been undecidable so far; `done` counts the decided sites.  The reciprocal y of
 // n_k + V*beta is recomputed ONCE per site, after the removal (it then also covers the previous site's add-back).
-template <int GS, int J>
-__device__ __forceinline__ void sparse_site(const KParams &P, int nb, int sf, int sz, int su_lo, int su_hi,
+template <int GS, int J, class PT>
+__device__ __forceinline__ void sparse_site(const PT &P, int nb, int sf, int sz, int su_lo, int su_hi,
                                             const int (&xg)[8], bool live, int pos, int A, int &ndk, int &nk,
                                             int &my_zn, int &ok, int &done, int lig, int lane, int gbase, uint64_t gmask)
 {

@@ -24,6 +24,8 @@
 //                       llda_sweep_kernel         tiered kernel, per-document state in LDS (the hot kernel)
 //   kernel_sparse.hpp   llda_sweep_sparse_kernel  one lane per ALLOWED topic for sparse label sets; hands
 //                                                 undecided documents to llda_sweep_kernel (resume list)
+//   kernel_batch.hpp    llda_sweep_batch_kernel   one sweep over many independent small problems (CascadeLDA's
+//                                                 ensemble) in one launch, sparse-kernel arithmetic
 //   kernel_readout.hpp  llda_loglik_kernel, llda_readout_phi / _theta kernels (thinning read-outs)
 //   kernel_foldin.hpp   llda_foldin_kernel (test-time sampler)
 //   kernel_counts.hpp   llda_commit_log_kernel, llda_apply_delta_kernel, llda_count_init_kernel, self test
@@ -41,6 +43,7 @@
 #include "draw_tiers.hpp"
 #include "kernel_sweep.hpp"
 #include "kernel_sparse.hpp"
+#include "kernel_batch.hpp"
 #include "kernel_readout.hpp"
 #include "kernel_foldin.hpp"
 #include "kernel_counts.hpp"
@@ -378,6 +381,42 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     case 64: return dispatch_sweep_T<64>(L.T, P, has_tail, fast, dense, blocks, st);
     }
     return LLDA_E_BAD_K;
+}
+
+int llda_sweep_batch(const llda_batch_args *a, void *stream)
+{
+    if (!a || a->n_inst < 0 || a->V < 1) return LLDA_E_BAD_ARG;
+    if (a->n_inst == 0) return LLDA_OK;
+    if (!a->inst_off || !a->order || !a->word || !a->freq || !a->z || !a->inst_prob || !a->inst_doc || !a->live_off ||
+        !a->live_pos || !a->ndk_off || !a->n_dk || !a->kw_off || !a->nk_off || !a->kp || !a->prob_stream || !a->counts ||
+        !a->delta)
+        return LLDA_E_BAD_ARG;
+    if (a->lanes != 8 && a->lanes != 16 && a->lanes != 32 && a->lanes != 64) return LLDA_E_BAD_ARG;
+    BParams P;
+    memset(&P, 0, sizeof P);
+    P.inst_off = a->inst_off; P.order = a->order; P.n_inst = a->n_inst; P.word = a->word; P.freq = a->freq; P.z = a->z;
+    P.inst_prob = a->inst_prob; P.inst_doc = a->inst_doc; P.live_off = a->live_off; P.live_pos = a->live_pos;
+    P.ndk_off = a->ndk_off; P.n_dk = a->n_dk; P.kw_off = a->kw_off; P.nk_off = a->nk_off; P.kp = a->kp;
+    P.prob_stream = a->prob_stream;
+    P.counts = a->counts; P.delta = a->delta; P.status = a->status;
+    P.alpha = a->alpha; P.beta = a->beta; P.vbeta = (double)a->V * a->beta;
+    // the sparse arithmetic needs strictly positive scores and an in-range reciprocal (as llda_sweep's tiered kernels)
+    if (!(a->alpha >= 1e-6 && a->beta >= 1e-6 && P.vbeta < 1099511627776.0)) return LLDA_E_BAD_ARG;
+    P.margin_rel = a->debug_margin == 0 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
+    P.key0 = (uint32_t)a->seed; P.key1 = (uint32_t)(a->seed >> 32); P.sweep = a->sweep;
+    const int gpb = 256 / a->lanes;
+    const int64_t blocks = (a->n_inst + gpb - 1) / gpb;
+    if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->lanes) {
+    case 8: hipLaunchKernelGGL(llda_sweep_batch_kernel<8>, grid, block, 0, st, P); break;
+    case 16: hipLaunchKernelGGL(llda_sweep_batch_kernel<16>, grid, block, 0, st, P); break;
+    case 32: hipLaunchKernelGGL(llda_sweep_batch_kernel<32>, grid, block, 0, st, P); break;
+    default: hipLaunchKernelGGL(llda_sweep_batch_kernel<64>, grid, block, 0, st, P); break;
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
 }
 
 int llda_commit_log(const int64_t *item_begin, const int32_t *item_len, const int32_t *item_word, int64_t n_items,

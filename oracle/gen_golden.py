@@ -341,6 +341,67 @@ def gen_cascade():
     print("cascade_toy: %d sub-problems, K=%d, ph sum %.6f" % (len(sizes), c.K, np.nansum(c.ph)))
 
 
+def gen_cascade_abstracts(it=4, thinning=2):
+    """BASELINE configs[4] at its real size: the reference's CascadeLDA.go_down_tree(it=4, s=2) on the abstracts
+    corpus (rebuilt from tests/golden/abstracts_d3.npz exactly as tools/bench_cascade.py and the GPU test do:
+    lda_thesis_amd.corpus.cascade_corpus_from_csr), 122 sub-problems, every SubLDA sweep executed as an O3 sweep by
+    the reference's own SubLDA.training_iteration on per-document views, sub-problem i keyed with RNG stream i.
+    Pins CascadeLDA.py:113-184 + 347-434.  The fixture holds digests only (ph is 513 x 15260 float64): the SHA-256
+    of the final ``ph``, a strided sample of it, and per sub-problem the digest of (n_k_v, n_d_k, n_zk, z) after its
+    last sweep plus its get_ph() digest."""
+    import hashlib
+    from lda_thesis_amd.corpus import cascade_corpus_from_csr
+    g = np.load(os.path.join(GOLDEN, "abstracts_d3.npz"))
+    names = [str(x) for x in g["labelset"]]
+    docs, labs, labelset = cascade_corpus_from_csr(g["doc_off"], g["word"], g["freq"], g["lab_off"], g["lab_idx"], names)
+    dicti = Dictionary(docs)
+    alpha, beta, seed, np_seed = 0.1, 0.01, 1, 0
+    np.random.seed(np_seed)
+    c = REF_C.CascadeLDA(docs, labs, list(labelset), dicti, alpha, beta)
+    cls = REF_C.SubLDA
+    orig_init, orig_sweep, orig_run = cls.__init__, cls.training_iteration, cls.run_training
+    counter = [0]
+    sizes, digests, ph_digests, init_digests = [], [], [], []
+    t0 = time.time()
+
+    def init(self, *a, **k):
+        orig_init(self, *a, **k)
+        self._stream, self._sweeps = counter[0], 0
+        counter[0] += 1
+        sizes.append((self.D, self.K, sum(len(d) for d in self.docs)))
+        init_digests.append(model_digest(self))
+
+    def sweep(self):
+        draw = orc.KeyedDraw(seed, self._stream)
+        o3_sweep(REF_C, cls, self, draw, self._sweeps, method=orig_sweep)
+        self._sweeps += 1
+
+    def run(self, *a, **k):
+        orig_run(self, *a, **k)
+        digests.append(model_digest(self))
+        ph_digests.append(hashlib.sha256(np.ascontiguousarray(self.get_ph()).tobytes()).hexdigest())
+        print("  sub-problem %3d  D=%5d K=%2d  %s  (%.0fs)" % (self._stream, self.D, self.K, digests[-1][:12],
+                                                             time.time() - t0), flush=True)
+
+    cls.__init__, cls.training_iteration, cls.run_training = init, sweep, run    # in-memory wrappers; bodies untouched
+    try:
+        import io
+        from contextlib import redirect_stdout
+        with redirect_stdout(io.StringIO()) as _:
+            pass
+        c.go_down_tree(it=it, s=thinning)
+    finally:
+        cls.__init__, cls.training_iteration, cls.run_training = orig_init, orig_sweep, orig_run
+    ph = np.ascontiguousarray(c.ph)
+    np.savez_compressed(os.path.join(GOLDEN, "cascade_abstracts.npz"), seed=seed, np_seed=np_seed, alpha=alpha, beta=beta,
+                        it=it, s=thinning, sizes=np.array(sizes), digests=np.array(digests),
+                        init_digests=np.array(init_digests), ph_digests=np.array(ph_digests),
+                        ph_sha256=np.array(hashlib.sha256(ph.tobytes()).hexdigest()),
+                        ph_sample=ph[:, ::53].copy(), ph_rowsum=np.nansum(ph, axis=1),
+                        labelset=np.array(list(c.labelmap.keys())), reference_seconds=time.time() - t0)
+    print("cascade_abstracts: %d sub-problems, K=%d V=%d, %.0f s" % (len(sizes), c.K, c.V, time.time() - t0))
+
+
 def gen_runtest():
     """LabeledLDA.run_test of the reference (LabeledLDA.py:155-212) with the keyed draw injected: the
     prep4test draws of document d use RNG sweep word 0xFFFFFFFF, iteration i uses sweep i; sites are
@@ -550,6 +611,8 @@ if __name__ == "__main__":
         gen_runtest()
     if "cascade" in what:
         gen_cascade()
+    if "cascade_abstracts" in what:
+        gen_cascade_abstracts()
     if "abstracts" in what:
         gen_abstracts()
     if "abstracts200" in what:

@@ -125,6 +125,78 @@ def test_cascade_go_down_tree_matches_reference(capsys):
     assert out.count("Working on parent node") == len(g["sizes"]) - 1
 
 
+def test_cascade_batched_ensemble_equals_one_by_one_and_falls_back():
+    """the batched ensemble (llda_sweep_batch: all sub-problems in one launch) leaves the state the sub-problems
+    reach one by one through llda_sweep, sub-problem by sub-problem; and when the batched arithmetic reports a site
+    it cannot decide (forced here) go_down_tree silently takes the one-by-one path -- same ph, same numpy stream."""
+    import llda_oracle as orc
+    from fixture_corpora import cascade_corpus
+    from lda_thesis_amd.CascadeLDA import CascadeLDA
+    from lda_thesis_amd.text import Dictionary
+    g = load_golden("cascade_toy")
+    docs, labs, labelset = cascade_corpus()
+    dicti = Dictionary(docs)
+
+    def run(**kw):
+        np.random.seed(int(g["np_seed"]))
+        c = CascadeLDA(docs, labs, list(labelset), dicti, float(g["alpha"]), float(g["beta"]), seed=int(g["seed"]))
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+    a = run()
+    a.go_down_tree(4, 2, batched=True, keep_state=True)
+    assert a._ensemble is not None and not a._ensemble.undecided()
+    after_a = np.random.random_sample()
+    b = run(_keep_subs=[])
+    b.go_down_tree(4, 2, batched=False)
+    after_b = np.random.random_sample()
+    assert after_a == after_b                                  # both consumed numpy's stream identically
+    np.testing.assert_array_equal(a.ph, g["ph"])
+    np.testing.assert_array_equal(b.ph, g["ph"])
+    assert len(b._keep_subs) == len(g["sizes"])
+    for i, sub in b._keep_subs:
+        n_k_v, n_d_k, n_zk, z = a._ensemble.problem_state(i)
+        assert orc.digest(n_k_v, n_d_k, n_zk, z) == orc.digest(sub.n_k_v, sub.n_d_k, sub.n_zk, np.concatenate(sub.z_dn))
+    # forced fall-back
+    c = run(_batch_debug_margin=-1)
+    c.go_down_tree(4, 2, batched=True, keep_state=True)
+    assert c._ensemble is None
+    np.testing.assert_array_equal(c.ph, g["ph"])
+    assert np.random.random_sample() == after_a
+
+
+def test_cascade_abstracts_ensemble_matches_reference():
+    """BASELINE configs[4] at its real size: go_down_tree(4, 2) on the abstracts corpus, 122 sub-problems, against
+    the reference's own go_down_tree run with per-document-snapshot sweeps (oracle/gen_golden.py
+    gen_cascade_abstracts; /root/reference/CascadeLDA.py:113-184, 347-434): every sub-problem's integer state after
+    its last sweep, and the final ph, bit for bit."""
+    import hashlib
+    import llda_oracle as orc
+    from lda_thesis_amd.CascadeLDA import CascadeLDA
+    from lda_thesis_amd.corpus import cascade_corpus_from_csr
+    from lda_thesis_amd.text import Dictionary
+    g = load_golden("cascade_abstracts")
+    a = load_golden("abstracts_d3")
+    names = [str(x) for x in a["labelset"]]
+    docs, labs, labelset = cascade_corpus_from_csr(a["doc_off"], a["word"], a["freq"], a["lab_off"], a["lab_idx"], names)
+    dicti = Dictionary(docs)
+    np.random.seed(int(g["np_seed"]))
+    c = CascadeLDA(docs, labs, list(labelset), dicti, float(g["alpha"]), float(g["beta"]), seed=int(g["seed"]))
+    assert list(c.labelmap.keys()) == [str(x) for x in g["labelset"]]
+    c.go_down_tree(int(g["it"]), int(g["s"]), keep_state=True)
+    ens = c._ensemble
+    assert ens is not None and len(ens.plans) == len(g["sizes"]) == 122
+    for i in range(len(ens.plans)):
+        n_k_v, n_d_k, n_zk, z = ens.problem_state(i)
+        assert (n_d_k.shape[0], n_d_k.shape[1], z.shape[0]) == tuple(int(x) for x in g["sizes"][i]), i
+        assert orc.digest(n_k_v, n_d_k, n_zk, z) == str(g["digests"][i]), "sub-problem %d" % i
+    np.testing.assert_array_equal(c.ph[:, ::53], g["ph_sample"])
+    ph = np.ascontiguousarray(c.ph)
+    with np.errstate(invalid="ignore"):
+        ph[np.isnan(ph)] = (np.zeros(1) / np.zeros(1))[0]      # the bit pattern numpy's own 0/0 has (a never-used child)
+    assert hashlib.sha256(ph.tobytes()).hexdigest() == str(g["ph_sha256"])
+
+
 @pytest.mark.parametrize("name", ["k12", "k40", "k130"])
 def test_fold_in_matches_reference_run_test(name):
     """llda_foldin (prep4test + run_test on the device) vs the reference's run_test with the keyed draw."""

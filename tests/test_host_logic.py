@@ -129,3 +129,69 @@ def test_synthetic_corpus_properties():
     assert torch.equal(w2.view(200, 30), w)
     head = (w < 50).float().mean()
     assert head > 0.3                               # Zipf: the 10% most frequent ids dominate
+
+
+def test_vectorised_choice_equals_numpy_choice():
+    """ensemble.draw_initial_topics restates numpy's legacy choice(K, size, p=lab/lab.sum()) (what the reference
+    draws per document, /root/reference/CascadeLDA.py:373-381): same uniforms, same topics, same stream position."""
+    from lda_thesis_amd.ensemble import draw_initial_topics
+    rng = np.random.default_rng(12)
+    for K in (2, 3, 7, 20, 57):
+        D = 300
+        labs = (rng.random((D, K)) < 0.35).astype(float)
+        labs[:, 0] = 1.0
+        lens = rng.integers(1, 40, size=D)
+        np.random.seed(K)
+        want = np.concatenate([np.random.choice(K, size=n, p=lab / lab.sum()) for lab, n in zip(labs, lens)])
+        after_want = np.random.random_sample()
+        np.random.seed(K)
+        u = np.random.random_sample(int(lens.sum()))
+        after_got = np.random.random_sample()
+        n_allowed = labs.sum(axis=1).astype(np.int64)
+        a_max = int(n_allowed.max())
+        allowed = np.full((D, a_max), -1, dtype=np.int64)
+        for d in range(D):
+            ids = np.flatnonzero(labs[d])
+            allowed[d, :len(ids)] = ids
+        got = draw_initial_topics(allowed, n_allowed, np.repeat(np.arange(D), lens), u)
+        np.testing.assert_array_equal(got, want)
+        assert after_got == after_want
+
+
+def test_plan_subproblems_equals_the_list_based_enumeration():
+    """CascadeLDA.plan_subproblems (index arrays for the batched ensemble) describes exactly the sub-problems
+    enumerate_subproblems + SubLDA.__init__ build (reference CascadeLDA.py:113-127, 135-184, 347-392), and the
+    vectorised initial assignments equal the per-document np.random.choice stream."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from fixture_corpora import cascade_corpus
+    from lda_thesis_amd.CascadeLDA import CascadeLDA, SubLDA
+    from lda_thesis_amd.ensemble import draw_initial_topics
+    from lda_thesis_amd.text import Dictionary
+    docs, labs, labelset = cascade_corpus()
+    labs[3] = labs[3] + [labs[3][0]]                         # a duplicated label, as short label fields produce
+    dicti = Dictionary(docs)
+    np.random.seed(3)
+    c = CascadeLDA(docs, labs, list(labelset), dicti, 0.1, 0.01, seed=5)
+    plans = c.plan_subproblems()
+    tasks = c.enumerate_subproblems()
+    assert [p["parent"] for p in plans] == [t["parent"] for t in tasks]
+    lens = np.array([len(t) for t in c.doc_tups])
+    np.random.seed(99)
+    subs = [SubLDA(t["doc_tups"], t["labs"], t["labset"], dicti, alpha=0.1, beta=0.01, seed=5, stream_id=i, defer=True)
+            for i, t in enumerate(tasks)]
+    np.random.seed(99)
+    for pl, t, sub in zip(plans, tasks, subs):
+        assert ["root"] + pl["labset"] == t["labset"] and pl["K"] == sub.K      # SubLDA inserted 'root'
+        assert [c.doc_tups[d] for d in pl["docs"]] == t["doc_tups"]
+        flags = np.zeros((len(pl["docs"]), pl["K"]))
+        for r, (row, n) in enumerate(zip(pl["allowed"], pl["n_allowed"])):
+            assert (row[:n] >= 0).all() and (row[n:] == -1).all() and (np.diff(row[:n]) > 0).all()
+            flags[r, row[:n]] = 1.0
+        np.testing.assert_array_equal(flags, sub.labs)
+        n_sites = lens[pl["docs"]]
+        u = np.random.random_sample(int(n_sites.sum()))
+        z = draw_initial_topics(pl["allowed"], pl["n_allowed"], np.repeat(np.arange(len(pl["docs"])), n_sites), u)
+        np.testing.assert_array_equal(z, sub._z0)
+        t["labset"].remove("root")
