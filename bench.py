@@ -407,6 +407,21 @@ def main():
         dist.all_reduce(t)
         total_sites = int(t.item())
 
+    # N > 1: the same shard once more with the exchange pipelined over two document ranges (the rows of the first
+    # range are all-reduced while the second is sampled) -- a probe, reported next to the timed line
+    probe = None
+    if dist is not None and name != "abstracts" and args.overlap < 0 and not args.no_extras:
+        keep = (info["K"], info["V"], info["N"], info["live_topics"], info["docs_local"], info["docs_total"], info["desc"])
+        del sampler, info
+        torch.cuda.empty_cache()
+        sampler, info = build_sampler(name, dev, rank, world, True, docs_total=args.docs,
+                                      docs_per_group=args.docs_per_group, overlap=2)
+        dt2, k2 = time_sweeps(sampler, max(5, args.steps // 4), 2, dist, dev)
+        probe = {"overlap_ranges": 2, "steps": max(5, args.steps // 4), "ms_per_step": dt2 / max(5, args.steps // 4) * 1e3,
+                 "exchange_ms": sampler.comm_stats(),
+                 "state_checksum_n_k_after_probe": int(sampler.n_k.to(torch.int64).mul(
+                     torch.arange(1, sampler.n_k.numel() + 1, device=dev)).sum().item())}
+
     if rank == 0:
         K, V, N = info["K"], info["V"], info["N"]
         live = info["live_topics"]
@@ -438,6 +453,8 @@ def main():
         }
         if comm is not None:
             line["exchange_ms"] = comm
+        if probe is not None:
+            line["overlap_probe"] = probe
         # ---- extras (N = 1, default workload): the other configurations, timed in this run ----
         extra = {}
         measured = {name: dict(kernel_ms=kavg, sites=sites_local, docs=info["docs_local"], live=live)}

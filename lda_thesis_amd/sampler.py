@@ -66,13 +66,18 @@ class GibbsSampler(object):
                ``llda_commit_log`` folds the log into n_kw without global atomics; False = int32 atomics on the
                delta buffer from inside the sweep kernels.  Same counts either way.  None (default) = log from
                2^20 local sites up (below that the extra pass costs more than the atomics it saves).
+    overlap_ranges : C > 1 = the local documents are cut into C contiguous ranges; the exchange rows of range i are
+               all-reduced (asynchronously, on the collective's own stream) while range i+1 is still being sampled.
+               Every range exchanges its own dense rows, so C ranges move C times the bytes -- see DESIGN.md section 7
+               for when that pays.  Needs the commit-log exchange rows on every rank (else it is ignored).
     backend  : module with the _native entry points (tests inject a CPU checker here; the product
                always uses the HIP library).
     """
 
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
                  stream_id=0, doc_base=0, device=None, group=None, backend=None, sort_docs=True,
-                 docs_per_group=0, sharded=True, sparse_labels=True, commit_log=None, exchange_always=False):
+                 docs_per_group=0, sharded=True, sparse_labels=True, commit_log=None, exchange_always=False,
+                 overlap_ranges=1):
         self.backend = backend if backend is not None else _native
         if backend is None:
             _native.lib()                                   # fail loudly when the extension is missing
@@ -90,6 +95,8 @@ class GibbsSampler(object):
         self.debug_margin = 0          # test hook of the two-tier draw (include/llda_gibbs.h)
         self.kernel_events = None      # set to [] to record a (start, end) HIP event pair per sweep kernel
         self.exchange_always = bool(exchange_always)   # take the exchange path even with a single rank (tests)
+        self.overlap_ranges = max(1, int(overlap_ranges))
+        self.comm_events = None        # set to [] to record (start, end) event pairs around the waits for the collectives
         self.layout = lay = group_layout(self.K)
         dev = self.device
 
@@ -116,6 +123,7 @@ class GibbsSampler(object):
         if sparse_labels and labs is not None and self.D > 0:
             self._make_live()
         self.csc_pos = self.commit_log = None
+        self._ranges = self._make_ranges()
         if commit_log is None:
             commit_log = self.S >= (1 << 20)
         if self.S >= (1 << 31):
@@ -123,7 +131,7 @@ class GibbsSampler(object):
         if commit_log and self.S > 0:
             self._make_commit_log()
         self._sort_docs = bool(sort_docs)
-        self._off_host = self.doc_off.cpu().numpy() if self.S > self.MAX_CALL_SITES else None
+        self._off_host = self.doc_off.cpu().numpy() if (self.S > self.MAX_CALL_SITES or len(self._ranges) > 2) else None
         self._calls = self._make_calls(self.doc_off[1:] - self.doc_off[:-1])
         self.doc_order = self._calls[0][2]       # (order of the first -- normally the only -- call)
 
@@ -148,7 +156,7 @@ class GibbsSampler(object):
             self.n_dk[:, self._topic_pos] = as_dev(counts["n_d_k"], torch.int32)
             self.n_kw[:, self._topic_pos] = as_dev(np.asarray(counts["n_k_v"]).T, torch.int32)
             self.n_k[self._topic_pos] = as_dev(counts["n_zk"], torch.int32)
-        self.row_off = self.rows = None
+        self.row_off = self.rows = self._rows_list = None
         if self.sharded and (_dist_active(self.group) or exchange_always):
             self._make_exchange_rows()
 
@@ -176,9 +184,12 @@ class GibbsSampler(object):
         off = torch.cumsum(size, 0) - size
         self.row_off = torch.where(torch.cat([pairs, torch.tensor([False], device=dev)]), ~off, off).contiguous()
         total = int(off[-1].item()) + KP
-        self.rows = torch.zeros((total,), dtype=torch.int32, device=dev)
+        # one buffer per overlap range (normally one): the rows of range i travel while range i+1 is sampled
+        self._rows_list = [torch.zeros((total,), dtype=torch.int32, device=dev) for _ in range(len(self._ranges) - 1)]
+        self.rows = self._rows_list[0]
         # the sweep kernels add the n_k changes straight into row V; the int32 delta buffer is not needed
-        self.n_k_delta = self.rows[total - KP:]
+        self._nk_delta_list = [r[total - KP:] for r in self._rows_list]
+        self.n_k_delta = self._nk_delta_list[0]
         self.n_kw_delta = None
         self._delta = self.rows
 
@@ -235,6 +246,13 @@ class GibbsSampler(object):
         self.resume = torch.zeros((cap, 66), dtype=torch.int32, device=dev)
         self.resume_count = torch.zeros((1,), dtype=torch.int32, device=dev)
 
+    def _make_ranges(self):
+        """document bounds of the overlap ranges (contiguous, balanced by site count); one range = no overlap."""
+        C = self.overlap_ranges
+        if C <= 1:
+            return [0, self.D]
+        return shard_documents(self.doc_off.cpu().numpy(), C)      # (empty ranges when D < C: every rank makes C)
+
     LOG_ITEM = 4096    # most log entries one wavefront of llda_commit_log folds (hot words are cut into items)
     MAX_CALL_SITES = (1 << 30) - 1   # llda_sweep addresses the sites of one call with 32-bit byte offsets
 
@@ -246,75 +264,114 @@ class GibbsSampler(object):
             if not self._sort_docs or hi - lo < 2 or int(ln.min()) == int(ln.max()):
                 return None
             return torch.sort(ln, descending=True, stable=True).indices.to(torch.int32)
-        if self.S <= self.MAX_CALL_SITES:
+        if self.S <= self.MAX_CALL_SITES and len(self._ranges) == 2:
             return [(0, self.D, order(0, self.D))]
         off = self._off_host
         if int(np.diff(off).max()) > self.MAX_CALL_SITES:
             raise ValueError("a document has more than %d sites" % self.MAX_CALL_SITES)
-        calls, lo = [], 0
-        while lo < self.D:
-            hi = int(np.searchsorted(off, off[lo] + self.MAX_CALL_SITES, side="right")) - 1
-            hi = max(min(hi, self.D), lo + 1)
-            calls.append((lo, hi, order(lo, hi)))
-            lo = hi
+        calls = []
+        for r in range(len(self._ranges) - 1):
+            lo, end = self._ranges[r], self._ranges[r + 1]
+            while lo < end:
+                hi = int(np.searchsorted(off, off[lo] + self.MAX_CALL_SITES, side="right")) - 1
+                hi = max(min(hi, end), lo + 1)
+                calls.append((lo, hi, order(lo, hi)))
+                lo = hi
         return calls
 
     def _make_commit_log(self):
-        """word-major (CSC) view of the sites: position of every site, frequencies in that order, and the work
-        items of llda_commit_log (runs of at most LOG_ITEM entries of one word)."""
-        dev = self.device
+        """word-major (CSC) view of the sites -- range by range when the exchange is pipelined over document ranges
+        -- : position of every site, frequencies in that order, and the work items of llda_commit_log (runs of at
+        most LOG_ITEM entries of one word of one range)."""
+        dev, V = self.device, self.V
+        C = len(self._ranges) - 1
         w64 = self.word.to(torch.int64)
+        if C > 1:                                            # key = range * V + word
+            site_bounds = self.doc_off[torch.as_tensor(self._ranges[1:-1], dtype=torch.int64, device=dev)]
+            rng = torch.bucketize(torch.arange(self.S, device=dev), site_bounds, right=True)
+            w64 = w64 + rng * V
         order = torch.sort(w64, stable=True).indices
         self.csc_pos = torch.empty((self.S,), dtype=torch.int32, device=dev)
         self.csc_pos[order] = torch.arange(self.S, dtype=torch.int32, device=dev)
         self.freq_csc = self.freq[order].contiguous()
         del order
-        per_word = torch.bincount(w64, minlength=self.V)
-        word_off = torch.zeros((self.V + 1,), dtype=torch.int64, device=dev)
+        per_word = torch.bincount(w64, minlength=C * V)
+        word_off = torch.zeros((C * V + 1,), dtype=torch.int64, device=dev)
         torch.cumsum(per_word, 0, out=word_off[1:])
         n_items = (per_word + (self.LOG_ITEM - 1)) // self.LOG_ITEM            # 0 for words without a site
-        words = torch.repeat_interleave(torch.arange(self.V, device=dev), n_items)
-        first = torch.zeros((self.V + 1,), dtype=torch.int64, device=dev)
+        words = torch.repeat_interleave(torch.arange(C * V, device=dev), n_items)
+        first = torch.zeros((C * V + 1,), dtype=torch.int64, device=dev)
         torch.cumsum(n_items, 0, out=first[1:])
         part = torch.arange(words.numel(), device=dev) - first[words]          # index of the item within its word
         self.item_begin = (word_off[words] + part * self.LOG_ITEM).contiguous()
         self.item_len = torch.minimum(per_word[words] - part * self.LOG_ITEM,
                                       torch.full_like(part, self.LOG_ITEM)).to(torch.int32).contiguous()
         shared = n_items[words] > 1
-        self.item_word = torch.where(shared, words - (1 << 31), words).to(torch.int32).contiguous()
+        wid = words % V
+        self.item_word = torch.where(shared, wid - (1 << 31), wid).to(torch.int32).contiguous()
+        self._item_bounds = first[::V].cpu().tolist()                          # items of range r: [b[r], b[r+1])
         self.commit_log = torch.zeros((self.S,), dtype=torch.int32, device=dev)
 
     # ------------------------------------------------------------------ the hot path
+    def _timed(self, fn):
+        """run fn(); with comm_events enabled on a GPU, bracket it with events on the current stream (the time the
+        compute stream spends in / waiting for the collective = the exposed communication)."""
+        if self.comm_events is None or self.device.type != "cuda":
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self.comm_events.append((a, b))
+        return out
+
     def sweep(self):
         """One Gibbs sweep over the local documents + exchange + fold."""
+        import torch.distributed as dist
         ev = None
         if self.kernel_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()              # same stream the kernel is enqueued on (torch's current stream)
         logged = self.commit_log is not None
+        have_group = dist.is_available() and dist.is_initialized()
+        exchange = self.sharded and (_dist_active(self.group) or self.exchange_always)
+        n_ranges = len(self._ranges) - 1
+        pipelined = exchange and self.rows is not None and n_ranges > 1 and logged
         if len(self._calls) == 1:
             self._calls[0] = (0, self.D, self.doc_order)
-        for lo, hi, order in self._calls:
-            s0 = 0 if len(self._calls) == 1 else int(self._off_host[lo])
-            s1 = self.S if len(self._calls) == 1 else int(self._off_host[hi])
-            self.backend.sweep(doc_off=self.doc_off[lo:hi + 1], doc_order=order, word=self.word, freq=self.freq,
-                               z=self.z, lab_mask=self.lab_mask[lo:hi], n_dk=self.n_dk[lo:hi], n_kw=self.n_kw,
-                               n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=self.n_k_delta,
-                               status=self.status, D=hi - lo, V=self.V, K=self.K, alpha=self.alpha,
-                               beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
-                               stream_id=self.stream_id, doc_base=self.doc_base + lo,
-                               docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
-                               debug_margin=self.debug_margin,
-                               live_off=None if self.live_off is None else self.live_off[lo:hi + 1],
-                               live_pos=self.live_pos, resume=self.resume, resume_count=self.resume_count,
-                               live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
-                               n_sites=s1 - s0)
+        works, call = [], 0
+        for r in range(n_ranges):
+            nk_delta = self._nk_delta_list[r] if pipelined else self.n_k_delta
+            while call < len(self._calls) and self._calls[call][0] < self._ranges[r + 1]:
+                lo, hi, order = self._calls[call]
+                call += 1
+                s0 = 0 if len(self._calls) == 1 else int(self._off_host[lo])
+                s1 = self.S if len(self._calls) == 1 else int(self._off_host[hi])
+                self.backend.sweep(doc_off=self.doc_off[lo:hi + 1], doc_order=order, word=self.word, freq=self.freq,
+                                   z=self.z, lab_mask=self.lab_mask[lo:hi], n_dk=self.n_dk[lo:hi], n_kw=self.n_kw,
+                                   n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=nk_delta,
+                                   status=self.status, D=hi - lo, V=self.V, K=self.K, alpha=self.alpha,
+                                   beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
+                                   stream_id=self.stream_id, doc_base=self.doc_base + lo,
+                                   docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
+                                   debug_margin=self.debug_margin,
+                                   live_off=None if self.live_off is None else self.live_off[lo:hi + 1],
+                                   live_pos=self.live_pos, resume=self.resume, resume_count=self.resume_count,
+                                   live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
+                                   n_sites=s1 - s0)
+            if pipelined:
+                # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
+                # collective's stream (ordered after the fold) while the next range is sampled on this one
+                i0, i1 = self._item_bounds[r], self._item_bounds[r + 1]
+                if i1 > i0:
+                    self.backend.commit_log(self.item_begin[i0:i1], self.item_len[i0:i1], self.item_word[i0:i1],
+                                            self.commit_log, self.freq_csc, self.K, self._rows_list[r],
+                                            row_off=self.row_off)
+                if have_group:
+                    works.append(dist.all_reduce(self._rows_list[r], group=self.group, async_op=True))
         if ev is not None:
             ev[1].record()
             self.kernel_events.append(ev)
-        exchange = self.sharded and (_dist_active(self.group) or self.exchange_always)
-        import torch.distributed as dist
-        have_group = dist.is_available() and dist.is_initialized()
         if not exchange:
             if logged:
                 # single device: the log is folded straight into n_kw (and n_k += its delta) -- no delta pass
@@ -322,6 +379,10 @@ class GibbsSampler(object):
                                         self.freq_csc, self.K, self.n_kw, self.n_k, self.n_k_delta)
             else:
                 self.backend.apply_delta(self._counts, self._delta)
+        elif pipelined:
+            self._timed(lambda: [w.wait() for w in works])
+            for r in range(n_ranges):
+                self.backend.apply_rows(self.row_off, self._rows_list[r], self.K, self._counts)
         elif self.rows is not None:
             # every rank folds its log into the exchange rows (int16 pairs for all but the hot words), ONE int32
             # all-reduce over xGMI, then the rows are decoded into [n_kw | n_k]
@@ -329,16 +390,27 @@ class GibbsSampler(object):
                 self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
                                         self.freq_csc, self.K, self.rows, row_off=self.row_off)
             if have_group:
-                dist.all_reduce(self.rows, group=self.group)
+                self._timed(lambda: dist.all_reduce(self.rows, group=self.group))
             self.backend.apply_rows(self.row_off, self.rows, self.K, self._counts)
         else:
             if logged:
                 self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
                                         self.freq_csc, self.K, self.n_kw_delta)
             if have_group:
-                dist.all_reduce(self._delta, group=self.group)      # RCCL over xGMI: SUM int32, one collective
+                self._timed(lambda: dist.all_reduce(self._delta, group=self.group))   # RCCL over xGMI: SUM int32, one collective
             self.backend.apply_delta(self._counts, self._delta)
         self.sweeps_done += 1
+
+    def comm_stats(self):
+        """mean exposed communication per sweep (ms the compute stream spent in / waiting for the collectives) from
+        the recorded comm_events, with the exchange geometry; None when nothing was recorded."""
+        if not self.comm_events:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self.comm_events]
+        n_coll = len(self._rows_list) if self._rows_list is not None else 1
+        nbytes = (self.rows.numel() if self.rows is not None else self._delta.numel()) * 4
+        return {"exposed_ms_per_sweep": float(np.mean(ms)), "collectives_per_sweep": n_coll,
+                "bytes_per_collective": int(nbytes), "overlap_ranges": len(self._ranges) - 1}
 
     def exchange_description(self):
         """what travels between the GPUs per sweep (for reports)."""

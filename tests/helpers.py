@@ -93,6 +93,54 @@ class OracleBackend(object):
         d_k[tp] = cs.n_zk - old_k
         n_k_delta += torch.from_numpy(d_k)
 
+    def sweep_batch(self, *, inst_off, order, word, freq, z, inst_prob, inst_doc, live_off, live_pos, ndk_off, n_dk,
+                    kw_off, nk_off, kp, prob_stream, counts, delta, status, V, lanes, alpha, beta, seed, sweep,
+                    debug_margin=0):
+        """llda_sweep_batch through the C oracle: the instances of ``order``, problem by problem, each a snapshot
+        sweep (llda_oracle_sweep_docs) in the reference's layout; changes go to ``delta`` as the kernel's atomics do."""
+        import torch
+        if debug_margin < 0:
+            status[0] |= 8
+            return
+        ioff, ip, idoc = inst_off.numpy(), inst_prob.numpy(), inst_doc.numpy()
+        loff, lpos, noff = live_off.numpy(), live_pos.numpy(), ndk_off.numpy()
+        cnt, dlt = counts.numpy(), delta.numpy()
+        zz, nd = z.numpy(), n_dk.numpy()
+        w_all, f_all = word.numpy(), freq.numpy()
+        order = order.numpy().astype(np.int64)
+        for p in np.unique(ip[order]):
+            ids = order[ip[order] == p]
+            KP = int(kp[p])
+            kw0, nk0 = int(kw_off[p]), int(nk_off[p])
+            n_kw = cnt[kw0:kw0 + V * KP].reshape(V, KP)
+            K = self.batch_K[int(prob_stream[p])]              # (the ABI passes KP only; the test tells the checker K)
+            lay = self._lay(K)
+            tp = lay.topic_pos.astype(np.int64)
+            n_k_v = np.ascontiguousarray(n_kw[:, tp].T.astype(np.int64))
+            n_zk = cnt[nk0:nk0 + KP][tp].astype(np.int64)
+            lens = ioff[ids + 1] - ioff[ids]
+            loc_off = np.concatenate(([0], np.cumsum(lens)))
+            sidx = np.concatenate([np.arange(ioff[i], ioff[i + 1]) for i in ids]) if len(ids) else np.zeros(0, np.int64)
+            labs = np.zeros((len(ids), K), dtype=np.uint8)
+            for r, i in enumerate(ids):
+                labs[r, lay.pos_topic[lpos[loff[i]:loff[i + 1]]]] = 1
+            ndk_rows = np.stack([nd[noff[i]:noff[i] + KP][tp] for i in ids]).astype(np.int64)
+            z_old_pos = zz[sidx].astype(np.int64)
+            z_new, ndk_new = self.co.sweep_docs(idoc[ids].astype(np.int64), loc_off, w_all[sidx], f_all[sidx],
+                                                lay.pos_topic[z_old_pos], labs, ndk_rows, n_k_v, n_zk, V, alpha, beta,
+                                                seed, sweep, stream=int(prob_stream[p]), threads=2)
+            z_new_pos = lay.topic_pos[z_new].astype(np.int64)
+            zz[sidx] = z_new_pos.astype(np.int32)
+            ws, fs = w_all[sidx].astype(np.int64), f_all[sidx].astype(np.int64)
+            np.add.at(dlt, kw0 + ws * KP + z_old_pos, (-fs).astype(np.int32))
+            np.add.at(dlt, kw0 + ws * KP + z_new_pos, fs.astype(np.int32))
+            for r, i in enumerate(ids):
+                row = np.zeros(KP, dtype=np.int64)
+                row[tp] = ndk_new[r] - ndk_rows[r]
+                dlt[nk0:nk0 + KP] += row.astype(np.int32)
+                full = nd[noff[i]:noff[i] + KP]
+                full[tp] = ndk_new[r].astype(np.int32)
+
     def commit_log(self, item_begin, item_len, item_word, log, freq_csc, K, target, n_k=None, n_k_delta=None,
                    row_off=None):
         """numpy statement of llda_commit_log (include/llda_gibbs.h), int16-pair rows included"""

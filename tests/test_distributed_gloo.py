@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, counts_mode, q):
+def _worker(rank, world, port, name, counts_mode, overlap, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -46,8 +46,11 @@ def _worker(rank, world, port, name, counts_mode, q):
     s = GibbsSampler(off[lo:hi + 1] - off[lo], g["word"][s0:s1], g["freq"][s0:s1], g["init_z"][s0:s1],
                      int(g["K"]), int(g["V"]), float(g["alpha"]), float(g["beta"]), labs=g["labs"][lo:hi],
                      counts=counts, seed=int(g["seed"]), doc_base=lo, device="cpu",
-                     backend=OracleBackend(c_oracle), commit_log=counts_mode == "built")   # both commit paths
+                     backend=OracleBackend(c_oracle), commit_log=counts_mode == "built",   # both commit paths
+                     overlap_ranges=overlap)
     ok = (s.rows is not None) == (counts_mode == "built")       # every rank logs -> packed exchange rows
+    if overlap > 1 and counts_mode == "built":                   # pipelined exchange: one set of rows per document range
+        ok &= len(s._rows_list) == overlap and len(s._calls) >= 2 and len(s._item_bounds) == overlap + 1
     if name == "tiny_k12":
         ok &= 0 < int((s.row_off < 0).sum()) < s.V
     for i in range(int(g["sweeps"])):
@@ -62,12 +65,18 @@ def _worker(rank, world, port, name, counts_mode, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,counts_mode", [("tiny_k40", "built"), ("tiny_k392", "given"), ("tiny_k12", "built")])
-def test_two_rank_sharded_sweeps_match_single_process_golden(name, counts_mode):
+@pytest.mark.parametrize("name,counts_mode,overlap", [("tiny_k40", "built", 1), ("tiny_k392", "given", 1),
+                                                      ("tiny_k12", "built", 1), ("tiny_k40", "built", 3),
+                                                      ("tiny_k12", "built", 2), ("tiny_k392", "given", 2),
+                                                      ("tiny_k1024", "built", 16)])
+def test_two_rank_sharded_sweeps_match_single_process_golden(name, counts_mode, overlap):
+    """overlap > 1: the exchange is pipelined over document ranges (the rows of range i are all-reduced
+    asynchronously while range i+1 is sampled) -- same state, bit for bit; ("given", 2): ranks that commit with
+    atomics ignore the ranges; ("tiny_k1024", 16): more ranges than a rank has documents."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, counts_mode, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, counts_mode, overlap, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -93,7 +102,7 @@ def test_single_process_oracle_backend_matches_golden(c_oracle):
         assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics())
 
 
-def _cascade_worker(rank, world, port, q):
+def _cascade_worker(rank, world, port, batched, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -112,23 +121,42 @@ def _cascade_worker(rank, world, port, q):
             k.update(device="cpu", backend=OracleBackend(c_oracle))
             super().__init__(*a, **k)
     C.GibbsSampler = CpuSampler
+    import lda_thesis_amd.ensemble as E
+
+    class CpuEnsemble(E.Ensemble):             # the batched ensemble, same stand-in
+        def __init__(self, plans, z_local, *a, **k):
+            be = OracleBackend(c_oracle)
+            be.batch_K = {st: pl["K"] for st, pl in zip(k["streams"], plans)}
+            k.update(device="cpu", backend=be)
+            super().__init__(plans, z_local, *a, **k)
+    E.Ensemble = CpuEnsemble
     g = load_golden("cascade_toy")
     docs, labs, labelset = cascade_corpus()
     np.random.seed(int(g["np_seed"]))
     c = C.CascadeLDA(docs, labs, list(labelset), Dictionary(docs), float(g["alpha"]), float(g["beta"]), seed=int(g["seed"]))
-    owner = c.go_down_tree(it=int(g["it"]), s=int(g["s"]))
-    q.put((rank, bool(np.array_equal(c.ph, g["ph"])), sorted(set(owner))))
+    owner = c.go_down_tree(it=int(g["it"]), s=int(g["s"]), batched=batched, keep_state=True)
+    ok = bool(np.array_equal(c.ph, g["ph"])) and (c._ensemble is not None) == batched
+    # a second call must not add the rows of the first call in again (the all-reduce sums only the owned rows)
+    ph1 = c.ph.copy()
+    np.random.seed(int(g["np_seed"]))
+    c2 = C.CascadeLDA(docs, labs, list(labelset), Dictionary(docs), float(g["alpha"]), float(g["beta"]), seed=int(g["seed"]))
+    c2.ph = ph1.copy()                          # stale rows from an earlier run
+    c2.go_down_tree(it=int(g["it"]), s=int(g["s"]), batched=batched)
+    ok &= bool(np.array_equal(c2.ph, g["ph"]))
+    q.put((rank, ok, sorted(set(owner))))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_cascade_subproblems_spread_over_two_ranks():
-    """CascadeLDA.go_down_tree with torch.distributed: sub-problems LPT-assigned to 2 ranks, disjoint ph
-    rows unioned by one all-reduce; both ranks must end with the single-process reference ph."""
+@pytest.mark.parametrize("batched", [True, False])
+def test_cascade_subproblems_spread_over_two_ranks(batched):
+    """CascadeLDA.go_down_tree with torch.distributed: sub-problems LPT-assigned to 2 ranks (each rank trains its
+    share as ONE batched ensemble, or one by one), disjoint ph rows unioned by one all-reduce; both ranks must end
+    with the single-process reference ph."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_cascade_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_cascade_worker, args=(r, 2, port, batched, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

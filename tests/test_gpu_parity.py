@@ -344,7 +344,7 @@ def test_sparse_and_dense_kernels_agree_on_a_large_sparse_workload(c_oracle):
     np.testing.assert_array_equal(s.z_topics(), cs.z)
 
 
-@pytest.mark.parametrize("commit", [True, False, "mixed rows"])
+@pytest.mark.parametrize("commit", [True, False, "mixed rows", "pipelined"])
 def test_exchange_path_on_one_rank(commit, monkeypatch):
     """the multi-GPU path of sweep() -- commit log folded into the DELTA buffer (or atomics on it), RCCL
     all-reduce of the fused delta buffer, llda_apply_delta -- driven on one GPU with a 1-rank nccl group."""
@@ -361,8 +361,11 @@ def test_exchange_path_on_one_rank(commit, monkeypatch):
         dist.init_process_group("nccl", rank=0, world_size=1)
         made = True
     try:
-        s = make_sampler(g, commit_log=bool(commit), exchange_always=True)
+        s = make_sampler(g, commit_log=bool(commit), exchange_always=True, overlap_ranges=3 if commit == "pipelined" else 1)
         assert (s.rows is not None) == bool(commit)    # int16-pair exchange rows whenever every rank folds a log
+        if commit == "pipelined":                      # the rows of a document range travel (async RCCL all-reduce)
+            assert len(s._rows_list) == 3              # while the next range is sampled
+            s.comm_events = []
         if commit == "mixed rows":
             assert 0 < int((s.row_off < 0).sum()) < s.V
         for i in range(int(g["sweeps"])):
@@ -370,6 +373,10 @@ def test_exchange_path_on_one_rank(commit, monkeypatch):
             assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics())
             assert int(s._delta.abs().sum()) == 0                  # folded and cleared
         s.check_status()
+        if commit == "pipelined":
+            assert all(int(r.abs().sum()) == 0 for r in s._rows_list)
+            st = s.comm_stats()
+            assert st["collectives_per_sweep"] == 3 and st["exposed_ms_per_sweep"] >= 0.0
     finally:
         if made:
             dist.destroy_process_group()
