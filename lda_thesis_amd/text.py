@@ -12,9 +12,16 @@ Interface kept (the parts the reference touches):
   Dictionary(docs)             token2id, id2token, dfs, num_docs, values(), keys(), __len__,
                                __getitem__, doc2bow(doc) -> sorted [(id, count)],
                                filter_extremes(no_below, no_above, keep_n)
-  preprocess_documents(texts)  list[str] -> list[list[str]]
+  preprocess_documents(texts)  list[str] -> list[list[str]], gensim's DEFAULT_FILTERS in their order: lower-case,
+                               strip tags, strip punctuation, collapse white space, strip digits ('abc123def' ->
+                               'abcdef'), drop stop words, drop tokens shorter than 3, Porter-stem -- the stop-word
+                               list and the stemmer are this module's own
+  simple_preprocess(text)      the UNSTEMMED tokenizer the committed fixtures (tests/golden/abstracts_d3*.npz,
+                               cascade_abstracts.npz, chain_quality.npz) were built with; kept so that
+                               oracle/gen_golden.py reproduces them array for array
 """
 import re
+import string
 from collections import Counter
 
 # A compact English stop-word list (function words only).
@@ -50,8 +57,29 @@ def simple_preprocess(text, min_len=3, stem=False):
     return toks
 
 
-def preprocess_documents(texts, stem=False):
-    return [simple_preprocess(t, stem=stem) for t in texts]
+_RE_TAGS = re.compile(r"<([^>]+)>")
+_RE_PUNCT = re.compile("([%s])+" % re.escape(string.punctuation))
+_RE_WS = re.compile(r"(\s)+")
+_RE_NUMERIC = re.compile(r"[0-9]+")
+
+
+def preprocess_string(text, stem=True, min_len=3):
+    """one document through gensim's DEFAULT_FILTERS, in gensim's order (gensim.parsing.preprocessing, 2.3.0:
+    lower, strip_tags, strip_punctuation, strip_multiple_whitespaces, strip_numeric, remove_stopwords,
+    strip_short, stem_text)."""
+    s = text.lower()
+    s = _RE_TAGS.sub("", s)
+    s = _RE_PUNCT.sub(" ", s)
+    s = _RE_WS.sub(" ", s)
+    s = _RE_NUMERIC.sub("", s)                   # 'abc123def' -> 'abcdef': digits vanish, the letters join
+    toks = [w for w in s.split() if w not in STOPWORDS]
+    toks = [w for w in toks if len(w) >= min_len]
+    return [porter_stem(w) for w in toks] if stem else toks
+
+
+def preprocess_documents(texts, stem=True):
+    """what both load_corpus functions call (reference LabeledLDA.py:45, CascadeLDA.py:48): stemmed tokens."""
+    return [preprocess_string(t, stem=stem) for t in texts]
 
 
 # --------------------------------------------------------------------------------------------

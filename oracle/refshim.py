@@ -18,8 +18,11 @@ REFERENCE_DIR = "/root/reference"
 
 
 def _tokenize(text):
+    # the FIXTURE tokenizer (unstemmed): the committed tokenised fixtures were built with it, and re-running
+    # gen_golden.py must reproduce them array for array.  The product's load_corpus stems (text.preprocess_documents);
+    # which tokens the sampler is fed does not matter for sampler parity -- both sides get the same integer arrays.
     from lda_thesis_amd.text import simple_preprocess
-    return simple_preprocess(text)
+    return simple_preprocess(text, stem=False)
 
 
 def install():
