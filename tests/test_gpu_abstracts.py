@@ -71,3 +71,20 @@ def test_abstracts_c_oracle_agrees_for_20_sweeps(c_oracle):
     np.testing.assert_array_equal(s.z_topics(), cs.z)
     np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
     np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+
+
+def test_abstracts_snapshot_chain_perplexity_trace():
+    """chain quality (tests/golden/chain_quality.npz, oracle/gen_chain_quality.py): the perplexity of the snapshot
+    chain the GPU runs, after sweeps 10, 20, ..., 200 -- equal to the trace the pinned oracle produced with the
+    reference's own read-outs (/root/reference/LabeledLDA.py:127-153, 256-265).  How that chain compares with the
+    reference's sequential chain is asserted on the CPU side (tests/test_oracle_golden.py)."""
+    g = load_golden("abstracts_d3")
+    q = load_golden("chain_quality")
+    s = make(g)
+    trace = []
+    for i in range(1, int(q["iters"]) + 1):
+        s.sweep()
+        if i % int(q["thinning"]) == 0:
+            trace.append(s.perplexity())
+    np.testing.assert_allclose(np.array(trace), q["o3_perplx"], rtol=1e-9, atol=0)
+    assert digest(s) == str(q["o3_digest_s200"])

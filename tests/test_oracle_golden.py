@@ -104,3 +104,26 @@ def test_c_oracle_selected_documents(c_oracle, name):
         prev = "o3_s%d_" % (s + 1)
         np.testing.assert_array_equal(z, g[prev + "z"][idx])
         np.testing.assert_array_equal(ndk, g[prev + "n_d_k"][sel])
+
+
+def test_chain_quality_snapshot_vs_sequential():
+    """tests/golden/chain_quality.npz (oracle/gen_chain_quality.py): the per-document snapshot chain (O3, what the GPU
+    runs) against the UNMODIFIED reference's sequential chain (O1, two numpy seeds) on abstracts, 200 sweeps, and on
+    three CascadeLDA sub-problems -- different chains of the same model: the fit (perplexity,
+    /root/reference/LabeledLDA.py:256-265) and the test-time metrics computed by the reference's own test_it and
+    evaluation functions (evaluate_LabeledLDA.py:8-107) agree to within the spread between two seeds of the reference
+    plus a small margin.  This documents the gap; it does not re-run the chains."""
+    q = load_golden("chain_quality")
+    o1, o3 = q["o1_perplx"], q["o3_perplx"]
+    assert o1.shape == (2, 20) and o3.shape == (20,)
+    # both chains burn in the same way: within 6 % of each other at every read-out, within 3 % at the end
+    rel = np.abs(o3[None, :] / o1 - 1.0)
+    assert rel.max() < 0.06 and rel[:, -1].max() < 0.03, rel.max(axis=0)
+    # the snapshot chain does not fit worse than the sequential one (lower perplexity is better)
+    assert o3[-1] < o1[:, -1].max() * 1.01
+    for key, tol in (("auc", 0.015), ("one_err", 0.03), ("two_err", 0.03), ("f1", 0.015)):
+        a, b = q["o1_" + key], float(q["o3_" + key])
+        assert abs(b - a.mean()) < tol + abs(a[0] - a[1]), (key, a, b)
+    for j in range(3):                                        # Cascade sub-problems of 825 / 163 / 37 documents
+        t1, t3 = q["sub%d_o1" % j], q["sub%d_o3" % j]
+        assert np.abs(t3[-5:].mean() / t1[-5:].mean() - 1.0) < 0.05, (j, t1[-1], t3[-1])
