@@ -132,6 +132,10 @@ class LabeledLDA(object):
                                      doc_base=lo, device=device)
 
     # ---- state in the reference's shapes / dtypes ----
+    # With torch.distributed initialised the documents are sharded over the ranks: n_d_k, z_dn, th_hat, get_theta()
+    # and pickling (__getstate__) GATHER the per-rank slices and are therefore COLLECTIVE -- every rank must read
+    # them (reading on one rank only, e.g. `if rank == 0: pickle.dump(model)`, blocks).  n_zk, n_k_v, ph_hat and
+    # perplexity() are replicated / already reduced and can be read anywhere.
     @property
     def n_zk(self):
         return self._sampler.n_zk()
