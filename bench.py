@@ -371,6 +371,9 @@ def main():
                     help="diagnostic: take the multi-GPU path (exchange rows, all-reduce if a group exists) on one GPU")
     ap.add_argument("--overlap", type=int, default=-1, help="document ranges per sweep for the overlapped exchange")
     ap.add_argument("--docs-per-group", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", help="diagnostic: gloo runs the N > 1 code path without RCCL")
+    ap.add_argument("--one-device", action="store_true",
+                    help="diagnostic: every rank uses cuda:0 (functional check of the N > 1 path on a one-GPU box, with gloo)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -380,6 +383,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if args.pmc_inner:
@@ -389,7 +394,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     name = args.workload
     sampler, info = build_sampler(name, dev, rank, world, dist is not None, docs_total=args.docs,

@@ -89,3 +89,30 @@ def test_device_entry_points_validate_arguments():
     assert L.llda_loglik(None, None, None, None, None, None, 1, 1, 8, 0.1, 0.1, None, None) == -2
     assert L.llda_foldin(None, None) == -2
     assert b"argument" in L.llda_strerror(-2)
+
+
+def test_batched_sweep_validates_arguments():
+    """llda_sweep_batch (ABI 9): NULL pointers, a lane count that is not 8/16/32/64 and priors the sparse arithmetic
+    does not cover are refused before anything touches HIP; an empty launch is a no-op."""
+    from lda_thesis_amd import _native
+    L = _native.lib()
+    assert L.llda_sweep_batch(None, None) == -2
+    a = _native.LldaBatchArgs()
+    a.n_inst, a.V, a.lanes = 0, 10, 8
+    assert L.llda_sweep_batch(ctypes.byref(a), None) == 0                     # nothing to sample
+    a.n_inst = 4
+    assert L.llda_sweep_batch(ctypes.byref(a), None) == -2                    # NULL pointers
+    a.V = 0
+    assert L.llda_sweep_batch(ctypes.byref(a), None) == -2
+
+
+def test_ensemble_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from lda_thesis_amd import _native
+    from lda_thesis_amd.ensemble import Ensemble
+    plan = dict(K=2, docs=np.array([0]), allowed=np.array([[0, 1]]), n_allowed=np.array([2]))
+    with pytest.raises(_native.NativeError):
+        Ensemble([plan], [np.array([0])], np.array([0, 1]), np.array([0], dtype=np.int32), np.array([1], dtype=np.int32),
+                 3, 0.1, 0.01, 1)

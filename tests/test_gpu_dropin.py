@@ -165,6 +165,20 @@ def test_cascade_batched_ensemble_equals_one_by_one_and_falls_back():
     assert np.random.random_sample() == after_a
 
 
+def test_cascade_tiny_priors_take_the_one_by_one_path():
+    """priors below 1e-6 are outside what the batched (sparse) arithmetic proves; go_down_tree then trains the
+    sub-problems through llda_sweep's general kernel -- and both settings agree on a prior both can run."""
+    from fixture_corpora import cascade_corpus
+    from lda_thesis_amd.CascadeLDA import CascadeLDA
+    from lda_thesis_amd.text import Dictionary
+    docs, labs, labelset = cascade_corpus()
+    dicti = Dictionary(docs)
+    np.random.seed(1)
+    c = CascadeLDA(docs, labs, list(labelset), dicti, 1e-9, 0.01, seed=3)
+    c.go_down_tree(2, 1, keep_state=True)
+    assert c._ensemble is None and np.isfinite(c.ph[1:]).any()
+
+
 def test_cascade_abstracts_ensemble_matches_reference():
     """BASELINE configs[4] at its real size: go_down_tree(4, 2) on the abstracts corpus, 122 sub-problems, against
     the reference's own go_down_tree run with per-document-snapshot sweeps (oracle/gen_golden.py
