@@ -232,6 +232,42 @@ def cpu_baseline_json(sampler, info, name, value):
     }, value / base["numpy"]["value"]
 
 
+def cascade_extra():
+    """BASELINE configs[4] on this GPU: CascadeLDA.go_down_tree(it=4, s=2) on the abstracts fixture -- the whole
+    ensemble of 122 per-node Labeled-LDA sub-problems, host enumeration and initial assignments included; first call
+    (cold) and the best of three more."""
+    import io
+    from contextlib import redirect_stdout
+    from lda_thesis_amd.CascadeLDA import CascadeLDA
+    from lda_thesis_amd.corpus import cascade_corpus_from_csr
+    from lda_thesis_amd.text import Dictionary
+    g = np.load(os.path.join(ROOT, "tests", "golden", "abstracts_d3.npz"))
+    names = [str(x) for x in g["labelset"]]
+    docs, labs, labelset = cascade_corpus_from_csr(g["doc_off"], g["word"], g["freq"], g["lab_off"], g["lab_idx"], names)
+    dicti = Dictionary(docs)
+    walls = []
+    for _ in range(4):
+        np.random.seed(0)
+        model = CascadeLDA(docs, labs, list(labelset), dicti, alpha=ALPHA, beta=BETA, seed=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with redirect_stdout(io.StringIO()):
+            model.go_down_tree(it=4, s=2)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+    plans = model.plan_subproblems()
+    lens = np.array([len(t) for t in model.doc_tups])
+    sites = int(sum(int(lens[p["docs"]].sum()) for p in plans))
+    return {"workload": "CascadeLDA on abstracts_data.csv (fixture), go_down_tree(it=4, s=2): ensemble of per-node L-LDA "
+                        "sub-problems, all trained together on this GPU (BASELINE configs[4])",
+            "value": min(walls[1:]), "unit": "s", "higher_is_better": False, "cold_first_call_s": walls[0],
+            "warm_calls_s": walls[1:], "sub_problems": len(plans), "sites_per_ensemble_sweep": sites,
+            "Msites_per_s": sites * 4 / min(walls[1:]) / 1e6,
+            "reference_cpu_s": 66.8, "reference_cpu_note": "the reference's go_down_tree(4, 2) on one core of the survey "
+            "container (SURVEY.md section 6); 368 s with per-document-snapshot sweeps (oracle/gen_golden.py, the run that "
+            "made tests/golden/cascade_abstracts.npz)"}
+
+
 # ------------------------------------------------------------------------------------------------ PMC passes
 PMC_WORKLOADS = ("synth2", "synth1", "synth2_hostile")     # dense kernels, in the order the inner run sweeps them
 PMC_SWEEPS = 3                                              # per workload in the inner run (all are measured)
@@ -472,7 +508,7 @@ def main():
         torch.cuda.empty_cache()
         if extras_on:
             for key, wname, st, wu in (("synth1", "synth1", 200, 5), ("hbm_bound", "synth2_hostile", 40, 3),
-                                       ("abstracts", "abstracts", 3000, 20)):
+                                       ("sparse_labels", "synth2_sparse", 100, 5), ("abstracts", "abstracts", 3000, 20)):
                 s2, i2 = build_sampler(wname, dev, 0, 1, False)
                 torch.cuda.synchronize()
                 dt2, k2 = time_sweeps(s2, st, wu)
@@ -489,9 +525,15 @@ def main():
                     if not args.no_cpu:
                         e["cpu_baseline"], e["speedup_vs_cpu_port"] = cpu_baseline_json(s2, i2, wname, v2)
                         e["target_speedup"] = 50.0
+                if wname == "synth2_sparse":
+                    e["live_topics_per_doc"] = i2["live_topics"]
+                    e["algorithmic_GBps"] = algorithmic_bytes(s2.S, i2["docs_local"], i2["live_topics"]) / (k2 * 1e-3) / 1e9
+                    e["note"] = ("one lane per allowed topic; every 4-byte gather of n_kw[v, pos] costs a 32-byte sector "
+                                 "(263 B fetched per site by the counters, profiles/r01v13_synth2_sparse_*), random labels")
                 extra[key] = e
                 del s2, i2
                 torch.cuda.empty_cache()
+            extra["cascade"] = cascade_extra()
         # ---- roofline: HBM-side counters collected in this run (separate rocprofv3 passes) ----
         pmc, source = ({}, "not collected (N > 1 or --no-pmc)")
         if pmc_names:
