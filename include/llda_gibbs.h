@@ -74,7 +74,7 @@ typedef struct llda_sweep_args {
     const int64_t  *doc_off;     /* [dev] [D+1] site offsets                                  */
     const int32_t  *doc_order;   /* [dev] [D] processing order (local doc ids) or NULL        */
     const int32_t  *word;        /* [dev] [S] word id of every site (unique, ascending per doc) */
-    const int32_t  *freq;        /* [dev] [S] frequency f of every site                        */
+    const int32_t  *freq;        /* [dev] [S] frequency f of every site, 0 <= f < 2^23 (not checked on the device) */
     int32_t        *z;           /* [dev] [S] in/out: device position of the site's topic      */
     const uint16_t *lab_mask;    /* [dev] [D*G] lane masks                                     */
     int32_t        *n_dk;        /* [dev] [D*KP] in/out                                        */

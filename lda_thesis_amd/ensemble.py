@@ -99,6 +99,8 @@ class Ensemble(object):
         w_s, f_s = word[site_src], freq[site_src]
         if f_s.size and int(f_s.max()) >= self.V:
             raise IndexError("index %d is out of bounds for axis 1 with size %d" % (int(f_s.max()), self.V))
+        if f_s.size and (int(f_s.min()) < 0 or int(f_s.max()) >= (1 << 23) or int(f_s.astype(np.int64).sum()) >= (1 << 31)):
+            raise ValueError("word frequencies must be in [0, 2^23) and the ensemble must hold fewer than 2^31 tokens")
         # local topic -> device position, per problem layout
         a_max = max(pl["allowed"].shape[1] for pl in plans)
         pos_tab = np.zeros((P, max(pl["K"] for pl in plans)), dtype=np.int64)

@@ -110,6 +110,17 @@ class GibbsSampler(object):
         self.freq = as_dev(freq, torch.int32)
         self.D = int(self.doc_off.shape[0] - 1)
         self.S = int(self.word.shape[0])
+        if self.S:
+            # device counts are int32 and the kernels move a site's count with a 24-bit multiply-add
+            fmin, fmax, ftot = int(self.freq.min()), int(self.freq.max()), int(self.freq.sum(dtype=torch.int64))
+            if fmin < 0 or fmax >= self.MAX_FREQ:
+                raise ValueError("word frequencies inside a document must be in [0, %d); got %d .. %d" %
+                                 (self.MAX_FREQ, fmin, fmax))
+            if ftot >= (1 << 31):
+                raise ValueError("the local shard holds %d tokens; the int32 device counts hold fewer than 2^31" % ftot)
+            wmin, wmax = int(self.word.min()), int(self.word.max())
+            if wmin < 0 or wmax >= self.V:
+                raise IndexError("word id %d is out of bounds for a vocabulary of %d" % (wmax if wmax >= self.V else wmin, self.V))
         self._topic_pos = torch.from_numpy(lay.topic_pos.astype(np.int64)).to(dev)
         self._pos_topic = torch.from_numpy(lay.pos_topic.astype(np.int64)).to(dev)
         self.z = self._topic_pos[as_dev(z, torch.int64)].to(torch.int32)
@@ -160,6 +171,7 @@ class GibbsSampler(object):
         if self.sharded and (_dist_active(self.group) or exchange_always):
             self._make_exchange_rows()
 
+    MAX_FREQ = 1 << 23   # v_mad_i32_i24 moves a site's count (include/llda_gibbs.h: freq)
     PAIR_LIMIT = 32767   # largest frequency mass of a word (all ranks) whose row is exchanged as int16 pairs
 
     def _make_exchange_rows(self):

@@ -409,3 +409,18 @@ def test_integration_md_ctypes_stub_runs_and_matches_reference():
         ns["training_iteration"](model)
         ns["pull"](model)
         assert_state_equal(g, "o3_s%d" % (i + 1), model.n_k_v, model.n_d_k, model.n_zk, np.concatenate(model.z_dn))
+
+
+def test_sampler_validates_frequencies_and_word_ids():
+    """inputs the int32 / 24-bit device arithmetic cannot hold are refused on the host, not miscounted."""
+    from lda_thesis_amd.sampler import GibbsSampler
+    off, w, z = np.array([0, 2]), np.array([0, 1]), np.array([0, 1])
+    with pytest.raises(ValueError):
+        GibbsSampler(off, w, np.array([1, 1 << 23]), z, 2, 3, 0.1, 0.01)
+    with pytest.raises(ValueError):
+        GibbsSampler(off, w, np.array([1, -1]), z, 2, 3, 0.1, 0.01)
+    with pytest.raises(IndexError):
+        GibbsSampler(off, np.array([0, 3]), np.array([1, 1]), z, 2, 3, 0.1, 0.01)
+    s = GibbsSampler(off, w, np.array([1, (1 << 23) - 1]), z, 2, 3, 0.1, 0.01)
+    s.sweep()
+    assert int(s.n_k.sum()) == 1 << 23
