@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 9
+#define LLDA_ABI_VERSION 10
 #define LLDA_MAX_K 1024
 #define LLDA_MAX_LEAVES 8
 #define LLDA_MAX_ROUNDS 4
@@ -84,8 +84,7 @@ typedef struct llda_sweep_args {
     int32_t        *n_k_delta;   /* [dev] [KP] += sweep changes                                */
     int32_t        *status;      /* [dev] optional (may be NULL), int32[4]: word 0 bit 0 is set when a site had no
                                     topic with positive probability (the reference would raise);
-                                    bit 1 (informational) when some site took the exact tier; bit 2 when
-                                    the sparse kernel's resume list overflowed (results invalid);
+                                    bit 1 (informational) when some site took the exact tier;
                                     word 1 += sites the fp32 tier was unsure about, word 2 += sites that
                                     reached the exact tier (statistics)                           */
     int64_t  D;                  /* local documents                                            */
@@ -103,14 +102,13 @@ typedef struct llda_sweep_args {
     uint32_t sweep;              /* RNG counter word 3                                         */
     uint32_t stream_id;          /* RNG counter word 2 (sub-problem id for CascadeLDA)         */
     int64_t  doc_base;           /* global id of local document 0 (RNG counter word 1)         */
-    /* optional sparse-label path (all four pointers non-NULL and live_max <= 64): one lane per allowed
+    /* optional sparse-label path (live_off, live_pos non-NULL and live_max <= 64): one lane per allowed
      * topic instead of one lane per 16 topics */
     const int64_t *live_off;     /* [dev] [D+1] offsets into live_pos                              */
     const int32_t *live_pos;     /* [dev] device positions of the topics every document allows, ascending */
-    int32_t       *resume;       /* [dev] [resume_cap * 66] scratch: documents handed from the sparse to the
-                                    dense kernel (doc, site, n_dk deltas of the allowed topics)     */
-    int32_t       *resume_count; /* [dev] [1] scratch (zeroed by llda_sweep)                          */
-    int32_t  resume_cap;         /* capacity of `resume` in documents                                */
+    int32_t       *resume;       /* unused since ABI 10 (pass NULL): a site the sparse kernel cannot decide is now   */
+    int32_t       *resume_count; /* resolved inside the kernel by the exact pipeline instead of being handed to a    */
+    int32_t  resume_cap;         /* second launch; the fields keep the struct layout                                 */
     int32_t  live_max;           /* largest number of allowed topics of any document                  */
     /* optional commit log (both non-NULL): instead of two int32 atomics on n_kw_delta per changed site the
      * kernels store ONE word (old position | new position << 16) at the site's place in WORD-major order;
@@ -147,9 +145,9 @@ int llda_sweep(const llda_sweep_args *args, void *stream);
  * with that stream_id and doc_base = 0 on the problem alone, so both paths leave identical states.
  * Arithmetic: one lane per ALLOWED topic (every instance of a launch has <= `lanes` allowed topics, lanes in
  * {8, 16, 32, 64}); the draw is decided from unnormalised fp64 prefix sums with a 2^-40 margin (it then equals the
- * reference pipeline's choice).  If some site cannot be decided (~1e-11 per site) status bit 3
- * (value 8) is set and the results of this sweep are INVALID: restore the state and run the problems through
- * llda_sweep.  Needs alpha, beta >= 1e-6 and V*beta < 2^40 (LLDA_E_BAD_ARG otherwise). */
+ * reference pipeline's choice); a site that cannot be decided that way (~1e-11 per site) goes through
+ * the reference's exact fp64 pipeline inside the kernel (status word 2 counts them).  Needs alpha, beta >= 1e-6,
+ * V*beta < 2^40 (LLDA_E_BAD_ARG otherwise) and K_p <= 128 for every problem (the caller's responsibility). */
 typedef struct llda_batch_args {
     const int64_t *inst_off;     /* [dev] [I+1] site offsets of all document instances               */
     const int32_t *order;        /* [dev] [n_inst] the instances this launch samples                  */
@@ -167,12 +165,13 @@ typedef struct llda_batch_args {
     const int64_t *nk_off;       /* [dev] [P] offset of problem p's n_k                               */
     const int32_t *kp;           /* [dev] [P] KP_p                                                    */
     const int32_t *prob_stream;  /* [dev] [P] RNG counter word 2 of problem p                         */
+    const int32_t *k;            /* [dev] [P] topics of problem p: 1 <= K_p <= 128 (one numpy pairwise leaf)  */
     const int32_t *counts;       /* [dev] sweep-start snapshot (read only)                            */
     int32_t       *delta;        /* [dev] += sweep changes                                            */
-    int32_t       *status;       /* [dev] optional int32[4] as in llda_sweep_args; bit 3 = undecidable site */
+    int32_t       *status;       /* [dev] optional int32[4] as in llda_sweep_args                       */
     int64_t  V;
     int32_t  lanes;              /* lanes per instance: 8, 16, 32 or 64                               */
-    int32_t  debug_margin;       /* 0 in production; n > 0 widens the margin to 2^-n; < 0: every site undecidable */
+    int32_t  debug_margin;       /* 0 in production; n > 0 widens the margin to 2^-n; < 0: every site through the exact pipeline */
     double   alpha, beta;
     uint64_t seed;
     uint32_t sweep, reserved;

@@ -496,9 +496,9 @@ class CascadeLDA(object):
         (reference CascadeLDA.py:135-184).  Sub-problem i (visiting order) uses RNG stream id i.
 
         batched=True: all sub-problems of this rank are trained TOGETHER (lda_thesis_amd/ensemble.py: a sweep of
-        the whole ensemble is a handful of launches); should the batched arithmetic meet a site it cannot decide
-        (~1e-11 per site) -- or priors it does not cover -- the sub-problems are trained one after another instead,
-        which gives the same result.  keep_state=True keeps the trained ensemble in ``self._ensemble`` (tests)."""
+        the whole ensemble is a handful of launches).  Priors below 1e-6 or a sub-problem of more than 128 topics --
+        outside what llda_sweep_batch covers -- take the one-by-one path instead, which gives the same result.
+        keep_state=True keeps the trained ensemble in ``self._ensemble`` (tests)."""
         import torch.distributed as dist
         world, rank = 1, 0
         if dist.is_available() and dist.is_initialized():
@@ -509,7 +509,7 @@ class CascadeLDA(object):
         done = False
         owner = None
         if batched and self.alpha >= 1e-6 and self.beta >= 1e-6 and self.V * self.beta < 2.0 ** 40:
-            owner, done = self._go_down_tree_batched(it, s, world, rank, keep_state)
+            owner, done = self._go_down_tree_batched(it, s, world, rank, keep_state)     # done=False: a problem too wide
         if not done:
             np.random.set_state(rng_state)                  # the batched attempt consumed the same stream
             owner = self._go_down_tree_sequential(it, s, world, rank)
@@ -550,6 +550,9 @@ class CascadeLDA(object):
         sites = [int(lens[pl["docs"]].sum()) for pl in plans]
         owner = lpt_assign(sites, world)
         mine = [i for i in range(len(plans)) if owner[i] == rank]
+        from .ensemble import MAX_BATCH_K
+        if any(pl["K"] > MAX_BATCH_K for pl in plans):
+            return owner, False
         ens = Ensemble([plans[i] for i in mine], [z_local[i] for i in mine], doc_off, word, freq,
                        self.V, self.alpha, self.beta, self.seed, device=self._device, streams=mine)
         ens.debug_margin = self._batch_debug_margin
@@ -561,8 +564,7 @@ class CascadeLDA(object):
             ens.sweep()
             if (i + 1) % s == 0:
                 print("Training iteration #", i + 1)
-        if ens.undecided():
-            return owner, False
+        ens.check_status()
         ph_dev = torch.zeros((self.K, self.V), dtype=torch.float64, device=ens.device)
         label_rows = [self._label_rows(i, plans[i]) for i in mine]
         ens.scatter_ph(ph_dev, label_rows)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libllda_gibbs.so")
 MAX_K = 1024
 MAX_LEAVES = 8
 MAX_ROUNDS = 4
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -56,7 +56,7 @@ class LldaBatchArgs(ctypes.Structure):
     """struct llda_batch_args (include/llda_gibbs.h)."""
     _fields_ = [("inst_off", _c_p), ("order", _c_p), ("n_inst", _c_i64), ("word", _c_p), ("freq", _c_p), ("z", _c_p),
                 ("inst_prob", _c_p), ("inst_doc", _c_p), ("live_off", _c_p), ("live_pos", _c_p), ("ndk_off", _c_p),
-                ("n_dk", _c_p), ("kw_off", _c_p), ("nk_off", _c_p), ("kp", _c_p), ("prob_stream", _c_p), ("counts", _c_p),
+                ("n_dk", _c_p), ("kw_off", _c_p), ("nk_off", _c_p), ("kp", _c_p), ("prob_stream", _c_p), ("k", _c_p), ("counts", _c_p),
                 ("delta", _c_p),
                 ("status", _c_p), ("V", _c_i64), ("lanes", _c_i32), ("debug_margin", _c_i32), ("alpha", _c_d),
                 ("beta", _c_d), ("seed", _c_u64), ("sweep", _c_u32), ("reserved", _c_u32)]
@@ -160,8 +160,8 @@ def _launch(ref, fn, what, *args):
 
 def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
           status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
-          dense_mask=False, debug_margin=0, live_off=None, live_pos=None, resume=None, resume_count=None,
-          live_max=0, csc_pos=None, commit_log=None, n_sites=None):
+          dense_mask=False, debug_margin=0, live_off=None, live_pos=None, live_max=0, csc_pos=None, commit_log=None,
+          n_sites=None):
     """llda_sweep on the current torch stream.  All array arguments are torch CUDA tensors.  n_sites = the sites
     the D documents span (default: all of ``word``)."""
     a = LldaSweepArgs(_ptr(doc_off), _ptr(doc_order), _ptr(word), _ptr(freq), _ptr(z), _ptr(lab_mask),
@@ -169,19 +169,19 @@ def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta
                       int(D), int(V), int(K), int(docs_per_group), 1 if dense_mask else 0, int(debug_margin),
                       float(alpha), float(beta),
                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(sweep) & 0xFFFFFFFF,
-                      int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), _ptr(resume),
-                      _ptr(resume_count), 0 if resume is None else int(resume.shape[0]), int(live_max),
+                      int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), None, None, 0,
+                      int(live_max),
                       _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites))
     _launch(z, lib().llda_sweep, "llda_sweep", ctypes.byref(a))
 
 
 def sweep_batch(*, inst_off, order, word, freq, z, inst_prob, inst_doc, live_off, live_pos, ndk_off, n_dk, kw_off,
-                nk_off, kp, prob_stream, counts, delta, status, V, lanes, alpha, beta, seed, sweep, debug_margin=0):
+                nk_off, kp, prob_stream, k, counts, delta, status, V, lanes, alpha, beta, seed, sweep, debug_margin=0):
     """llda_sweep_batch on the current torch stream: one sweep of the instances in ``order`` (each with at most
     ``lanes`` allowed topics) of an ensemble of small problems."""
     a = LldaBatchArgs(_ptr(inst_off), _ptr(order), int(order.numel()), _ptr(word), _ptr(freq), _ptr(z),
                       _ptr(inst_prob), _ptr(inst_doc), _ptr(live_off), _ptr(live_pos), _ptr(ndk_off), _ptr(n_dk),
-                      _ptr(kw_off), _ptr(nk_off), _ptr(kp), _ptr(prob_stream), _ptr(counts), _ptr(delta), _ptr(status), int(V),
+                      _ptr(kw_off), _ptr(nk_off), _ptr(kp), _ptr(prob_stream), _ptr(k), _ptr(counts), _ptr(delta), _ptr(status), int(V),
                       int(lanes), int(debug_margin), float(alpha), float(beta), int(seed) & 0xFFFFFFFFFFFFFFFF,
                       int(sweep) & 0xFFFFFFFF, 0)
     _launch(z, lib().llda_sweep_batch, "llda_sweep_batch", ctypes.byref(a))

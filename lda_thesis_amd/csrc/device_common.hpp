@@ -36,12 +36,6 @@ struct KParams {
     const int64_t *live_off;
     const int32_t *live_pos;
     int32_t KP;             // row length (the sparse kernel is not templated on the layout)
-    // hand-over from the sparse kernel to the dense tiered kernel: documents whose draw the sparse kernel
-    // could not decide within its margin continue there from the recorded site
-    int32_t *resume;        // [cap][2 + LLDA_MAX_LIVE]: doc, site, n_dk delta of the live topics so far
-    int32_t *resume_count;  // [1]
-    int32_t resume_cap;
-    int32_t resume_mode;    // 1: this launch of the dense kernel walks the resume list instead of all documents
     // commit log (both NULL: n_kw_delta atomics): one word per site at its word-major position
     const int32_t *csc_pos;
     uint32_t *commit_log;

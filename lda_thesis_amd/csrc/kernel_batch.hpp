@@ -12,9 +12,9 @@ namespace {
 // per instance.  All problems share the vocabulary (same V, so the same V*beta) and the corpus.
 // The per-site arithmetic is the sparse kernel's (one lane per ALLOWED topic, sparse_site<>): the draw is decided
 // from unnormalised fp64 prefix sums with a 2^-40 margin, which provably picks the exact pipeline's topic
-// (DESIGN.md 4.3).  A site it cannot decide (~1e-11 per site) sets status bit 3; the caller then discards the
-// batched result and trains the problems one by one through llda_sweep, whose hand-over path runs the exact
-// pipeline -- so the ensemble's result is the reference's either way.
+// (DESIGN.md 4.3).  A site it cannot decide (~1e-11 per site) is resolved on the spot by exact_site_wave(), the
+// reference's fp64 pipeline in the dense layout of the instance's own problem (every problem has at most 128 topics:
+// one numpy pairwise leaf, 8 lanes) -- so the ensemble's result is the reference's either way.
 // Count changes: int32 atomics on the delta image of the fused [n_kw | n_k] buffers of all problems.
 // ---------------------------------------------------------------------------------------------
 struct BParams {
@@ -33,6 +33,7 @@ struct BParams {
     const int64_t *nk_off;       // [P] offset of the problem's n_k (KP)
     const int32_t *kp;           // [P] row length
     const int32_t *prob_stream;  // [P] RNG stream of the problem (its index in the ensemble's visiting order)
+    const int32_t *k;            // [P] number of topics of the problem (<= 128)
     const int32_t *counts;       // sweep-start snapshot of all problems
     int32_t *delta;              // += sweep changes
     int32_t *status;
@@ -51,19 +52,20 @@ __global__ void __launch_bounds__(256) llda_sweep_batch_kernel(const BParams P)
     const int gbase = lane & ~(GS - 1);
     const uint64_t gmask = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
 
+    // wave-uniform control flow (a lane group without an instance, or with a shorter document, idles through flags):
+    // the exact tier of sparse_site() needs all 64 lanes
     const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
-    if (idx >= P.n_inst) return;
-    const int64_t inst = P.order[idx];
+    const bool valid = idx < P.n_inst;
+    const int64_t inst = valid ? P.order[idx] : P.order[0];
     const int64_t s0 = P.inst_off[inst];
-    const int len = (int)(P.inst_off[inst + 1] - s0);
-    if (len <= 0) return;
+    const int len = valid ? (int)(P.inst_off[inst + 1] - s0) : 0;
     const int prob = P.inst_prob[inst];
     const int KP = P.kp[prob];
     const int32_t *n_kw = P.counts + P.kw_off[prob];
     int32_t *d_kw = P.delta + P.kw_off[prob];
     const int64_t l0 = P.live_off[inst];
     const int A = (int)(P.live_off[inst + 1] - l0);
-    const bool live = lig < A;
+    const bool live = valid && len > 0 && lig < A;
     const int pos = live ? P.live_pos[l0 + lig] : -1;
     int32_t *ndk_p = P.n_dk + P.ndk_off[inst] + (live ? pos : 0);
     int ndk = live ? *ndk_p : 0;
@@ -71,13 +73,27 @@ __global__ void __launch_bounds__(256) llda_sweep_batch_kernel(const BParams P)
     int nk = live ? P.counts[P.nk_off[prob] + pos] : 0;
     const uint32_t gdoc = (uint32_t)P.inst_doc[inst];
     const uint32_t stream = (uint32_t)P.prob_stream[prob];
-    bool failed = false;
+    // dense layout of this instance's problem (at most 128 topics: one pairwise leaf, 8 lanes x KP/8 slots); the
+    // instances of a wavefront belong to different problems, so the exact tier gets the layout of the group it serves
+    ExactLayout lay;
+    {
+        const int K = P.k[prob];
+        lay.G = 8; lay.T = KP >> 3; lay.last_leaf = 0; lay.tail = K & 7; lay.tail_row = K >> 3; lay.n_rounds = 0; lay.xor_tree = 1;
+#pragma unroll
+        for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) lay.rounds_pk[r] = 0;
+    }
+    int max_len = len;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) max_len = max(max_len, __shfl_xor(max_len, o, 64));
 
-    for (int n0 = 0; n0 < len && !failed; n0 += 8) {
-        const int nb = min(8, len - n0);
+    for (int n0 = 0; n0 < max_len; n0 += 8) {
+        const int nb = max(0, min(8, len - n0));
         const int jj = lig & 7;
-        const int64_t si = s0 + n0 + (jj < nb ? jj : nb - 1);
-        const int sv = P.word[si], sf = P.freq[si], sz = P.z[si];
+        int sv = 0, sf = 0, sz = 0;
+        if (nb > 0) {
+            const int64_t si = s0 + n0 + (jj < nb ? jj : nb - 1);
+            sv = P.word[si]; sf = P.freq[si]; sz = P.z[si];
+        }
         int su_lo, su_hi;
         {   // keyed uniform of site n0+jj: Philox block (site >> 1), words (0,1) / (2,3) by parity
             const int n = n0 + jj;
@@ -91,22 +107,20 @@ __global__ void __launch_bounds__(256) llda_sweep_batch_kernel(const BParams P)
                   w3 = bcast_lane<GS, 3>(sv, lig), w4 = bcast_lane<GS, 4>(sv, lig), w5 = bcast_lane<GS, 5>(sv, lig),
                   w6 = bcast_lane<GS, 6>(sv, lig), w7 = bcast_lane<GS, 7>(sv, lig);
         int xg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (live) {
+        if (live && nb > 0) {
             const int32_t *col = n_kw + pos;
             xg[0] = col[(int64_t)w0 * KP]; xg[1] = col[(int64_t)w1 * KP]; xg[2] = col[(int64_t)w2 * KP];
             xg[3] = col[(int64_t)w3 * KP]; xg[4] = col[(int64_t)w4 * KP]; xg[5] = col[(int64_t)w5 * KP];
             xg[6] = col[(int64_t)w6 * KP]; xg[7] = col[(int64_t)w7 * KP];
         }
         int my_zn = sz;
-        int ok = -1;
         int done = 0;
 #define LLDA_BATCH_SITE(J)                                                                                     \
-        sparse_site<GS, J>(P, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, ok, done, lig, lane, \
+        sparse_site<GS, J>(P, lay, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
                            gbase, gmask);
         LLDA_BATCH_SITE(0) LLDA_BATCH_SITE(1) LLDA_BATCH_SITE(2) LLDA_BATCH_SITE(3)
         LLDA_BATCH_SITE(4) LLDA_BATCH_SITE(5) LLDA_BATCH_SITE(6) LLDA_BATCH_SITE(7)
 #undef LLDA_BATCH_SITE
-        if (!ok) failed = true;
         if (lig < 8 && lig < done) {
             P.z[s0 + n0 + lig] = my_zn;
             if (my_zn != sz) {
@@ -116,7 +130,6 @@ __global__ void __launch_bounds__(256) llda_sweep_batch_kernel(const BParams P)
             }
         }
     }
-    if (failed && lig == 0 && P.status) atomicOr(P.status, 8);      // undecidable site: the caller falls back
     if (live) {
         *ndk_p = ndk;
         if (ndk != ndk0) atomicAdd(P.delta + P.nk_off[prob] + pos, ndk - ndk0);

@@ -103,21 +103,22 @@ __device__ __forceinline__ int allor_i32(int x, int lane)
     return x;
 }
 
-// One site of the sparse kernel (J = index inside the current batch of 8 sites), branch free: every lane of the
-// wavefront executes every instruction and the per-group conditions (is site J part of this batch? has an
-// earlier site of the batch been undecidable?) are data -- divergent branches here cost more in exec-mask
-// bookkeeping (SGPR spills) than the arithmetic they skip.
-// `ok` = no site of this batch has been undecidable so far; `done` counts the decided sites.  The reciprocal y of
-// n_k + V*beta is recomputed ONCE per site, after the removal (it then also covers the previous site's add-back).
+// One site of the sparse kernel (J = index inside the current batch of 8 sites), branch free on the decided path:
+// every lane of the wavefront executes every instruction and the per-group condition "is site J part of this batch?"
+// is data -- divergent branches here cost more in exec-mask bookkeeping (SGPR spills) than the arithmetic they skip.
+// The reciprocal y of n_k + V*beta is recomputed ONCE per site, after the removal (it then also covers the previous
+// site's add-back).  A site the margin cannot decide (~1e-11 per site; the only branch, wave-uniform) is resolved on
+// the spot by exact_site_wave(): the reference's fp64 pipeline in the dense layout of the problem (`lay`), run by
+// the whole wavefront for that document -- the topic is the exact pipeline's either way.
 template <int GS, int J, class PT>
-__device__ __forceinline__ void sparse_site(const PT &P, int nb, int sf, int sz, int su_lo, int su_hi,
-                                            const int (&xg)[8], bool live, int pos, int A, int &ndk, int &nk,
-                                            int &my_zn, int &ok, int &done, int lig, int lane, int gbase, uint64_t gmask)
+__device__ __forceinline__ void sparse_site(const PT &P, const ExactLayout &lay, int nb, int sf, int sz, int su_lo,
+                                            int su_hi, const int (&xg)[8], bool live, int pos, int A, int &ndk, int &nk,
+                                            int &my_zn, int &done, int lig, int lane, int gbase, uint64_t gmask)
 {
     // (the per-group flags are 0 / -1 integers in VGPRs: as `bool`s they would each occupy an SGPR pair)
     const int f = bcast_lane<GS, J>(sf, lig), zo = bcast_lane<GS, J>(sz, lig);
     const double u = __hiloint2double(bcast_lane<GS, J>(su_hi, lig), bcast_lane<GS, J>(su_lo, lig));
-    const int active = ok & ((J < nb) ? -1 : 0);
+    const int active = (J < nb) ? -1 : 0;
     const int rm = f & active & ((pos == zo) ? -1 : 0);                             // LabeledLDA.py:109-111
     ndk -= rm; nk -= rm;
     const double y = rcp_newton((double)nk + P.vbeta);
@@ -126,18 +127,50 @@ __device__ __forceinline__ void sparse_site(const PT &P, int nb, int sf, int sz,
     const double tot = allsum_any_f64<GS>(w, lane);
     const double t = u * tot, margin = tot * P.margin_rel;
     const bool unsure = active && ((live && !(fabs(Q - t) > margin)) || !(tot > 0.0) || !(margin < tot));
-    const int bad = (((__ballot(unsure) >> gbase) & gmask) != 0) ? -1 : 0;         // group-uniform
     const uint64_t gf = (__ballot(live && Q > t) >> gbase) & gmask;
     const int sel = gf ? (int)__ffsll((unsigned long long)gf) - 1 : A - 1;          // none: last allowed topic
-    const int zn = allor_i32<GS>((lig == sel) ? pos : 0, lane);
-    const int commit = active & ~bad;
-    // decided: add the site back (LabeledLDA.py:121-125); undecidable: undo the removal, the dense kernel
-    // starts at this site
-    const int back = (commit & f & ((pos == zn) ? -1 : 0)) | (~commit & rm);
+    int zn = allor_i32<GS>((lig == sel) ? pos : 0, lane);
+    uint64_t todo = __ballot(unsure);
+    if (__builtin_expect(todo != 0, 0)) {
+        // exact tier: one undecided document of the wavefront at a time (all 64 lanes take part)
+        if (lane == 0 && P.status) { atomicOr(P.status, 2); }
+        const double wx = live ? ((double)ndk + P.alpha) * (((double)(xg[J] - rm) + P.beta) / ((double)nk + P.vbeta)) : 0.0;
+        while (todo) {
+            const int first = (int)__ffsll((unsigned long long)todo) - 1;
+            const int base = first & ~(GS - 1);
+            todo &= ~(gmask << base);
+            const int A_g = __builtin_amdgcn_readlane(A, base);
+            const double u_g = readlane_var_f64(u, base);
+            ExactLayout lg = lay;                    // (the batched kernel serves a different problem per lane group)
+            lg.T = __builtin_amdgcn_readlane(lay.T, base); lg.G = __builtin_amdgcn_readlane(lay.G, base);
+            lg.tail = __builtin_amdgcn_readlane(lay.tail, base); lg.tail_row = __builtin_amdgcn_readlane(lay.tail_row, base);
+            lg.last_leaf = __builtin_amdgcn_readlane(lay.last_leaf, base);
+            const int r = exact_site_wave(wx, pos, base, A_g, u_g, lg, lane);
+            if ((lane & ~(GS - 1)) == base) {
+                zn = r < 0 ? zo : r;
+                if (r < 0 && lig == 0 && P.status) atomicOr(P.status, 1);           // no topic with positive probability
+                if (lig == 0 && P.status) atomicAdd(P.status + 2, 1);               // statistics: exact-tier sites
+            }
+        }
+    }
+    // add the site back (LabeledLDA.py:121-125)
+    const int back = active & f & ((pos == zn) ? -1 : 0);
     ndk += back; nk += back;
-    my_zn = (commit & ((lig == J) ? -1 : 0)) ? zn : my_zn;
-    done -= commit;                                                                 // commit is 0 or -1
-    ok &= ~bad;
+    my_zn = (active & ((lig == J) ? -1 : 0)) ? zn : my_zn;
+    done -= active;                                                                 // active is 0 or -1
+}
+
+// dense layout of the K topics as exact_site_wave needs it, from the sweep parameters
+__device__ __forceinline__ ExactLayout exact_layout_of(const KParams &P)
+{
+    ExactLayout L;
+    int P2 = 1;
+    while (P2 < P.last_leaf + 1) P2 *= 2;
+    L.G = 8 * P2; L.T = P.KP / L.G;
+    L.last_leaf = P.last_leaf; L.tail = P.tail; L.tail_row = P.tail_row; L.n_rounds = P.n_rounds; L.xor_tree = P.xor_tree;
+#pragma unroll
+    for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) L.rounds_pk[r] = P.rounds_pk[r];
+    return L;
 }
 
 template <int GS>
@@ -154,34 +187,42 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
     const int grp = tid / GS;
     const int gbase = lane & ~(GS - 1);
     const uint64_t gmask = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
+    const ExactLayout lay = exact_layout_of(P);
 
+    // The document loops are WAVE-UNIFORM (a lane group whose document is shorter, empty or past the end of the shard
+    // idles through flags, it does not leave the loop): the exact tier of sparse_site() needs all 64 lanes.
     for (int it = 0; it < P.dpg; ++it) {
         const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
-        if (idx >= P.D) break;
-        const int64_t d = P.doc_order ? (int64_t)P.doc_order[idx] : idx;
+        const bool valid = idx < P.D;
+        if (!__any(valid)) break;
+        const int64_t d = valid ? (P.doc_order ? (int64_t)P.doc_order[idx] : idx) : 0;
         const int64_t s0 = P.doc_off[d];
-        const int len = (int)(P.doc_off[d + 1] - s0);
-        if (len <= 0) continue;
+        const int len = valid ? (int)(P.doc_off[d + 1] - s0) : 0;
         const int64_t l0 = P.live_off[d];
         const int A = (int)(P.live_off[d + 1] - l0);
-        const bool live = lig < A;
+        const bool live = valid && len > 0 && lig < A;
         const int pos = live ? P.live_pos[l0 + lig] : -1;
         int32_t *ndk_p = P.n_dk + d * KP + (live ? pos : 0);
         int ndk = live ? *ndk_p : 0;
         const int ndk0 = ndk;
         int nk = live ? P.n_k[pos] : 0;
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
-        int stop_at = -1;
+        int max_len = len;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) max_len = max(max_len, __shfl_xor(max_len, o, 64));
 
         // Sites are processed in batches of 8 so that memory latency is paid once per batch: lane j < 8 of
         // the group loads the scalars of site n0+j and draws its uniform, every lane gathers its own topic's
         // n_kw entry for all 8 words, then 8 sites run back to back on registers / DPP only, and lane j
         // commits site n0+j (z store + two atomics) while the next batch loads.
-        for (int n0 = 0; n0 < len && stop_at < 0; n0 += 8) {
-            const int nb = min(8, len - n0);
+        for (int n0 = 0; n0 < max_len; n0 += 8) {
+            const int nb = max(0, min(8, len - n0));
             const int jj = lig & 7;
-            const int64_t si = s0 + n0 + (jj < nb ? jj : nb - 1);
-            const int sv = P.word[si], sf = P.freq[si], sz = P.z[si], sc = P.csc_pos ? P.csc_pos[si] : 0;
+            int sv = 0, sf = 0, sz = 0, sc = 0;
+            if (nb > 0) {
+                const int64_t si = s0 + n0 + (jj < nb ? jj : nb - 1);
+                sv = P.word[si]; sf = P.freq[si]; sz = P.z[si]; sc = P.csc_pos ? P.csc_pos[si] : 0;
+            }
             int su_lo, su_hi;
             {   // keyed uniform of site n0+jj: Philox block (site >> 1), words (0,1) / (2,3) by parity
                 const int n = n0 + jj;
@@ -196,7 +237,7 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
                       w3 = bcast_lane<GS, 3>(sv, lig), w4 = bcast_lane<GS, 4>(sv, lig), w5 = bcast_lane<GS, 5>(sv, lig),
                       w6 = bcast_lane<GS, 6>(sv, lig), w7 = bcast_lane<GS, 7>(sv, lig);
             int xg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (live) {
+            if (live && nb > 0) {
                 const int32_t *col = P.n_kw + pos;
                 xg[0] = col[(int64_t)w0 * KP]; xg[1] = col[(int64_t)w1 * KP]; xg[2] = col[(int64_t)w2 * KP];
                 xg[3] = col[(int64_t)w3 * KP]; xg[4] = col[(int64_t)w4 * KP]; xg[5] = col[(int64_t)w5 * KP];
@@ -204,31 +245,15 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
             }
 
             int my_zn = sz;
-            int ok = -1;                      // 0 once a site of this batch was undecidable
-            int done = 0;                     // sites of this batch that were decided
+            int done = 0;                     // sites of this batch
 #define LLDA_SPARSE_SITE(J)                                                                                    \
-            sparse_site<GS, J>(P, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, ok, done, lig, lane, \
+            sparse_site<GS, J>(P, lay, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
                                gbase, gmask);
             LLDA_SPARSE_SITE(0) LLDA_SPARSE_SITE(1) LLDA_SPARSE_SITE(2) LLDA_SPARSE_SITE(3)
             LLDA_SPARSE_SITE(4) LLDA_SPARSE_SITE(5) LLDA_SPARSE_SITE(6) LLDA_SPARSE_SITE(7)
 #undef LLDA_SPARSE_SITE
-            if (!ok) stop_at = n0 + done;
-            // commit the decided sites of the batch: lane j handles site n0+j
+            // commit the sites of the batch: lane j handles site n0+j
             if (lig < 8 && lig < done) commit_site(P, s0 + n0 + lig, sv, sf, sz, my_zn, sc, KP);
-        }
-
-        if (stop_at >= 0) {
-            // hand the document over to the dense kernel: record (doc, site, n_dk deltas so far)
-            int slot = 0;
-            if (lig == 0) slot = atomicAdd(P.resume_count, 1);
-            slot = __shfl(slot, 0, GS);
-            if (slot < P.resume_cap) {
-                int32_t *rec = P.resume + (int64_t)slot * (2 + LLDA_MAX_LIVE);
-                if (lig == 0) { rec[0] = (int32_t)d; rec[1] = stop_at; }
-                if (live) rec[2 + lig] = ndk - ndk0;
-            } else if (lig == 0 && P.status) {
-                atomicOr(P.status, 4);                  // resume list overflow (cannot happen with production margins)
-            }
         }
         if (live) {
             *ndk_p = ndk;

@@ -158,26 +158,15 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
     const int grp = tid / G;
     const float vbeta32 = (float)P.vbeta, alpha32 = (float)P.alpha, beta32 = (float)P.beta;
 
-    const int n_resume = P.resume_mode ? min(*P.resume_count, P.resume_cap) : 0;
     const int64_t site_base = P.doc_off[0];                 // uniform: the bases below stay in SGPRs
     const int32_t *word_b = P.word + site_base, *freq_b = P.freq + site_base;
     const int32_t *csc_b = P.csc_pos ? P.csc_pos + site_base : nullptr;
     int32_t *z_b = P.z + site_base;
-    for (int it = 0; P.resume_mode || it < P.dpg; ++it) {
-        int64_t d;
-        int n0 = 0;                           // first site to sample (resume mode: where the sparse kernel stopped)
-        const int32_t *rec = nullptr;
-        if (P.resume_mode) {
-            const int64_t idx = ((int64_t)it * gridDim.x + blockIdx.x) * GPB + grp;
-            if (idx >= n_resume) break;
-            rec = P.resume + idx * (2 + LLDA_MAX_LIVE);
-            d = rec[0];
-            n0 = rec[1];
-        } else {
-            const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
-            if (idx >= P.D) break;
-            d = P.doc_order ? (int64_t)P.doc_order[idx] : idx;
-        }
+    for (int it = 0; it < P.dpg; ++it) {
+        constexpr int n0 = 0;                 // first site to sample
+        const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
+        if (idx >= P.D) break;
+        const int64_t d = P.doc_order ? (int64_t)P.doc_order[idx] : idx;
         const int64_t s0 = P.doc_off[d];
         const int len = (int)(P.doc_off[d + 1] - s0);
         if (len <= n0) continue;
@@ -192,19 +181,6 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 s_ndk[s][tid] = r[s];
                 s_nkc[s][tid] = k[s];                              // sweep-start n_k
                 s_pa[s][tid] = tier0_factor(r[s], k[s], alpha32, vbeta32);
-            }
-        }
-        if (rec) {
-            // resumed document: the n_k it sees already moved by its own earlier sites (n_dk row holds them)
-            const int64_t l0 = P.live_off[d];
-            const int A = (int)(P.live_off[d + 1] - l0);
-            for (int j = 0; j < A; ++j) {
-                const int pos = P.live_pos[l0 + j], dl = rec[2 + j];
-                if (dl != 0 && lig == pos / T) {
-                    const int nk = s_nkc[pos % T][tid] + dl;
-                    s_nkc[pos % T][tid] = nk;
-                    s_pa[pos % T][tid] = tier0_factor(s_ndk[pos % T][tid], nk, alpha32, vbeta32);
-                }
             }
         }
         const uint32_t mask = P.lab_mask[d * G + lig];

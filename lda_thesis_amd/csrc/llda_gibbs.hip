@@ -20,10 +20,11 @@
 //   device_common.hpp   kernel parameters, Philox, row loads, one-hot updates, exact division, DPP / permlane
 //                       cross-lane moves, numpy-ordered group sum, keyed categorical draw (exact)
 //   draw_tiers.hpp      tier-0 (fp32) decision, cold tiers (fp64 decision, exact pipeline), commit of a site
+//   exact_generic.hpp   exact_site_wave           the exact pipeline with the layout known at run time (a whole wave per
+//                                                 document): the sparse kernels' answer to a site they cannot decide
 //   kernel_sweep.hpp    llda_sweep_exact_kernel   general kernel, every site through the exact pipeline
 //                       llda_sweep_kernel         tiered kernel, per-document state in LDS (the hot kernel)
-//   kernel_sparse.hpp   llda_sweep_sparse_kernel  one lane per ALLOWED topic for sparse label sets; hands
-//                                                 undecided documents to llda_sweep_kernel (resume list)
+//   kernel_sparse.hpp   llda_sweep_sparse_kernel  one lane per ALLOWED topic for sparse label sets
 //   kernel_batch.hpp    llda_sweep_batch_kernel   one sweep over many independent small problems (CascadeLDA's
 //                                                 ensemble) in one launch, sparse-kernel arithmetic
 //   kernel_readout.hpp  llda_loglik_kernel, llda_readout_phi / _theta kernels (thinning read-outs)
@@ -41,6 +42,7 @@
 
 #include "device_common.hpp"
 #include "draw_tiers.hpp"
+#include "exact_generic.hpp"
 #include "kernel_sweep.hpp"
 #include "kernel_sparse.hpp"
 #include "kernel_batch.hpp"
@@ -331,9 +333,9 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     P.margin0_rel = a->debug_margin == 0 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
     hipStream_t st = (hipStream_t)stream;
 
-    // sparse label sets: one lane per allowed topic, undecided documents continue in the dense kernel
-    const bool sparse = fast && !dense && a->live_off && a->live_pos && a->resume && a->resume_count &&
-                        a->resume_cap > 0 && a->live_max >= 1 && a->live_max <= LLDA_MAX_LIVE;
+    // sparse label sets: one lane per allowed topic (a site the margin cannot decide is resolved inside the kernel by
+    // the exact pipeline, exact_site_wave)
+    const bool sparse = fast && !dense && a->live_off && a->live_pos && a->live_max >= 1 && a->live_max <= LLDA_MAX_LIVE;
     const int G = sparse ? (a->live_max <= 8 ? 8 : a->live_max <= 16 ? 16 : a->live_max <= 32 ? 32 : 64) : L.G;
     const int gpb = 256 / G;
     int dpg = a->docs_per_group;
@@ -348,10 +350,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
 
     if (sparse) {
         P.live_off = a->live_off; P.live_pos = a->live_pos;
-        P.resume = a->resume; P.resume_count = a->resume_count; P.resume_cap = a->resume_cap;
-        hipError_t e = hipMemsetAsync(a->resume_count, 0, sizeof(int32_t), st);
-        if (e != hipSuccess) return hip_fail(e);
-        if (a->debug_margin < 0) P.margin_rel = 2.0;       // test hook: every document is handed to the dense kernel
+        if (a->debug_margin < 0) P.margin_rel = 2.0;       // test hook: every site goes through the exact pipeline
         const dim3 grid((unsigned)blocks), block(256);
         switch (G) {
         case 8: hipLaunchKernelGGL(llda_sweep_sparse_kernel<8>, grid, block, 0, st, P); break;
@@ -359,20 +358,8 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         case 32: hipLaunchKernelGGL(llda_sweep_sparse_kernel<32>, grid, block, 0, st, P); break;
         default: hipLaunchKernelGGL(llda_sweep_sparse_kernel<64>, grid, block, 0, st, P); break;
         }
-        e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e);
-        // second launch: the dense tiered kernel walks the (almost always empty) resume list
-        P.resume_mode = 1;
-        P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
-        int64_t rblocks = ((int64_t)a->resume_cap + (256 / L.G) - 1) / (256 / L.G);
-        if (rblocks > 256) rblocks = 256;
-        switch (L.G) {
-        case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, true, false, rblocks, st);
-        case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, true, false, rblocks, st);
-        case 32: return dispatch_sweep_T<32>(L.T, P, has_tail, true, false, rblocks, st);
-        case 64: return dispatch_sweep_T<64>(L.T, P, has_tail, true, false, rblocks, st);
-        }
-        return LLDA_E_BAD_K;
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? LLDA_OK : hip_fail(e);
     }
     switch (L.G) {
     case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, fast, dense, blocks, st);
@@ -388,7 +375,7 @@ int llda_sweep_batch(const llda_batch_args *a, void *stream)
     if (!a || a->n_inst < 0 || a->V < 1) return LLDA_E_BAD_ARG;
     if (a->n_inst == 0) return LLDA_OK;
     if (!a->inst_off || !a->order || !a->word || !a->freq || !a->z || !a->inst_prob || !a->inst_doc || !a->live_off ||
-        !a->live_pos || !a->ndk_off || !a->n_dk || !a->kw_off || !a->nk_off || !a->kp || !a->prob_stream || !a->counts ||
+        !a->live_pos || !a->ndk_off || !a->n_dk || !a->kw_off || !a->nk_off || !a->kp || !a->prob_stream || !a->k || !a->counts ||
         !a->delta)
         return LLDA_E_BAD_ARG;
     if (a->lanes != 8 && a->lanes != 16 && a->lanes != 32 && a->lanes != 64) return LLDA_E_BAD_ARG;
@@ -397,7 +384,7 @@ int llda_sweep_batch(const llda_batch_args *a, void *stream)
     P.inst_off = a->inst_off; P.order = a->order; P.n_inst = a->n_inst; P.word = a->word; P.freq = a->freq; P.z = a->z;
     P.inst_prob = a->inst_prob; P.inst_doc = a->inst_doc; P.live_off = a->live_off; P.live_pos = a->live_pos;
     P.ndk_off = a->ndk_off; P.n_dk = a->n_dk; P.kw_off = a->kw_off; P.nk_off = a->nk_off; P.kp = a->kp;
-    P.prob_stream = a->prob_stream;
+    P.prob_stream = a->prob_stream; P.k = a->k;
     P.counts = a->counts; P.delta = a->delta; P.status = a->status;
     P.alpha = a->alpha; P.beta = a->beta; P.vbeta = (double)a->V * a->beta;
     // the sparse arithmetic needs strictly positive scores and an in-range reciprocal (as llda_sweep's tiered kernels)

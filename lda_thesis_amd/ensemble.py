@@ -4,7 +4,8 @@ The reference trains the 122 sub-problems of the abstracts corpus one after anot
 (/root/reference/CascadeLDA.py:135-184, each a SubLDA, CascadeLDA.py:347-434).  They share nothing but the read-only
 corpus, and most are tiny (6 .. 4171 documents, 2 .. 20 topics), so here all of them live in ONE set of device
 buffers and every sweep of the whole ensemble is at most four launches of ``llda_sweep_batch``
-(include/llda_gibbs.h) plus one ``llda_apply_delta``:
+(include/llda_gibbs.h) plus one ``llda_apply_delta`` (a site the kernel's margin cannot decide goes through the exact
+fp64 pipeline inside the kernel, so the result is always the reference's):
 
     document instance i = (sub-problem p, member document d)      I = sum_p D_p instances, visiting order
     inst_off (I+1), word / freq / z (S_tot)                       CSR over instance sites (z = device positions)
@@ -30,7 +31,7 @@ import torch
 from . import _native
 from .layout import group_layout
 
-BATCH_UNDECIDED = 8          # status bit of llda_sweep_batch: a site could not be decided -> fall back
+MAX_BATCH_K = 128            # llda_sweep_batch: every problem is one numpy pairwise leaf (8 lanes)
 
 
 def choice_cdf_table(a_max):
@@ -78,6 +79,8 @@ class Ensemble(object):
         for pl in plans:
             if pl["K"] not in layouts:
                 layouts[pl["K"]] = group_layout(pl["K"])
+        if any(pl["K"] > MAX_BATCH_K for pl in plans):
+            raise ValueError("the batched ensemble handles sub-problems of at most %d topics" % MAX_BATCH_K)
         kp = np.array([layouts[pl["K"]].KP for pl in plans], dtype=np.int64)
         n_docs = np.array([len(pl["docs"]) for pl in plans], dtype=np.int64)
         # fused [n_kw | n_k] per problem
@@ -135,6 +138,7 @@ class Ensemble(object):
         self.ndk_off = up(ndk_off[:-1], torch.int64)
         self.kw_off, self.nk_off, self.kp = up(kw_off, torch.int64), up(nk_off, torch.int64), up(kp, torch.int32)
         self.prob_stream = up(np.arange(P) if streams is None else np.asarray(streams), torch.int32)
+        self.prob_k = up(np.array([pl["K"] for pl in plans]), torch.int32)
         self._kp_h, self._kw_off_h, self._nk_off_h, self._ndk_off_h = kp, kw_off, nk_off, ndk_off
         self._inst_off_h, self._n_docs_h, self._layouts = inst_off, n_docs, layouts
         self.status = torch.zeros((4,), dtype=torch.int32, device=dev)
@@ -168,16 +172,16 @@ class Ensemble(object):
             self.backend.sweep_batch(inst_off=self.inst_off, order=order, word=self.word, freq=self.freq, z=self.z,
                                 inst_prob=self.inst_prob, inst_doc=self.inst_doc, live_off=self.live_off,
                                 live_pos=self.live_pos, ndk_off=self.ndk_off, n_dk=self.n_dk, kw_off=self.kw_off,
-                                nk_off=self.nk_off, kp=self.kp, prob_stream=self.prob_stream, counts=self.counts, delta=self.delta,
+                                nk_off=self.nk_off, kp=self.kp, prob_stream=self.prob_stream, k=self.prob_k, counts=self.counts, delta=self.delta,
                                 status=self.status, V=self.V, lanes=lanes, alpha=self.alpha, beta=self.beta,
                                 seed=self.seed, sweep=self.sweeps_done, debug_margin=self.debug_margin)
         self.backend.apply_delta(self.counts, self.delta)
         self.sweeps_done += 1
 
-    def undecided(self):
-        """True when some site could not be decided by the batched arithmetic: the state is then invalid and the
-        caller trains the problems one by one (synchronises)."""
-        return bool(int(self.status[0].item()) & BATCH_UNDECIDED)
+    def check_status(self):
+        """Raise like the reference would (numpy's multinomial rejects a NaN pvals vector); synchronises."""
+        if int(self.status[0].item()) & 1:
+            raise ValueError("a site had no topic with positive probability (pvals would be NaN)")
 
     # ------------------------------------------------------------------ read-outs
     def ph_rows(self):

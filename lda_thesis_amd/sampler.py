@@ -129,7 +129,7 @@ class GibbsSampler(object):
         self.dense_mask = labs is None
         # sparse label sets (Labeled LDA proper): positions of the allowed topics per document, ascending;
         # the library then runs one lane per ALLOWED topic (llda_sweep_sparse_kernel)
-        self.live_off = self.live_pos = self.resume = self.resume_count = None
+        self.live_off = self.live_pos = None
         self.live_max = 0
         if sparse_labels and labs is not None and self.D > 0:
             self._make_live()
@@ -254,9 +254,6 @@ class GibbsSampler(object):
         torch.cumsum(counts, 0, out=self.live_off[1:])
         self.live_pos = pos.to(torch.int32).contiguous()
         self.live_max = live_max
-        cap = min(self.D, 1 << 16)
-        self.resume = torch.zeros((cap, 66), dtype=torch.int32, device=dev)
-        self.resume_count = torch.zeros((1,), dtype=torch.int32, device=dev)
 
     def _make_ranges(self):
         """document bounds of the overlap ranges (contiguous, balanced by site count); one range = no overlap."""
@@ -368,7 +365,7 @@ class GibbsSampler(object):
                                    docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
                                    debug_margin=self.debug_margin,
                                    live_off=None if self.live_off is None else self.live_off[lo:hi + 1],
-                                   live_pos=self.live_pos, resume=self.resume, resume_count=self.resume_count,
+                                   live_pos=self.live_pos,
                                    live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
                                    n_sites=s1 - s0)
             if pipelined:
@@ -436,8 +433,6 @@ class GibbsSampler(object):
     def check_status(self):
         """Raise like the reference would (numpy's multinomial rejects a NaN pvals vector)."""
         st = int(self.status[0].item())
-        if st & 4:
-            raise _native.NativeError("sparse kernel: resume list overflow")
         if st & 1:
             raise ValueError("a site had no topic with positive probability (pvals would be NaN)")
 

@@ -66,8 +66,7 @@ class OracleBackend(object):
 
     def sweep(self, *, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
               status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
-              dense_mask=False, debug_margin=0, live_off=None, live_pos=None, resume=None, resume_count=None,
-              live_max=0, csc_pos=None, commit_log=None, n_sites=None):
+              dense_mask=False, debug_margin=0, live_off=None, live_pos=None, live_max=0, csc_pos=None, commit_log=None, n_sites=None):
         import torch
         lay = self._lay(K)
         tp = lay.topic_pos.astype(np.int64)
@@ -94,14 +93,11 @@ class OracleBackend(object):
         n_k_delta += torch.from_numpy(d_k)
 
     def sweep_batch(self, *, inst_off, order, word, freq, z, inst_prob, inst_doc, live_off, live_pos, ndk_off, n_dk,
-                    kw_off, nk_off, kp, prob_stream, counts, delta, status, V, lanes, alpha, beta, seed, sweep,
+                    kw_off, nk_off, kp, prob_stream, k, counts, delta, status, V, lanes, alpha, beta, seed, sweep,
                     debug_margin=0):
         """llda_sweep_batch through the C oracle: the instances of ``order``, problem by problem, each a snapshot
         sweep (llda_oracle_sweep_docs) in the reference's layout; changes go to ``delta`` as the kernel's atomics do."""
         import torch
-        if debug_margin < 0:
-            status[0] |= 8
-            return
         ioff, ip, idoc = inst_off.numpy(), inst_prob.numpy(), inst_doc.numpy()
         loff, lpos, noff = live_off.numpy(), live_pos.numpy(), ndk_off.numpy()
         cnt, dlt = counts.numpy(), delta.numpy()
@@ -113,7 +109,7 @@ class OracleBackend(object):
             KP = int(kp[p])
             kw0, nk0 = int(kw_off[p]), int(nk_off[p])
             n_kw = cnt[kw0:kw0 + V * KP].reshape(V, KP)
-            K = self.batch_K[int(prob_stream[p])]              # (the ABI passes KP only; the test tells the checker K)
+            K = int(k[p])
             lay = self._lay(K)
             tp = lay.topic_pos.astype(np.int64)
             n_k_v = np.ascontiguousarray(n_kw[:, tp].T.astype(np.int64))

@@ -125,9 +125,7 @@ def _cascade_worker(rank, world, port, batched, q):
 
     class CpuEnsemble(E.Ensemble):             # the batched ensemble, same stand-in
         def __init__(self, plans, z_local, *a, **k):
-            be = OracleBackend(c_oracle)
-            be.batch_K = {st: pl["K"] for st, pl in zip(k["streams"], plans)}
-            k.update(device="cpu", backend=be)
+            k.update(device="cpu", backend=OracleBackend(c_oracle))
             super().__init__(plans, z_local, *a, **k)
     E.Ensemble = CpuEnsemble
     g = load_golden("cascade_toy")

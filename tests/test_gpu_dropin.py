@@ -125,10 +125,10 @@ def test_cascade_go_down_tree_matches_reference(capsys):
     assert out.count("Working on parent node") == len(g["sizes"]) - 1
 
 
-def test_cascade_batched_ensemble_equals_one_by_one_and_falls_back():
+def test_cascade_batched_ensemble_equals_one_by_one():
     """the batched ensemble (llda_sweep_batch: all sub-problems in one launch) leaves the state the sub-problems
-    reach one by one through llda_sweep, sub-problem by sub-problem; and when the batched arithmetic reports a site
-    it cannot decide (forced here) go_down_tree silently takes the one-by-one path -- same ph, same numpy stream."""
+    reach one by one through llda_sweep, sub-problem by sub-problem -- also when sites are forced through the exact
+    pipeline inside the batched kernel."""
     import llda_oracle as orc
     from fixture_corpora import cascade_corpus
     from lda_thesis_amd.CascadeLDA import CascadeLDA
@@ -145,7 +145,7 @@ def test_cascade_batched_ensemble_equals_one_by_one_and_falls_back():
         return c
     a = run()
     a.go_down_tree(4, 2, batched=True, keep_state=True)
-    assert a._ensemble is not None and not a._ensemble.undecided()
+    assert a._ensemble is not None and int(a._ensemble.status[2]) == 0      # production margin: no exact-tier site
     after_a = np.random.random_sample()
     b = run(_keep_subs=[])
     b.go_down_tree(4, 2, batched=False)
@@ -157,12 +157,14 @@ def test_cascade_batched_ensemble_equals_one_by_one_and_falls_back():
     for i, sub in b._keep_subs:
         n_k_v, n_d_k, n_zk, z = a._ensemble.problem_state(i)
         assert orc.digest(n_k_v, n_d_k, n_zk, z) == orc.digest(sub.n_k_v, sub.n_d_k, sub.n_zk, np.concatenate(sub.z_dn))
-    # forced fall-back
-    c = run(_batch_debug_margin=-1)
-    c.go_down_tree(4, 2, batched=True, keep_state=True)
-    assert c._ensemble is None
-    np.testing.assert_array_equal(c.ph, g["ph"])
-    assert np.random.random_sample() == after_a
+    # every site through the exact pipeline INSIDE the batched kernel (exact_site_wave), and a widened margin that
+    # mixes decided and exact sites inside one wavefront: same state
+    for margin in (-1, 4):
+        c = run(_batch_debug_margin=margin)
+        c.go_down_tree(4, 2, batched=True, keep_state=True)
+        assert c._ensemble is not None and int(c._ensemble.status[2]) > 0
+        np.testing.assert_array_equal(c.ph, g["ph"])
+        assert np.random.random_sample() == after_a
 
 
 def test_cascade_tiny_priors_take_the_one_by_one_path():
