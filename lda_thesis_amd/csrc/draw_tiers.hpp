@@ -266,11 +266,12 @@ __device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, 
 }
 
 // the same through base + 32-bit byte offsets (site_off = 4 * site index relative to z_base, c = log position)
+template <bool LOGGED>
 __device__ __forceinline__ void commit_site_off(const KParams &P, int32_t *z_base, uint32_t site_off, int v, int f, int zo,
                                                 int zn, int c, int KP)
 {
     gstore_i32(z_base, site_off, zn);
-    if (P.commit_log) {
+    if (LOGGED) {
         ((LLDA_GLOBAL uint32_t *)P.commit_log)[(uint32_t)c] = (uint32_t)zo | ((uint32_t)zn << 16);   // (log of any length)
     } else if (zn != zo) {
         int32_t *row = P.n_kw_delta + (int64_t)v * KP;

@@ -139,7 +139,10 @@ __device__ __forceinline__ void count_update(int (*s_ndk)[256], int (*s_nkc)[256
     s_pa[slot][tid] = tier0_factor(nd, nk, alpha32, vbeta32);
 }
 
-template <int G, int T, bool HAS_TAIL, bool DENSE>
+// LOGGED: the commit goes to the word-major commit log (csc_pos / commit_log non-NULL) -- a compile-time fact, so the
+// instantiation carries neither the atomics path nor the pointer tests (the kernel is VALU-issue bound and short of
+// SGPRs: every uniform test in the site loop costs).
+template <int G, int T, bool HAS_TAIL, bool DENSE, bool LOGGED>
 __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KParams P)
 {
     constexpr int KP = G * T;
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
 
     const int64_t site_base = P.doc_off[0];                 // uniform: the bases below stay in SGPRs
     const int32_t *word_b = P.word + site_base, *freq_b = P.freq + site_base;
-    const int32_t *csc_b = P.csc_pos ? P.csc_pos + site_base : nullptr;
+    const int32_t *csc_b = LOGGED ? P.csc_pos + site_base : nullptr;
     int32_t *z_b = P.z + site_base;
     for (int it = 0; it < P.dpg; ++it) {
         constexpr int n0 = 0;                 // first site to sample
@@ -203,9 +206,9 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         const uint32_t o0 = opaque_u32(sb + (uint32_t)n0 * 4u), o1 = opaque_u32(sb + (uint32_t)(n0 + 1 < len ? n0 + 1 : n0) * 4u);
         SiteRegs R0, R1, R2;
         R0.v = gload_i32(word_b, o0); R0.f = gload_i32(freq_b, o0); R0.zo = gload_i32(z_b, o0);
-        R0.c = P.csc_pos ? gload_i32(csc_b, o0) : 0; R0.zn = 0;
+        R0.c = LOGGED ? gload_i32(csc_b, o0) : 0; R0.zn = 0;
         R1.v = gload_i32(word_b, o1); R1.f = gload_i32(freq_b, o1); R1.zo = gload_i32(z_b, o1);
-        R1.c = P.csc_pos ? gload_i32(csc_b, o1) : 0; R1.zn = 0;
+        R1.c = LOGGED ? gload_i32(csc_b, o1) : 0; R1.zn = 0;
         R2.v = R2.f = R2.zo = R2.c = R2.zn = 0;
         int xn[T];
         gload_row<T>(P.n_kw, (int64_t)R0.v * KP + lig * T, xn);
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             }
 #ifndef ABL_NOCOMMIT
             if (lig == 0 && n > n0)
-                commit_site_off(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn, prv.c, KP);
+                commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn, prv.c, KP);
 #endif
 #ifndef ABL_NOLOAD
             gload_row<T>(P.n_kw, (int64_t)nxt.v * KP + lig * T, xn);      // row of site n+1 (clamped)
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             {
                 const uint32_t o2 = opaque_u32(sb + (uint32_t)(n + 2 < len ? n + 2 : len - 1) * 4u);   // scalars of site n+2 (clamped)
                 prv.v = gload_i32(word_b, o2); prv.f = gload_i32(freq_b, o2); prv.zo = gload_i32(z_b, o2);
-                if (P.csc_pos) prv.c = gload_i32(csc_b, o2);
+                if (LOGGED) prv.c = gload_i32(csc_b, o2);
             }
             uint32_t ra, rb;
             site_random_bits<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3, ra, rb);
@@ -286,7 +289,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
 #ifndef ABL_NOCOMMIT
             // the last site of the document is committed right away
             if (lig == 0 && n + 1 == len)
-                commit_site_off(P, z_b, opaque_u32(sb + (uint32_t)n * 4u), cur.v, cur.f, cur.zo, cur.zn, cur.c, KP);
+                commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)n * 4u), cur.v, cur.f, cur.zo, cur.zn, cur.c, KP);
 #endif
         };
         for (int n = n0; n < len; n += 3) {

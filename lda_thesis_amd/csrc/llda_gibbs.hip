@@ -109,11 +109,14 @@ int launch_sweep(const KParams &P, bool has_tail, bool fast, bool dense, int64_t
         if (has_tail) hipLaunchKernelGGL((llda_sweep_exact_kernel<G, T, true>), grid, block, 0, st, P);
         else hipLaunchKernelGGL((llda_sweep_exact_kernel<G, T, false>), grid, block, 0, st, P);
     } else if (dense) {
-        hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true>), grid, block, 0, st, P);
+        if (P.commit_log) hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true, true>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true, false>), grid, block, 0, st, P);
     } else if (has_tail) {
-        hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, false>), grid, block, 0, st, P);
+        if (P.commit_log) hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, false, true>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, false, false>), grid, block, 0, st, P);
     } else {
-        hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, false>), grid, block, 0, st, P);
+        if (P.commit_log) hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, false, true>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, false, false>), grid, block, 0, st, P);
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
