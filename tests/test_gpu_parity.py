@@ -297,8 +297,8 @@ def test_edge_tiny_priors_take_the_exact_kernel(c_oracle):
 @pytest.mark.parametrize("margin", [0, 6, -1])
 @pytest.mark.parametrize("name", ["tiny_k40", "tiny_k392", "tiny_k200", "sublda"])
 def test_sparse_kernel_matches_reference_o3(name, margin):
-    """fixtures whose documents allow few topics run through llda_sweep_sparse_kernel; margin 6 hands many
-    documents over to the dense kernel mid-way, -1 hands over every document at its first site."""
+    """fixtures whose documents allow few topics run through llda_sweep_sparse_kernel; margin 6 sends many sites
+    through the in-kernel exact tier (exact_site_wave), -1 every site."""
     g = load_golden(name)
     s = make_sampler(g)
     if s.live_off is None:
@@ -308,6 +308,39 @@ def test_sparse_kernel_matches_reference_o3(name, margin):
         s.sweep()
         assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics(), name)
     s.check_status()
+
+
+@pytest.mark.parametrize("margin", [-1, 6])
+@pytest.mark.parametrize("K", [9, 40, 100, 129, 190, 257, 392, 640, 777, 900, 968, 1024])
+def test_sparse_kernel_exact_tier_on_every_layout_shape(c_oracle, K, margin):
+    """exact_site_wave (the reference's fp64 pipeline run by a whole wavefront in the dense layout, with G, T, tail and
+    the leaf-combine schedule as run-time values): every site (margin -1) or a mixture with decided sites inside one
+    wavefront (margin 2^-6) of sparse-label documents, for one / two / four / seven (unbalanced tree) / eight leaves,
+    with and without a tail -- against the C oracle (LabeledLDA.py:113-119), three sweeps, ragged documents incl.
+    one-site ones."""
+    from lda_thesis_amd.sampler import GibbsSampler
+    rng = np.random.default_rng(K)
+    D, V = 150, 400
+    doc_off, word, freq, _, _ = synth(rng, D, V, K, 1, 60, True)
+    labs = np.zeros((D, K), dtype=np.uint8)
+    labs[:, 0] = 1
+    for d in range(D):                                 # root + up to K/4 - 1 (at most 20) other labels
+        n = int(rng.integers(0, min(20, K // 4 - 1) + 1))
+        labs[d, rng.choice(K - 1, size=n, replace=False) + 1] = 1
+    z = np.concatenate([rng.choice(np.nonzero(labs[d])[0], size=doc_off[d + 1] - doc_off[d]) for d in range(D)])
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=77, doc_base=3)
+    assert s.live_off is not None                      # the sparse kernel runs
+    s.debug_margin = margin
+    cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
+    for i in range(3):
+        s.sweep()
+        cs.sweep(1, 77, i, doc_base=3, threads=4)
+        np.testing.assert_array_equal(s.z_topics(), cs.z)
+        np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+        np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+        np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
+    s.check_status()
+    assert int(s.status[2]) > 0                        # sites really went through the exact tier
 
 
 def test_sparse_and_dense_kernels_agree_on_a_large_sparse_workload(c_oracle):
