@@ -18,7 +18,11 @@
  *
  * Device layout ("group layout")
  *   The K topics of a document are spread over G lanes x T slots; per-topic arrays are stored in
- *   device order  pos = lane*T + slot  with padded row length KP = G*T:
+ *   device order with padded row length KP = G*T.  The position of (lane, slot) in a row is
+ *       pos = ((slot / 4) * G + lane) * 4 + slot % 4      when T is a multiple of 4
+ *       pos = lane * T + slot                               when T is 1 or 2
+ *   i.e. the 16-byte chunk `slot / 4` of ALL lanes is contiguous, so that every vector load of a wavefront reads
+ *   one contiguous run of the row (llda_layout.pos_lane / pos_slot / topic_pos hold the permutation):
  *       n_kw  [V][KP] int32   word-major  (the reference's n_k_v (K,V) transposed + permuted)
  *       n_dk  [D][KP] int32   (the reference's n_d_k (D,K) permuted)
  *       n_k   [KP]    int32   (the reference's n_zk permuted)
@@ -35,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 10
+#define LLDA_ABI_VERSION 11
 #define LLDA_MAX_K 1024
 #define LLDA_MAX_LEAVES 8
 #define LLDA_MAX_ROUNDS 4
@@ -63,6 +67,8 @@ typedef struct llda_layout {
     int32_t rounds[LLDA_MAX_ROUNDS][LLDA_MAX_LEAVES];   /* partner leaf per round (self = idle) */
     int32_t topic_pos[LLDA_MAX_K];   /* topic id -> device position                           */
     int32_t pos_topic[LLDA_MAX_K];   /* device position -> topic id, -1 in the padding        */
+    int32_t pos_lane[LLDA_MAX_K];    /* device position -> lane of the group that holds it     */
+    int32_t pos_slot[LLDA_MAX_K];    /* device position -> slot of that lane (bit of lab_mask) */
 } llda_layout;
 
 /* Arguments of one sweep over a shard of documents.

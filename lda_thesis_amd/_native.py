@@ -9,12 +9,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libllda_gibbs.so")
+LIB_PATH = os.environ.get("LLDA_GIBBS_LIB") or os.path.join(_HERE, "libllda_gibbs.so")   # (override: ablation builds, tools/)
 
 MAX_K = 1024
 MAX_LEAVES = 8
 MAX_ROUNDS = 4
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -26,7 +26,8 @@ class LldaLayout(ctypes.Structure):
                 ("tail", _c_i32), ("tail_row", _c_i32), ("n_rounds", _c_i32),
                 ("leaf_start", _c_i32 * MAX_LEAVES), ("leaf_len", _c_i32 * MAX_LEAVES),
                 ("rounds", (_c_i32 * MAX_LEAVES) * MAX_ROUNDS),
-                ("topic_pos", _c_i32 * MAX_K), ("pos_topic", _c_i32 * MAX_K)]
+                ("topic_pos", _c_i32 * MAX_K), ("pos_topic", _c_i32 * MAX_K),
+                ("pos_lane", _c_i32 * MAX_K), ("pos_slot", _c_i32 * MAX_K)]
 
 
 class LldaFoldinArgs(ctypes.Structure):
@@ -141,7 +142,9 @@ def layout_init(K):
                 leaf_len=np.array(out.leaf_len[:out.n_leaves]),
                 rounds=np.array([list(r) for r in out.rounds])[:out.n_rounds],
                 topic_pos=np.array(out.topic_pos[:out.K], dtype=np.int32),
-                pos_topic=np.array(out.pos_topic[:out.KP], dtype=np.int32))
+                pos_topic=np.array(out.pos_topic[:out.KP], dtype=np.int32),
+                pos_lane=np.array(out.pos_lane[:out.KP], dtype=np.int32),
+                pos_slot=np.array(out.pos_slot[:out.KP], dtype=np.int32))
 
 
 def _ptr(t):

@@ -96,6 +96,99 @@ __device__ __forceinline__ void gload_row(const int32_t *base, int64_t elem, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row layout in memory.  A row of KP = G*T entries belongs to G lanes x T slots.  The 16-byte
+// chunk i (slots 4i .. 4i+3) of ALL lanes is contiguous:  pos(g, s) = ((s >> 2) * G + g) * 4 + (s & 3)  -- so the
+// i-th global_load_dwordx4 of the wavefront reads one contiguous run of the row (G * 16 bytes per lane group)
+// instead of 16 bytes out of every lane's 64 (which made the vector cache look up every line of the row once per
+// instruction: 4x the tag traffic).  Rows with T < 4 (one 4- or 8-byte access per lane) keep pos = g*T + s.
+// ---------------------------------------------------------------------------------------------
+template <int G, int T>
+__device__ __forceinline__ int pos_of(int g, int s)
+{
+    if constexpr (T % 4 == 0) return ((((s >> 2) * G) + g) << 2) | (s & 3);
+    else return g * T + s;
+}
+template <int G, int T>
+__device__ __forceinline__ void lane_slot_of(int pos, int &g, int &s)
+{
+    if constexpr (T % 4 == 0) {
+        const unsigned q = (unsigned)pos >> 2;
+        g = (int)(q & (unsigned)(G - 1));
+        s = (int)(((q / (unsigned)G) << 2) | ((unsigned)pos & 3u));
+    } else {
+        g = (int)((unsigned)pos / (unsigned)T);
+        s = pos - g * T;
+    }
+}
+// the same with G, T as run-time values (read-outs, exact_site_wave)
+__device__ __forceinline__ int pos_of_rt(int G, int T, int g, int s)
+{
+    return (T & 3) == 0 ? ((((s >> 2) * G) + g) << 2) | (s & 3) : g * T + s;
+}
+__device__ __forceinline__ void lane_slot_of_rt(int G, int T, int pos, int &g, int &s)
+{
+    if ((T & 3) == 0) {
+        const int q = pos >> 2;
+        g = q % G;
+        s = ((q / G) << 2) | (pos & 3);
+    } else {
+        g = pos / T;
+        s = pos - g * T;
+    }
+}
+
+// the T slots of lane `lig` of the row starting at `row`
+template <int G, int T>
+__device__ __forceinline__ void load_lane_row(const int32_t *__restrict__ row, int lig, int (&x)[T])
+{
+    if constexpr (T % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < T / 4; ++i) {
+            const int4 v = reinterpret_cast<const int4 *>(row)[i * G + lig];
+            x[4 * i + 0] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+        }
+    } else if constexpr (T == 2) {
+        const int2 v = reinterpret_cast<const int2 *>(row)[lig];
+        x[0] = v.x; x[1] = v.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) x[i] = row[lig * T + i];
+    }
+}
+template <int G, int T>
+__device__ __forceinline__ void store_lane_row(int32_t *__restrict__ row, int lig, const int (&x)[T])
+{
+    if constexpr (T % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < T / 4; ++i)
+            reinterpret_cast<int4 *>(row)[i * G + lig] = make_int4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+    } else if constexpr (T == 2) {
+        reinterpret_cast<int2 *>(row)[lig] = make_int2(x[0], x[1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) row[lig * T + i] = x[i];
+    }
+}
+// the same for the hot loop: uniform base pointer + element offset of the row, global address space
+template <int G, int T>
+__device__ __forceinline__ void gload_lane_row(const int32_t *base, int64_t row_elem, int lig, int (&x)[T])
+{
+    const LLDA_GLOBAL int32_t *q = (const LLDA_GLOBAL int32_t *)base + row_elem;
+    if constexpr (T % 4 == 0) {
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const LLDA_GLOBAL v4i *p = (const LLDA_GLOBAL v4i *)q;
+#pragma unroll
+        for (int i = 0; i < T / 4; ++i) {
+            const v4i v = p[i * G + lig];
+            x[4 * i + 0] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) x[i] = q[lig * T + i];
+    }
+}
+
 // T contiguous int32 starting at p (p is 4*T-byte aligned when T is a multiple of 4).
 template <int T>
 __device__ __forceinline__ void load_row(const int32_t *__restrict__ p, int (&x)[T])
@@ -408,7 +501,7 @@ __device__ __forceinline__ int draw_position(const double (&w)[T], double u, uin
         const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)gp);
         const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(pm | 1u));
         const int ss = __shfl(my, sl, G);
-        zn = sl * T + ss;
+        zn = pos_of<G, T>(sl, ss);
     }
     return zn;
 }

@@ -151,7 +151,7 @@ __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uin
     const bool hit = gf != 0;
     const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)(gp | 1ull));
     const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
-    zn = sl * T + group_pick<G>(my, sl, lig);
+    zn = pos_of<G, T>(sl, group_pick<G>(my, sl, lig));
     return true;
 }
 
@@ -209,7 +209,7 @@ __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, co
             const bool hit = gf != 0;
             const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)(gp | 1ull));
             const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
-            return sl * T + __shfl(my, sl, G);
+            return pos_of<G, T>(sl, __shfl(my, sl, G));
         }
     }
     // ---- exact tier: the reference's fp64 pipeline, bit for bit ----
@@ -248,7 +248,7 @@ __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, co
     const bool hit = gf != 0;
     const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)gp);
     const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
-    return sl * T + __shfl(my, sl, G);
+    return pos_of<G, T>(sl, __shfl(my, sl, G));
 }
 
 // store the new assignment of a site and move its count in n_kw_delta (int32 atomics, no return value)

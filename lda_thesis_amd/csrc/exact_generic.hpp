@@ -28,7 +28,8 @@ __device__ __forceinline__ double readlane_var_f64(double x, int l)       // l w
 }
 
 // Wave-collective: call with all 64 lanes active and wave-uniform (base, A, u).  Sparse lane base + i (i < A) holds
-// the exact score `w_mine` and the device position `pos_mine` of the document's i-th allowed topic (ascending).
+// the exact score `w_mine` and the device position `pos_mine` of the document's i-th allowed topic (in draw order:
+// ascending (lane, slot) of the dense layout).
 // Returns the chosen device position (the same value in every lane) or -1 when no topic has a positive probability.
 __device__ __noinline__ int exact_site_wave(double w_mine, int pos_mine, int base, int A, double u, const ExactLayout L,
                                             int lane)
@@ -42,7 +43,8 @@ __device__ __noinline__ int exact_site_wave(double w_mine, int pos_mine, int bas
     for (int i = 0; i < A; ++i) {                               // scatter the allowed topics into the dense layout
         const double wi = readlane_var_f64(w_mine, base + i);
         const int pi = __builtin_amdgcn_readlane(pos_mine, base + i);
-        const int g = pi / T, s = pi - g * T;
+        int g, s;
+        lane_slot_of_rt(G, T, pi, g, s);
 #pragma unroll
         for (int k = 0; k < 16; ++k) w[k] = (lane == g && k == s) ? wi : w[k];
     }
@@ -111,7 +113,7 @@ __device__ __noinline__ int exact_site_wave(double w_mine, int pos_mine, int bas
     const bool hit = gf != 0;
     const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)gp);
     const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(pm | 1u));
-    return sl * T + __builtin_amdgcn_readlane(my, sl);
+    return pos_of_rt(G, T, sl, __builtin_amdgcn_readlane(my, sl));
 }
 
 }  // namespace

@@ -8,7 +8,8 @@ namespace {
 // Test-time fold-in sampler: LabeledLDA.prep4test / run_test (LabeledLDA.py:155-212).
 // One lane group per held-out document; topic-word loadings ph_hat are fixed, only the document's n_dk
 // moves.  phn = ph_hat with every word column normalised (prep4test, LabeledLDA.py:162-167, done by
-// the host); both matrices are word-major in device order: (V, KP) doubles.
+// the host); both matrices are word-major, (V, KP) doubles, LANE-MAJOR (entry lane*T + slot: a lane's slots are
+// contiguous 16-byte pairs of doubles already); z holds positions of the sweep kernels' row layout (pos_of<G, T>).
 // ---------------------------------------------------------------------------------------------
 struct FParams {
     const int64_t *doc_off;
@@ -111,7 +112,8 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
             } else {
                 zo = P.z[s0 + n];
                 {
-                    const int lo = zo / T, so = zo - lo * T;
+                    int lo, so;
+                    lane_slot_of<G, T>(zo, lo, so);
                     onehot_add1<T>(ndk, (lig == lo) ? (1u << so) : 0u, f);       // n_dk[z] -= f
                 }
                 double b[T];
@@ -138,7 +140,8 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
                 if (lig == 0 && P.status) atomicOr(P.status, 1);
             }
             {
-                const int ln = zn / T, sn = zn - ln * T;
+                int ln, sn;
+                lane_slot_of<G, T>(zn, ln, sn);
                 onehot_add1<T>(ndk, (lig == ln) ? (1u << sn) : 0u, -f);          // n_dk[new_z] += f
             }
             if (lig == 0) P.z[s0 + n] = zn;

@@ -37,8 +37,8 @@ __global__ void __launch_bounds__(256) llda_loglik_kernel(const LParams P)
     const int64_t d = (int64_t)blockIdx.x * GPB + tid / G;
     if (d >= P.D) return;
     int ndk[T], nk[T];
-    load_row<T>(P.n_dk + d * KP + lig * T, ndk);
-    load_row<T>(P.n_k + lig * T, nk);
+    load_lane_row<G, T>(P.n_dk + d * KP, lig, ndk);
+    load_lane_row<G, T>(P.n_k, lig, nk);
     const uint32_t mask = P.lab_mask[d * G + lig];
     double th[T], rden[T], rs = 0.0;
 #pragma unroll
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) llda_loglik_kernel(const LParams P)
     double acc = 0.0;
     for (int64_t i = P.doc_off[d]; i < P.doc_off[d + 1]; ++i) {
         int x[T];
-        load_row<T>(P.n_kw + (int64_t)P.word[i] * KP + lig * T, x);
+        load_lane_row<G, T>(P.n_kw + (int64_t)P.word[i] * KP, lig, x);
         double dot = 0.0;
 #pragma unroll
         for (int s = 0; s < T; ++s) dot = dot + th[s] * (((double)x[s] + P.beta) / rden[s]);
@@ -85,7 +85,8 @@ struct RParams {
 // topic held by a device position, -1 for padding (inverse of llda_layout.topic_pos)
 __device__ __forceinline__ int topic_of_position(const RParams &P, int pos)
 {
-    const int g = pos / P.T, slot = pos - g * P.T;
+    int g, slot;
+    lane_slot_of_rt(P.KP / P.T, P.T, pos, g, slot);
     const int leaf = g >> 3, rel = (g & 7) + 8 * slot;
     return rel < P.leaf_len[leaf] ? P.leaf_start[leaf] + rel : -1;
 }
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(256) llda_readout_theta_kernel(const RParams P
 #pragma unroll
     for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) K.rounds_pk[r] = P.rounds_pk[r];
     int ndk[T];
-    load_row<T>(P.n_dk + d * KP + lig * T, ndk);
+    load_lane_row<G, T>(P.n_dk + d * KP, lig, ndk);
     const uint32_t mask = P.lab_mask[d * G + lig];
     double num[T];
 #pragma unroll
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(256) llda_readout_theta_kernel(const RParams P
     const double rs = group_sum<G, T, HAS_TAIL>(num, K, lig, lane);                              // np.sum, axis 1
 #pragma unroll
     for (int s = 0; s < T; ++s) {
-        const int k = topic_of_position(P, lig * T + s);
+        const int k = topic_of_position(P, pos_of<G, T>(lig, s));
         if (k < 0) continue;
         double *o = P.out + d * P.K + k;
         *o = running_mean(P, P.mode ? *o : 0.0, num[s] / rs);

@@ -30,9 +30,9 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
         if (len <= 0) continue;
 
         int ndk[T], nkb[T];           // nkb = n_k(sweep start) - n_dk(sweep start): n_k seen by the
-        int32_t *ndk_row = P.n_dk + d * KP + lig * T;   // document is nkb + ndk at any time
-        load_row<T>(ndk_row, ndk);
-        load_row<T>(P.n_k + lig * T, nkb);
+        int32_t *ndk_row = P.n_dk + d * KP;             // document is nkb + ndk at any time
+        load_lane_row<G, T>(ndk_row, lig, ndk);
+        load_lane_row<G, T>(P.n_k, lig, nkb);
 #pragma unroll
         for (int s = 0; s < T; ++s) nkb[s] -= ndk[s];
         const uint32_t mask = P.lab_mask[d * G + lig];
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
         const int64_t i1 = s0 + (len > 1 ? 1 : 0);
         int v_1 = P.word[i1], f_1 = P.freq[i1], zo_1 = P.z[i1], c_1 = P.csc_pos ? P.csc_pos[i1] : 0;
         int xn[T];
-        load_row<T>(P.n_kw + (int64_t)v_c * KP + lig * T, xn);
+        load_lane_row<G, T>(P.n_kw + (int64_t)v_c * KP, lig, xn);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         int64_t pend_i = -1;
         int pend_v = 0, pend_f = 0, pend_zo = 0, pend_zn = 0, pend_c = 0;
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
 #pragma unroll
             for (int s = 0; s < T; ++s) x[s] = xn[s];
             if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
-            load_row<T>(P.n_kw + (int64_t)v_1 * KP + lig * T, xn);
+            load_lane_row<G, T>(P.n_kw + (int64_t)v_1 * KP, lig, xn);
             v_c = v_1; f_c = f_1; zo_c = zo_1; c_c = c_1;
             {
                 const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);
@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
 
             // remove the site (LabeledLDA.py:109-111)
             {
-                const int lo = zo / T, so = zo - lo * T;
+                int lo, so;
+                lane_slot_of<G, T>(zo, lo, so);
                 onehot_add2<T>(ndk, x, (lig == lo) ? (1u << so) : 0u, f);
             }
             // scores (LabeledLDA.py:113-116), np.sum, prob /= sum, keyed draw
@@ -82,7 +83,8 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
             }
             // add the site back (LabeledLDA.py:121-125)
             {
-                const int ln = zn / T, sn = zn - ln * T;
+                int ln, sn;
+                lane_slot_of<G, T>(zn, ln, sn);
                 onehot_add1<T>(ndk, (lig == ln) ? (1u << sn) : 0u, -f);
             }
             pend_i = s0 + n; pend_v = v; pend_f = f; pend_zo = zo; pend_zn = zn; pend_c = c;
@@ -90,13 +92,13 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
         if (lig == 0 && pend_i >= 0) commit_site(P, pend_i, pend_v, pend_f, pend_zo, pend_zn, pend_c, KP);
 
         int old[T];
-        load_row<T>(ndk_row, old);
+        load_lane_row<G, T>(ndk_row, lig, old);
 #pragma unroll
         for (int s = 0; s < T; ++s) {
             const int dl = ndk[s] - old[s];
-            if (dl) atomicAdd(&s_nk[lig * T + s], dl);
+            if (dl) atomicAdd(&s_nk[pos_of<G, T>(lig, s)], dl);
         }
-        store_row<T>(ndk_row, ndk);
+        store_lane_row<G, T>(ndk_row, lig, ndk);
     }
     __syncthreads();
     for (int i = tid; i < KP; i += 256) {
@@ -174,11 +176,11 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         const int len = (int)(P.doc_off[d + 1] - s0);
         if (len <= n0) continue;
 
-        int32_t *ndk_row = P.n_dk + d * KP + lig * T;
+        int32_t *ndk_row = P.n_dk + d * KP;
         {
             int r[T], k[T];
-            load_row<T>(ndk_row, r);
-            load_row<T>(P.n_k + lig * T, k);
+            load_lane_row<G, T>(ndk_row, lig, r);
+            load_lane_row<G, T>(P.n_k, lig, k);
 #pragma unroll
             for (int s = 0; s < T; ++s) {
                 s_ndk[s][tid] = r[s];
@@ -211,11 +213,12 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         R1.c = LOGGED ? gload_i32(csc_b, o1) : 0; R1.zn = 0;
         R2.v = R2.f = R2.zo = R2.c = R2.zn = 0;
         int xn[T];
-        gload_row<T>(P.n_kw, (int64_t)R0.v * KP + lig * T, xn);
+        gload_lane_row<G, T>(P.n_kw, (int64_t)R0.v * KP, lig, xn);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the previous site
-            const int lo = (int)((unsigned)R0.zo / (unsigned)T);   // positions are never negative: unsigned division
-            if (lig == lo) count_update(s_ndk, s_nkc, s_pa, R0.zo - lo * T, tid, alpha32, vbeta32, -R0.f);
+            int lo, so;
+            lane_slot_of<G, T>(R0.zo, lo, so);
+            if (lig == lo) count_update(s_ndk, s_nkc, s_pa, so, tid, alpha32, vbeta32, -R0.f);
         }
 
         // one site: `cur` holds its scalars, `nxt` those of site n+1, `prv` those of site n-1 (committed here, then
@@ -226,7 +229,8 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             // array so that the next row can be loaded into xn right away
             int x[T];
             {
-                const int lo = (int)((unsigned)zo / (unsigned)T), so = zo - lo * T;
+                int lo, so;
+                lane_slot_of<G, T>(zo, lo, so);
                 onehot_add_to<T>(x, xn, (lig == lo) ? (1u << so) : 0u, f);   // m = -1 at the slot: += (-1) * f
             }
 #ifndef ABL_NOCOMMIT
@@ -234,7 +238,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn, prv.c, KP);
 #endif
 #ifndef ABL_NOLOAD
-            gload_row<T>(P.n_kw, (int64_t)nxt.v * KP + lig * T, xn);      // row of site n+1 (clamped)
+            gload_lane_row<G, T>(P.n_kw, (int64_t)nxt.v * KP, lig, xn);   // row of site n+1 (clamped)
 #else
 #pragma unroll
             for (int s = 0; s < T; ++s) xn[s] = (nxt.v + s) & 7;          // ablation: no n_kw traffic
@@ -277,14 +281,14 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             // Both updates usually belong to different lanes and are done in ONE masked pass; a second pass runs
             // only for groups where the same lane owns both.
             {
-                const int ln = (int)((unsigned)zn / (unsigned)T);
+                int ln, sn, lo2, so2;
+                lane_slot_of<G, T>(zn, ln, sn);
+                lane_slot_of<G, T>(nxt.zo, lo2, so2);
                 const bool more = n + 1 < len;
-                const int lo2 = more ? (int)((unsigned)nxt.zo / (unsigned)T) : -1;
-                const bool own_new = lig == ln, own_old = lig == lo2;
+                const bool own_new = lig == ln, own_old = more && lig == lo2;
                 if (own_new || own_old)
-                    count_update(s_ndk, s_nkc, s_pa, own_new ? zn - ln * T : nxt.zo - lo2 * T, tid, alpha32, vbeta32,
-                                 own_new ? f : -nxt.f);
-                if (own_new && own_old) count_update(s_ndk, s_nkc, s_pa, nxt.zo - lo2 * T, tid, alpha32, vbeta32, -nxt.f);
+                    count_update(s_ndk, s_nkc, s_pa, own_new ? sn : so2, tid, alpha32, vbeta32, own_new ? f : -nxt.f);
+                if (own_new && own_old) count_update(s_ndk, s_nkc, s_pa, so2, tid, alpha32, vbeta32, -nxt.f);
             }
 #ifndef ABL_NOCOMMIT
             // the last site of the document is committed right away
@@ -300,14 +304,14 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
 
         // document done: fold its n_dk change into the workgroup's n_k accumulator, store the row
         int old[T], cur[T];
-        load_row<T>(ndk_row, old);
+        load_lane_row<G, T>(ndk_row, lig, old);
 #pragma unroll
         for (int s = 0; s < T; ++s) {
             cur[s] = s_ndk[s][tid];
             const int dl = cur[s] - old[s];
-            if (dl) atomicAdd(&s_nk[lig * T + s], dl);
+            if (dl) atomicAdd(&s_nk[pos_of<G, T>(lig, s)], dl);
         }
-        store_row<T>(ndk_row, cur);
+        store_lane_row<G, T>(ndk_row, lig, cur);
     }
 
     __syncthreads();

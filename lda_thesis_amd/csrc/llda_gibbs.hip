@@ -283,9 +283,19 @@ int llda_layout_init(int32_t K, llda_layout *L)
     L->tail = L->leaf_len[L->n_leaves - 1] % 8;
     L->tail_row = L->leaf_len[L->n_leaves - 1] / 8;
     for (int i = 0; i < LLDA_MAX_K; ++i) L->pos_topic[i] = -1;
+    // memory position of (lane g, slot s): the 16-byte chunk s >> 2 of all lanes is contiguous (rows with fewer than
+    // 4 slots per lane: pos = g*T + s)
+    const int w = (t % 4 == 0) ? 4 : t;
+    for (int g = 0; g < L->G; ++g)
+        for (int s = 0; s < t; ++s) {
+            const int pos = ((s / w) * L->G + g) * w + (s % w);
+            L->pos_lane[pos] = g;
+            L->pos_slot[pos] = s;
+        }
     for (int p = 0; p < L->n_leaves; ++p)
         for (int rel = 0; rel < L->leaf_len[p]; ++rel) {
-            const int pos = (8 * p + (rel & 7)) * t + (rel >> 3);
+            const int g = 8 * p + (rel & 7), s = rel >> 3;
+            const int pos = ((s / w) * L->G + g) * w + (s % w);
             L->topic_pos[L->leaf_start[p] + rel] = pos;
             L->pos_topic[pos] = L->leaf_start[p] + rel;
         }

@@ -11,7 +11,7 @@ fp64 pipeline inside the kernel, so the result is always the reference's):
     inst_off (I+1), word / freq / z (S_tot)                       CSR over instance sites (z = device positions)
     counts / delta                                                per problem [n_kw (V x KP_p) | n_k (KP_p)], fused
     n_dk                                                          per instance a KP_p row
-    live_off / live_pos                                           allowed positions of every instance, ascending
+    live_off / live_pos                                           allowed positions of every instance, in draw order
 
 Host side, everything the reference does per sub-problem in python loops is done once, vectorised:
   * the initial assignments -- the reference draws ``np.random.choice(K, size=len(doc), p=lab/lab.sum())`` per
@@ -107,11 +107,13 @@ class Ensemble(object):
         # local topic -> device position, per problem layout
         a_max = max(pl["allowed"].shape[1] for pl in plans)
         pos_tab = np.zeros((P, max(pl["K"] for pl in plans)), dtype=np.int64)
+        rank_tab = np.zeros_like(pos_tab)                        # place of the topic in the draw order ((lane, slot))
         for i, pl in enumerate(plans):
             pos_tab[i, :pl["K"]] = layouts[pl["K"]].topic_pos
+            rank_tab[i, :pl["K"]] = layouts[pl["K"]].lm_topic_pos
         z_loc = np.concatenate(z_local) if P else np.zeros(0, np.int64)
         z_pos = pos_tab[inst_prob[inst_of_site], z_loc]
-        # allowed positions of every instance, ascending
+        # allowed positions of every instance, in draw order
         allowed = np.full((self.I, a_max), -1, dtype=np.int64)
         row = 0
         for pl in plans:
@@ -119,11 +121,13 @@ class Ensemble(object):
             allowed[row:row + n, :a] = pl["allowed"]
             row += n
         valid = allowed >= 0
-        apos = np.where(valid, pos_tab[inst_prob[:, None], np.maximum(allowed, 0)], np.iinfo(np.int64).max)
-        apos.sort(axis=1)
+        big = np.iinfo(np.int64).max
+        akey = np.where(valid, rank_tab[inst_prob[:, None], np.maximum(allowed, 0)], big)
+        order = np.argsort(akey, axis=1, kind="stable")
+        apos = np.take_along_axis(np.where(valid, pos_tab[inst_prob[:, None], np.maximum(allowed, 0)], big), order, axis=1)
         n_allowed = valid.sum(axis=1)
         live_off = np.concatenate(([0], np.cumsum(n_allowed)))
-        live_pos = apos[apos != np.iinfo(np.int64).max]
+        live_pos = apos[apos != big]
         self.n_allowed_max = int(n_allowed.max()) if self.I else 0
         if self.n_allowed_max > 64:
             raise ValueError("a document allows %d topics; the batched ensemble handles at most 64" % self.n_allowed_max)

@@ -44,7 +44,8 @@ class Pending(object):
             if int(self.status.item()) != 0:       # (synchronises with the launch)
                 raise ValueError("pvals < 0, pvals > 1 or pvals contains NaNs")     # numpy.random.multinomial's complaint
             lay, dev, doc_off = self.lay, self.th.device, self.doc_off
-            tp = torch.from_numpy(lay.topic_pos.astype(np.int64)).to(dev)
+            # (the fold-in kernel keeps its own matrices lane-major: entry lane*T + slot; z holds row positions)
+            tp = torch.from_numpy(lay.lm_topic_pos.astype(np.int64)).to(dev)
             zt = torch.from_numpy(lay.pos_topic.astype(np.int64)).to(dev)[self.z.to(torch.int64)].cpu().numpy()
             out = dict(th_hat=self.th[:, tp].cpu().numpy(), n_dk=self.n_dk[:, tp].cpu().numpy().astype(np.int64),
                        z=[zt[doc_off[d]:doc_off[d + 1]] for d in range(len(doc_off) - 1)])
@@ -68,7 +69,7 @@ def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, see
 
     def rows_to_dev(m):                       # (R, K) -> (R, KP) device order
         out = np.zeros((m.shape[0], lay.KP), dtype=np.float64)
-        out[:, lay.topic_pos] = m
+        out[:, lay.lm_topic_pos] = m
         return torch.from_numpy(out).to(dev)
 
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)
@@ -77,7 +78,7 @@ def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, see
     d_off, d_word, d_freq = t(doc_off, torch.int64), t(word, torch.int32), t(freq, torch.int32)
     d_idx = t(np.asarray(init_idx, dtype=np.int32), torch.int32)
     d_ph, d_init = rows_to_dev(np.ascontiguousarray(ph.T)), rows_to_dev(init_rows)
-    valid = t((lay.pos_topic >= 0).astype(np.uint8), torch.uint8)
+    valid = t((lay.lm_pos_topic >= 0).astype(np.uint8), torch.uint8)
     z = torch.zeros((max(int(doc_off[-1]), 1),), dtype=torch.int32, device=dev)
     n_dk = torch.zeros((D, lay.KP), dtype=torch.int32, device=dev)
     th = torch.zeros((D, lay.KP), dtype=torch.float64, device=dev)

@@ -9,14 +9,20 @@ multiple of 8.  Bit-exact parity with the reference therefore fixes the associat
 sum.  The layout below makes that order lane-local on a 64-wide wavefront:
 
     leaf p (start_p, n_p), rel = k - start_p, chain j = rel & 7, row = rel >> 3
-    lane g = 8*p + j     slot s = row     device position pos = g*T + s
+    lane g = 8*p + j     slot s = row
 
 so that one accumulator chain is one lane walking its T slots, the 8 accumulators of a leaf are 8
 neighbouring lanes (xor butterfly 1,2,4), and leaves are 8-lane groups combined by a short
 butterfly schedule.  A document occupies G = 8 * P lanes (P = number of leaves rounded up to a
 power of two), i.e. 64/G documents share a wavefront.  All per-topic device arrays (rows of n_kw,
-rows of n_dk, n_k, label masks) are stored in ``pos`` order with row length KP = G*T, so a lane's T
-slots are one contiguous, 16-byte aligned run.
+rows of n_dk, n_k) have row length KP = G*T; the MEMORY position of (lane g, slot s) in a row is
+
+    pos = ((s // 4) * G + g) * 4 + s % 4      (T a multiple of 4)         pos = g*T + s   (T = 1, 2)
+
+-- the 16-byte chunk s // 4 of all lanes is contiguous, so each of the T/4 vector loads a wavefront issues for a
+row reads one contiguous run of it (with lane-major rows every instruction touched every cache line of the row).
+The DRAW order of the keyed draw (oracle/llda_oracle.py draw_keyed) is the (lane, slot) order -- ``draw_rank`` --
+not the memory order.
 """
 import numpy as np
 
@@ -55,7 +61,9 @@ def _members(t):
 class GroupLayout(object):
     """Layout of K topics.  Attributes: K, leaves, P, G (lanes per document), T (slots per lane),
     KP (padded row length), tail (n % 8 of the last leaf), tail_row, topic_pos[K] (topic -> device
-    position), pos_topic[KP] (device position -> topic, -1 in the padding), rounds (leaf-combine
+    position), pos_topic[KP] (device position -> topic, -1 in the padding), pos_lane / pos_slot[KP] and
+    topic_lane / topic_slot[K] (which lane and slot hold a position / topic), draw_rank[KP] (position -> its place
+    in the draw order), lm_pos[KP] (lane*T + slot -> position), rounds (leaf-combine
     schedule: ``n_rounds`` arrays of 8 partner-leaf ids, identity where a leaf idles)."""
 
     def __init__(self, K):
@@ -84,13 +92,28 @@ class GroupLayout(object):
         self.tail_row = self.leaves[-1][1] // 8
         for _, n in self.leaves[:-1]:
             assert n % 8 == 0
+        self.W = W = 4 if T % 4 == 0 else T          # slots of one lane that are contiguous in memory
+        g_all, s_all = np.divmod(np.arange(self.KP), T)
+        self.lm_pos = (((s_all // W) * self.G + g_all) * W + s_all % W).astype(np.int32)   # lane-major index -> position
+        self.pos_lane = np.zeros(self.KP, dtype=np.int32)
+        self.pos_slot = np.zeros(self.KP, dtype=np.int32)
+        self.pos_lane[self.lm_pos], self.pos_slot[self.lm_pos] = g_all, s_all
+        self.draw_rank = (self.pos_lane * T + self.pos_slot).astype(np.int32)               # position -> draw order
         self.topic_pos = np.zeros(K, dtype=np.int32)
         self.pos_topic = np.full(self.KP, -1, dtype=np.int32)
+        self.topic_lane = np.zeros(K, dtype=np.int32)
+        self.topic_slot = np.zeros(K, dtype=np.int32)
         for p, (st, n) in enumerate(self.leaves):
             for rel in range(n):
-                pos = (8 * p + (rel & 7)) * T + (rel >> 3)
+                g, sl = 8 * p + (rel & 7), rel >> 3
+                pos = int(self.lm_pos[g * T + sl])
                 self.topic_pos[st + rel] = pos
                 self.pos_topic[pos] = st + rel
+                self.topic_lane[st + rel], self.topic_slot[st + rel] = g, sl
+        # lane-major numbering (position = lane*T + slot): the fold-in kernel keeps its own arrays that way
+        self.lm_topic_pos = (self.topic_lane * T + self.topic_slot).astype(np.int32)
+        self.lm_pos_topic = np.full(self.KP, -1, dtype=np.int32)
+        self.lm_pos_topic[self.lm_topic_pos] = np.arange(K, dtype=np.int32)
         self.leaf_start = np.zeros(8, dtype=np.int32)
         self.leaf_rows = np.zeros(8, dtype=np.int32)
         for p, (st, n) in enumerate(self.leaves):
@@ -137,10 +160,15 @@ class GroupLayout(object):
     def lane_masks(self, labs):
         """(D, K) 0/1 label matrix -> (D, G) uint16: bit s of [d, g] = label of the topic at slot s
         of lane g (0 in the padding)."""
-        dev = self.to_device((np.asarray(labs) != 0).astype(np.uint16))
-        dev = dev.reshape(dev.shape[0], self.G, self.T)
-        weights = (1 << np.arange(self.T, dtype=np.uint32)).astype(np.uint16)
-        return (dev * weights).sum(axis=2).astype(np.uint16)
+        labs = (np.asarray(labs) != 0).astype(np.uint32)
+        out = np.zeros((labs.shape[0], self.G), dtype=np.uint32)
+        np.add.at(out, (slice(None), self.topic_lane), labs << self.topic_slot.astype(np.uint32))
+        return out.astype(np.uint16)
+
+    def labs_from_masks(self, masks):
+        """inverse of lane_masks: (D, G) lane masks -> (D, K) 0/1."""
+        bits = np.asarray(masks).astype(np.int64) & 0xFFFF
+        return ((bits[:, self.topic_lane] >> self.topic_slot) & 1).astype(np.uint8)
 
 
 _CACHE = {}

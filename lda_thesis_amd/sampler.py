@@ -9,7 +9,7 @@ CascadeLDA.py:358-372) but lives in HBM as PyTorch-ROCm tensors in the group lay
     n_k   (KP,)   int32   <->  reference n_zk  (K,)   int64
     z     (S,)    int32   <->  reference z_dn  (list of D int arrays), stored as device positions
     CSR corpus: doc_off (D+1) int64, word (S) int32, freq (S) int32   <->  docs / freqs lists
-    lab_mask (D, G) int16 bit masks                                   <->  labs (D, K) float 0/1
+    lab_mask (D, G) int16 bit masks (bit s of lane g)                 <->  labs (D, K) float 0/1
 
 One sweep = ``llda_sweep`` (HIP, include/llda_gibbs.h) under per-document snapshot semantics,
 then -- when the documents are sharded over several GPUs -- one RCCL all-reduce (SUM, int32) of the
@@ -228,9 +228,10 @@ class GibbsSampler(object):
             lab_idx = torch.as_tensor(np.asarray(lab_idx).astype(np.int64), dtype=torch.int64, device=dev)
             counts = lab_off[1:] - lab_off[:-1]
             rows = torch.repeat_interleave(torch.arange(self.D, device=dev), counts)
-            pos = self._topic_pos[lab_idx]
+            lane = torch.from_numpy(lay.topic_lane.astype(np.int64)).to(dev)[lab_idx]
+            slot = torch.from_numpy(lay.topic_slot.astype(np.int64)).to(dev)[lab_idx]
             m = torch.zeros((self.D, lay.G), dtype=torch.int64, device=dev)
-            m.index_put_((rows, pos // lay.T), torch.ones_like(pos) << (pos % lay.T), accumulate=True)
+            m.index_put_((rows, lane), torch.ones_like(slot) << slot, accumulate=True)
         else:
             labs = np.asarray(labs)
             if labs.shape != (self.D, self.K):
@@ -244,12 +245,13 @@ class GibbsSampler(object):
         lay, dev = self.layout, self.device
         bits = (self.lab_mask.to(torch.int32) & 0xFFFF)                       # (D, G) lane masks
         shifts = torch.arange(lay.T, device=dev, dtype=torch.int32)
-        allowed = ((bits.unsqueeze(-1) >> shifts) & 1).reshape(self.D, lay.KP)  # device order already
+        allowed = ((bits.unsqueeze(-1) >> shifts) & 1).reshape(self.D, lay.KP)  # (lane, slot) order = draw order
         counts = allowed.sum(dim=1)
         live_max = int(counts.max().item())
         if live_max > 64 or live_max * 4 > self.K:
             return                                                             # dense kernel is the better fit
-        rows, pos = torch.nonzero(allowed, as_tuple=True)                      # row-major => positions ascending
+        rows, lm = torch.nonzero(allowed, as_tuple=True)                       # row-major => draw order ascending
+        pos = torch.from_numpy(lay.lm_pos.astype(np.int64)).to(dev)[lm]        # ... as memory positions
         self.live_off = torch.zeros((self.D + 1,), dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=self.live_off[1:])
         self.live_pos = pos.to(torch.int32).contiguous()

@@ -70,9 +70,7 @@ class OracleBackend(object):
         import torch
         lay = self._lay(K)
         tp = lay.topic_pos.astype(np.int64)
-        bits = lab_mask.numpy().astype(np.int64) & 0xFFFF
-        dev_labs = ((bits[:, :, None] >> np.arange(lay.T)) & 1).reshape(D, lay.KP)
-        labs = dev_labs[:, tp].astype(np.uint8)
+        labs = lay.labs_from_masks(lab_mask.numpy())
         old_kv = n_kw.numpy()[:, tp].T.astype(np.int64)
         old_k = n_k.numpy()[tp].astype(np.int64)
         cs = self.co.CState(doc_off.numpy(), word.numpy(), freq.numpy(), lay.pos_topic[z.numpy()], labs,
@@ -214,8 +212,7 @@ class OracleBackend(object):
     def readout_theta(self, n_dk, lab_mask, D, K, alpha, out, keep=None, share=None):
         lay = self._lay(K)
         tp = lay.topic_pos.astype(np.int64)
-        bits = lab_mask.numpy().astype(np.int64) & 0xFFFF
-        labs = ((bits[:, :, None] >> np.arange(lay.T)) & 1).reshape(D, lay.KP)[:, tp].astype(np.float64)
+        labs = lay.labs_from_masks(lab_mask.numpy()).astype(np.float64)
         num = np.ascontiguousarray(n_dk.numpy()[:, tp].astype(np.int64) + labs * alpha)   # C order: np.sum is pairwise per row
         cur = num / num.sum(axis=1)[:, np.newaxis]
         o = out.numpy()

@@ -61,6 +61,8 @@ def test_layout_init_matches_python_layout(K):
     assert a["n_leaves"] == b.m
     np.testing.assert_array_equal(a["topic_pos"], b.topic_pos)
     np.testing.assert_array_equal(a["pos_topic"], b.pos_topic)
+    np.testing.assert_array_equal(a["pos_lane"], b.pos_lane)
+    np.testing.assert_array_equal(a["pos_slot"], b.pos_slot)
     for r in range(a["n_rounds"]):
         np.testing.assert_array_equal(a["rounds"][r], b.rounds[r])
 

@@ -14,11 +14,18 @@ def test_layout_is_a_permutation_with_aligned_rows(K):
     assert (L.pos_topic[L.topic_pos] == np.arange(K)).all() and (L.pos_topic >= 0).sum() == K
     x = np.arange(1, K + 1)
     np.testing.assert_array_equal(L.from_device(L.to_device(x)), x)
-    # chain structure: topic k sits in lane 8*leaf + (rel & 7), slot rel >> 3
+    # chain structure: topic k sits in lane 8*leaf + (rel & 7), slot rel >> 3 ...
     for p, (start, n) in enumerate(L.leaves):
         for rel in (0, n - 1):
-            pos = L.topic_pos[start + rel]
-            assert pos // L.T == 8 * p + (rel & 7) and pos % L.T == rel >> 3
+            k = start + rel
+            assert L.topic_lane[k] == 8 * p + (rel & 7) and L.topic_slot[k] == rel >> 3
+            assert L.pos_lane[L.topic_pos[k]] == L.topic_lane[k] and L.pos_slot[L.topic_pos[k]] == L.topic_slot[k]
+    # ... and in memory the 16-byte chunk s // 4 of ALL lanes is contiguous (rows of 1 or 2 slots: lane-major)
+    g, sl = np.divmod(np.arange(L.KP), L.T)
+    want = ((sl // 4) * L.G + g) * 4 + sl % 4 if L.T % 4 == 0 else g * L.T + sl
+    np.testing.assert_array_equal(L.lm_pos, want)
+    assert sorted(L.lm_pos.tolist()) == list(range(L.KP))
+    np.testing.assert_array_equal(L.draw_rank[L.lm_pos], np.arange(L.KP))
 
 
 def test_lane_masks_roundtrip():
@@ -28,9 +35,9 @@ def test_lane_masks_roundtrip():
         L = GroupLayout(K)
         labs = (rng.random((7, K)) < 0.3).astype(np.uint8)
         m = L.lane_masks(labs).astype(np.int64)
-        dev = ((m[:, :, None] >> np.arange(L.T)) & 1).reshape(7, L.KP)
-        np.testing.assert_array_equal(dev[:, L.topic_pos], labs)
-        assert dev.sum() == labs.sum()                      # nothing set in the padding
+        np.testing.assert_array_equal(L.labs_from_masks(m), labs)
+        bits = ((m[:, :, None] >> np.arange(16)) & 1)
+        assert bits.sum() == labs.sum()                     # nothing set in the padding
 
 
 @settings(max_examples=60, deadline=None)
