@@ -245,7 +245,8 @@ class LabeledLDA(object):
         (LabeledLDA.py:179-212); all documents and sweeps in one llda_foldin launch."""
         from .foldin import TEST_STREAM, fold_in
         tups = [self.dicti.doc2bow(x) for x in newdocs]
-        r = fold_in(self.ph_hat, self.alpha, tups, it, thinning, self.seed if seed is None else seed,
+        ph = self._ph_hat.dev if self._ph_hat.dev is not None else self.ph_hat     # still on the device after training
+        r = fold_in(ph, self.alpha, tups, it, thinning, self.seed if seed is None else seed,
                     TEST_STREAM if stream_id is None else stream_id)
         return r["th_hat"]
 

@@ -8,8 +8,9 @@ document, all sweeps inside the kernel.  Three reference code paths map onto it:
   CascadeLDA.prep4test / cascade_test      /root/reference/CascadeLDA.py:186-247
   CascadeLDA.prep4test / run_test          /root/reference/CascadeLDA.py:299-344
 
-The initial probabilities (``prep4test``) are prepared on the host with the reference's own numpy
-expressions -- they are a K x len(doc) elementwise normalisation -- and handed to the kernel as rows.
+The initial probabilities (``prep4test``) are a K x len(doc) elementwise normalisation: LabeledLDA's are computed on
+the device (``fold_in``), CascadeLDA's per-document ones on the host with the reference's own numpy expressions; both
+are handed to the kernel as rows.
 """
 import zlib
 
@@ -54,7 +55,7 @@ class Pending(object):
 
 
 def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, seed, stream_id, doc_ids, c_init,
-            c_loop, beta_fallback, avg_mode, device=None, stream=None):
+            c_loop, beta_fallback, avg_mode, device=None, stream=None, K_true=None):
     """ph (K, V) float64; init_rows (R, K) float64; init_idx[S] row per site.  doc_ids: RNG id per document (any
     values: the whole batch is one launch).  Enqueues on ``stream`` (default: the current one), returns Pending."""
     _native.lib()
@@ -62,12 +63,16 @@ def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, see
         raise _native.NativeError("no HIP device visible: the fold-in sampler has no CPU fallback")
     dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
     stream = stream if stream is not None else torch.cuda.current_stream(dev)
-    K, V = ph.shape
+    K, V = (ph.shape[1], ph.shape[0]) if isinstance(ph, torch.Tensor) else ph.shape     # device form: (V, KP) rows
+    if K_true is not None:
+        K = K_true
     lay = group_layout(K)
     doc_off, word, freq = csr_from_doc_tups(doc_tups)
     D = len(doc_tups)
 
-    def rows_to_dev(m):                       # (R, K) -> (R, KP) device order
+    def rows_to_dev(m):                       # (R, K) -> (R, KP) lane-major rows on the device
+        if isinstance(m, torch.Tensor):       # prepared on the device already (fold_in)
+            return m
         out = np.zeros((m.shape[0], lay.KP), dtype=np.float64)
         out[:, lay.lm_topic_pos] = m
         return torch.from_numpy(out).to(dev)
@@ -77,7 +82,8 @@ def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, see
     # only the kernel runs on ``stream``, after an event on the current stream
     d_off, d_word, d_freq = t(doc_off, torch.int64), t(word, torch.int32), t(freq, torch.int32)
     d_idx = t(np.asarray(init_idx, dtype=np.int32), torch.int32)
-    d_ph, d_init = rows_to_dev(np.ascontiguousarray(ph.T)), rows_to_dev(init_rows)
+    d_ph = rows_to_dev(ph if isinstance(ph, torch.Tensor) else np.ascontiguousarray(ph.T))
+    d_init = rows_to_dev(init_rows)
     valid = t((lay.lm_pos_topic >= 0).astype(np.uint8), torch.uint8)
     z = torch.zeros((max(int(doc_off[-1]), 1),), dtype=torch.int32, device=dev)
     n_dk = torch.zeros((D, lay.KP), dtype=torch.int32, device=dev)
@@ -97,30 +103,47 @@ def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, see
 # LabeledLDA
 # ------------------------------------------------------------------------------------------------
 def fold_in(ph_hat, alpha, doc_tups, it, thinning, seed, stream_id=TEST_STREAM, doc_base=0, device=None):
-    """LabeledLDA.prep4test + run_test for a batch of doc2bow lists.  Returns dict(th_hat (D, K),
-    n_dk (D, K), z)."""
-    ph_hat = np.asarray(ph_hat, dtype=np.float64)
-    K, V = ph_hat.shape
+    """LabeledLDA.prep4test + run_test for a batch of doc2bow lists.  ``ph_hat``: (K, V) float64, numpy or a torch
+    tensor already on the device (the running mean run_training left there).  Returns dict(th_hat (D, K),
+    n_dk (D, K), z).
+
+    prep4test's column normalisation (LabeledLDA.py:159-167: ``probs = ph_hat[:, doc]; probs /= probs.sum(axis=0)``,
+    uniform 1/K for a document that holds a column which cannot be normalised) runs on the device: numpy reduces
+    axis 0 of a C-contiguous matrix row by row, i.e. sequentially over the topics, which K in-place row additions
+    reproduce bit for bit; the division is IEEE on both sides."""
+    _native.lib()
+    if not torch.cuda.is_available():
+        raise _native.NativeError("no HIP device visible: the fold-in sampler has no CPU fallback")
+    dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+    ph = ph_hat.to(device=dev, dtype=torch.float64) if isinstance(ph_hat, torch.Tensor) else \
+        torch.from_numpy(np.ascontiguousarray(ph_hat, dtype=np.float64)).to(dev)
+    K, V = ph.shape
     for doc in doc_tups:
         if not doc:
             raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
-    # probs = ph_hat[:, doc]; probs /= probs.sum(axis=0)  -- per word; a document with a column that
-    # cannot be normalised falls back to the uniform 1/K for ALL its sites (LabeledLDA.py:162-167)
-    colsum = ph_hat.sum(axis=0)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        phn = ph_hat / colsum
-    bad = ~np.isfinite(phn).all(axis=0) | (colsum == 0)
+    lay = group_layout(K)
+    colsum = ph[0].clone()
+    for k in range(1, K):
+        colsum += ph[k]                                              # sequential over k, as numpy's axis-0 sum
+    phn = ph / colsum                                                # 0/0 -> nan, x/0 -> inf as numpy (errstate ignore)
+    bad = ~torch.isfinite(phn).all(dim=0) | (colsum == 0)
+    lm = torch.from_numpy(lay.lm_topic_pos.astype(np.int64)).to(dev)
+    d_ph = torch.zeros((V, lay.KP), dtype=torch.float64, device=dev)
+    d_ph[:, lm] = ph.t()
+    d_init = torch.zeros((V + 1, lay.KP), dtype=torch.float64, device=dev)
+    d_init[:V, lm] = torch.where(bad[None, :], torch.zeros((), dtype=torch.float64, device=dev), phn).t()
+    d_init[V, lm] = 1 / K                                            # row V = uniform
     doc_off, word, _ = csr_from_doc_tups(doc_tups)
     init_idx = word.copy()
-    rows = np.vstack([np.where(bad, 0.0, phn).T, np.full((1, K), 1 / K)])          # row V = uniform
-    if bad.any():
+    if bool(bad.any().item()):
+        bad_h = bad.cpu().numpy()
         site_doc = np.repeat(np.arange(len(doc_tups)), np.diff(doc_off))
         doc_bad = np.zeros(len(doc_tups), dtype=bool)
-        np.logical_or.at(doc_bad, site_doc, bad[word])
+        np.logical_or.at(doc_bad, site_doc, bad_h[word])
         init_idx = np.where(doc_bad[site_doc], V, word)
-    return _launch(ph_hat, rows, init_idx, doc_tups, alpha=alpha, beta=0.0, it=it, thinning=thinning, seed=seed,
+    return _launch(d_ph, d_init, init_idx, doc_tups, alpha=alpha, beta=0.0, it=it, thinning=thinning, seed=seed,
                    stream_id=stream_id, doc_ids=np.arange(len(doc_tups)) + doc_base, c_init=1.0000000005,
-                   c_loop=1.0000005, beta_fallback=False, avg_mode=0, device=device).result()
+                   c_loop=1.0000005, beta_fallback=False, avg_mode=0, device=dev, K_true=K).result()
 
 
 # ------------------------------------------------------------------------------------------------
