@@ -283,6 +283,10 @@ typedef struct llda_foldin_args {
     uint32_t stream_id, reserved2;
     const int64_t *doc_ids;     /* [dev] [D] optional: RNG counter word 1 of every document (its low 32 bits);
                                    NULL = doc_base + d.  Lets documents with unrelated ids share one launch. */
+    int64_t n_sites;            /* doc_off[D] (ABI 11).  > 0: the initial assignments are drawn by a separate launch with
+                                   one lane group per SITE (they are independent of one another, and the reference's
+                                   `while prob.sum() > 1: prob /= c` can run tens of thousands of times for one site);
+                                   n_dk must then be zeroed by the caller.  0: inside the per-document launch. */
 } llda_foldin_args;
 
 int llda_foldin(const llda_foldin_args *args, void *stream);

@@ -335,7 +335,7 @@ class CascadeLDA(object):
         return level_1, level_2, level_3
 
     def cascade_test_batch(self, docs, it, thinning, labels, seed=None, doc_ids=None, stream=None, defer=False,
-                           bows=None):
+                           bows=None, ph_dev=None):
         """cascade_test for several documents against the SAME label subset: one llda_foldin launch, one lane
         group per document.  Row d equals cascade_test(docs[d], ...) -- the RNG is keyed by the document, not by
         its place in the batch.  defer=True: enqueue on ``stream`` and return the pending launch."""
@@ -343,7 +343,9 @@ class CascadeLDA(object):
         ids = [self.labelmap[x] for x in labels]
         tups = [self.dicti.doc2bow(doc) for doc in docs] if bows is None else bows     # (bows: doc2bow done by the caller)
         keys = [doc_key(t) for t in tups] if doc_ids is None else list(doc_ids)
-        r = cascade_fold_in(self.ph[ids, :], self.alpha, self.beta, tups, it, thinning, self._seed(seed),
+        # ph_dev: self.ph on the device already (test_down_tree_batch uploads it once for all nodes of the tree)
+        ph = self.ph[ids, :] if ph_dev is None else ph_dev[ids]
+        r = cascade_fold_in(ph, self.alpha, self.beta, tups, it, thinning, self._seed(seed),
                             self._test_stream(labels), keys, device=self._device, stream=stream, defer=defer)
         return r if defer else r["th_hat"]
 
@@ -357,6 +359,10 @@ class CascadeLDA(object):
         children = lambda parent: [parent] + list(filter(re.compile("^" + parent + "[0-9]{1}$").match, self.lablist))
         out = [[None, [], []] for _ in docs]
         pool = [torch.cuda.Stream() for _ in range(max(1, streams))] if torch.cuda.is_available() else [None]
+        ph_dev = None
+        if torch.cuda.is_available():        # the loadings go to the device ONCE; every node gathers its rows there
+            dev = torch.device(self._device if self._device is not None else "cuda:%d" % torch.cuda.current_device())
+            ph_dev = torch.from_numpy(np.ascontiguousarray(self.ph, dtype=np.float64)).to(dev)
         bows = [self.dicti.doc2bow(doc) for doc in docs]
         keys = None
         if bows:
@@ -370,12 +376,12 @@ class CascadeLDA(object):
                 labels = children(parent)
                 pending.append((parent, labels, self.cascade_test_batch(
                     None, it, thinning, labels, seed=seed, stream=pool[i % len(pool)], defer=True,
-                    bows=[bows[d] for d in members], doc_ids=[keys[d] for d in members])))
+                    bows=[bows[d] for d in members], doc_ids=[keys[d] for d in members], ph_dev=ph_dev)))
             return {parent: (labels, p.result()["th_hat"]) for parent, labels, p in pending}
 
         # level 1: every document against the one-character labels
         labels = self.lablist_l1
-        th = self.cascade_test_batch(None, it, thinning, labels, seed=seed, bows=bows, doc_ids=keys)
+        th = self.cascade_test_batch(None, it, thinning, labels, seed=seed, bows=bows, doc_ids=keys, ph_dev=ph_dev)
         todo2 = {}                                      # parent -> documents that kept it, in visiting order
         for d in range(len(docs)):
             keep, loads = self._head(th[d], labels, threshold)

@@ -34,6 +34,7 @@ struct FParams {
     int32_t avg_mode;        // 0: (s-1)/s*avg + (1/s)*cur   1: m*avg + (1-m)*cur with m = (s-1)/s
     int32_t last_leaf, tail, tail_row, n_rounds, xor_tree;
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];
+    int64_t n_sites;         // > 0: the initial assignments were drawn by llda_foldin_init_kernel (one lane group per SITE)
 };
 
 template <int T>
@@ -88,9 +89,14 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
     for (int s = 0; s < T; ++s) { ndk[s] = 0; avg[s] = 0.0; }
     int ntot = 0;
     const double c0 = P.c_init, c0r = 1.0 / c0, c1 = P.c_loop, c1r = 1.0 / c1;
+    const bool pre = P.n_sites > 0;
+    if (pre) {                                      // start state left by llda_foldin_init_kernel
+        load_row<T>(P.n_dk + d * KP + lig * T, ndk);
+        for (int n = 0; n < len; ++n) ntot += P.freq[s0 + n];
+    }
 
     // sweep = -1: prep4test (initial assignments from the normalised loadings), then `iters` sweeps
-    for (int sweep = -1; sweep < P.iters; ++sweep) {
+    for (int sweep = pre ? 0 : -1; sweep < P.iters; ++sweep) {
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         for (int n = 0; n < len; ++n) {
             const int v = P.word[s0 + n], f = P.freq[s0 + n];
@@ -175,6 +181,55 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
     store_row<T>(P.n_dk + d * KP + lig * T, ndk);
 #pragma unroll
     for (int s = 0; s < T; ++s) P.th[d * KP + lig * T + s] = avg[s];
+}
+
+// prep4test's initial assignments (LabeledLDA.py:168-175, CascadeLDA.py:199-206), one lane group per SITE: the draw of
+// a site depends only on its word's row of initial probabilities and on its keyed uniform, not on the other sites,
+// and the reference's `while prob.sum() > 1: prob /= c` can take tens of thousands of iterations for one site (the
+// CascadeLDA rows sum to 1 - p_0 + 1/len(doc) and c = 1.0000005), so walking a document's sites one after the other
+// made this phase cost more than all the sweeps.  z gets the position, n_dk the count (integer atomics).
+template <int G, int T, bool HAS_TAIL>
+__global__ void __launch_bounds__(256) llda_foldin_init_kernel(const FParams P)
+{
+    constexpr int KP = G * T;
+    constexpr int GPB = 256 / G;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int lig = tid & (G - 1);
+    const int64_t site = (int64_t)blockIdx.x * GPB + tid / G;
+    if (site >= P.n_sites) return;
+    KParams K;
+    K.last_leaf = P.last_leaf; K.tail = P.tail; K.tail_row = P.tail_row; K.n_rounds = P.n_rounds;
+    K.xor_tree = P.xor_tree;
+#pragma unroll
+    for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) K.rounds_pk[r] = P.rounds_pk[r];
+    // document of the site: last d with doc_off[d] <= site
+    int64_t lo = 0, hi = P.D;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (P.doc_off[mid] <= site) lo = mid; else hi = mid;
+    }
+    const int64_t d = lo;
+    const int n = (int)(site - P.doc_off[d]);
+    const uint32_t gdoc = P.doc_ids ? (uint32_t)P.doc_ids[d] : (uint32_t)(d + P.doc_base);
+    uint32_t r0 = (uint32_t)(n >> 1), r1 = gdoc, r2 = P.stream_id, r3 = 0xFFFFFFFFu;     // sweep word of prep4test: -1
+    philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
+    const uint32_t ra = (n & 1) ? r2 : r0, rb = (n & 1) ? r3 : r1;
+    const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+    double w[T];
+    load_row_f64<T>(P.phn + (int64_t)P.init_idx[site] * KP + lig * T, w);
+    shrink_to_one<G, T, HAS_TAIL>(w, P.c_init, 1.0 / P.c_init, K, lig, lane);
+    int zn = draw_position<G, T, false>(w, u, 0u, true, lig, lane);
+    if (zn < 0) {
+        zn = 0;
+        if (lig == 0 && P.status) atomicOr(P.status, 1);
+    }
+    if (lig == 0) {
+        int ln, sn;
+        lane_slot_of<G, T>(zn, ln, sn);
+        P.z[site] = zn;
+        atomicAdd(P.n_dk + d * KP + ln * T + sn, P.freq[site]);
+    }
 }
 
 }  // namespace

@@ -170,6 +170,12 @@ int dispatch_loglik_T(int T, const LParams &P, hipStream_t st)
 template <int G, int T>
 int launch_foldin(const FParams &P, bool has_tail, hipStream_t st)
 {
+    if (P.n_sites > 0) {                              // initial assignments: one lane group per site
+        const int64_t ib = (P.n_sites + (256 / G) - 1) / (256 / G);
+        if (ib > 0x7fffffffLL) return LLDA_E_BAD_ARG;
+        if (has_tail) hipLaunchKernelGGL((llda_foldin_init_kernel<G, T, true>), dim3((unsigned)ib), dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((llda_foldin_init_kernel<G, T, false>), dim3((unsigned)ib), dim3(256), 0, st, P);
+    }
     const int64_t blocks = (P.D + (256 / G) - 1) / (256 / G);
     if (has_tail) hipLaunchKernelGGL((llda_foldin_kernel<G, T, true>), dim3((unsigned)blocks), dim3(256), 0, st, P);
     else hipLaunchKernelGGL((llda_foldin_kernel<G, T, false>), dim3((unsigned)blocks), dim3(256), 0, st, P);
@@ -578,6 +584,7 @@ int llda_foldin(const llda_foldin_args *a, void *stream)
     P.c_init = a->c_init; P.c_loop = a->c_loop;
     P.key0 = (uint32_t)a->seed; P.key1 = (uint32_t)(a->seed >> 32); P.stream_id = a->stream_id;
     P.iters = a->iters; P.thinning = a->thinning; P.beta_fallback = a->beta_fallback; P.avg_mode = a->avg_mode;
+    P.n_sites = a->n_sites > 0 ? a->n_sites : 0;
     fill_schedule(L, P.last_leaf, P.tail, P.tail_row, P.n_rounds, P.xor_tree, P.rounds_pk);
     hipStream_t st = (hipStream_t)stream;
     const bool has_tail = L.tail != 0;

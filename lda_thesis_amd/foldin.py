@@ -164,17 +164,47 @@ def cascade_init_rows(ph, beta, doc_tups):
     return rows, np.arange(rows.shape[0])
 
 
+def cascade_init_rows_device(ph, beta, doc_off, word_dev, lay):
+    """cascade_init_rows on the device for loadings ``ph`` (K, V) that live there: the same elementwise expressions
+    (CascadeLDA.py:193-198); ``probs.sum(axis=0)`` of the (K, n) matrix is numpy's sequential sum over the K rows.
+    -> (S, KP) lane-major rows."""
+    K = ph.shape[0]
+    probs = ph[:, word_dev] + beta                                   # (K, S): probs = ph[:, ids]; probs += beta
+    colsum = probs[0].clone()
+    for k in range(1, K):
+        colsum += probs[k]
+    probs /= colsum
+    lens = np.diff(doc_off)
+    inv_len = np.repeat(1 / lens.astype(np.float64), lens)           # probs[0, :] = 1 / len(ids)
+    probs[0] = torch.from_numpy(inv_len).to(ph.device)
+    rows = torch.zeros((probs.shape[1], lay.KP), dtype=torch.float64, device=ph.device)
+    rows[:, torch.from_numpy(lay.lm_topic_pos.astype(np.int64)).to(ph.device)] = probs.t()
+    return rows
+
+
 def cascade_fold_in(ph, alpha, beta, doc_tups, it, thinning, seed, stream_id, doc_ids, flat=False, device=None,
                     stream=None, defer=False):
     """CascadeLDA.cascade_test (flat=False) / CascadeLDA.run_test (flat=True) for a batch of documents
-    against the label subset whose loadings are ``ph`` (K_sub, V).  defer=True: enqueue on ``stream`` and return
-    the Pending launch (``.result()`` gives the dict) so that launches of different label subsets overlap."""
-    ph = np.ascontiguousarray(ph, dtype=np.float64)
+    against the label subset whose loadings are ``ph`` (K_sub, V) -- numpy, or a torch tensor on the device (then
+    the preparation of CascadeLDA.prep4test runs there too and nothing but the documents is uploaded).
+    defer=True: enqueue on ``stream`` and return the Pending launch (``.result()`` gives the dict) so that launches
+    of different label subsets overlap."""
     for doc in doc_tups:
         if not doc:
             raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
-    rows, idx = cascade_init_rows(ph, beta, doc_tups)
-    pending = _launch(ph, rows, idx, doc_tups, alpha=alpha, beta=beta, it=it, thinning=thinning, seed=seed,
-                      stream_id=stream_id, doc_ids=doc_ids, c_init=1.0000005, c_loop=1.000005,
-                      beta_fallback=not flat, avg_mode=1 if flat else 0, device=device, stream=stream)
+    kw = dict(alpha=alpha, beta=beta, it=it, thinning=thinning, seed=seed, stream_id=stream_id, doc_ids=doc_ids,
+              c_init=1.0000005, c_loop=1.000005, beta_fallback=not flat, avg_mode=1 if flat else 0, stream=stream)
+    if isinstance(ph, torch.Tensor):
+        K, V = ph.shape
+        lay = group_layout(K)
+        doc_off, word, _ = csr_from_doc_tups(doc_tups)
+        w_dev = torch.from_numpy(word.astype(np.int64)).to(ph.device)
+        rows = cascade_init_rows_device(ph, beta, doc_off, w_dev, lay)
+        d_ph = torch.zeros((V, lay.KP), dtype=torch.float64, device=ph.device)
+        d_ph[:, torch.from_numpy(lay.lm_topic_pos.astype(np.int64)).to(ph.device)] = ph.t()
+        pending = _launch(d_ph, rows, np.arange(rows.shape[0]), doc_tups, device=ph.device, K_true=K, **kw)
+    else:
+        ph = np.ascontiguousarray(ph, dtype=np.float64)
+        rows, idx = cascade_init_rows(ph, beta, doc_tups)
+        pending = _launch(ph, rows, idx, doc_tups, device=device, **kw)
     return pending if defer else pending.result()
