@@ -287,6 +287,10 @@ typedef struct llda_foldin_args {
                                    one lane group per SITE (they are independent of one another, and the reference's
                                    `while prob.sum() > 1: prob /= c` can run tens of thousands of times for one site);
                                    n_dk must then be zeroed by the caller.  0: inside the per-document launch. */
+    const int64_t  *ph_base;    /* [dev] [D] optional (ABI 11): element offset of document d's loadings inside `ph` ...  */
+    const uint32_t *doc_stream; /* [dev] [D] optional: ... and its RNG stream id (instead of stream_id): documents that are
+                                   sampled against DIFFERENT label subsets of the same size (the nodes of one level of
+                                   CascadeLDA.test_down_tree) share one launch                                        */
 } llda_foldin_args;
 
 int llda_foldin(const llda_foldin_args *args, void *stream);

@@ -335,19 +335,20 @@ class CascadeLDA(object):
         return level_1, level_2, level_3
 
     def cascade_test_batch(self, docs, it, thinning, labels, seed=None, doc_ids=None, stream=None, defer=False,
-                           bows=None, ph_dev=None):
+                           bows=None, ph_dev=None, hold=False):
         """cascade_test for several documents against the SAME label subset: one llda_foldin launch, one lane
         group per document.  Row d equals cascade_test(docs[d], ...) -- the RNG is keyed by the document, not by
         its place in the batch.  defer=True: enqueue on ``stream`` and return the pending launch."""
+        import torch
         from .foldin import cascade_fold_in, doc_key
         ids = [self.labelmap[x] for x in labels]
         tups = [self.dicti.doc2bow(doc) for doc in docs] if bows is None else bows     # (bows: doc2bow done by the caller)
         keys = [doc_key(t) for t in tups] if doc_ids is None else list(doc_ids)
         # ph_dev: self.ph on the device already (test_down_tree_batch uploads it once for all nodes of the tree)
-        ph = self.ph[ids, :] if ph_dev is None else ph_dev[ids]
+        ph = self.ph[ids, :] if ph_dev is None else ph_dev.index_select(0, torch.from_numpy(np.asarray(ids, dtype=np.int64)).to(ph_dev.device))
         r = cascade_fold_in(ph, self.alpha, self.beta, tups, it, thinning, self._seed(seed),
-                            self._test_stream(labels), keys, device=self._device, stream=stream, defer=defer)
-        return r if defer else r["th_hat"]
+                            self._test_stream(labels), keys, device=self._device, stream=stream, defer=defer, hold=hold)
+        return r if (defer or hold) else r["th_hat"]
 
     def test_down_tree_batch(self, docs, it, thinning, threshold, seed=None, streams=32):
         """test_down_tree for a list of documents, level by level: all documents that reach the same node of the
@@ -370,14 +371,38 @@ class CascadeLDA(object):
             keys = [doc_key(b) if b else 0 for b in bows]
 
         def level(todo):
-            """todo: parent -> documents.  Enqueue every node, then collect: parent -> (labels, th rows)."""
-            pending = []
-            for i, (parent, members) in enumerate(todo.items()):
+            """todo: parent -> documents.  Nodes whose label lists have the same length share ONE launch
+            (foldin.cascade_fold_in_many); all uploads first, then the launches.  -> parent -> (labels, th rows)."""
+            from .foldin import cascade_fold_in, cascade_fold_in_many
+            groups = {}
+            for parent, members in todo.items():
                 labels = children(parent)
-                pending.append((parent, labels, self.cascade_test_batch(
-                    None, it, thinning, labels, seed=seed, stream=pool[i % len(pool)], defer=True,
-                    bows=[bows[d] for d in members], doc_ids=[keys[d] for d in members], ph_dev=ph_dev)))
-            return {parent: (labels, p.result()["th_hat"]) for parent, labels, p in pending}
+                groups.setdefault(len(labels), []).append((parent, labels, members))
+            held = []
+            for i, (K_sub, nodes) in enumerate(groups.items()):
+                if ph_dev is None:                      # (no device: the one-launch-per-node path reports the error)
+                    for parent, labels, members in nodes:
+                        held.append(([(parent, labels)], None, self.cascade_test_batch(
+                            None, it, thinning, labels, seed=seed, defer=True, hold=True,
+                            bows=[bows[d] for d in members], doc_ids=[keys[d] for d in members])))
+                    continue
+                jobs = []
+                for parent, labels, members in nodes:
+                    ids = torch.from_numpy(np.asarray([self.labelmap[x] for x in labels], dtype=np.int64)).to(ph_dev.device)
+                    jobs.append((ph_dev.index_select(0, ids), [bows[d] for d in members], self._test_stream(labels),
+                                 [keys[d] for d in members]))
+                held.append(([(p_, l_) for p_, l_, _ in nodes], cascade_fold_in_many(
+                    jobs, self.alpha, self.beta, it, thinning, self._seed(seed), stream=pool[i % len(pool)]), None))
+            out_level = {}
+            waiting = [(nodes, many() if many is not None else None, single() if single is not None else None)
+                       for nodes, many, single in held]
+            for nodes, res_many, pend in waiting:
+                if res_many is not None:
+                    for (parent, labels), th_rows in zip(nodes, res_many()):
+                        out_level[parent] = (labels, th_rows)
+                else:
+                    out_level[nodes[0][0]] = (nodes[0][1], pend.result()["th_hat"])
+            return {parent: out_level[parent] for parent in todo}
 
         # level 1: every document against the one-character labels
         labels = self.lablist_l1

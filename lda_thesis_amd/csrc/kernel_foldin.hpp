@@ -35,6 +35,8 @@ struct FParams {
     int32_t last_leaf, tail, tail_row, n_rounds, xor_tree;
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];
     int64_t n_sites;         // > 0: the initial assignments were drawn by llda_foldin_init_kernel (one lane group per SITE)
+    const int64_t *ph_base;  // optional [D]: element offset of the document's loadings inside ph (several label subsets,
+    const uint32_t *doc_stream;   // optional [D]: ... and its RNG stream id) -- documents of different calls in one launch
 };
 
 template <int T>
@@ -83,6 +85,8 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
     const int64_t s0 = P.doc_off[d];
     const int len = (int)(P.doc_off[d + 1] - s0);
     const uint32_t gdoc = P.doc_ids ? (uint32_t)P.doc_ids[d] : (uint32_t)(d + P.doc_base);
+    const uint32_t stream_id = P.doc_stream ? P.doc_stream[d] : P.stream_id;
+    const double *ph = P.ph + (P.ph_base ? P.ph_base[d] : 0);
     int ndk[T];
     double avg[T];
 #pragma unroll
@@ -101,7 +105,7 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
         for (int n = 0; n < len; ++n) {
             const int v = P.word[s0 + n], f = P.freq[s0 + n];
             if ((n & (2 * G - 1)) == 0) {
-                r0 = (uint32_t)(n >> 1) + (uint32_t)lig; r1 = gdoc; r2 = P.stream_id; r3 = (uint32_t)sweep;
+                r0 = (uint32_t)(n >> 1) + (uint32_t)lig; r1 = gdoc; r2 = stream_id; r3 = (uint32_t)sweep;
                 philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
             }
             const int holder = (n >> 1) & (G - 1);
@@ -123,7 +127,7 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
                     onehot_add1<T>(ndk, (lig == lo) ? (1u << so) : 0u, f);       // n_dk[z] -= f
                 }
                 double b[T];
-                load_row_f64<T>(P.ph + (int64_t)v * KP + lig * T, b);
+                load_row_f64<T>(ph + (int64_t)v * KP + lig * T, b);
 #pragma unroll
                 for (int s = 0; s < T; ++s) w[s] = ((double)ndk[s] + P.alpha) * b[s];   // num_a * b
                 double S = group_sum<G, T, HAS_TAIL>(w, K, lig, lane);
@@ -212,7 +216,7 @@ __global__ void __launch_bounds__(256) llda_foldin_init_kernel(const FParams P)
     const int64_t d = lo;
     const int n = (int)(site - P.doc_off[d]);
     const uint32_t gdoc = P.doc_ids ? (uint32_t)P.doc_ids[d] : (uint32_t)(d + P.doc_base);
-    uint32_t r0 = (uint32_t)(n >> 1), r1 = gdoc, r2 = P.stream_id, r3 = 0xFFFFFFFFu;     // sweep word of prep4test: -1
+    uint32_t r0 = (uint32_t)(n >> 1), r1 = gdoc, r2 = P.doc_stream ? P.doc_stream[d] : P.stream_id, r3 = 0xFFFFFFFFu;   // sweep word of prep4test: -1
     philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
     const uint32_t ra = (n & 1) ? r2 : r0, rb = (n & 1) ? r3 : r1;
     const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);

@@ -585,6 +585,7 @@ int llda_foldin(const llda_foldin_args *a, void *stream)
     P.key0 = (uint32_t)a->seed; P.key1 = (uint32_t)(a->seed >> 32); P.stream_id = a->stream_id;
     P.iters = a->iters; P.thinning = a->thinning; P.beta_fallback = a->beta_fallback; P.avg_mode = a->avg_mode;
     P.n_sites = a->n_sites > 0 ? a->n_sites : 0;
+    P.ph_base = a->ph_base; P.doc_stream = a->doc_stream;
     fill_schedule(L, P.last_leaf, P.tail, P.tail_row, P.n_rounds, P.xor_tree, P.rounds_pk);
     hipStream_t st = (hipStream_t)stream;
     const bool has_tail = L.tail != 0;

@@ -55,7 +55,7 @@ class Pending(object):
 
 
 def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, seed, stream_id, doc_ids, c_init,
-            c_loop, beta_fallback, avg_mode, device=None, stream=None, K_true=None):
+            c_loop, beta_fallback, avg_mode, device=None, stream=None, K_true=None, hold=False):
     """ph (K, V) float64; init_rows (R, K) float64; init_idx[S] row per site.  doc_ids: RNG id per document (any
     values: the whole batch is one launch).  Enqueues on ``stream`` (default: the current one), returns Pending."""
     _native.lib()
@@ -90,13 +90,19 @@ def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, see
     th = torch.zeros((D, lay.KP), dtype=torch.float64, device=dev)
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
     d_ids = t(np.asarray(doc_ids, dtype=np.int64), torch.int64)   # every document carries its own RNG id
-    stream.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(stream):
-        _native.foldin(doc_off=d_off, n_dk=n_dk, th=th, D=D, doc_ids=d_ids, word=d_word, init_idx=d_idx, freq=d_freq,
-                       ph=d_ph, init_rows=d_init, slot_valid=valid, z=z, status=status, K=K, iters=it,
-                       thinning=thinning, alpha=alpha, beta=beta, c_init=c_init, c_loop=c_loop, seed=seed,
-                       stream_id=stream_id, beta_fallback=beta_fallback, avg_mode=avg_mode)
-    return Pending(stream, lay, doc_off, z, n_dk, th, status, (d_off, d_word, d_freq, d_idx, d_ph, d_init, valid, d_ids))
+
+    def go():
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(stream):
+            _native.foldin(doc_off=d_off, n_dk=n_dk, th=th, D=D, doc_ids=d_ids, word=d_word, init_idx=d_idx, freq=d_freq,
+                           ph=d_ph, init_rows=d_init, slot_valid=valid, z=z, status=status, K=K, iters=it,
+                           thinning=thinning, alpha=alpha, beta=beta, c_init=c_init, c_loop=c_loop, seed=seed,
+                           stream_id=stream_id, beta_fallback=beta_fallback, avg_mode=avg_mode)
+        return Pending(stream, lay, doc_off, z, n_dk, th, status, (d_off, d_word, d_freq, d_idx, d_ph, d_init, valid, d_ids))
+    # hold=True: everything is uploaded and prepared, the kernels are enqueued when the caller calls the returned
+    # function -- a synchronous host-to-device copy waits for kernels that are already running, so a caller with many
+    # launches (CascadeLDA.test_down_tree_batch) uploads for all of them first
+    return go if hold else go()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -183,17 +189,19 @@ def cascade_init_rows_device(ph, beta, doc_off, word_dev, lay):
 
 
 def cascade_fold_in(ph, alpha, beta, doc_tups, it, thinning, seed, stream_id, doc_ids, flat=False, device=None,
-                    stream=None, defer=False):
+                    stream=None, defer=False, hold=False):
     """CascadeLDA.cascade_test (flat=False) / CascadeLDA.run_test (flat=True) for a batch of documents
     against the label subset whose loadings are ``ph`` (K_sub, V) -- numpy, or a torch tensor on the device (then
     the preparation of CascadeLDA.prep4test runs there too and nothing but the documents is uploaded).
     defer=True: enqueue on ``stream`` and return the Pending launch (``.result()`` gives the dict) so that launches
-    of different label subsets overlap."""
+    of different label subsets overlap; hold=True (with defer): upload and prepare only, and return a function that
+    enqueues the launch and gives the Pending."""
     for doc in doc_tups:
         if not doc:
             raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
     kw = dict(alpha=alpha, beta=beta, it=it, thinning=thinning, seed=seed, stream_id=stream_id, doc_ids=doc_ids,
-              c_init=1.0000005, c_loop=1.000005, beta_fallback=not flat, avg_mode=1 if flat else 0, stream=stream)
+              c_init=1.0000005, c_loop=1.000005, beta_fallback=not flat, avg_mode=1 if flat else 0, stream=stream,
+              hold=hold)
     if isinstance(ph, torch.Tensor):
         K, V = ph.shape
         lay = group_layout(K)
@@ -207,4 +215,70 @@ def cascade_fold_in(ph, alpha, beta, doc_tups, it, thinning, seed, stream_id, do
         ph = np.ascontiguousarray(ph, dtype=np.float64)
         rows, idx = cascade_init_rows(ph, beta, doc_tups)
         pending = _launch(ph, rows, idx, doc_tups, device=device, **kw)
-    return pending if defer else pending.result()
+    return pending if (defer or hold) else pending.result()
+
+
+def cascade_fold_in_many(jobs, alpha, beta, it, thinning, seed, stream=None):
+    """cascade_test for SEVERAL label subsets of the same size in ONE llda_foldin launch (the nodes of one level of
+    CascadeLDA.test_down_tree whose label lists have the same length): jobs = [(ph (K, V) device tensor, doc_tups,
+    stream_id, doc_ids), ...].  Every document carries the offset of its node's loadings and its node's RNG stream
+    (llda_foldin_args.ph_base / doc_stream), so the result of each job equals cascade_fold_in of that job alone.
+    Returns a function that waits for the launch and gives the list of th_hat arrays, one per job.  (ROCm runs only a
+    few hardware queues at a time: a hundred small launches on as many streams mostly queue behind one another.)"""
+    ph0 = jobs[0][0]
+    dev, (K, V) = ph0.device, ph0.shape
+    lay = group_layout(K)
+    lm = torch.from_numpy(lay.lm_topic_pos.astype(np.int64)).to(dev)
+    offs, words, freqs, ids, streams, bases, rows, phs, n_docs = [0], [], [], [], [], [], [], [], []
+    for j, (ph, doc_tups, stream_id, doc_ids) in enumerate(jobs):
+        for doc in doc_tups:
+            if not doc:
+                raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
+        doc_off, word, freq = csr_from_doc_tups(doc_tups)
+        offs.append(doc_off[1:] + offs[-1][-1] if isinstance(offs[-1], np.ndarray) else doc_off[1:])
+        words.append(word); freqs.append(freq)
+        ids.append(np.asarray(doc_ids, dtype=np.int64))
+        streams.append(np.full(len(doc_tups), stream_id & 0xFFFFFFFF, dtype=np.int64))
+        bases.append(np.full(len(doc_tups), j * V * lay.KP, dtype=np.int64))
+        n_docs.append(len(doc_tups))
+        w_dev = torch.from_numpy(word.astype(np.int64)).to(dev)
+        rows.append(cascade_init_rows_device(ph, beta, doc_off, w_dev, lay))
+        d_ph = torch.zeros((V, lay.KP), dtype=torch.float64, device=dev)
+        d_ph[:, lm] = ph.t()
+        phs.append(d_ph)
+    doc_off = np.concatenate([np.zeros(1, dtype=np.int64)] + [np.asarray(o, dtype=np.int64) for o in offs[1:]])
+    word, freq = np.concatenate(words), np.concatenate(freqs)
+    D, S = int(sum(n_docs)), int(word.shape[0])
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)
+    d_off, d_word, d_freq = t(doc_off, torch.int64), t(word, torch.int32), t(freq, torch.int32)
+    d_idx = torch.arange(S, dtype=torch.int32, device=dev)
+    d_ids, d_base = t(np.concatenate(ids), torch.int64), t(np.concatenate(bases), torch.int64)
+    d_stream = t(np.concatenate(streams), torch.int64).to(torch.int32)      # (uint32 bit patterns)
+    d_ph, d_init = torch.cat(phs), torch.cat(rows)
+    valid = t((lay.lm_pos_topic >= 0).astype(np.uint8), torch.uint8)
+    z = torch.zeros((max(S, 1),), dtype=torch.int32, device=dev)
+    n_dk = torch.zeros((D, lay.KP), dtype=torch.int32, device=dev)
+    th = torch.zeros((D, lay.KP), dtype=torch.float64, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    stream = stream if stream is not None else torch.cuda.current_stream(dev)
+
+    def go():
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(stream):
+            _native.foldin(doc_off=d_off, n_dk=n_dk, th=th, D=D, doc_ids=d_ids, word=d_word, init_idx=d_idx, freq=d_freq,
+                           ph=d_ph, init_rows=d_init, slot_valid=valid, z=z, status=status, K=K, iters=it,
+                           thinning=thinning, alpha=alpha, beta=beta, c_init=1.0000005, c_loop=1.000005, seed=seed,
+                           stream_id=0, beta_fallback=True, avg_mode=0, ph_base=d_base, doc_stream=d_stream)
+        keep = [(d_off, d_word, d_freq, d_idx, d_ids, d_base, d_stream, d_ph, d_init, valid)]   # alive until it has run
+
+        def result():
+            with torch.cuda.stream(stream):
+                if int(status.item()) != 0:
+                    raise ValueError("pvals < 0, pvals > 1 or pvals contains NaNs")
+                tp = torch.from_numpy(lay.lm_topic_pos.astype(np.int64)).to(dev)
+                allth = th[:, tp].cpu().numpy()
+            keep.clear()
+            bounds = np.concatenate(([0], np.cumsum(n_docs)))
+            return [allth[bounds[j]:bounds[j + 1]] for j in range(len(jobs))]
+        return result
+    return go
