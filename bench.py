@@ -286,7 +286,7 @@ def pmc_inner(dev, workloads):
         torch.cuda.empty_cache()
 
 
-def pmc_collect(workloads, keep_dir=None, timeout=600):
+def pmc_collect(workloads, keep_dir=None, timeout=240):
     """Run this script under rocprofv3, one --pmc group per pass (kernel trace only, as the guide prescribes), and
     return {workload: {counter: mean per sweep-kernel launch}}.  Any failure returns {} (traffic is then null)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
