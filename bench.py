@@ -303,10 +303,18 @@ def pmc_collect(workloads, keep_dir=None, timeout=240):
             cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "pmc", "--",
                                                                  sys.executable, os.path.join(ROOT, "bench.py"),
                                                                  "--pmc-inner", ",".join(workloads)]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+            # own session: on a timeout the whole process group (rocprofv3 AND the python under it) is ended
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                    start_new_session=True)
+            try:
+                out_text, _ = proc.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, 9)
+                proc.communicate()
+                return {}, "rocprofv3 pass %s did not finish in %d s" % (tag, timeout)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return {}, "rocprofv3 pass %s failed (rc %d): %s" % (tag, r.returncode, r.stdout.decode(errors="replace")[-300:])
+            if proc.returncode != 0 or not files:
+                return {}, "rocprofv3 pass %s failed (rc %d): %s" % (tag, proc.returncode, out_text.decode(errors="replace")[-300:])
             rows = []
             for r_ in csv.DictReader(open(files[0])):
                 nm = r_["Kernel_Name"]
