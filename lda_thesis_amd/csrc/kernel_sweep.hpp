@@ -204,21 +204,20 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         // next site) rotate with the site index, and the site loop is unrolled by three: no register-to-register
         // moves for the pipeline (a rolled loop spends 17 v_mov per site on them; the compiler cannot unroll it
         // itself because the body contains convergent cross-lane operations).
-        struct SiteRegs { int v, f, zo, c, zn; };
+        struct SiteRegs { int v, f, zo, c, zn, lo, so; };    // (lo, so) = lane and slot of zo, decoded once per site
         const uint32_t o0 = opaque_u32(sb + (uint32_t)n0 * 4u), o1 = opaque_u32(sb + (uint32_t)(n0 + 1 < len ? n0 + 1 : n0) * 4u);
         SiteRegs R0, R1, R2;
         R0.v = gload_i32(word_b, o0); R0.f = gload_i32(freq_b, o0); R0.zo = gload_i32(z_b, o0);
-        R0.c = LOGGED ? gload_i32(csc_b, o0) : 0; R0.zn = 0;
+        R0.c = LOGGED ? gload_i32(csc_b, o0) : 0; R0.zn = 0; R0.lo = R0.so = 0;
         R1.v = gload_i32(word_b, o1); R1.f = gload_i32(freq_b, o1); R1.zo = gload_i32(z_b, o1);
-        R1.c = LOGGED ? gload_i32(csc_b, o1) : 0; R1.zn = 0;
-        R2.v = R2.f = R2.zo = R2.c = R2.zn = 0;
+        R1.c = LOGGED ? gload_i32(csc_b, o1) : 0; R1.zn = 0; R1.lo = R1.so = 0;
+        R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = 0;
         int xn[T];
         gload_lane_row<G, T>(P.n_kw, (int64_t)R0.v * KP, lig, xn);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the previous site
-            int lo, so;
-            lane_slot_of<G, T>(R0.zo, lo, so);
-            if (lig == lo) count_update(s_ndk, s_nkc, s_pa, so, tid, alpha32, vbeta32, -R0.f);
+            lane_slot_of<G, T>(R0.zo, R0.lo, R0.so);
+            if (lig == R0.lo) count_update(s_ndk, s_nkc, s_pa, R0.so, tid, alpha32, vbeta32, -R0.f);
         }
 
         // one site: `cur` holds its scalars, `nxt` those of site n+1, `prv` those of site n-1 (committed here, then
@@ -228,11 +227,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             // the fetched row minus the site's own count (n_dk / n_k were updated already), written to a second
             // array so that the next row can be loaded into xn right away
             int x[T];
-            {
-                int lo, so;
-                lane_slot_of<G, T>(zo, lo, so);
-                onehot_add_to<T>(x, xn, (lig == lo) ? (1u << so) : 0u, f);   // m = -1 at the slot: += (-1) * f
-            }
+            onehot_add_to<T>(x, xn, (lig == cur.lo) ? (1u << cur.so) : 0u, f);   // m = -1 at the slot: += (-1) * f
 #ifndef ABL_NOCOMMIT
             if (lig == 0 && n > n0)
                 commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn, prv.c, KP);
@@ -281,9 +276,10 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
             // Both updates usually belong to different lanes and are done in ONE masked pass; a second pass runs
             // only for groups where the same lane owns both.
             {
-                int ln, sn, lo2, so2;
+                int ln, sn;
                 lane_slot_of<G, T>(zn, ln, sn);
-                lane_slot_of<G, T>(nxt.zo, lo2, so2);
+                lane_slot_of<G, T>(nxt.zo, nxt.lo, nxt.so);                  // (kept for the next site's removal from x)
+                const int lo2 = nxt.lo, so2 = nxt.so;
                 const bool more = n + 1 < len;
                 const bool own_new = lig == ln, own_old = more && lig == lo2;
                 if (own_new || own_old)
