@@ -454,6 +454,16 @@ def main():
     total_sites = sites_local
     checksum = int(sampler.n_k.to(torch.int64).mul(torch.arange(1, sampler.n_k.numel() + 1, device=dev)).sum().item())
     comm = sampler.comm_stats() if hasattr(sampler, "comm_stats") else None
+    if dist is not None and comm is not None and sampler.rows is not None:
+        # the collective alone (no sweep beside it), outside the timed region: what an ideal overlap could hide
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        a.record()
+        for _ in range(10):
+            dist.all_reduce(sampler.rows)          # (the rows are all zero between sweeps: the sums stay zero)
+        b.record()
+        torch.cuda.synchronize()
+        comm["allreduce_alone_ms"] = a.elapsed_time(b) / 10
     if dist is not None:
         t = torch.tensor([sites_local], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
