@@ -452,7 +452,7 @@ def main():
     dt, kavg = time_sweeps(sampler, args.steps, args.warmup, dist, dev)
     tier = sampler.status.cpu().numpy().astype(np.int64)
     total_sites = sites_local
-    checksum = int(sampler.n_k.to(torch.int64).mul(torch.arange(1, sampler.n_k.numel() + 1, device=dev)).sum().item())
+    checksum = int((sampler.n_k[sampler._topic_pos].to(torch.int64) * torch.arange(1, sampler.K + 1, device=dev)).sum().item())   # topic order
     comm = sampler.comm_stats() if hasattr(sampler, "comm_stats") else None
     if dist is not None and comm is not None and sampler.rows is not None:
         # the collective alone (no sweep beside it), outside the timed region: what an ideal overlap could hide
@@ -481,8 +481,8 @@ def main():
         dt2, k2 = time_sweeps(sampler, max(5, args.steps // 4), 2, dist, dev)
         probe = {"overlap_ranges": 2, "steps": max(5, args.steps // 4), "ms_per_step": dt2 / max(5, args.steps // 4) * 1e3,
                  "exchange_ms": sampler.comm_stats(),
-                 "state_checksum_n_k_after_probe": int(sampler.n_k.to(torch.int64).mul(
-                     torch.arange(1, sampler.n_k.numel() + 1, device=dev)).sum().item())}
+                 "state_checksum_n_k_after_probe": int((sampler.n_k[sampler._topic_pos].to(torch.int64) *
+                                                        torch.arange(1, sampler.K + 1, device=dev)).sum().item())}
 
     if rank == 0:
         K, V, N = info["K"], info["V"], info["N"]
