@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 11
+#define LLDA_ABI_VERSION 12
 #define LLDA_MAX_K 1024
 #define LLDA_MAX_LEAVES 8
 #define LLDA_MAX_ROUNDS 4
@@ -128,6 +128,12 @@ typedef struct llda_sweep_args {
                                     the first document of the call).  Larger shards: one call per document
                                     range -- pass doc_off + d0, D = d1 - d0, n_dk + d0*KP, lab_mask + d0*G,
                                     doc_base + d0 (and live_off + d0); every other pointer stays as it is. */
+    const int32_t *site_rec;     /* [dev] [S][4] optional (ABI 12), with the commit log: {word, freq, csc_pos, 0} of
+                                    every site as one 16-byte record.  Layouts with 8 or 16 lanes per document (K <= 256)
+                                    read it instead of the three arrays: a wavefront then walks 8 / 4 documents and
+                                    every scalar load touches that many cache lines, which makes the vector-memory
+                                    address pipeline the bound.  A call that passes it with such a layout may span at
+                                    most 2^28 - 1 sites. */
 } llda_sweep_args;
 
 /* ---- host-only (no device needed) ---- */

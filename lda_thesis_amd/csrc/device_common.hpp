@@ -39,6 +39,7 @@ struct KParams {
     // commit log (both NULL: n_kw_delta atomics): one word per site at its word-major position
     const int32_t *csc_pos;
     uint32_t *commit_log;
+    const int32_t *site_rec;   // optional [S][4]: {word, freq, csc_pos, 0} per site (kernels with <= 16 lanes per document)
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];   // 4 bits per leaf: partner leaf
 };
 

@@ -166,6 +166,8 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
     const int64_t site_base = P.doc_off[0];                 // uniform: the bases below stay in SGPRs
     const int32_t *word_b = P.word + site_base, *freq_b = P.freq + site_base;
     const int32_t *csc_b = LOGGED ? P.csc_pos + site_base : nullptr;
+    constexpr bool PACKED = LOGGED && G <= 16;
+    const int32_t *rec_b = (PACKED && P.site_rec) ? P.site_rec + site_base * 4 : nullptr;
     int32_t *z_b = P.z + site_base;
     for (int it = 0; it < P.dpg; ++it) {
         constexpr int n0 = 0;                 // first site to sample
@@ -205,12 +207,26 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         // moves for the pipeline (a rolled loop spends 17 v_mov per site on them; the compiler cannot unroll it
         // itself because the body contains convergent cross-lane operations).
         struct SiteRegs { int v, f, zo, c, zn, lo, so; };    // (lo, so) = lane and slot of zo, decoded once per site
+        // scalars of one site.  With 8 or 16 lanes per document a wavefront walks 8 / 4 documents, and every scalar
+        // load touches that many cache lines: the kernel is then bound by the vector-memory address pipeline (TA
+        // busy 74 % at K = 128), not by VALU issue.  PACKED: {word, freq, csc_pos} come as ONE 16-byte record per
+        // site (llda_sweep_args.site_rec) -- one stream and one instruction instead of three.
+        auto load_scalars = [&](SiteRegs &R, const uint32_t o) {
+            if (PACKED && rec_b) {
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                const v4i r = *(const LLDA_GLOBAL v4i *)((const LLDA_GLOBAL char *)rec_b + (o << 2));
+                R.v = r.x; R.f = r.y; R.c = r.z;
+            } else {
+                R.v = gload_i32(word_b, o); R.f = gload_i32(freq_b, o);
+                R.c = LOGGED ? gload_i32(csc_b, o) : 0;
+            }
+            R.zo = gload_i32(z_b, o);
+        };
         const uint32_t o0 = opaque_u32(sb + (uint32_t)n0 * 4u), o1 = opaque_u32(sb + (uint32_t)(n0 + 1 < len ? n0 + 1 : n0) * 4u);
         SiteRegs R0, R1, R2;
-        R0.v = gload_i32(word_b, o0); R0.f = gload_i32(freq_b, o0); R0.zo = gload_i32(z_b, o0);
-        R0.c = LOGGED ? gload_i32(csc_b, o0) : 0; R0.zn = 0; R0.lo = R0.so = 0;
-        R1.v = gload_i32(word_b, o1); R1.f = gload_i32(freq_b, o1); R1.zo = gload_i32(z_b, o1);
-        R1.c = LOGGED ? gload_i32(csc_b, o1) : 0; R1.zn = 0; R1.lo = R1.so = 0;
+        R0.c = R1.c = 0;
+        load_scalars(R0, o0); R0.zn = 0; R0.lo = R0.so = 0;
+        load_scalars(R1, o1); R1.zn = 0; R1.lo = R1.so = 0;
         R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = 0;
         int xn[T];
         gload_lane_row<G, T>(P.n_kw, (int64_t)R0.v * KP, lig, xn);
@@ -240,8 +256,7 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
 #endif
             {
                 const uint32_t o2 = opaque_u32(sb + (uint32_t)(n + 2 < len ? n + 2 : len - 1) * 4u);   // scalars of site n+2 (clamped)
-                prv.v = gload_i32(word_b, o2); prv.f = gload_i32(freq_b, o2); prv.zo = gload_i32(z_b, o2);
-                if (LOGGED) prv.c = gload_i32(csc_b, o2);
+                load_scalars(prv, o2);
             }
             uint32_t ra, rb;
             site_random_bits<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3, ra, rb);

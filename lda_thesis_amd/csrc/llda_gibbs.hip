@@ -333,6 +333,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     P.lab_mask = a->lab_mask; P.n_dk = a->n_dk; P.n_kw = a->n_kw; P.n_kw_delta = a->n_kw_delta;
     P.n_k = a->n_k; P.n_k_delta = a->n_k_delta; P.status = a->status;
     P.csc_pos = a->csc_pos; P.commit_log = a->commit_log;
+    P.site_rec = logged ? a->site_rec : nullptr;
     P.D = a->D; P.doc_base = a->doc_base;
     P.alpha = a->alpha; P.beta = a->beta;
     P.vbeta = (double)a->V * a->beta;                       // V * beta evaluated first (LabeledLDA.py:115)
@@ -340,6 +341,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     P.sweep = a->sweep; P.stream_id = a->stream_id;
     fill_schedule(L, P.last_leaf, P.tail, P.tail_row, P.n_rounds, P.xor_tree, P.rounds_pk);
     P.KP = L.KP;
+    if (P.site_rec && L.G <= 16 && a->n_sites >= (1LL << 28)) return LLDA_E_BAD_ARG;   // 16-byte records: 32-bit offsets
     const bool has_tail = L.tail != 0;
     // with alpha, beta >= 1e-6 and int32 counts no label-allowed score can underflow to zero ...
     // ... and with V*beta < 2^40 the fp32 / fp64 reciprocals of n_k + V*beta stay in range

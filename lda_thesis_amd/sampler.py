@@ -133,7 +133,7 @@ class GibbsSampler(object):
         self.live_max = 0
         if sparse_labels and labs is not None and self.D > 0:
             self._make_live()
-        self.csc_pos = self.commit_log = None
+        self.csc_pos = self.commit_log = self.site_rec = None
         self._ranges = self._make_ranges()
         if commit_log is None:
             commit_log = self.S >= (1 << 20)
@@ -142,7 +142,8 @@ class GibbsSampler(object):
         if commit_log and self.S > 0:
             self._make_commit_log()
         self._sort_docs = bool(sort_docs)
-        self._off_host = self.doc_off.cpu().numpy() if (self.S > self.MAX_CALL_SITES or len(self._ranges) > 2) else None
+        self._call_limit = min(self.MAX_CALL_SITES, self.MAX_CALL_SITES_REC) if self.site_rec is not None else self.MAX_CALL_SITES
+        self._off_host = self.doc_off.cpu().numpy() if (self.S > self._call_limit or len(self._ranges) > 2) else None
         self._calls = self._make_calls(self.doc_off[1:] - self.doc_off[:-1])
         self.doc_order = self._calls[0][2]       # (order of the first -- normally the only -- call)
 
@@ -266,6 +267,7 @@ class GibbsSampler(object):
 
     LOG_ITEM = 4096    # most log entries one wavefront of llda_commit_log folds (hot words are cut into items)
     MAX_CALL_SITES = (1 << 30) - 1   # llda_sweep addresses the sites of one call with 32-bit byte offsets
+    MAX_CALL_SITES_REC = (1 << 28) - 1   # ... and the 16-byte site records of narrow layouts
 
     def _make_calls(self, lens):
         """document ranges of the llda_sweep calls of one sweep (one range unless the shard spans 2^30 sites),
@@ -275,16 +277,16 @@ class GibbsSampler(object):
             if not self._sort_docs or hi - lo < 2 or int(ln.min()) == int(ln.max()):
                 return None
             return torch.sort(ln, descending=True, stable=True).indices.to(torch.int32)
-        if self.S <= self.MAX_CALL_SITES and len(self._ranges) == 2:
+        if self.S <= self._call_limit and len(self._ranges) == 2:
             return [(0, self.D, order(0, self.D))]
         off = self._off_host
-        if int(np.diff(off).max()) > self.MAX_CALL_SITES:
-            raise ValueError("a document has more than %d sites" % self.MAX_CALL_SITES)
+        if int(np.diff(off).max()) > self._call_limit:
+            raise ValueError("a document has more than %d sites" % self._call_limit)
         calls = []
         for r in range(len(self._ranges) - 1):
             lo, end = self._ranges[r], self._ranges[r + 1]
             while lo < end:
-                hi = int(np.searchsorted(off, off[lo] + self.MAX_CALL_SITES, side="right")) - 1
+                hi = int(np.searchsorted(off, off[lo] + self._call_limit, side="right")) - 1
                 hi = max(min(hi, end), lo + 1)
                 calls.append((lo, hi, order(lo, hi)))
                 lo = hi
@@ -322,6 +324,11 @@ class GibbsSampler(object):
         self.item_word = torch.where(shared, wid - (1 << 31), wid).to(torch.int32).contiguous()
         self._item_bounds = first[::V].cpu().tolist()                          # items of range r: [b[r], b[r+1])
         self.commit_log = torch.zeros((self.S,), dtype=torch.int32, device=dev)
+        # layouts with 8 or 16 lanes per document: {word, freq, csc_pos} as one 16-byte record per site
+        # (llda_sweep_args.site_rec: those kernels are bound by the number of cache lines their scalar loads touch)
+        self.site_rec = None
+        if self.layout.G <= 16:
+            self.site_rec = torch.stack([self.word, self.freq, self.csc_pos, torch.zeros_like(self.word)], dim=1).contiguous()
 
     # ------------------------------------------------------------------ the hot path
     def _timed(self, fn):
@@ -369,7 +376,7 @@ class GibbsSampler(object):
                                    live_off=None if self.live_off is None else self.live_off[lo:hi + 1],
                                    live_pos=self.live_pos,
                                    live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
-                                   n_sites=s1 - s0)
+                                   n_sites=s1 - s0, site_rec=self.site_rec)
             if pipelined:
                 # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
                 # collective's stream (ordered after the fold) while the next range is sampled on this one

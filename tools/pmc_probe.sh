@@ -19,7 +19,7 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in glob.glob("$P/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "llda_sweep_kernel" in r["Kernel_Name"]:
+        if "llda_sweep" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg):
     v = agg[k]
