@@ -140,6 +140,9 @@ typedef struct llda_sweep_args {
 int         llda_abi_version(void);
 const char *llda_strerror(int code);
 int         llda_last_hip_error(void);
+/* sizeof of the argument structs as the library was compiled (0 llda_layout, 1 llda_sweep_args, 2 llda_batch_args,
+ * 3 llda_foldin_args): a binding checks its own struct definitions against it once, at load time. */
+int         llda_struct_size(int which);
 /* Fill *out for K topics.  Mirrors numpy's pairwise-sum recursion (np.sum at LabeledLDA.py:117). */
 int         llda_layout_init(int32_t K, llda_layout *out);
 

@@ -64,7 +64,7 @@ class LldaBatchArgs(ctypes.Structure):
                 ("beta", _c_d), ("seed", _c_u64), ("sweep", _c_u32), ("reserved", _c_u32)]
 
 
-EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_layout_init",
+EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_struct_size", "llda_layout_init",
            "llda_sweep", "llda_sweep_batch", "llda_commit_log", "llda_apply_rows", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
            "llda_readout_phi", "llda_readout_theta", "llda_selftest_div")
 
@@ -122,6 +122,12 @@ def lib():
     L.llda_selftest_div.argtypes = [_c_u64, _c_i64, _c_p, _c_p]
     if L.llda_abi_version() != ABI_VERSION:
         raise NativeError("libllda_gibbs.so ABI %d != binding ABI %d" % (L.llda_abi_version(), ABI_VERSION))
+    L.llda_struct_size.restype = ctypes.c_int
+    L.llda_struct_size.argtypes = [ctypes.c_int]
+    for which, struct in enumerate((LldaLayout, LldaSweepArgs, LldaBatchArgs, LldaFoldinArgs)):
+        if L.llda_struct_size(which) != ctypes.sizeof(struct):
+            raise NativeError("%s: binding has %d bytes, the library %d" % (struct.__name__, ctypes.sizeof(struct),
+                                                                           L.llda_struct_size(which)))
     _LIB = L
     return L
 

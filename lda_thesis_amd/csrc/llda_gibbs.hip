@@ -255,6 +255,17 @@ int llda_abi_version(void) { return LLDA_ABI_VERSION; }
 
 int llda_last_hip_error(void) { return g_last_hip_error; }
 
+int llda_struct_size(int which)
+{
+    switch (which) {
+    case 0: return (int)sizeof(llda_layout);
+    case 1: return (int)sizeof(llda_sweep_args);
+    case 2: return (int)sizeof(llda_batch_args);
+    case 3: return (int)sizeof(llda_foldin_args);
+    default: return -1;
+    }
+}
+
 const char *llda_strerror(int code)
 {
     switch (code) {
