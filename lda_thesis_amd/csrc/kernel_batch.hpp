@@ -41,6 +41,15 @@ struct BParams {
     uint32_t key0, key1, sweep;
 };
 
+// ... or one problem per lane group (at most 128 topics: one pairwise leaf, 8 lanes x KP/8 slots); the layout of the
+// group that is served comes from its lanes
+__device__ __noinline__ int exact_call(const BParams *, int layK, int layKP, double wx, int pos, int base, int A, double u,
+                                       int lane)
+{
+    const int K = __builtin_amdgcn_readlane(layK, base), KP = __builtin_amdgcn_readlane(layKP, base);
+    return exact_site_wave(wx, pos, base, A, u, 8, KP >> 3, 0, K & 7, K >> 3, 0, 1, nullptr, lane);
+}
+
 template <int GS>
 __global__ void __launch_bounds__(256) llda_sweep_batch_kernel(const BParams P)
 {
@@ -73,15 +82,7 @@ __global__ void __launch_bounds__(256) llda_sweep_batch_kernel(const BParams P)
     int nk = live ? P.counts[P.nk_off[prob] + pos] : 0;
     const uint32_t gdoc = (uint32_t)P.inst_doc[inst];
     const uint32_t stream = (uint32_t)P.prob_stream[prob];
-    // dense layout of this instance's problem (at most 128 topics: one pairwise leaf, 8 lanes x KP/8 slots); the
-    // instances of a wavefront belong to different problems, so the exact tier gets the layout of the group it serves
-    ExactLayout lay;
-    {
-        const int K = P.k[prob];
-        lay.G = 8; lay.T = KP >> 3; lay.last_leaf = 0; lay.tail = K & 7; lay.tail_row = K >> 3; lay.n_rounds = 0; lay.xor_tree = 1;
-#pragma unroll
-        for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) lay.rounds_pk[r] = 0;
-    }
+    const int layK = P.k[prob];                  // (for the exact tier: the dense layout of THIS group's problem)
     int max_len = len;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) max_len = max(max_len, __shfl_xor(max_len, o, 64));
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(256) llda_sweep_batch_kernel(const BParams P)
         int my_zn = sz;
         int done = 0;
 #define LLDA_BATCH_SITE(J)                                                                                     \
-        sparse_site<GS, J>(P, lay, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
+        sparse_site<GS, J>(P, layK, KP, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
                            gbase, gmask);
         LLDA_BATCH_SITE(0) LLDA_BATCH_SITE(1) LLDA_BATCH_SITE(2) LLDA_BATCH_SITE(3)
         LLDA_BATCH_SITE(4) LLDA_BATCH_SITE(5) LLDA_BATCH_SITE(6) LLDA_BATCH_SITE(7)

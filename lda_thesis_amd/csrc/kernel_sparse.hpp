@@ -103,6 +103,17 @@ __device__ __forceinline__ int allor_i32(int x, int lane)
     return x;
 }
 
+// exact_site_wave with the dense layout of the problem: one problem per launch (its layout is in the kernel
+// arguments, read through the kernel-argument segment so that nothing of it stays live in the hot loop) ...
+__device__ __noinline__ int exact_call(const KParams *K, int, int, double wx, int pos, int base, int A, double u, int lane)
+{
+    int P2 = 1;
+    while (P2 < K->last_leaf + 1) P2 *= 2;
+    const int G = 8 * P2;
+    return exact_site_wave(wx, pos, base, A, u, G, K->KP / G, K->last_leaf, K->tail, K->tail_row, K->n_rounds, K->xor_tree,
+                           K->rounds_pk, lane);
+}
+
 // One site of the sparse kernel (J = index inside the current batch of 8 sites), branch free on the decided path:
 // every lane of the wavefront executes every instruction and the per-group condition "is site J part of this batch?"
 // is data -- divergent branches here cost more in exec-mask bookkeeping (SGPR spills) than the arithmetic they skip.
@@ -110,8 +121,10 @@ __device__ __forceinline__ int allor_i32(int x, int lane)
 // site's add-back).  A site the margin cannot decide (~1e-11 per site; the only branch, wave-uniform) is resolved on
 // the spot by exact_site_wave(): the reference's fp64 pipeline in the dense layout of the problem (`lay`), run by
 // the whole wavefront for that document -- the topic is the exact pipeline's either way.
+// (layK, layKP: topics and row length of the caller's problem in the batched kernel -- per lane group; the sparse
+// kernel of one problem passes -1 and the layout is read from the kernel arguments in the rare branch that needs it)
 template <int GS, int J, class PT>
-__device__ __forceinline__ void sparse_site(const PT &P, const ExactLayout &lay, int nb, int sf, int sz, int su_lo,
+__device__ __forceinline__ void sparse_site(const PT &P, int layK, int layKP, int nb, int sf, int sz, int su_lo,
                                             int su_hi, const int (&xg)[8], bool live, int pos, int A, int &ndk, int &nk,
                                             int &my_zn, int &done, int lig, int lane, int gbase, uint64_t gmask)
 {
@@ -141,11 +154,8 @@ __device__ __forceinline__ void sparse_site(const PT &P, const ExactLayout &lay,
             todo &= ~(gmask << base);
             const int A_g = __builtin_amdgcn_readlane(A, base);
             const double u_g = readlane_var_f64(u, base);
-            ExactLayout lg = lay;                    // (the batched kernel serves a different problem per lane group)
-            lg.T = __builtin_amdgcn_readlane(lay.T, base); lg.G = __builtin_amdgcn_readlane(lay.G, base);
-            lg.tail = __builtin_amdgcn_readlane(lay.tail, base); lg.tail_row = __builtin_amdgcn_readlane(lay.tail_row, base);
-            lg.last_leaf = __builtin_amdgcn_readlane(lay.last_leaf, base);
-            const int r = exact_site_wave(wx, pos, base, A_g, u_g, lg, lane);
+            // (the kernel-argument segment, taken here in kernel scope: taking &P would pin all of P in registers)
+            const int r = exact_call((const PT *)__builtin_amdgcn_kernarg_segment_ptr(), layK, layKP, wx, pos, base, A_g, u_g, lane);
             if ((lane & ~(GS - 1)) == base) {
                 zn = r < 0 ? zo : r;
                 if (r < 0 && lig == 0 && P.status) atomicOr(P.status, 1);           // no topic with positive probability
@@ -160,18 +170,6 @@ __device__ __forceinline__ void sparse_site(const PT &P, const ExactLayout &lay,
     done -= active;                                                                 // active is 0 or -1
 }
 
-// dense layout of the K topics as exact_site_wave needs it, from the sweep parameters
-__device__ __forceinline__ ExactLayout exact_layout_of(const KParams &P)
-{
-    ExactLayout L;
-    int P2 = 1;
-    while (P2 < P.last_leaf + 1) P2 *= 2;
-    L.G = 8 * P2; L.T = P.KP / L.G;
-    L.last_leaf = P.last_leaf; L.tail = P.tail; L.tail_row = P.tail_row; L.n_rounds = P.n_rounds; L.xor_tree = P.xor_tree;
-#pragma unroll
-    for (int r = 0; r < LLDA_MAX_ROUNDS; ++r) L.rounds_pk[r] = P.rounds_pk[r];
-    return L;
-}
 
 template <int GS>
 __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
@@ -187,7 +185,6 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
     const int grp = tid / GS;
     const int gbase = lane & ~(GS - 1);
     const uint64_t gmask = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
-    const ExactLayout lay = exact_layout_of(P);
 
     // The document loops are WAVE-UNIFORM (a lane group whose document is shorter, empty or past the end of the shard
     // idles through flags, it does not leave the loop): the exact tier of sparse_site() needs all 64 lanes.
@@ -247,7 +244,7 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
             int my_zn = sz;
             int done = 0;                     // sites of this batch
 #define LLDA_SPARSE_SITE(J)                                                                                    \
-            sparse_site<GS, J>(P, lay, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
+            sparse_site<GS, J>(P, -1, -1, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
                                gbase, gmask);
             LLDA_SPARSE_SITE(0) LLDA_SPARSE_SITE(1) LLDA_SPARSE_SITE(2) LLDA_SPARSE_SITE(3)
             LLDA_SPARSE_SITE(4) LLDA_SPARSE_SITE(5) LLDA_SPARSE_SITE(6) LLDA_SPARSE_SITE(7)
