@@ -571,14 +571,18 @@ class CascadeLDA(object):
         lens = np.diff(doc_off)
         # initial assignments of EVERY sub-problem, in visiting order, from numpy's global stream -- exactly the
         # uniforms the reference's per-document np.random.choice calls consume (CascadeLDA.py:373-381)
-        z_local = []
-        for pl in plans:
-            n_sites = lens[pl["docs"]]
-            u = np.random.random_sample(int(n_sites.sum()))
-            inst = np.repeat(np.arange(len(pl["docs"])), n_sites)
-            z_local.append(draw_initial_topics(pl["allowed"], pl["n_allowed"], inst, u) if len(u) else
-                           np.zeros(0, dtype=np.int64))
         sites = [int(lens[pl["docs"]].sum()) for pl in plans]
+        a_max = max(pl["allowed"].shape[1] for pl in plans)
+        allowed_all = np.full((sum(len(pl["docs"]) for pl in plans), a_max), -1, dtype=np.int64)
+        row = 0
+        for pl in plans:
+            allowed_all[row:row + len(pl["docs"]), :pl["allowed"].shape[1]] = pl["allowed"]
+            row += len(pl["docs"])
+        n_allowed_all = np.concatenate([pl["n_allowed"] for pl in plans])
+        inst_len = np.concatenate([lens[pl["docs"]] for pl in plans])
+        u = np.random.random_sample(int(inst_len.sum()))            # (= the plans' draws one after the other)
+        z_all = draw_initial_topics(allowed_all, n_allowed_all, np.repeat(np.arange(len(inst_len)), inst_len), u)
+        z_local = np.split(z_all, np.cumsum(sites)[:-1])
         owner = lpt_assign(sites, world)
         mine = [i for i in range(len(plans)) if owner[i] == rank]
         from .ensemble import MAX_BATCH_K

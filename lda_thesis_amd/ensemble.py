@@ -50,8 +50,11 @@ def draw_initial_topics(allowed, n_allowed, inst_of_site, uniforms):
     """np.random.choice(K, size=n, p=lab/lab.sum()) for every instance at once: ``allowed`` (I, A_max) local topic ids
     ascending (padded), ``n_allowed`` (I,), one uniform per site.  -> local topic per site."""
     tab = choice_cdf_table(int(n_allowed.max()))
-    cdf = tab[n_allowed[inst_of_site] - 1]                         # (S, A_max)
-    k = (cdf <= uniforms[:, None]).sum(axis=1)                     # searchsorted(..., side='right')
+    a_site = n_allowed[inst_of_site]
+    k = np.zeros(uniforms.shape[0], dtype=np.int64)
+    for A in np.unique(a_site):                                    # one searchsorted per label-set size
+        m = a_site == A
+        k[m] = np.searchsorted(tab[A - 1, :A], uniforms[m], side="right")
     return allowed[inst_of_site, k]
 
 
