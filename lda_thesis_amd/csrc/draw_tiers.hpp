@@ -129,12 +129,34 @@ __device__ __forceinline__ void count_sorted_f32(const float (&q)[T], float lo, 
     }
 }
 
+// lane predicate "my group's half / the whole of the uniform 64-bit mask b is non-zero" for 32- and 64-lane groups:
+// scalar instructions and an inverse ballot instead of per-lane 64-bit shifts and compares (the kernel is bound by
+// VALU issue; the scalar unit idles)
+// upper half of a uniform 64-bit value, hidden from the optimiser (it would turn "hi != 0" into a 64-bit compare,
+// which only the vector unit has)
+__device__ __forceinline__ uint32_t uniform_hi32(uint64_t b)
+{
+    uint32_t hi = (uint32_t)(b >> 32);
+    asm("" : "+s"(hi));
+    return hi;
+}
+template <int G>
+__device__ __forceinline__ uint64_t spread_any(uint64_t b)
+{
+    static_assert(G == 32 || G == 64, "wide groups only");
+    if constexpr (G == 64) {
+        return b ? ~0ull : 0ull;
+    } else {
+        const uint32_t lo = (uint32_t)b, hi = uniform_hi32(b);
+        return (lo ? 0xFFFFFFFFull : 0ull) | (hi ? 0xFFFFFFFF00000000ull : 0ull);
+    }
+}
+
+// gp_all = __ballot(mask != 0) of the whole wavefront (uniform) for G >= 32, the group's own bits (per lane) below
 template <int G, int T>
 __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uint32_t mask, uint64_t gp,
                                               float margin_rel, int lig, int lane, int &zn)
 {
-    const int gbase = lane & ~(G - 1);
-    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
     const float X = group_scan_f32<G>(qw[T - 1], lig);
     const float tot = bcast_last_f32<G>(X, lane);
     const float prev = dpp_f32<DPP_WAVE_SHR1>(X);
@@ -144,15 +166,42 @@ __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uin
     int cnt_lo;
     bool clean;
     count_sorted_f32<T>(qw, lo, hi, cnt_lo, clean);
-    const bool unsure = !clean || !(tot > 0.0f) || !(margin < tot) || !(tot < 3.0e38f);
-    if (((__ballot(unsure) >> gbase) & gmask) != 0) return false;
-    const uint32_t fm = mask & (0xFFFFu << cnt_lo);
-    const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
-    const bool hit = gf != 0;
-    const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)(gp | 1ull));
-    const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
-    zn = pos_of<G, T>(sl, group_pick<G>(my, sl, lig));
-    return true;
+    if constexpr (G >= 32) {
+        // one or two groups per wavefront: everything that is the same for a whole group is computed once, on the
+        // scalar unit, from the ballots (a ballot of a comparison IS the comparison's result mask; the ballot of an
+        // OR of them costs two vector instructions more)
+        const uint64_t ub = __ballot(!clean) | __ballot(!(tot > 0.0f)) | __ballot(!(margin < tot)) | __ballot(!(tot < 3.0e38f));
+        if (__builtin_amdgcn_inverse_ballot_w64(spread_any<G>(ub))) return false;
+        const uint32_t fm = mask & (0xFFFFu << cnt_lo);
+        const uint64_t gf = __ballot(fm != 0);
+        const int my_hit = (int)__ffs((int)(fm | 0x10000u)) - 1, my_miss = 31 - (int)__clz((int)(mask | 1u));
+        const int my = __builtin_amdgcn_inverse_ballot_w64(spread_any<G>(gf)) ? my_hit : my_miss;
+        if constexpr (G == 64) {
+            const int sl = gf ? (int)__builtin_ctzll(gf) : 63 - (int)__builtin_clzll(gp | 1ull);
+            zn = pos_of<G, T>(sl, __builtin_amdgcn_readlane(my, sl));
+        } else {
+            const uint32_t f0 = (uint32_t)gf, f1 = uniform_hi32(gf);
+            const uint32_t p0 = (uint32_t)gp, p1 = uniform_hi32(gp);
+            const int sl0 = f0 ? (int)__builtin_ctz(f0) : 31 - (int)__builtin_clz(p0 | 1u);
+            const int sl1 = f1 ? (int)__builtin_ctz(f1) : 31 - (int)__builtin_clz(p1 | 1u);
+            const int z0 = pos_of<G, T>(sl0, __builtin_amdgcn_readlane(my, sl0));
+            const int z1 = pos_of<G, T>(sl1, __builtin_amdgcn_readlane(my, sl1 + 32));
+            zn = (lane & 32) ? z1 : z0;
+        }
+        return true;
+    } else {
+        const bool unsure = !clean || !(tot > 0.0f) || !(margin < tot) || !(tot < 3.0e38f);
+        const int gbase = lane & ~(G - 1);
+        const uint64_t gmask = (1ull << G) - 1ull;
+        if (((__ballot(unsure) >> gbase) & gmask) != 0) return false;
+        const uint32_t fm = mask & (0xFFFFu << cnt_lo);
+        const uint64_t gf = (__ballot(fm != 0) >> gbase) & gmask;
+        const bool hit = gf != 0;
+        const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)(gp | 1ull));
+        const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
+        zn = pos_of<G, T>(sl, group_pick<G>(my, sl, lig));
+        return true;
+    }
 }
 
 // Cold tiers of the FAST kernels, out of line: they run for the ~0.65 % of the sites

@@ -192,7 +192,10 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         }
         const uint32_t mask = P.lab_mask[d * G + lig];
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
-        const uint64_t gp_doc = (__ballot(mask != 0) >> (lane & ~(G - 1))) & ((G == 64) ? ~0ull : ((1ull << G) - 1ull));   // lanes with an allowed topic
+        // lanes with an allowed topic: the wavefront's ballot (uniform) for 32- and 64-lane groups, the group's own
+        // bits below that (draw_fast_f32)
+        const uint64_t gp_doc = G >= 32 ? __ballot(mask != 0)
+                                        : (__ballot(mask != 0) >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1ull);
 
         // Software pipeline of the memory operations: at the top of iteration n the registers hold the
         // scalars (word, freq, z) of site n, the row of site n is in flight (xn) and so are the scalars of
@@ -228,7 +231,13 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
         load_scalars(R0, o0); R0.zn = 0; R0.lo = R0.so = 0;
         load_scalars(R1, o1); R1.zn = 0; R1.lo = R1.so = 0;
         R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = 0;
-        int xn[T];
+        // INDEXED (one or two documents per wavefront, 16 slots): the row lives in one of two 16-register tuples whose
+        // roles (row of this site / row of the next site, in flight) alternate, and the site's own count is removed
+        // from it in place through a register index held in M0 -- 6 vector instructions per document instead of 34
+        // for the 16 compare-free selects of onehot_add_to.  The site loop is then unrolled by six (two tuples x
+        // three scalar sets).
+        constexpr bool INDEXED = G >= 32 && T == 16;
+        int xn[T], xm[INDEXED ? T : 1];
         gload_lane_row<G, T>(P.n_kw, (int64_t)R0.v * KP, lig, xn);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the previous site
@@ -238,21 +247,37 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
 
         // one site: `cur` holds its scalars, `nxt` those of site n+1, `prv` those of site n-1 (committed here, then
         // reloaded with the scalars of site n+2)
-        auto site = [&](const int n, SiteRegs &cur, SiteRegs &nxt, SiteRegs &prv) {
+        auto site = [&](const int n, SiteRegs &cur, SiteRegs &nxt, SiteRegs &prv, int (&xc)[T], int (&xnx)[INDEXED ? T : 1]) {
             const int f = cur.f, zo = cur.zo;
-            // the fetched row minus the site's own count (n_dk / n_k were updated already), written to a second
-            // array so that the next row can be loaded into xn right away
+            // the fetched row minus the site's own count (n_dk / n_k were updated already)
             int x[T];
-            onehot_add_to<T>(x, xn, (lig == cur.lo) ? (1u << cur.so) : 0u, f);   // m = -1 at the slot: += (-1) * f
+            if constexpr (INDEXED) {
+                typedef int v16i __attribute__((ext_vector_type(16)));
+                v16i xv;
+#pragma unroll
+                for (int s = 0; s < T; ++s) xv[s] = xc[s];
+#pragma unroll
+                for (int g = 0; g < 64 / G; ++g) {
+                    int lo_g, so_g;                                   // scalar: zo is the same in every lane of a group
+                    lane_slot_of<G, T>(__builtin_amdgcn_readlane(zo, g * G), lo_g, so_g);
+                    xv[so_g & (T - 1)] -= (lane == g * G + lo_g) ? f : 0;
+                }
+#pragma unroll
+                for (int s = 0; s < T; ++s) x[s] = xv[s];
+            } else {
+                // written to a second array so that the next row can be loaded into xn right away
+                onehot_add_to<T>(x, xc, (lig == cur.lo) ? (1u << cur.so) : 0u, f);   // m = -1 at the slot: += (-1) * f
+            }
+            int (&xl)[T] = *(int (*)[T])(INDEXED ? (void *)&xnx : (void *)&xc);     // where the next row goes
 #ifndef ABL_NOCOMMIT
             if (lig == 0 && n > n0)
                 commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn, prv.c, KP);
 #endif
 #ifndef ABL_NOLOAD
-            gload_lane_row<G, T>(P.n_kw, (int64_t)nxt.v * KP, lig, xn);   // row of site n+1 (clamped)
+            gload_lane_row<G, T>(P.n_kw, (int64_t)nxt.v * KP, lig, xl);   // row of site n+1 (clamped)
 #else
 #pragma unroll
-            for (int s = 0; s < T; ++s) xn[s] = (nxt.v + s) & 7;          // ablation: no n_kw traffic
+            for (int s = 0; s < T; ++s) xl[s] = (nxt.v + s) & 7;          // ablation: no n_kw traffic
 #endif
             {
                 const uint32_t o2 = opaque_u32(sb + (uint32_t)(n + 2 < len ? n + 2 : len - 1) * 4u);   // scalars of site n+2 (clamped)
@@ -307,10 +332,33 @@ __global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KPara
                 commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)n * 4u), cur.v, cur.f, cur.zo, cur.zn, cur.c, KP);
 #endif
         };
-        for (int n = n0; n < len; n += 3) {
-            site(n, R0, R1, R2);
-            if (n + 1 < len) site(n + 1, R1, R2, R0);
-            if (n + 2 < len) site(n + 2, R2, R0, R1);
+        // (a short document LEAVES the loop after its last site: were the remaining sites merely skipped, the
+        // compiler would have to keep the unmodified row of the skipped sites alive for the next trip round the loop,
+        // and the in-place update would need a copy of the tuple)
+        if constexpr (INDEXED) {
+            for (int n = n0;; n += 6) {                         // len > n0 here
+                site(n, R0, R1, R2, xn, xm);
+                if (n + 1 >= len) break;
+                site(n + 1, R1, R2, R0, xm, xn);
+                if (n + 2 >= len) break;
+                site(n + 2, R2, R0, R1, xn, xm);
+                if (n + 3 >= len) break;
+                site(n + 3, R0, R1, R2, xm, xn);
+                if (n + 4 >= len) break;
+                site(n + 4, R1, R2, R0, xn, xm);
+                if (n + 5 >= len) break;
+                site(n + 5, R2, R0, R1, xm, xn);
+                if (n + 6 >= len) break;
+            }
+        } else {
+            for (int n = n0;; n += 3) {
+                site(n, R0, R1, R2, xn, xm);
+                if (n + 1 >= len) break;
+                site(n + 1, R1, R2, R0, xn, xm);
+                if (n + 2 >= len) break;
+                site(n + 2, R2, R0, R1, xn, xm);
+                if (n + 3 >= len) break;
+            }
         }
 
         // document done: fold its n_dk change into the workgroup's n_k accumulator, store the row
