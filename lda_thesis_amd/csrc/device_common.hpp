@@ -181,9 +181,6 @@ __device__ __forceinline__ void gload_lane_row(const int32_t *base, int64_t row_
         const LLDA_GLOBAL v4i *p = (const LLDA_GLOBAL v4i *)q;
 #pragma unroll
         for (int i = 0; i < T / 4; ++i) {
-#ifdef ABL_NARROW          // ablation: only the first ABL_NARROW 16-byte chunks per lane are fetched (results are garbage)
-            if (i >= ABL_NARROW) { x[4 * i + 0] = x[0] >> 8; x[4 * i + 1] = x[1] >> 8; x[4 * i + 2] = x[2] >> 8; x[4 * i + 3] = x[3] >> 8; continue; }
-#endif
             const v4i v = p[i * G + lig];
             x[4 * i + 0] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
         }

@@ -121,8 +121,13 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
                                 // worst-case error bound of DESIGN.md section 4.3 is 105 * 2^-24
 #endif
 #ifndef LLDA_WAVES
-#define LLDA_WAVES 3          // waves per SIMD the register allocator must leave room for
+#define LLDA_WAVES 3          // waves per SIMD the register allocator must leave room for (16 slots per lane: LDS allows 3)
 #endif
+// Up to 12 slots per lane LDS (<= 40 KB per workgroup) allows one more, and 128 VGPRs suffice without spills in the site
+// loop: + 10 % at 16 lanes per document (K = 192), + 17 % at 32 and 64 (K = 384, 768); the 8-lane layouts, bound by the
+// vector-memory address pipeline, lose 6 % with a fourth wave and stay at 3 (tools/abl_vocab.py).  With 16 slots per lane
+// a fourth wave needs both LDS packing and ~40 fewer VGPRs: a packed-LDS build at 128 VGPRs spilled six values per site,
+// and every scratch reload waits for vmcnt(0), i.e. for the row prefetch -- 98 ms instead of 58 at K = 512.
 
 // tier-0 factor of one topic: fl32(a * y) with a = fl32(n_dk + alpha), y = v_rcp_f32(fl32(n_k + V*beta)).
 // n_dk and n_k of a topic always change together, so the product is cached as ONE float per slot.
@@ -145,7 +150,7 @@ __device__ __forceinline__ void count_update(int (*s_ndk)[256], int (*s_nkc)[256
 // instantiation carries neither the atomics path nor the pointer tests (the kernel is VALU-issue bound and short of
 // SGPRs: every uniform test in the site loop costs).
 template <int G, int T, bool HAS_TAIL, bool DENSE, bool LOGGED>
-__global__ void __launch_bounds__(256, LLDA_WAVES) llda_sweep_kernel(const KParams P)
+__global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : LLDA_WAVES) llda_sweep_kernel(const KParams P)
 {
     constexpr int KP = G * T;
     constexpr int GPB = 256 / G;              // lane groups (documents in flight) per workgroup
