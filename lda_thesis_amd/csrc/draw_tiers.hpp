@@ -27,26 +27,27 @@ __device__ __forceinline__ float dpp_f32(float x)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
 }
 
+// pa = the lane's cached tier-0 factors (s_pa[.][tid]), read by the caller at the top of the site so that their LDS
+// latency is covered by the wait for the row
 template <int T, bool DENSE, int S = 0>
-__device__ __forceinline__ void prefix_scores_f32(float (&qw)[T], const int (&x)[T], const float (*s_pa)[256], int tid,
-                                                  uint32_t mask, float beta)
+__device__ __forceinline__ void prefix_scores_f32(float (&qw)[T], const int (&x)[T], const float (&pa)[T], uint32_t mask, float beta)
 {
     if constexpr (DENSE && T % 2 == 0 && S + 1 < T) {
         // two slots per instruction: (x + beta) * factor as packed fp32 (v_pk_add_f32, v_pk_mul_f32); a wave64
         // VALU instruction takes 4 cycles whether it produces one or two fp32 results per lane
         typedef float v2f __attribute__((ext_vector_type(2)));
-        const v2f xf = {(float)x[S], (float)x[S + 1]}, pa = {s_pa[S][tid], s_pa[S + 1][tid]}, b2 = {beta, beta};
-        const v2f ws = (xf + b2) * pa;
+        const v2f xf = {(float)x[S], (float)x[S + 1]}, p2 = {pa[S], pa[S + 1]}, b2 = {beta, beta};
+        const v2f ws = (xf + b2) * p2;
         if constexpr (S == 0) qw[0] = ws.x;
         else qw[S] = qw[S - 1] + ws.x;
         qw[S + 1] = qw[S] + ws.y;
-        prefix_scores_f32<T, DENSE, S + 2>(qw, x, s_pa, tid, mask, beta);
+        prefix_scores_f32<T, DENSE, S + 2>(qw, x, pa, mask, beta);
     } else if constexpr (S < T) {
-        float ws = ((float)x[S] + beta) * s_pa[S][tid];          // num_b * fl32(a / den_b)
+        float ws = ((float)x[S] + beta) * pa[S];                 // num_b * fl32(a / den_b)
         if constexpr (!DENSE) ws = __int_as_float(__float_as_int(ws) & onehot_bit<S>(mask));
         if constexpr (S == 0) qw[0] = ws;
         else qw[S] = qw[S - 1] + ws;
-        prefix_scores_f32<T, DENSE, S + 1>(qw, x, s_pa, tid, mask, beta);
+        prefix_scores_f32<T, DENSE, S + 1>(qw, x, pa, mask, beta);
     }
 }
 

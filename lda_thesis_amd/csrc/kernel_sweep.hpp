@@ -254,6 +254,13 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         // reloaded with the scalars of site n+2)
         auto site = [&](const int n, SiteRegs &cur, SiteRegs &nxt, SiteRegs &prv, int (&xc)[T], int (&xnx)[INDEXED ? T : 1]) {
             const int f = cur.f, zo = cur.zo;
+            // the cached tier-0 factors of the lane, fetched from LDS first thing: nothing below depends on them until
+            // the scores, and the kernel is bound by the latency of one wavefront's instruction stream (39 % of the
+            // wave cycles sat in s_waitcnt, mostly on LDS: eight waits per site when the reads trickle in pairs)
+            float pa[T];
+#pragma unroll
+            for (int s = 0; s < T; ++s) pa[s] = s_pa[s][tid];
+            __builtin_amdgcn_sched_barrier(0);
             // the fetched row minus the site's own count (n_dk / n_k were updated already)
             int x[T];
             if constexpr (INDEXED) {
@@ -296,7 +303,7 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
             bool decided = false;
             if (P.margin0_rel < 1.0f) {           // tier 0: fp32
                 float qf[T];
-                prefix_scores_f32<T, DENSE>(qf, x, s_pa, tid, mask, beta32);
+                prefix_scores_f32<T, DENSE>(qf, x, pa, mask, beta32);
                 // fp32 image of the uniform: the top 27 bits (within 2^-24 relative + 2^-27 absolute of u)
                 const float u32 = (float)(ra >> 5) * 0x1p-27f;
                 decided = draw_fast_f32<G, T>(qf, u32, mask, gp_doc, P.margin0_rel, lig, lane, zn);
