@@ -260,6 +260,9 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
             float pa[T];
 #pragma unroll
             for (int s = 0; s < T; ++s) pa[s] = s_pa[s][tid];
+            // ... and so are the site's random bits (a cross-lane pick through LDS for groups wider than 16 lanes)
+            uint32_t ra, rb;
+            site_random_bits<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3, ra, rb);
             __builtin_amdgcn_sched_barrier(0);
             // the fetched row minus the site's own count (n_dk / n_k were updated already)
             int x[T];
@@ -295,9 +298,6 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 const uint32_t o2 = opaque_u32(sb + (uint32_t)(n + 2 < len ? n + 2 : len - 1) * 4u);   // scalars of site n+2 (clamped)
                 load_scalars(prv, o2);
             }
-            uint32_t ra, rb;
-            site_random_bits<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3, ra, rb);
-
             // tiered draw
             int zn = -1;
             bool decided = false;
