@@ -172,7 +172,7 @@ __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uin
         // scalar unit, from the ballots (a ballot of a comparison IS the comparison's result mask; the ballot of an
         // OR of them costs two vector instructions more)
         const uint64_t ub = __ballot(!clean) | __ballot(!(tot > 0.0f)) | __ballot(!(margin < tot)) | __ballot(!(tot < 3.0e38f));
-        if (__builtin_amdgcn_inverse_ballot_w64(spread_any<G>(ub))) return false;
+        if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(spread_any<G>(ub)), 0)) return false;
         const uint32_t fm = mask & (0xFFFFu << cnt_lo);
         const uint64_t gf = __ballot(fm != 0);
         const int my_hit = (int)__ffs((int)(fm | 0x10000u)) - 1, my_miss = 31 - (int)__clz((int)(mask | 1u));
@@ -341,7 +341,7 @@ __device__ __forceinline__ void site_random_bits(const KParams &P, int n, bool f
                                                  uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t &r3,
                                                  uint32_t &ra, uint32_t &rb)
 {
-    if (first || (n & (2 * G - 1)) == 0) {
+    if (__builtin_expect(first || (n & (2 * G - 1)) == 0, 0)) {
         r0 = (uint32_t)((n >> 1) & ~(G - 1)) + (uint32_t)lig; r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
         philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
     }

@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 const float u32 = (float)(ra >> 5) * 0x1p-27f;
                 decided = draw_fast_f32<G, T>(qf, u32, mask, gp_doc, P.margin0_rel, lig, lane, zn);
             }
-            if (!decided) {
+            if (__builtin_expect(!decided, 0)) {
                 int x_c[T];
 #pragma unroll
                 for (int s = 0; s < T; ++s) x_c[s] = x[s];
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 zn = cold_tiers<G, T, HAS_TAIL, DENSE>(s_ndk, x_c, s_nkc, tid, mask, uniform53(ra, rb), lig, lane,
                                                        (const KParams *)__builtin_amdgcn_kernarg_segment_ptr());
             }
-            if (zn < 0) {
+            if (__builtin_expect(zn < 0, 0)) {
                 zn = zo;
                 if (lig == 0 && P.status) atomicOr(P.status, 1);    // no topic with positive probability
             }
@@ -336,11 +336,11 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 const bool own_new = lig == ln, own_old = more && lig == lo2;
                 if (own_new || own_old)
                     count_update(s_ndk, s_nkc, s_pa, own_new ? sn : so2, tid, alpha32, vbeta32, own_new ? f : -nxt.f);
-                if (own_new && own_old) count_update(s_ndk, s_nkc, s_pa, so2, tid, alpha32, vbeta32, -nxt.f);
+                if (__builtin_expect(own_new && own_old, 0)) count_update(s_ndk, s_nkc, s_pa, so2, tid, alpha32, vbeta32, -nxt.f);
             }
 #ifndef ABL_NOCOMMIT
             // the last site of the document is committed right away
-            if (lig == 0 && n + 1 == len)
+            if (__builtin_expect(lig == 0 && n + 1 == len, 0))
                 commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)n * 4u), cur.v, cur.f, cur.zo, cur.zn, cur.c, KP);
 #endif
         };
