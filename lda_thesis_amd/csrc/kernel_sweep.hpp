@@ -195,11 +195,12 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 s_pa[s][tid] = tier0_factor(r[s], k[s], alpha32, vbeta32);
             }
         }
-        const uint32_t mask = P.lab_mask[d * G + lig];
+        // (DENSE: every slot of every lane is an allowed topic -- a constant, not a register)
+        const uint32_t mask = DENSE ? (1u << T) - 1u : P.lab_mask[d * G + lig];
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
         // lanes with an allowed topic: the wavefront's ballot (uniform) for 32- and 64-lane groups, the group's own
         // bits below that (draw_fast_f32)
-        const uint64_t gp_doc = G >= 32 ? __ballot(mask != 0)
+        const uint64_t gp_doc = DENSE ? (G >= 32 ? ~0ull : (1ull << (G & 63)) - 1ull) : G >= 32 ? __ballot(mask != 0)
                                         : (__ballot(mask != 0) >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1ull);
 
         // Software pipeline of the memory operations: at the top of iteration n the registers hold the
