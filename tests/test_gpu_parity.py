@@ -177,6 +177,32 @@ def test_seeded_inputs_vs_c_oracle(c_oracle, K, dense, D, V):
     assert (s.n_d_k()[labs == 0] == 0).all() and s.n_d_k().min() >= 0 and s.n_k_v().min() >= 0
 
 
+@pytest.mark.parametrize("K,dense", [(96, True), (128, True), (192, True), (256, True), (384, True), (512, True), (768, True),
+                                     (1024, True), (100, False), (250, False), (392, False), (500, False), (777, False),
+                                     (1000, False)])
+def test_logged_instantiations_vs_c_oracle(c_oracle, K, dense):
+    """the commit-log instantiations of the tiered kernel for every layout class -- 8 / 16 / 32 / 64 lanes per document x
+    12 / 16 slots per lane: three or four waves per SIMD, own count removed by one-hot selects or through a register
+    index, group decisions per lane or on the scalar unit, label mask constant or per document -- against the C oracle
+    (masked cases through the DENSE-layout kernel: sparse_labels=False)."""
+    from lda_thesis_amd.sampler import GibbsSampler
+    rng = np.random.default_rng(K * 13 + 5)
+    D, V = 120, 700
+    doc_off, word, freq, labs, z = synth(rng, D, V, K, 1, 70, dense)
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=123, doc_base=50, commit_log=True,
+                     sparse_labels=False)
+    assert s.commit_log is not None
+    cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
+    for i in range(3):
+        s.sweep()
+        cs.sweep(1, 123, i, doc_base=50, threads=4)
+        np.testing.assert_array_equal(s.z_topics(), cs.z)
+        np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+        np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+        np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
+    s.check_status()
+
+
 def test_reciprocal_division_equals_ieee_division():
     """the kernel's p = w/S shortcut (one IEEE reciprocal + two exact-residual corrections) must be
     the correctly rounded quotient: 4e9 random pairs against the hardware division."""
