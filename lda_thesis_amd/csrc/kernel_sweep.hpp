@@ -149,7 +149,10 @@ __device__ __forceinline__ void count_update(int (*s_ndk)[256], int (*s_nkc)[256
 // LOGGED: the commit goes to the word-major commit log (csc_pos / commit_log non-NULL) -- a compile-time fact, so the
 // instantiation carries neither the atomics path nor the pointer tests (the kernel is VALU-issue bound and short of
 // SGPRs: every uniform test in the site loop costs).
-template <int G, int T, bool HAS_TAIL, bool DENSE, bool LOGGED>
+// REC: the scalars of a site come from llda_sweep_args.site_rec -- a compile-time fact too: as a run-time pointer test the two
+// load paths met in a phi, the record's fields had to be COPIED into the registers of the other path, the copy needs the
+// value, and the compiler put s_waitcnt vmcnt(0) right behind the load -- i.e. behind the row prefetch issued just before.
+template <int G, int T, bool HAS_TAIL, bool DENSE, bool LOGGED, bool REC = false>
 __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : LLDA_WAVES) llda_sweep_kernel(const KParams P)
 {
     constexpr int KP = G * T;
@@ -171,8 +174,9 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
     const int64_t site_base = P.doc_off[0];                 // uniform: the bases below stay in SGPRs
     const int32_t *word_b = P.word + site_base, *freq_b = P.freq + site_base;
     const int32_t *csc_b = LOGGED ? P.csc_pos + site_base : nullptr;
-    constexpr bool PACKED = LOGGED && G <= 16;
-    const int32_t *rec_b = (PACKED && P.site_rec) ? P.site_rec + site_base * 4 : nullptr;
+    constexpr bool PACKED = REC;
+    static_assert(!REC || (LOGGED && G <= 16), "site records: commit log, <= 16 lanes per document");
+    const int32_t *rec_b = PACKED ? P.site_rec + site_base * 4 : nullptr;
     int32_t *z_b = P.z + site_base;
     for (int it = 0; it < P.dpg; ++it) {
         constexpr int n0 = 0;                 // first site to sample
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         // busy 74 % at K = 128), not by VALU issue.  PACKED: {word, freq, csc_pos} come as ONE 16-byte record per
         // site (llda_sweep_args.site_rec) -- one stream and one instruction instead of three.
         auto load_scalars = [&](SiteRegs &R, const uint32_t o) {
-            if (PACKED && rec_b) {
+            if constexpr (PACKED) {
                 typedef int v4i __attribute__((ext_vector_type(4)));
                 const v4i r = *(const LLDA_GLOBAL v4i *)((const LLDA_GLOBAL char *)rec_b + (o << 2));
                 R.v = r.x; R.f = r.y; R.c = r.z;

@@ -105,6 +105,15 @@ template <int G, int T>
 int launch_sweep(const KParams &P, bool has_tail, bool fast, bool dense, int64_t blocks, hipStream_t st)
 {
     const dim3 grid((unsigned)blocks), block(256);
+    if constexpr (G <= 16) {
+        if (fast && P.commit_log && P.site_rec) {       // 16-byte site records (llda_sweep_args.site_rec)
+            if (dense) hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true, true, true>), grid, block, 0, st, P);
+            else if (has_tail) hipLaunchKernelGGL((llda_sweep_kernel<G, T, true, false, true, true>), grid, block, 0, st, P);
+            else hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, false, true, true>), grid, block, 0, st, P);
+            const hipError_t e = hipGetLastError();
+            return e == hipSuccess ? LLDA_OK : hip_fail(e);
+        }
+    }
     if (!fast) {
         if (has_tail) hipLaunchKernelGGL((llda_sweep_exact_kernel<G, T, true>), grid, block, 0, st, P);
         else hipLaunchKernelGGL((llda_sweep_exact_kernel<G, T, false>), grid, block, 0, st, P);
