@@ -39,36 +39,49 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 12
-#define LLDA_MAX_K 1024
-#define LLDA_MAX_LEAVES 8
+#define LLDA_ABI_VERSION 13
+#define LLDA_MAX_K 7688          /* every K up to here splits into <= 64 pairwise leaves                       */
+#define LLDA_MAX_KP 8192         /* longest padded row: 64 leaves x 128                                        */
+#define LLDA_MAX_LEAVES 8        /* "narrow" layouts: one lane group of <= 64 lanes x <= 16 slots per document  */
+#define LLDA_MAX_WIDE_LEAVES 64  /* "wide" layouts (more than 8 leaves: some K in 969..1023, every K > 1024)    */
 #define LLDA_MAX_ROUNDS 4
 
 enum {
     LLDA_OK = 0,
-    LLDA_E_BAD_K = -1,      /* K outside 1..1024 or more than 8 pairwise leaves            */
+    LLDA_E_BAD_K = -1,      /* K outside 1..LLDA_MAX_K, or an entry point that only takes narrow layouts */
     LLDA_E_BAD_ARG = -2,    /* NULL pointer, negative size, layout fields do not match K   */
     LLDA_E_HIP = -3,        /* a HIP runtime call failed (see llda_last_hip_error)          */
     LLDA_E_NO_DEVICE = -4   /* no gfx950 device visible                                     */
 };
 
-/* Layout of K topics over the lanes of a wavefront (host-side description). */
+/* Layout of K topics over the lanes of a wavefront (host-side description).
+ * Narrow layouts (n_leaves <= 8): G = 8 * (leaves rounded up to a power of two) <= 64 lanes per document, 64/G documents
+ * per wavefront.  Wide layouts (wide = 1; ABI 13): G = 8 * (leaves rounded up to a multiple of 8) = 64 * tiers; the G
+ * "lanes" of the formulas above are VIRTUAL lanes, virtual lane gv = 64 * tier + physical lane of the one wavefront that
+ * walks the document; T is 8, 12 or 16.  The leaf totals of a wide layout are combined along numpy's recursion tree by
+ * n_leaves - 1 in-place adds  total[comb_dst[i]] += total[comb_src[i]]  (post-order; total[0] is the sum).  Wide layouts
+ * are served by llda_sweep (atomics commit path, no sparse-label list), llda_count_init, llda_apply_delta, llda_loglik,
+ * llda_readout_phi / _theta and llda_foldin; llda_commit_log, llda_apply_rows and llda_sweep_batch return LLDA_E_BAD_K. */
 typedef struct llda_layout {
     int32_t K;                       /* number of topics (labels incl. 'root')                */
     int32_t n_leaves;                /* numpy pairwise-sum leaves                             */
-    int32_t G;                       /* lanes per document: 8, 16, 32 or 64                   */
+    int32_t G;                       /* lanes per document: 8, 16, 32, 64; wide: 64 * tiers   */
     int32_t T;                       /* slots per lane: 1, 2, 4, 8, 12 or 16                  */
     int32_t KP;                      /* G*T                                                   */
     int32_t tail;                    /* K % 8 of the last leaf                                */
     int32_t tail_row;                /* slot that holds the tail topics                       */
-    int32_t n_rounds;                /* leaf-combine rounds                                   */
-    int32_t leaf_start[LLDA_MAX_LEAVES];
-    int32_t leaf_len[LLDA_MAX_LEAVES];
-    int32_t rounds[LLDA_MAX_ROUNDS][LLDA_MAX_LEAVES];   /* partner leaf per round (self = idle) */
-    int32_t topic_pos[LLDA_MAX_K];   /* topic id -> device position                           */
-    int32_t pos_topic[LLDA_MAX_K];   /* device position -> topic id, -1 in the padding        */
-    int32_t pos_lane[LLDA_MAX_K];    /* device position -> lane of the group that holds it     */
-    int32_t pos_slot[LLDA_MAX_K];    /* device position -> slot of that lane (bit of lab_mask) */
+    int32_t n_rounds;                /* leaf-combine rounds (narrow)                          */
+    int32_t wide;                    /* 1: more than 8 leaves                                 */
+    int32_t tiers;                   /* wide: G / 64; narrow: 0                               */
+    int32_t leaf_start[LLDA_MAX_WIDE_LEAVES];
+    int32_t leaf_len[LLDA_MAX_WIDE_LEAVES];
+    int32_t rounds[LLDA_MAX_ROUNDS][LLDA_MAX_LEAVES];   /* narrow: partner leaf per round (self = idle) */
+    int32_t comb_dst[LLDA_MAX_WIDE_LEAVES];             /* numpy's recursion tree, post-order (n_leaves - 1 entries) */
+    int32_t comb_src[LLDA_MAX_WIDE_LEAVES];
+    int32_t topic_pos[LLDA_MAX_KP];  /* topic id -> device position                           */
+    int32_t pos_topic[LLDA_MAX_KP];  /* device position -> topic id, -1 in the padding        */
+    int32_t pos_lane[LLDA_MAX_KP];   /* device position -> (virtual) lane that holds it        */
+    int32_t pos_slot[LLDA_MAX_KP];   /* device position -> slot of that lane (bit of lab_mask) */
 } llda_layout;
 
 /* Arguments of one sweep over a shard of documents.

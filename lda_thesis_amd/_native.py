@@ -11,10 +11,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLDA_GIBBS_LIB") or os.path.join(_HERE, "libllda_gibbs.so")   # (override: ablation builds, tools/)
 
-MAX_K = 1024
-MAX_LEAVES = 8
+MAX_K = 7688            # LLDA_MAX_K: every K up to here has <= 64 pairwise leaves
+MAX_KP = 8192
+MAX_LEAVES = 8          # narrow layouts
+MAX_WIDE_LEAVES = 64
 MAX_ROUNDS = 4
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -23,11 +25,12 @@ _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
 class LldaLayout(ctypes.Structure):
     """struct llda_layout (include/llda_gibbs.h)."""
     _fields_ = [("K", _c_i32), ("n_leaves", _c_i32), ("G", _c_i32), ("T", _c_i32), ("KP", _c_i32),
-                ("tail", _c_i32), ("tail_row", _c_i32), ("n_rounds", _c_i32),
-                ("leaf_start", _c_i32 * MAX_LEAVES), ("leaf_len", _c_i32 * MAX_LEAVES),
+                ("tail", _c_i32), ("tail_row", _c_i32), ("n_rounds", _c_i32), ("wide", _c_i32), ("tiers", _c_i32),
+                ("leaf_start", _c_i32 * MAX_WIDE_LEAVES), ("leaf_len", _c_i32 * MAX_WIDE_LEAVES),
                 ("rounds", (_c_i32 * MAX_LEAVES) * MAX_ROUNDS),
-                ("topic_pos", _c_i32 * MAX_K), ("pos_topic", _c_i32 * MAX_K),
-                ("pos_lane", _c_i32 * MAX_K), ("pos_slot", _c_i32 * MAX_K)]
+                ("comb_dst", _c_i32 * MAX_WIDE_LEAVES), ("comb_src", _c_i32 * MAX_WIDE_LEAVES),
+                ("topic_pos", _c_i32 * MAX_KP), ("pos_topic", _c_i32 * MAX_KP),
+                ("pos_lane", _c_i32 * MAX_KP), ("pos_slot", _c_i32 * MAX_KP)]
 
 
 class LldaFoldinArgs(ctypes.Structure):
@@ -144,7 +147,8 @@ def layout_init(K):
     out = LldaLayout()
     check(lib().llda_layout_init(int(K), ctypes.byref(out)), "llda_layout_init(K=%d)" % K)
     return dict(K=out.K, n_leaves=out.n_leaves, G=out.G, T=out.T, KP=out.KP, tail=out.tail,
-                tail_row=out.tail_row, n_rounds=out.n_rounds,
+                tail_row=out.tail_row, n_rounds=out.n_rounds, wide=out.wide, tiers=out.tiers,
+                comb=[(out.comb_dst[i], out.comb_src[i]) for i in range(out.n_leaves - 1)],
                 leaf_start=np.array(out.leaf_start[:out.n_leaves]),
                 leaf_len=np.array(out.leaf_len[:out.n_leaves]),
                 rounds=np.array([list(r) for r in out.rounds])[:out.n_rounds],

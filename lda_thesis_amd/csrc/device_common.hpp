@@ -7,6 +7,7 @@ namespace {
 thread_local int g_last_hip_error = 0;
 
 #define LLDA_MAX_LIVE 64   // most allowed topics per document the sparse kernel handles
+#define LLDA_NARROW_KP 1024  // longest row of a narrow layout (<= 8 leaves: 64 lanes x 16 slots)
 
 struct KParams {
     const int64_t *doc_off;

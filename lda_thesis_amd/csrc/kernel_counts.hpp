@@ -178,13 +178,14 @@ __global__ void __launch_bounds__(256) llda_count_init_kernel(const int64_t *__r
     // one wavefront per document at a time, lanes stride over its sites.  The document's n_dk row and the
     // workgroup's share of n_k are histograms in LDS (the row is then written with plain stores, n_k with KP
     // atomics per workgroup); only n_kw takes one global atomic per site.
-    extern __shared__ int s_init[];               // [KP] n_k of the workgroup, then [4][KP] per-wavefront rows
+    extern __shared__ int s_init[];               // [KP] n_k of the workgroup, then [waves][KP] per-wavefront rows
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nthr = blockDim.x, nw = nthr >> 6;  // 4 wavefronts per workgroup; 1 for the long rows of wide layouts (LDS)
     int *s_nk = s_init, *hist = s_init + (1 + w) * KP;
-    for (int p = tid; p < KP; p += 256) s_nk[p] = 0;
+    for (int p = tid; p < KP; p += nthr) s_nk[p] = 0;
     for (int p = lane; p < KP; p += 64) hist[p] = 0;
     __syncthreads();
-    for (int64_t d = (int64_t)blockIdx.x * 4 + w; d < D; d += (int64_t)gridDim.x * 4) {
+    for (int64_t d = (int64_t)blockIdx.x * nw + w; d < D; d += (int64_t)gridDim.x * nw) {
         for (int64_t i = doc_off[d] + lane; i < doc_off[d + 1]; i += 64) {
             const int f = freq[i], p = z[i];
             atomicAdd(&hist[p], f);
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(256) llda_count_init_kernel(const int64_t *__r
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
     __syncthreads();
-    for (int p = tid; p < KP; p += 256) {
+    for (int p = tid; p < KP; p += nthr) {
         const int h = s_nk[p];
         if (h) atomicAdd(n_k + p, h);
     }

@@ -77,7 +77,7 @@ struct RParams {
     int64_t V, D;
     int32_t K, KP, T, mode;
     double alpha, beta, vbeta, keep, share;
-    int32_t leaf_start[LLDA_MAX_LEAVES], leaf_len[LLDA_MAX_LEAVES];
+    int32_t leaf_start[LLDA_MAX_WIDE_LEAVES], leaf_len[LLDA_MAX_WIDE_LEAVES];
     int32_t last_leaf, tail, tail_row, n_rounds, xor_tree;
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];
 };

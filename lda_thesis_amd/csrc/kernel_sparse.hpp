@@ -175,7 +175,7 @@ template <int GS>
 __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
 {
     constexpr int GPB = 256 / GS;
-    __shared__ int s_nk[LLDA_MAX_K];          // workgroup accumulator of the n_k changes
+    __shared__ int s_nk[LLDA_NARROW_KP];      // workgroup accumulator of the n_k changes (narrow layouts only)
     const int tid = threadIdx.x;
     const int KP = P.KP;
     for (int i = tid; i < KP; i += 256) s_nk[i] = 0;

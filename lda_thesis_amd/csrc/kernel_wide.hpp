@@ -1,0 +1,526 @@
+// kernel_wide.hpp -- "wide" layouts: K with more than 8 pairwise leaves (some K in 969..1023, every K > 1024, up to
+// LLDA_MAX_K): llda_sweep_wide_kernel, llda_loglik_wide_kernel, llda_readout_theta_wide_kernel, llda_foldin_wide_kernel
+// Part of the single translation unit llda_gibbs.hip (included in order; see the contents list there).
+#pragma once
+
+namespace {
+
+// The reference takes any K (LabeledLDA.py:52); numpy's pairwise sum (np.sum at LabeledLDA.py:117) then has more than
+// 8 leaves and a document no longer fits the <= 64 lanes x <= 16 slots of the narrow kernels.  Here ONE wavefront walks
+// one document and its 64 lanes play G = 64 * NT VIRTUAL lanes, tier by tier: virtual lane gv = 64 * tier + lane, the
+// same position formula pos = ((s >> 2) * G + gv) * 4 + (s & 3) with the larger G (so every 16-byte chunk of the row is
+// still read as one contiguous run per tier), the same (virtual lane, slot) draw order, and the Hillis-Steele scan of
+// the keyed draw over all G virtual lanes (oracle/llda_oracle.py draw_keyed).  Everything is a run-time loop (NT, T from
+// the kernel arguments): this is the GENERAL path -- every site through the reference's exact fp64 pipeline, per-topic
+// scores staged in LDS in position order -- not a tuned one; none of the five BASELINE configs needs it.
+struct WideLayout {
+    int32_t NT, T, G, KP;              // tiers, slots per virtual lane (8 / 12 / 16), 64 * NT, G * T
+    int32_t m, last_leaf, tail, tail_row;
+    uint8_t comb_dst[LLDA_MAX_WIDE_LEAVES], comb_src[LLDA_MAX_WIDE_LEAVES];   // numpy's recursion tree, post-order
+};
+
+struct WParams {
+    KParams k;
+    WideLayout w;
+};
+
+constexpr int WIDE_MAX_TIERS = LLDA_MAX_WIDE_LEAVES / 8;
+
+// np.sum of the KP values at wv (position order; exact zeros in masked / padded places) in numpy's pairwise order:
+// per-virtual-lane chains, xor butterfly over the 8 chains of a leaf, the last leaf's tail, then the recursion tree
+// over the leaf totals (lane l holds the total of leaf l; m <= 64).  Every lane returns the sum.
+__device__ __forceinline__ double wide_sum(const double *wv, const WideLayout &W, int lane)
+{
+    const int T = W.T, G = W.G;
+    double lt = 0.0;
+    for (int t = 0; t < W.NT; ++t) {
+        const int gv = t * 64 + lane, leaf = gv >> 3;
+        const bool tail_lane = W.tail != 0 && leaf == W.last_leaf;
+        double acc = 0.0, tv = 0.0;
+        for (int c = 0; c < (T >> 2); ++c) {
+            const double *p = wv + ((c * G + gv) << 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double v = p[j];
+                if (tail_lane && 4 * c + j == W.tail_row) tv = v;
+                else acc = acc + v;
+            }
+        }
+        acc = acc + dpp_f64<DPP_XOR1>(acc);
+        acc = acc + dpp_f64<DPP_XOR2>(acc);
+        acc = acc + dpp_f64<DPP_HALF_MIRROR>(acc);
+        if (W.tail != 0 && (W.last_leaf >> 3) == t) {
+            for (int i = 0; i < W.tail; ++i) {
+                const double o = __shfl(tv, (W.last_leaf & 7) * 8 + i, 64);
+                if (leaf == W.last_leaf) acc = acc + o;
+            }
+        }
+        const double mine = __shfl(acc, 8 * (lane & 7), 64);     // total of leaf 8t + (lane & 7)
+        if ((lane >> 3) == t) lt = mine;
+    }
+    for (int i = 0; i + 1 < W.m; ++i) {
+        const int a = W.comb_dst[i], b = W.comb_src[i];
+        const double s = readlane_var_f64(lt, a) + readlane_var_f64(lt, b);
+        if (lane == a) lt = s;
+    }
+    return readlane_var_f64(lt, 0);
+}
+
+// wv[i] = wv[i] / c for the entries this lane owns (the 32-byte chunks lane, lane + 64, ...); y = RN(1 / c)
+__device__ __forceinline__ void wide_div(double *wv, const WideLayout &W, int lane, double c, double y)
+{
+    for (int q = lane; q < (W.KP >> 2); q += 64) {
+        double *p = wv + (q << 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = div_by(p[j], c, y);
+    }
+}
+
+// Keyed categorical draw over the KP probabilities at wv (overwritten by their per-lane prefix sums): the statements of
+// draw_position<> with the G virtual lanes spread over NT tiers.  Returns the position (wave-uniform) or -1.
+__device__ __forceinline__ int wide_draw(double *wv, const WideLayout &W, double u, int lane)
+{
+    const int T = W.T, G = W.G, NT = W.NT;
+    double X[WIDE_MAX_TIERS];
+    uint32_t pm[WIDE_MAX_TIERS];
+#pragma unroll
+    for (int t = 0; t < WIDE_MAX_TIERS; ++t) {
+        X[t] = 0.0; pm[t] = 0;
+        if (t < NT) {
+            const int gv = t * 64 + lane;
+            double run = 0.0;
+            uint32_t m = 0;
+            for (int c = 0; c < (T >> 2); ++c) {
+                double *p = wv + ((c * G + gv) << 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double v = p[j];
+                    run = (c == 0 && j == 0) ? v : run + v;
+                    p[j] = run;
+                    m |= (v > 0.0 ? 1u : 0u) << (4 * c + j);
+                }
+            }
+            X[t] = run; pm[t] = m;
+        }
+    }
+    // Hillis-Steele inclusive scan over the virtual lanes: x[gv] <- x[gv - d] + x[gv] for gv >= d, d = 1, 2, 4, ... < G
+    for (int d = 1; d < 64; d <<= 1) {
+        const int src = (lane - d) & 63;
+#pragma unroll
+        for (int t = WIDE_MAX_TIERS - 1; t >= 0; --t) {          // descending: X[t - 1] is still the old value
+            if (t < NT) {
+                const double a = __shfl(X[t], src, 64);
+                const double b = (t > 0) ? __shfl(X[t > 0 ? t - 1 : 0], src, 64) : 0.0;
+                const double up = (lane >= d) ? a : b;
+                if (lane >= d || t > 0) X[t] = up + X[t];
+            }
+        }
+    }
+    for (int dt = 1; dt < NT; dt <<= 1) {
+#pragma unroll
+        for (int t = WIDE_MAX_TIERS - 1; t >= 1; --t) {
+            if (t < NT && t >= dt) {
+                double lower = 0.0;
+#pragma unroll
+                for (int q = 0; q < WIDE_MAX_TIERS - 1; ++q)
+                    if (q == t - dt) lower = X[q];
+                X[t] = lower + X[t];
+            }
+        }
+    }
+    double tot = 0.0;
+#pragma unroll
+    for (int t = 0; t < WIDE_MAX_TIERS; ++t)
+        if (t == NT - 1) tot = readlane_f64(X[t], 63);
+    const double tt = u * tot;
+    int hit = -1, last = -1;
+#pragma unroll
+    for (int t = 0; t < WIDE_MAX_TIERS; ++t) {
+        if (t < NT) {
+            const double a = __shfl(X[t], (lane - 1) & 63, 64);
+            const double b = (t > 0) ? readlane_f64(X[t > 0 ? t - 1 : 0], 63) : 0.0;
+            const double tg = tt - (lane ? a : b);
+            const int gv = t * 64 + lane;
+            uint32_t fm = 0;
+            for (int c = 0; c < (T >> 2); ++c) {
+                const double *p = wv + ((c * G + gv) << 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    fm |= (((pm[t] >> (4 * c + j)) & 1u) && p[j] > tg) ? (1u << (4 * c + j)) : 0u;
+            }
+            const uint64_t bf = __ballot(fm != 0), bp = __ballot(pm[t] != 0);
+            if (hit < 0 && bf != 0) {
+                const int sl = (int)__ffsll((unsigned long long)bf) - 1;
+                const int ss = __shfl((int)__ffs((int)(fm | 0x10000u)) - 1, sl, 64);
+                hit = pos_of_rt(G, T, t * 64 + sl, ss);
+            }
+            if (bp != 0) {
+                const int sl = 63 - (int)__clzll((unsigned long long)bp);
+                const int ss = __shfl(31 - (int)__clz((int)(pm[t] | 1u)), sl, 64);
+                last = pos_of_rt(G, T, t * 64 + sl, ss);
+            }
+        }
+    }
+    return hit >= 0 ? hit : last;
+}
+
+// topic held by a position of a wide row (-1: padding)
+__device__ __forceinline__ int wide_topic_of(const int32_t *leaf_start, const int32_t *leaf_len, int G, int T, int pos)
+{
+    int gv, s;
+    lane_slot_of_rt(G, T, pos, gv, s);
+    const int leaf = gv >> 3, rel = (gv & 7) + 8 * s;
+    return rel < leaf_len[leaf] ? leaf_start[leaf] + rel : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sweep, wide layouts: LabeledLDA.training_iteration (LabeledLDA.py:101-125), one wavefront per document, every site
+// through the exact pipeline.  LDS per wavefront: KP doubles (scores -> probabilities -> prefix sums), the document's
+// n_dk row and the n_k it sees (int32, position order; lane 0 applies the two +-f of a site).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
+{
+    extern __shared__ double s_wide[];
+    const KParams &K = P.k;
+    const WideLayout &W = P.w;
+    const int lane = threadIdx.x, KP = W.KP, G = W.G, T = W.T, NT = W.NT;
+    double *wv = s_wide;
+    int *s_ndk = reinterpret_cast<int *>(wv + KP), *s_nkc = s_ndk + KP;
+
+    for (int64_t idx = blockIdx.x; idx < K.D; idx += gridDim.x) {
+        const int64_t d = K.doc_order ? (int64_t)K.doc_order[idx] : idx;
+        const int64_t s0 = K.doc_off[d];
+        const int len = (int)(K.doc_off[d + 1] - s0);
+        if (len <= 0) continue;
+        int32_t *ndk_row = K.n_dk + d * KP;
+        for (int q = lane; q < (KP >> 2); q += 64) {
+            reinterpret_cast<int4 *>(s_ndk)[q] = reinterpret_cast<const int4 *>(ndk_row)[q];
+            reinterpret_cast<int4 *>(s_nkc)[q] = reinterpret_cast<const int4 *>(K.n_k)[q];
+        }
+        const uint16_t *mrow = K.lab_mask + d * G;
+        const uint32_t gdoc = (uint32_t)(d + K.doc_base);
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+
+        for (int n = 0; n < len; ++n) {
+            const int64_t i = s0 + n;
+            const int v = K.word[i], f = K.freq[i], zo = K.z[i];
+            const double u = site_uniform<64>(K, n, n == 0, gdoc, lane, r0, r1, r2, r3);
+            if (lane == 0) { s_ndk[zo] -= f; s_nkc[zo] -= f; }          // remove the site (LabeledLDA.py:109-111)
+            const int4 *xrow = reinterpret_cast<const int4 *>(K.n_kw + (int64_t)v * KP);
+            for (int t = 0; t < NT; ++t) {
+                const int gv = t * 64 + lane;
+                const uint32_t mask = mrow[gv];
+                for (int c = 0; c < (T >> 2); ++c) {
+                    const int q = c * G + gv;
+                    const int4 x4 = xrow[q];
+                    const int4 nd4 = reinterpret_cast<const int4 *>(s_ndk)[q];
+                    const int4 nk4 = reinterpret_cast<const int4 *>(s_nkc)[q];
+                    const int xs[4] = {x4.x, x4.y, x4.z, x4.w}, nds[4] = {nd4.x, nd4.y, nd4.z, nd4.w},
+                              nks[4] = {nk4.x, nk4.y, nk4.z, nk4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int pos = (q << 2) | j;
+                        const double a = (double)nds[j] + K.alpha;
+                        const double num_b = (double)(xs[j] - (pos == zo ? f : 0)) + K.beta;
+                        const double den_b = (double)nks[j] + K.vbeta;
+                        const double ws = a * (num_b / den_b);               // LabeledLDA.py:113-116
+                        wv[pos] = ((mask >> (4 * c + j)) & 1u) ? ws : 0.0;
+                    }
+                }
+            }
+            const double S = wide_sum(wv, W, lane);                          // np.sum(prob)
+            wide_div(wv, W, lane, S, 1.0 / S);                               // prob /= np.sum(prob)
+            int zn = wide_draw(wv, W, u, lane);
+            if (zn < 0 || !(S > 0.0)) {
+                zn = zo;
+                if (lane == 0 && K.status) atomicOr(K.status, 1);            // no topic with positive probability
+            }
+            if (lane == 0) {                                                 // add the site back (LabeledLDA.py:121-125)
+                s_ndk[zn] += f; s_nkc[zn] += f;
+                commit_site(K, i, v, f, zo, zn, 0, KP);
+            }
+        }
+        for (int q = lane; q < (KP >> 2); q += 64) {
+            const int4 old = reinterpret_cast<const int4 *>(ndk_row)[q];
+            const int4 cur = reinterpret_cast<const int4 *>(s_ndk)[q];
+            const int dl[4] = {cur.x - old.x, cur.y - old.y, cur.z - old.z, cur.w - old.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (dl[j]) atomicAdd(K.n_k_delta + ((q << 2) | j), dl[j]);
+            reinterpret_cast<int4 *>(ndk_row)[q] = cur;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Read-outs, wide layouts
+// ---------------------------------------------------------------------------------------------
+struct WLParams {
+    LParams l;
+    int32_t NT, T, G, KP;
+};
+
+__device__ __forceinline__ double wave_allsum(double x)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) x = x + __shfl_xor(x, d, 64);
+    return x;
+}
+
+// log-likelihood (LabeledLDA.py:256-265); as llda_loglik_kernel, theta of the document staged in LDS
+__global__ void __launch_bounds__(64) llda_loglik_wide_kernel(const WLParams P)
+{
+    extern __shared__ double s_wide[];
+    const LParams &L = P.l;
+    const int lane = threadIdx.x, KP = P.KP, G = P.G;
+    double *th = s_wide, *rden = s_wide + KP;
+    for (int64_t d = blockIdx.x; d < L.D; d += gridDim.x) {
+        double rs = 0.0;
+        for (int q = lane; q < (KP >> 2); q += 64) {
+            const int c = q / G, gv = q - c * G;
+            const uint32_t mask = L.lab_mask[d * G + gv];
+            const int4 nd4 = reinterpret_cast<const int4 *>(L.n_dk + d * KP)[q];
+            const int4 nk4 = reinterpret_cast<const int4 *>(L.n_k)[q];
+            const int nds[4] = {nd4.x, nd4.y, nd4.z, nd4.w}, nks[4] = {nk4.x, nk4.y, nk4.z, nk4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double t = (double)nds[j] + (((mask >> (4 * c + j)) & 1u) ? L.alpha : 0.0);
+                th[(q << 2) | j] = t;
+                rden[(q << 2) | j] = (double)nks[j] + L.vbeta;
+                rs = rs + t;
+            }
+        }
+        rs = wave_allsum(rs);
+        double acc = 0.0;
+        for (int64_t i = L.doc_off[d]; i < L.doc_off[d + 1]; ++i) {
+            const int4 *xrow = reinterpret_cast<const int4 *>(L.n_kw + (int64_t)L.word[i] * KP);
+            double dot = 0.0;
+            for (int q = lane; q < (KP >> 2); q += 64) {
+                const int4 x4 = xrow[q];
+                const int xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dot = dot + (th[(q << 2) | j] / rs) * (((double)xs[j] + L.beta) / rden[(q << 2) | j]);
+            }
+            dot = wave_allsum(dot);
+            acc = acc - log(dot);
+        }
+        if (lane == 0) L.out_doc[d] = acc;
+    }
+}
+
+struct WRParams {
+    const int32_t *n_dk;
+    const uint16_t *lab_mask;
+    double *out;
+    int64_t D;
+    int32_t K, mode;
+    double alpha, keep, share;
+    int32_t leaf_start[LLDA_MAX_WIDE_LEAVES], leaf_len[LLDA_MAX_WIDE_LEAVES];
+    WideLayout w;
+};
+
+// get_theta and its running mean (LabeledLDA.py:236-239, 131-145): the row sum in numpy's order
+__global__ void __launch_bounds__(64) llda_readout_theta_wide_kernel(const WRParams P)
+{
+    extern __shared__ double s_wide[];
+    const WideLayout &W = P.w;
+    const int lane = threadIdx.x, KP = W.KP, G = W.G, T = W.T;
+    double *wv = s_wide;
+    for (int64_t d = blockIdx.x; d < P.D; d += gridDim.x) {
+        for (int q = lane; q < (KP >> 2); q += 64) {
+            const int c = q / G, gv = q - c * G;
+            const uint32_t mask = P.lab_mask[d * G + gv];
+            const int4 nd4 = reinterpret_cast<const int4 *>(P.n_dk + d * KP)[q];
+            const int nds[4] = {nd4.x, nd4.y, nd4.z, nd4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wv[(q << 2) | j] = (double)nds[j] + (((mask >> (4 * c + j)) & 1u) ? P.alpha : 0.0);   // n_d_k + labs*alpha
+        }
+        const double rs = wide_sum(wv, W, lane);
+        for (int q = lane; q < (KP >> 2); q += 64) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pos = (q << 2) | j;
+                const int k = wide_topic_of(P.leaf_start, P.leaf_len, G, T, pos);
+                if (k < 0) continue;
+                double *o = P.out + d * P.K + k;
+                const double cur = wv[pos] / rs;
+                if (P.mode == 0) *o = cur;
+                else {
+                    const double a = P.keep * *o, b = P.share * cur;       // two roundings, then the sum (no FMA)
+                    *o = a + b;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Test-time fold-in, wide layouts (LabeledLDA.prep4test / run_test, LabeledLDA.py:155-212; see kernel_foldin.hpp for the
+// narrow kernels and the meaning of the arguments).  The global matrices keep the fold-in's LANE-MAJOR order (entry
+// gv * T + s); the wavefront's LDS copy is in position order, which is what wide_sum / wide_draw walk.
+// ---------------------------------------------------------------------------------------------
+struct WFParams {
+    FParams f;
+    WideLayout w;
+};
+
+// `while prob.sum() > 1: prob /= c`
+__device__ __forceinline__ void wide_shrink(double *wv, const WideLayout &W, int lane, double c, double c_rcp)
+{
+    for (int guard = 0; guard < (1 << 28); ++guard) {
+        const double s = wide_sum(wv, W, lane);
+        if (!(s > 1.0)) break;
+        wide_div(wv, W, lane, c, c_rcp);
+    }
+}
+
+// wv (position order) <- row of a lane-major matrix
+__device__ __forceinline__ void wide_load_lm(double *wv, const double *row, const WideLayout &W, int lane)
+{
+    for (int t = 0; t < W.NT; ++t) {
+        const int gv = t * 64 + lane;
+        for (int s = 0; s < W.T; ++s) wv[pos_of_rt(W.G, W.T, gv, s)] = row[gv * W.T + s];
+    }
+}
+
+__global__ void __launch_bounds__(64) llda_foldin_init_wide_kernel(const WFParams P)
+{
+    extern __shared__ double s_wide[];
+    const FParams &F = P.f;
+    const WideLayout &W = P.w;
+    const int lane = threadIdx.x;
+    double *wv = s_wide;
+    for (int64_t site = blockIdx.x; site < F.n_sites; site += gridDim.x) {
+        int64_t lo = 0, hi = F.D;                       // document of the site: last d with doc_off[d] <= site
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (F.doc_off[mid] <= site) lo = mid; else hi = mid;
+        }
+        const int64_t d = lo;
+        const int n = (int)(site - F.doc_off[d]);
+        const uint32_t gdoc = F.doc_ids ? (uint32_t)F.doc_ids[d] : (uint32_t)(d + F.doc_base);
+        uint32_t r0 = (uint32_t)(n >> 1), r1 = gdoc, r2 = F.doc_stream ? F.doc_stream[d] : F.stream_id, r3 = 0xFFFFFFFFu;
+        philox4x32_10(r0, r1, r2, r3, F.key0, F.key1);
+        const uint32_t ra = (n & 1) ? r2 : r0, rb = (n & 1) ? r3 : r1;
+        const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+        wide_load_lm(wv, F.phn + (int64_t)F.init_idx[site] * W.KP, W, lane);
+        wide_shrink(wv, W, lane, F.c_init, 1.0 / F.c_init);
+        int zn = wide_draw(wv, W, u, lane);
+        if (zn < 0) {
+            zn = 0;
+            if (lane == 0 && F.status) atomicOr(F.status, 1);
+        }
+        if (lane == 0) {
+            int ln, sn;
+            lane_slot_of_rt(W.G, W.T, zn, ln, sn);
+            F.z[site] = zn;
+            atomicAdd(F.n_dk + d * W.KP + ln * W.T + sn, F.freq[site]);
+        }
+    }
+}
+
+// the sweeps (the initial assignments always come from llda_foldin_init_wide_kernel)
+__global__ void __launch_bounds__(64) llda_foldin_wide_kernel(const WFParams P)
+{
+    extern __shared__ double s_wide[];
+    const FParams &F = P.f;
+    const WideLayout &W = P.w;
+    const int lane = threadIdx.x, KP = W.KP, G = W.G, T = W.T, NT = W.NT;
+    double *wv = s_wide;
+    int *s_ndk = reinterpret_cast<int *>(wv + KP);              // position order
+    for (int64_t d = blockIdx.x; d < F.D; d += gridDim.x) {
+        const int64_t s0 = F.doc_off[d];
+        const int len = (int)(F.doc_off[d + 1] - s0);
+        const uint32_t gdoc = F.doc_ids ? (uint32_t)F.doc_ids[d] : (uint32_t)(d + F.doc_base);
+        const uint32_t stream_id = F.doc_stream ? F.doc_stream[d] : F.stream_id;
+        const double *ph = F.ph + (F.ph_base ? F.ph_base[d] : 0);
+        int32_t *ndk_row = F.n_dk + d * KP;                     // lane-major
+        double *th_row = F.th + d * KP;
+        for (int t = 0; t < NT; ++t) {
+            const int gv = t * 64 + lane;
+            for (int s = 0; s < T; ++s) {
+                s_ndk[pos_of_rt(G, T, gv, s)] = ndk_row[gv * T + s];
+                th_row[gv * T + s] = 0.0;
+            }
+        }
+        int ntot = 0;
+        for (int n = 0; n < len; ++n) ntot += F.freq[s0 + n];
+        const double c1 = F.c_loop, c1r = 1.0 / c1;
+
+        for (int sweep = 0; sweep < F.iters; ++sweep) {
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            for (int n = 0; n < len; ++n) {
+                const int v = F.word[s0 + n], f = F.freq[s0 + n];
+                if ((n & 127) == 0) {
+                    r0 = (uint32_t)(n >> 1) + (uint32_t)lane; r1 = gdoc; r2 = stream_id; r3 = (uint32_t)sweep;
+                    philox4x32_10(r0, r1, r2, r3, F.key0, F.key1);
+                }
+                const int holder = (n >> 1) & 63;
+                const uint32_t ra = (uint32_t)__shfl((int)((n & 1) ? r2 : r0), holder, 64);
+                const uint32_t rb = (uint32_t)__shfl((int)((n & 1) ? r3 : r1), holder, 64);
+                const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+                const int zo = F.z[s0 + n];
+                if (lane == 0) s_ndk[zo] -= f;                                   // n_dk[z] -= f
+                const double *brow = ph + (int64_t)v * KP;
+                for (int t = 0; t < NT; ++t) {
+                    const int gv = t * 64 + lane;
+                    for (int s = 0; s < T; ++s) {
+                        const int pos = pos_of_rt(G, T, gv, s);
+                        wv[pos] = ((double)s_ndk[pos] + F.alpha) * brow[gv * T + s];      // num_a * b
+                    }
+                }
+                double S = wide_sum(wv, W, lane);
+                if (F.beta_fallback && S == 0.0) {         // 0/0 raises in the reference (CascadeLDA.py:225-230)
+                    for (int t = 0; t < NT; ++t) {
+                        const int gv = t * 64 + lane;
+                        for (int s = 0; s < T; ++s) {
+                            const int pos = pos_of_rt(G, T, gv, s);
+                            const bool real = F.slot_valid[gv * T + s] != 0;
+                            wv[pos] = real ? ((double)s_ndk[pos] + F.alpha) * (brow[gv * T + s] + F.beta) : 0.0;
+                        }
+                    }
+                    S = wide_sum(wv, W, lane);
+                }
+                wide_div(wv, W, lane, S, 1.0 / S);                               // prob /= prob.sum()
+                wide_shrink(wv, W, lane, c1, c1r);
+                int zn = wide_draw(wv, W, u, lane);
+                if (zn < 0) {                              // all-zero / NaN probabilities: the reference would raise
+                    zn = zo;
+                    if (lane == 0 && F.status) atomicOr(F.status, 1);
+                }
+                if (lane == 0) {
+                    s_ndk[zn] += f;                                              // n_dk[new_z] += f
+                    F.z[s0 + n] = zn;
+                }
+            }
+            // thinned running average of the document-topic state (LabeledLDA.py:199-211)
+            if ((sweep + 1) % F.thinning == 0) {
+                const int s2 = (sweep + 1) / F.thinning;
+                const double tot = (double)ntot;
+                const double f_old = F.avg_mode == 0 ? (double)(s2 - 1) / (double)s2 : (double)(s2 - 1) / (double)s2;
+                const double f_new = F.avg_mode == 0 ? 1.0 / (double)s2 : 1.0 - f_old;
+                for (int t = 0; t < NT; ++t) {
+                    const int gv = t * 64 + lane;
+                    for (int s = 0; s < T; ++s) {
+                        const double cur = (double)s_ndk[pos_of_rt(G, T, gv, s)] / tot;
+                        double *a = th_row + gv * T + s;
+                        if (s2 == 1) *a = cur;
+                        else {
+                            const double old_part = f_old * *a;
+                            const double new_part = f_new * cur;
+                            *a = old_part + new_part;
+                        }
+                    }
+                }
+            }
+        }
+        for (int t = 0; t < NT; ++t) {
+            const int gv = t * 64 + lane;
+            for (int s = 0; s < T; ++s) ndk_row[gv * T + s] = s_ndk[pos_of_rt(G, T, gv, s)];
+        }
+    }
+}
+
+}  // namespace

@@ -30,11 +30,14 @@
 //   kernel_readout.hpp  llda_loglik_kernel, llda_readout_phi / _theta kernels (thinning read-outs)
 //   kernel_foldin.hpp   llda_foldin_kernel (test-time sampler)
 //   kernel_counts.hpp   llda_commit_log_kernel, llda_apply_delta_kernel, llda_count_init_kernel, self test
+//   kernel_wide.hpp     the general path for K with more than 8 pairwise leaves (one wavefront per document)
 //   this file           host side: layout (llda_layout_init), dispatch, C entry points
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
 #include <string.h>
+#include <map>
+#include <memory>
 
 #include "llda_gibbs.h"
 
@@ -49,6 +52,7 @@
 #include "kernel_readout.hpp"
 #include "kernel_foldin.hpp"
 #include "kernel_counts.hpp"
+#include "kernel_wide.hpp"
 
 namespace {
 
@@ -58,7 +62,7 @@ namespace {
 void add_leaves(llda_layout *L, int n, int start)
 {
     if (n <= 128) {
-        if (L->n_leaves < LLDA_MAX_LEAVES) {
+        if (L->n_leaves < LLDA_MAX_WIDE_LEAVES) {
             L->leaf_start[L->n_leaves] = start;
             L->leaf_len[L->n_leaves] = n;
         }
@@ -95,10 +99,66 @@ int schedule(llda_layout *L, int n, int *next_leaf, int *first_out, int *count_o
     return d + 1;
 }
 
+// numpy's recursion as in-place adds over the leaf totals, post-order: returns the first leaf of the subtree
+int comb_tree(llda_layout *L, int n, int *next_leaf, int *n_comb)
+{
+    if (n <= 128) return (*next_leaf)++;
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const int a = comb_tree(L, n2, next_leaf, n_comb);
+    const int b = comb_tree(L, n - n2, next_leaf, n_comb);
+    if (*n_comb < LLDA_MAX_WIDE_LEAVES) { L->comb_dst[*n_comb] = a; L->comb_src[*n_comb] = b; }
+    ++*n_comb;
+    return a;
+}
+
 int hip_fail(hipError_t e)
 {
     g_last_hip_error = (int)e;
     return LLDA_E_HIP;
+}
+
+// The layout of K (128 KB of tables): built once per host thread and K, not once per call.
+const llda_layout *layout_of(int32_t K, int *rc)
+{
+    static thread_local std::map<int32_t, std::unique_ptr<llda_layout>> cache;
+    auto it = cache.find(K);
+    if (it != cache.end()) { *rc = LLDA_OK; return it->second.get(); }
+    std::unique_ptr<llda_layout> L(new llda_layout);
+    *rc = llda_layout_init(K, L.get());
+    if (*rc) return nullptr;
+    if (cache.size() >= 256) cache.clear();
+    return (cache[K] = std::move(L)).get();
+}
+
+// kernels of the wide path take their LDS as a run-time size; above 64 KB a kernel has to be told once
+template <typename Kern>
+int allow_lds(Kern kern, size_t bytes)
+{
+    if (bytes > 160 * 1024) return LLDA_E_BAD_K;
+    if (bytes > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return hip_fail(e);
+    }
+    return LLDA_OK;
+}
+
+void fill_wide(const llda_layout &L, WideLayout &W)
+{
+    W.NT = L.tiers; W.T = L.T; W.G = L.G; W.KP = L.KP;
+    W.m = L.n_leaves; W.last_leaf = L.n_leaves - 1; W.tail = L.tail; W.tail_row = L.tail_row;
+    for (int i = 0; i < LLDA_MAX_WIDE_LEAVES; ++i) {
+        W.comb_dst[i] = (uint8_t)L.comb_dst[i];
+        W.comb_src[i] = (uint8_t)L.comb_src[i];
+    }
+}
+
+// one wavefront per document (or site): enough workgroups to fill the chip a few times over
+unsigned wide_blocks(int64_t n)
+{
+    const int64_t cap = 256 * 16;
+    return (unsigned)(n < 1 ? 1 : (n < cap ? n : cap));
 }
 
 template <int G, int T>
@@ -279,7 +339,7 @@ const char *llda_strerror(int code)
 {
     switch (code) {
     case LLDA_OK: return "ok";
-    case LLDA_E_BAD_K: return "K outside 1..1024 or more than 8 pairwise leaves";
+    case LLDA_E_BAD_K: return "K outside 1..7688, or a wide layout (more than 8 pairwise leaves) handed to an entry point that only takes narrow ones";
     case LLDA_E_BAD_ARG: return "bad argument";
     case LLDA_E_HIP: return "HIP runtime error";
     case LLDA_E_NO_DEVICE: return "no HIP device";
@@ -294,10 +354,14 @@ int llda_layout_init(int32_t K, llda_layout *L)
     memset(L, 0, sizeof *L);
     L->K = K;
     add_leaves(L, K, 0);
-    if (L->n_leaves > LLDA_MAX_LEAVES) return LLDA_E_BAD_K;
+    if (L->n_leaves > LLDA_MAX_WIDE_LEAVES) return LLDA_E_BAD_K;
+    L->wide = L->n_leaves > LLDA_MAX_LEAVES ? 1 : 0;
     int P = 1;
-    while (P < L->n_leaves) P *= 2;
+    if (L->wide) P = (L->n_leaves + 7) / 8 * 8;          // 64-lane tiers of one wavefront
+    else
+        while (P < L->n_leaves) P *= 2;
     L->G = 8 * P;
+    L->tiers = L->wide ? P / 8 : 0;
     int t = 0;
     for (int p = 0; p < L->n_leaves; ++p) {
         const int r = (L->leaf_len[p] + 7) / 8;
@@ -308,7 +372,7 @@ int llda_layout_init(int32_t K, llda_layout *L)
     L->KP = L->G * t;
     L->tail = L->leaf_len[L->n_leaves - 1] % 8;
     L->tail_row = L->leaf_len[L->n_leaves - 1] / 8;
-    for (int i = 0; i < LLDA_MAX_K; ++i) L->pos_topic[i] = -1;
+    for (int i = 0; i < LLDA_MAX_KP; ++i) L->pos_topic[i] = -1;
     // memory position of (lane g, slot s): the 16-byte chunk s >> 2 of all lanes is contiguous (rows with fewer than
     // 4 slots per lane: pos = g*T + s)
     const int w = (t % 4 == 0) ? 4 : t;
@@ -325,20 +389,27 @@ int llda_layout_init(int32_t K, llda_layout *L)
             L->topic_pos[L->leaf_start[p] + rel] = pos;
             L->pos_topic[pos] = L->leaf_start[p] + rel;
         }
+    {
+        int next = 0, n_comb = 0;
+        comb_tree(L, K, &next, &n_comb);
+    }
     for (int r = 0; r < LLDA_MAX_ROUNDS; ++r)
         for (int p = 0; p < LLDA_MAX_LEAVES; ++p) L->rounds[r][p] = p;
-    int next = 0, first, count;
-    schedule(L, K, &next, &first, &count);
-    if (L->n_rounds > LLDA_MAX_ROUNDS) return LLDA_E_BAD_K;
+    if (!L->wide) {
+        int next = 0, first, count;
+        schedule(L, K, &next, &first, &count);
+        if (L->n_rounds > LLDA_MAX_ROUNDS) return LLDA_E_BAD_K;
+    }
     return LLDA_OK;
 }
 
 int llda_sweep(const llda_sweep_args *a, void *stream)
 {
     if (!a || a->D < 0 || a->V < 1) return LLDA_E_BAD_ARG;
-    llda_layout L;
-    const int rc = llda_layout_init(a->K, &L);
+    int rc;
+    const llda_layout *Lp = layout_of(a->K, &rc);
     if (rc) return rc;
+    const llda_layout &L = *Lp;
     if (a->D == 0) return LLDA_OK;            // an empty shard: nothing to do, array pointers may be NULL
     if (a->n_sites < 0 || a->n_sites >= (1LL << 30)) return LLDA_E_BAD_ARG;   // split the shard (llda_gibbs.h)
     const bool logged = a->csc_pos && a->commit_log;
@@ -373,6 +444,21 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
     P.margin0_rel = a->debug_margin == 0 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
     hipStream_t st = (hipStream_t)stream;
+
+    if (L.wide) {                                           // more than 8 pairwise leaves: the general path
+        if (logged) return LLDA_E_BAD_ARG;                  // (atomics commit path only)
+        WParams W;
+        memset(&W, 0, sizeof W);
+        W.k = P;
+        W.k.site_rec = nullptr; W.k.csc_pos = nullptr; W.k.commit_log = nullptr;
+        fill_wide(L, W.w);
+        const size_t lds = (size_t)L.KP * 16;               // scores (f64) + n_dk + n_k (int32), per wavefront
+        const int rl = allow_lds(llda_sweep_wide_kernel, lds);
+        if (rl) return rl;
+        hipLaunchKernelGGL(llda_sweep_wide_kernel, dim3(wide_blocks(a->D)), dim3(64), lds, st, W);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? LLDA_OK : hip_fail(e);
+    }
 
     // sparse label sets: one lane per allowed topic (a site the margin cannot decide is resolved inside the kernel by
     // the exact pipeline, exact_site_wave)
@@ -452,9 +538,11 @@ int llda_commit_log(const int64_t *item_begin, const int32_t *item_len, const in
                     int32_t *target, int32_t *n_k, int32_t *n_k_delta, void *stream)
 {
     if (n_items < 0 || (n_k != nullptr) != (n_k_delta != nullptr)) return LLDA_E_BAD_ARG;
-    llda_layout L;
-    const int rc = llda_layout_init(K, &L);
+    int rc;
+    const llda_layout *Lp = layout_of(K, &rc);
     if (rc) return rc;
+    const llda_layout &L = *Lp;
+    if (L.wide) return LLDA_E_BAD_K;                        // wide layouts keep the atomics commit path
     if (n_items > 0 && (!item_begin || !item_len || !item_word || !commit_log || !freq_csc || !target)) return LLDA_E_BAD_ARG;
     if (n_items == 0 && !n_k) return LLDA_OK;
     CParams P;
@@ -472,9 +560,11 @@ int llda_commit_log(const int64_t *item_begin, const int32_t *item_len, const in
 int llda_apply_rows(const int64_t *row_off, int32_t *rows, int64_t n_rows, int32_t K, int32_t *counts, void *stream)
 {
     if (n_rows < 0) return LLDA_E_BAD_ARG;
-    llda_layout L;
-    const int rc = llda_layout_init(K, &L);
+    int rc;
+    const llda_layout *Lp = layout_of(K, &rc);
     if (rc) return rc;
+    const llda_layout &L = *Lp;
+    if (L.wide) return LLDA_E_BAD_K;
     if (n_rows == 0) return LLDA_OK;
     if (!row_off || !rows || !counts) return LLDA_E_BAD_ARG;
     const int64_t blocks = (n_rows + 3) / 4;
@@ -504,14 +594,20 @@ int llda_count_init(const int64_t *doc_off, const int32_t *word, const int32_t *
                     int64_t D, int32_t K, int32_t *n_dk, int32_t *n_kw, int32_t *n_k, void *stream)
 {
     if (D < 0) return LLDA_E_BAD_ARG;
-    llda_layout L;
-    const int rc = llda_layout_init(K, &L);
+    int rc;
+    const llda_layout *Lp = layout_of(K, &rc);
     if (rc) return rc;
+    const llda_layout &L = *Lp;
     if (D == 0) return LLDA_OK;
     if (!doc_off || !word || !freq || !z || !n_dk || !n_kw || !n_k) return LLDA_E_BAD_ARG;
-    int64_t blocks = (D + 3) / 4;
+    // rows too long for five LDS histograms per workgroup (wide layouts): one wavefront per workgroup, two histograms
+    const int waves = (size_t)5 * L.KP * sizeof(int) <= 48 * 1024 ? 4 : 1;
+    const size_t lds = (size_t)(1 + waves) * L.KP * sizeof(int);
+    const int rl = allow_lds(llda_count_init_kernel, lds);
+    if (rl) return rl;
+    int64_t blocks = (D + waves - 1) / waves;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(llda_count_init_kernel, dim3((unsigned)blocks), dim3(256), 5 * L.KP * sizeof(int),
+    hipLaunchKernelGGL(llda_count_init_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds,
                        (hipStream_t)stream, doc_off, word, freq, z, D, L.KP, n_dk, n_kw, n_k);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
@@ -522,15 +618,26 @@ int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab
                 double beta, double *out_doc, void *stream)
 {
     if (D < 0 || V < 1) return LLDA_E_BAD_ARG;
-    llda_layout L;
-    const int rc = llda_layout_init(K, &L);
+    int rc;
+    const llda_layout *Lp = layout_of(K, &rc);
     if (rc) return rc;
+    const llda_layout &L = *Lp;
     if (D == 0) return LLDA_OK;
     if (!doc_off || !word || !lab_mask || !n_dk || !n_kw || !n_k || !out_doc) return LLDA_E_BAD_ARG;
     LParams P;
     P.doc_off = doc_off; P.word = word; P.lab_mask = lab_mask; P.n_dk = n_dk; P.n_kw = n_kw; P.n_k = n_k;
     P.out_doc = out_doc; P.D = D; P.alpha = alpha; P.beta = beta; P.vbeta = (double)V * beta;
     hipStream_t st = (hipStream_t)stream;
+    if (L.wide) {
+        WLParams W;
+        W.l = P; W.NT = L.tiers; W.T = L.T; W.G = L.G; W.KP = L.KP;
+        const size_t lds = (size_t)L.KP * 16;
+        const int rl = allow_lds(llda_loglik_wide_kernel, lds);
+        if (rl) return rl;
+        hipLaunchKernelGGL(llda_loglik_wide_kernel, dim3(wide_blocks(D)), dim3(64), lds, st, W);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? LLDA_OK : hip_fail(e);
+    }
     switch (L.G) {
     case 8: return dispatch_loglik_T<8>(L.T, P, st);
     case 16: return dispatch_loglik_T<16>(L.T, P, st);
@@ -543,7 +650,7 @@ int llda_loglik(const int64_t *doc_off, const int32_t *word, const uint16_t *lab
 static void readout_layout(const llda_layout &L, RParams &P)
 {
     P.K = L.K; P.KP = L.KP; P.T = L.T;
-    for (int p = 0; p < LLDA_MAX_LEAVES; ++p) { P.leaf_start[p] = L.leaf_start[p]; P.leaf_len[p] = L.leaf_len[p]; }
+    for (int p = 0; p < LLDA_MAX_WIDE_LEAVES; ++p) { P.leaf_start[p] = L.leaf_start[p]; P.leaf_len[p] = L.leaf_len[p]; }
     fill_schedule(L, P.last_leaf, P.tail, P.tail_row, P.n_rounds, P.xor_tree, P.rounds_pk);
 }
 
@@ -551,9 +658,10 @@ int llda_readout_phi(const int32_t *n_kw, const int32_t *n_k, const double *den,
                      int32_t mode, double keep, double share, double *out, int32_t *flags, void *stream)
 {
     if (V < 1 || (mode != 0 && mode != 1) || !n_kw || (!n_k && !den) || !out) return LLDA_E_BAD_ARG;
-    llda_layout L;
-    const int rc = llda_layout_init(K, &L);
+    int rc;
+    const llda_layout *Lp = layout_of(K, &rc);
     if (rc) return rc;
+    const llda_layout &L = *Lp;
     RParams P;
     memset(&P, 0, sizeof P);
     readout_layout(L, P);
@@ -568,11 +676,26 @@ int llda_readout_theta(const int32_t *n_dk, const uint16_t *lab_mask, int64_t D,
                        double keep, double share, double *out, void *stream)
 {
     if (D < 0 || (mode != 0 && mode != 1)) return LLDA_E_BAD_ARG;
-    llda_layout L;
-    const int rc = llda_layout_init(K, &L);
+    int rc;
+    const llda_layout *Lp = layout_of(K, &rc);
     if (rc) return rc;
+    const llda_layout &L = *Lp;
     if (D == 0) return LLDA_OK;
     if (!n_dk || !lab_mask || !out) return LLDA_E_BAD_ARG;
+    if (L.wide) {
+        WRParams W;
+        memset(&W, 0, sizeof W);
+        W.n_dk = n_dk; W.lab_mask = lab_mask; W.out = out; W.D = D; W.K = L.K; W.mode = mode; W.alpha = alpha;
+        W.keep = keep; W.share = share;
+        for (int p = 0; p < LLDA_MAX_WIDE_LEAVES; ++p) { W.leaf_start[p] = L.leaf_start[p]; W.leaf_len[p] = L.leaf_len[p]; }
+        fill_wide(L, W.w);
+        const size_t lds = (size_t)L.KP * 8;
+        const int rl = allow_lds(llda_readout_theta_wide_kernel, lds);
+        if (rl) return rl;
+        hipLaunchKernelGGL(llda_readout_theta_wide_kernel, dim3(wide_blocks(D)), dim3(64), lds, (hipStream_t)stream, W);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? LLDA_OK : hip_fail(e);
+    }
     RParams P;
     memset(&P, 0, sizeof P);
     readout_layout(L, P);
@@ -594,9 +717,10 @@ int llda_foldin(const llda_foldin_args *a, void *stream)
     if (!a || !a->doc_off || !a->word || !a->init_idx || !a->freq || !a->ph || !a->init_rows || !a->z || !a->n_dk ||
         !a->th || !a->slot_valid || a->D < 0 || a->iters < 0 || a->thinning < 1)
         return LLDA_E_BAD_ARG;
-    llda_layout L;
-    const int rc = llda_layout_init(a->K, &L);
+    int rc;
+    const llda_layout *Lp = layout_of(a->K, &rc);
     if (rc) return rc;
+    const llda_layout &L = *Lp;
     if (a->D == 0) return LLDA_OK;
     FParams P;
     memset(&P, 0, sizeof P);
@@ -611,6 +735,22 @@ int llda_foldin(const llda_foldin_args *a, void *stream)
     fill_schedule(L, P.last_leaf, P.tail, P.tail_row, P.n_rounds, P.xor_tree, P.rounds_pk);
     hipStream_t st = (hipStream_t)stream;
     const bool has_tail = L.tail != 0;
+    if (L.wide) {
+        WFParams W;
+        memset(&W, 0, sizeof W);
+        W.f = P;
+        fill_wide(L, W.w);
+        // (the wide path always draws the initial assignments with one wavefront per site; n_sites = 0: no site at all)
+        int rl = allow_lds(llda_foldin_init_wide_kernel, (size_t)L.KP * 8);
+        if (rl) return rl;
+        if (P.n_sites > 0)
+            hipLaunchKernelGGL(llda_foldin_init_wide_kernel, dim3(wide_blocks(P.n_sites)), dim3(64), (size_t)L.KP * 8, st, W);
+        rl = allow_lds(llda_foldin_wide_kernel, (size_t)L.KP * 12);
+        if (rl) return rl;
+        hipLaunchKernelGGL(llda_foldin_wide_kernel, dim3(wide_blocks(P.D)), dim3(64), (size_t)L.KP * 12, st, W);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? LLDA_OK : hip_fail(e);
+    }
     switch (L.G) {
     case 8: return dispatch_foldin_T<8>(L.T, P, has_tail, st);
     case 16: return dispatch_foldin_T<16>(L.T, P, has_tail, st);

@@ -14,7 +14,11 @@ sum.  The layout below makes that order lane-local on a 64-wide wavefront:
 so that one accumulator chain is one lane walking its T slots, the 8 accumulators of a leaf are 8
 neighbouring lanes (xor butterfly 1,2,4), and leaves are 8-lane groups combined by a short
 butterfly schedule.  A document occupies G = 8 * P lanes (P = number of leaves rounded up to a
-power of two), i.e. 64/G documents share a wavefront.  All per-topic device arrays (rows of n_kw,
+power of two), i.e. 64/G documents share a wavefront.  K with more than 8 leaves (some K in 969..1023, every
+K > 1024; "wide" layouts, up to 64 leaves): P = leaves rounded up to a multiple of 8 and the G = 8 * P lanes are
+NT = P / 8 "tiers" of ONE wavefront -- virtual lane gv = 64 * tier + physical lane; everything else (positions, masks,
+draw order) is the same formula with the larger G, and the leaf totals are combined by walking numpy's recursion tree
+(``comb``: (dst leaf, src leaf) per internal node in post-order).  All per-topic device arrays (rows of n_kw,
 rows of n_dk, n_k) have row length KP = G*T; the MEMORY position of (lane g, slot s) in a row is
 
     pos = ((s // 4) * G + g) * 4 + s % 4      (T a multiple of 4)         pos = g*T + s   (T = 1, 2)
@@ -27,8 +31,9 @@ not the memory order.
 import numpy as np
 
 PW_BLOCK = 128          # numpy's pairwise-sum block size
-MAX_K = 1024            # 8 leaves x 128 topics = 64 lanes x 16 slots
-MAX_ROUNDS = 4          # depth of the leaf-combine schedule handed to the kernel
+MAX_K = 7688            # every K up to here splits into <= 64 leaves (llda_gibbs.h LLDA_MAX_K)
+MAX_NARROW_LEAVES = 8   # up to 8 leaves a document is one lane group of <= 64 lanes x <= 16 slots ("narrow" layouts)
+MAX_ROUNDS = 4          # depth of the leaf-combine schedule handed to the narrow kernels
 
 
 def _leaves(n, start=0):
@@ -73,14 +78,15 @@ class GroupLayout(object):
         self.K = K
         self.leaves = _leaves(K)
         m = len(self.leaves)
-        if m > 8:
-            # happens only for some K in 969..1023: numpy's recursion yields 9 leaves there
-            raise ValueError("K=%d splits into %d pairwise leaves; at most 8 (64 lanes) supported"
-                             % (K, m))
-        P = 1
-        while P < m:
-            P *= 2
+        self.wide = m > MAX_NARROW_LEAVES
+        if self.wide:
+            P = (m + 7) // 8 * 8
+        else:
+            P = 1
+            while P < m:
+                P *= 2
         self.m, self.P, self.G = m, P, 8 * P
+        self.NT = P // 8 if self.wide else 0        # 64-lane tiers of a wide layout
         t_used = max((n + 7) // 8 for _, n in self.leaves)
         T = t_used
         if T > 2:
@@ -114,15 +120,35 @@ class GroupLayout(object):
         self.lm_topic_pos = (self.topic_lane * T + self.topic_slot).astype(np.int32)
         self.lm_pos_topic = np.full(self.KP, -1, dtype=np.int32)
         self.lm_pos_topic[self.lm_topic_pos] = np.arange(K, dtype=np.int32)
-        self.leaf_start = np.zeros(8, dtype=np.int32)
-        self.leaf_rows = np.zeros(8, dtype=np.int32)
+        self.leaf_start = np.zeros(max(8, P), dtype=np.int32)
+        self.leaf_rows = np.zeros(max(8, P), dtype=np.int32)
         for p, (st, n) in enumerate(self.leaves):
             self.leaf_start[p] = st
             self.leaf_rows[p] = n // 8
-        self.rounds = self._schedule()
-        self.n_rounds = len(self.rounds)
-        if self.n_rounds > MAX_ROUNDS:
-            raise ValueError("leaf-combine schedule deeper than %d" % MAX_ROUNDS)
+        self.comb = self._post_order()
+        if self.wide:
+            self.rounds, self.n_rounds = [], 0
+        else:
+            self.rounds = self._schedule()
+            self.n_rounds = len(self.rounds)
+            if self.n_rounds > MAX_ROUNDS:
+                raise ValueError("leaf-combine schedule deeper than %d" % MAX_ROUNDS)
+
+    def _post_order(self):
+        """numpy's recursion as a list of in-place adds over the leaf totals: for every internal node, in post-order,
+        total[first leaf of its left child] += total[first leaf of its right child]; total[0] ends up as the sum."""
+        tree, _ = _tree(self.K)
+        out = []
+
+        def visit(t):
+            if isinstance(t, int):
+                return t
+            a, b = visit(t[0]), visit(t[1])
+            out.append((a, b))
+            return a
+
+        visit(tree)
+        return out
 
     def _schedule(self):
         tree, _ = _tree(self.K)
@@ -135,7 +161,7 @@ class GroupLayout(object):
             visit(t[1])
             d = _depth(t) - 1
             while len(rounds) <= d:
-                rounds.append(np.arange(8, dtype=np.int32))
+                rounds.append(np.arange(max(8, self.P), dtype=np.int32))
             lm, rm = _members(t[0]), _members(t[1])
             for a in lm:
                 rounds[d][a] = rm[0]
@@ -159,7 +185,7 @@ class GroupLayout(object):
 
     def lane_masks(self, labs):
         """(D, K) 0/1 label matrix -> (D, G) uint16: bit s of [d, g] = label of the topic at slot s
-        of lane g (0 in the padding)."""
+        of lane g (0 in the padding).  Wide layouts: g is the virtual lane 64 * tier + lane."""
         labs = (np.asarray(labs) != 0).astype(np.uint32)
         out = np.zeros((labs.shape[0], self.G), dtype=np.uint32)
         np.add.at(out, (slice(None), self.topic_lane), labs << self.topic_slot.astype(np.uint32))

@@ -131,12 +131,14 @@ class GibbsSampler(object):
         # the library then runs one lane per ALLOWED topic (llda_sweep_sparse_kernel)
         self.live_off = self.live_pos = None
         self.live_max = 0
-        if sparse_labels and labs is not None and self.D > 0:
+        if sparse_labels and labs is not None and self.D > 0 and not lay.wide:
             self._make_live()
         self.csc_pos = self.commit_log = self.site_rec = None
         self._ranges = self._make_ranges()
         if commit_log is None:
             commit_log = self.S >= (1 << 20)
+        if lay.wide:
+            commit_log = False                      # wide layouts (more than 8 pairwise leaves): atomics commit path
         if self.S >= (1 << 31):
             commit_log = False                      # log positions are int32
         if commit_log and self.S > 0:

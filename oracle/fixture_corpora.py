@@ -35,7 +35,12 @@ TINY = [
     ("k392",     30, 150,  391,   7,      (10, 60),  0.1, 0.01, 2),    # abstracts-shaped, 4 leaves
     ("k512",     24, 150,  511, 200,      (10, 60),  0.1, 0.01, 2),    # 4 full leaves
     ("k777",     16, 120,  776, 300,      (10, 50),  0.1, 0.01, 2),    # unbalanced tree
-    ("k1024",    12, 100, 1023, 400,      (10, 40),  0.1, 0.01, 2),    # the largest K: 8 full leaves, 64 lanes x 16 slots
+    ("k1024",    12, 100, 1023, 400,      (10, 40),  0.1, 0.01, 2),    # the largest narrow K: 8 full leaves, 64 lanes x 16 slots
+    # wide layouts (more than 8 pairwise leaves: 64-lane tiers of one wavefront)
+    ("k1031",    10, 100, 1030, 400,      (10, 40),  0.1, 0.01, 2),    # 9 leaves -> 2 tiers x 16 slots, tail 7
+    ("k1100",    10, 100, 1099,  30,      (10, 40),  0.1, 0.01, 2),    # 16 leaves, 12 slots per lane, tail 4, sparse labels
+    ("k2100",     8,  80, 2099, 900,      (10, 40),  0.1, 0.01, 2),    # 22 leaves -> 3 tiers (not a power of two), tail 4
+    ("k3000",     6,  80, 2999, 1500,     (10, 30),  0.5, 0.1,  2),    # 32 leaves -> 4 tiers x 12 slots, no tail
 ]
 
 

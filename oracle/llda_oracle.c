@@ -25,8 +25,9 @@
 #include <string.h>
 
 #define PW_BLOCK 128
-#define MAX_LEAVES 8
-#define MAX_KP 1024
+#define MAX_LEAVES 64    /* K <= MAX_K always splits into <= 64 leaves */
+#define MAX_K 7688
+#define MAX_KP 8192      /* 64 leaves x 128 */
 
 /* ---------------- numpy pairwise sum ---------------- */
 static double pairwise_sum(const double *a, int64_t n)
@@ -114,13 +115,16 @@ static void add_leaves(layout_t *L, int n, int start)
 
 static int make_layout(layout_t *L, int K)
 {
-    if (K < 1 || K > MAX_KP) return -1;
+    if (K < 1 || K > MAX_K) return -1;
     memset(L, 0, sizeof *L);
     L->K = K;
     add_leaves(L, K, 0);
     if (L->m > MAX_LEAVES) return -1;
-    L->P = 1;
-    while (L->P < L->m) L->P *= 2;
+    if (L->m > 8) L->P = (L->m + 7) / 8 * 8;        /* wide layouts: 64-lane tiers of one wavefront */
+    else {
+        L->P = 1;
+        while (L->P < L->m) L->P *= 2;
+    }
     L->G = 8 * L->P;
     int t = 0;
     for (int p = 0; p < L->m; p++) {
@@ -143,7 +147,7 @@ static int make_layout(layout_t *L, int K)
 /* ---------------- the keyed categorical draw (llda_oracle.py draw_keyed) ---------------- */
 static int draw_keyed(const layout_t *L, const double *prob, double u)
 {
-    double p[MAX_KP], q[MAX_KP], x[64], y[64];
+    double p[MAX_KP], q[MAX_KP], x[8 * MAX_LEAVES], y[8 * MAX_LEAVES];
     const int G = L->G, T = L->T;
     for (int i = 0; i < L->KP; i++) p[i] = 0.0;
     for (int k = 0; k < L->K; k++) p[L->topic_pos[k]] = prob[k];

@@ -38,7 +38,7 @@ import numpy as np
 # Group layout of the K topics  (mirrors numpy's pairwise_sum blocking)
 # ----------------------------------------------------------------------------------------------
 PW_BLOCK = 128     # numpy PW_BLOCKSIZE
-MAX_K = 1024       # 8 leaves x 128
+MAX_K = 7688       # every K up to here splits into <= 64 leaves (8 'tiers' of 64 lanes on the device)
 
 
 def pairwise_leaves(n, start=0):
@@ -66,7 +66,8 @@ class Layout(object):
 
     leaf p = numpy pairwise leaf containing k, rel = k - start_p, chain j = rel & 7, row = rel >> 3
       lane g = 8*p + j,  slot s = row,  storage position pos = g*T + s   (pos is the device index)
-    P = leaves rounded up to a power of two, G = 8*P lanes, T = slots per lane (rounded up to a
+    P = leaves rounded up to a power of two (up to 8 leaves) or to a multiple of 8 (more: "wide" layouts, the 8*P
+    lanes are then 64-lane tiers of one wavefront), G = 8*P lanes, T = slots per lane (rounded up to a
     multiple of 4 when > 2), KP = G*T padded row length.  A leaf of n topics has R = n//8 full rows
     (slots 0..R-1, summed by the 8 chains) and n%8 tail topics in slot R of lanes j < n%8
     (added sequentially after the chains are combined) -- only the last leaf can have a tail.
@@ -79,10 +80,11 @@ class Layout(object):
         self.leaves = pairwise_leaves(K)
         m = len(self.leaves)
         if m > 8:
-            raise ValueError("K=%d splits into %d pairwise leaves; at most 8 supported" % (K, m))
-        P = 1
-        while P < m:
-            P *= 2
+            P = (m + 7) // 8 * 8
+        else:
+            P = 1
+            while P < m:
+                P *= 2
         self.m, self.P, self.G = m, P, 8 * P
         t_used = max((n + 7) // 8 for _, n in self.leaves)
         T = t_used

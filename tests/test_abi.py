@@ -51,14 +51,16 @@ def test_sampler_refuses_to_run_without_gpu():
         GibbsSampler(np.array([0, 1]), np.array([0]), np.array([1]), np.array([0]), 2, 3, 0.1, 0.01)
 
 
-@pytest.mark.parametrize("K", [1, 5, 8, 12, 20, 64, 100, 128, 129, 130, 200, 255, 256, 392, 512, 513, 777, 968, 1024])
+@pytest.mark.parametrize("K", [1, 5, 8, 12, 20, 64, 100, 128, 129, 130, 200, 255, 256, 392, 512, 513, 777, 968, 1024,
+                               969, 1023, 1031, 1500, 2047, 2100, 3000, 4096, 5000, 7688])
 def test_layout_init_matches_python_layout(K):
     from lda_thesis_amd import _native
     from lda_thesis_amd.layout import GroupLayout
     a, b = _native.layout_init(K), GroupLayout(K)
     for k in ("G", "T", "KP", "tail", "tail_row", "n_rounds"):
         assert a[k] == getattr(b, k), k
-    assert a["n_leaves"] == b.m
+    assert a["n_leaves"] == b.m and bool(a["wide"]) == b.wide and a["tiers"] == b.NT
+    assert a["comb"] == list(b.comb)
     np.testing.assert_array_equal(a["topic_pos"], b.topic_pos)
     np.testing.assert_array_equal(a["pos_topic"], b.pos_topic)
     np.testing.assert_array_equal(a["pos_lane"], b.pos_lane)
@@ -67,7 +69,7 @@ def test_layout_init_matches_python_layout(K):
         np.testing.assert_array_equal(a["rounds"][r], b.rounds[r])
 
 
-@pytest.mark.parametrize("K", [0, -3, 1025, 969, 1023])
+@pytest.mark.parametrize("K", [0, -3, 7689, 100000])
 def test_layout_init_rejects_bad_k(K):
     from lda_thesis_amd import _native
     out = _native.LldaLayout()

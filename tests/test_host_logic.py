@@ -5,11 +5,15 @@ from hypothesis import given, settings, strategies as st
 
 
 @settings(max_examples=120, deadline=None)
-@given(st.integers(1, 968))
+@given(st.one_of(st.integers(1, 1100), st.integers(1101, 7688)))
 def test_layout_is_a_permutation_with_aligned_rows(K):
     from lda_thesis_amd.layout import GroupLayout
     L = GroupLayout(K)
-    assert L.G in (8, 16, 32, 64) and L.T in (1, 2, 4, 8, 12, 16) and L.KP == L.G * L.T
+    if L.wide:          # more than 8 pairwise leaves: 64-lane tiers of one wavefront
+        assert L.m > 8 and L.G == 64 * L.NT and L.NT <= 8 and L.T in (8, 12, 16) and L.KP == L.G * L.T <= 8192
+        assert len(L.comb) == L.m - 1 and L.comb[-1][0] == 0
+    else:
+        assert L.G in (8, 16, 32, 64) and L.T in (1, 2, 4, 8, 12, 16) and L.KP == L.G * L.T
     assert sorted(L.topic_pos.tolist()) == sorted(set(L.topic_pos.tolist())) and L.topic_pos.max() < L.KP
     assert (L.pos_topic[L.topic_pos] == np.arange(K)).all() and (L.pos_topic >= 0).sum() == K
     x = np.arange(1, K + 1)
@@ -31,7 +35,7 @@ def test_layout_is_a_permutation_with_aligned_rows(K):
 def test_lane_masks_roundtrip():
     from lda_thesis_amd.layout import GroupLayout
     rng = np.random.default_rng(0)
-    for K in (5, 20, 130, 392):
+    for K in (5, 20, 130, 392, 1000, 1031, 2100):
         L = GroupLayout(K)
         labs = (rng.random((7, K)) < 0.3).astype(np.uint8)
         m = L.lane_masks(labs).astype(np.int64)
