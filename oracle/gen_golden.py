@@ -407,7 +407,7 @@ def gen_runtest():
     prep4test draws of document d use RNG sweep word 0xFFFFFFFF, iteration i uses sweep i; sites are
     counted from 0 inside each (document, sweep)."""
     from fixture_corpora import tiny_corpus
-    for name, it, thin in (("k12", 6, 2), ("k40", 5, 1), ("k130", 4, 3)):
+    for name, it, thin in (("k12", 6, 2), ("k40", 5, 1), ("k130", 4, 3), ("k1031", 4, 2), ("k2100", 3, 1)):
         docs, labs, labelset, alpha, beta, _, npseed = tiny_corpus(name)
         dicti = Dictionary(docs)
         np.random.seed(npseed)

@@ -23,7 +23,7 @@ def build_model(name, seed=12345):
     return m, ls, sweeps
 
 
-@pytest.mark.parametrize("name", ["k05", "k12", "k20dense", "k40", "k130", "k392"])
+@pytest.mark.parametrize("name", ["k05", "k12", "k20dense", "k40", "k130", "k392", "k1031", "k2100"])
 def test_labeledlda_init_and_sweeps(name):
     g = load_golden("tiny_" + name)
     m, ls, sweeps = build_model(name)
@@ -213,7 +213,7 @@ def test_cascade_abstracts_ensemble_matches_reference():
     assert hashlib.sha256(ph.tobytes()).hexdigest() == str(g["ph_sha256"])
 
 
-@pytest.mark.parametrize("name", ["k12", "k40", "k130"])
+@pytest.mark.parametrize("name", ["k12", "k40", "k130", "k1031", "k2100"])
 def test_fold_in_matches_reference_run_test(name):
     """llda_foldin (prep4test + run_test on the device) vs the reference's run_test with the keyed draw."""
     from lda_thesis_amd.foldin import fold_in
@@ -232,7 +232,7 @@ def test_fold_in_against_numpy_oracle_on_seeded_inputs():
     import llda_oracle as orc
     from lda_thesis_amd.foldin import fold_in
     rng = np.random.default_rng(5)
-    for K, V in ((7, 40), (64, 90), (200, 60), (512, 50)):
+    for K, V in ((7, 40), (64, 90), (200, 60), (512, 50), (1100, 30), (3003, 24)):     # the last two: wide layouts
         ph = rng.random((K, V)) ** 3
         ph[rng.random((K, V)) < 0.2] = 0.0
         ph /= ph.sum(axis=1, keepdims=True)

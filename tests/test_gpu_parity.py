@@ -156,7 +156,12 @@ def synth(rng, D, V, K, n_lo, n_hi, dense, fmax=3):
                                          (33, True, 150, 200), (60, True, 120, 300), (90, True, 120, 300),
                                          (96, True, 100, 300), (129, True, 100, 300), (190, False, 100, 400),
                                          (256, True, 80, 400), (257, True, 80, 400), (640, True, 50, 500),
-                                         (777, True, 40, 500), (900, True, 40, 500), (968, True, 32, 500)])
+                                         (777, True, 40, 500), (900, True, 40, 500), (968, True, 32, 500),
+                                         # wide layouts: more than 8 pairwise leaves, 2 .. 8 tiers of 64 lanes (the last
+                                         # three need more than 64 KB of LDS per wavefront)
+                                         (969, True, 32, 500), (1500, False, 40, 400), (2047, True, 24, 300),
+                                         (4096, True, 16, 300), (5000, False, 24, 300), (6000, True, 12, 200),
+                                         (7688, True, 12, 200)])
 def test_seeded_inputs_vs_c_oracle(c_oracle, K, dense, D, V):
     """larger seeded inputs: HIP == C oracle (snapshot mode) after 3 sweeps, every integer."""
     from lda_thesis_amd.sampler import GibbsSampler

@@ -82,7 +82,7 @@ def test_wide_vocabulary_tiles():
     """V not a multiple of the 64-word tile, KP not a multiple of 64: every (k, v) written exactly once."""
     from lda_thesis_amd.corpus import synthetic_corpus
     from lda_thesis_amd.sampler import GibbsSampler
-    for K, V in ((12, 1000), (96, 333), (200, 65)):
+    for K, V in ((12, 1000), (96, 333), (200, 65), (1031, 70), (5000, 65), (7688, 40)):      # the last three: wide layouts
         doc_off, word, freq, z = synthetic_corpus(50, 20, V, K, K, "cuda")
         s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, seed=1)
         out = torch.full((K, V), -1.0, dtype=torch.float64, device="cuda")
@@ -91,3 +91,23 @@ def test_wide_vocabulary_tiles():
         np.testing.assert_array_equal(out.cpu().numpy(), want)
         num = s.n_d_k() + np.ones((50, K)) * 0.1
         np.testing.assert_array_equal(s.theta().cpu().numpy(), num / num.sum(axis=1)[:, np.newaxis])
+
+
+def test_perplexity_of_wide_layouts():
+    """llda_loglik on layouts with more than 8 pairwise leaves (one wavefront per document; 128 KB of LDS at K = 7688)
+    against numpy's evaluation of LabeledLDA.py:256-265 on the same counts."""
+    from lda_thesis_amd.corpus import synthetic_corpus
+    from lda_thesis_amd.sampler import GibbsSampler
+    for K, V in ((1100, 60), (7688, 40)):
+        doc_off, word, freq, z = synthetic_corpus(30, 20, V, K, K, "cuda")
+        s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, seed=1)
+        s.sweep()
+        phi = (s.n_k_v() + 0.01) / (s.n_zk()[:, np.newaxis] + V * 0.01)
+        num = s.n_d_k() + 0.1
+        th = num / num.sum(axis=1)[:, np.newaxis]
+        off, w = doc_off.cpu().numpy(), word.cpu().numpy()
+        ll = 0.0
+        for d in range(30):
+            for i in range(off[d], off[d + 1]):
+                ll -= np.log(np.inner(phi[:, w[i]], th[d]))
+        assert abs(s.perplexity() / np.exp(ll / off[-1]) - 1) < 1e-9
