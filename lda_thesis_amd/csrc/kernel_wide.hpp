@@ -76,34 +76,10 @@ __device__ __forceinline__ void wide_div(double *wv, const WideLayout &W, int la
     }
 }
 
-// Keyed categorical draw over the KP probabilities at wv (overwritten by their per-lane prefix sums): the statements of
-// draw_position<> with the G virtual lanes spread over NT tiers.  Returns the position (wave-uniform) or -1.
-__device__ __forceinline__ int wide_draw(double *wv, const WideLayout &W, double u, int lane)
+// Hillis-Steele inclusive scan of the lane totals over the G = 64 * NT virtual lanes: x[gv] <- x[gv - d] + x[gv] for
+// gv >= d, d = 1, 2, 4, ... < G (oracle/llda_oracle.py draw_keyed).  Returns x[G - 1] in every lane.
+__device__ __forceinline__ double wide_scan(double (&X)[WIDE_MAX_TIERS], int NT, int lane)
 {
-    const int T = W.T, G = W.G, NT = W.NT;
-    double X[WIDE_MAX_TIERS];
-    uint32_t pm[WIDE_MAX_TIERS];
-#pragma unroll
-    for (int t = 0; t < WIDE_MAX_TIERS; ++t) {
-        X[t] = 0.0; pm[t] = 0;
-        if (t < NT) {
-            const int gv = t * 64 + lane;
-            double run = 0.0;
-            uint32_t m = 0;
-            for (int c = 0; c < (T >> 2); ++c) {
-                double *p = wv + ((c * G + gv) << 2);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const double v = p[j];
-                    run = (c == 0 && j == 0) ? v : run + v;
-                    p[j] = run;
-                    m |= (v > 0.0 ? 1u : 0u) << (4 * c + j);
-                }
-            }
-            X[t] = run; pm[t] = m;
-        }
-    }
-    // Hillis-Steele inclusive scan over the virtual lanes: x[gv] <- x[gv - d] + x[gv] for gv >= d, d = 1, 2, 4, ... < G
     for (int d = 1; d < 64; d <<= 1) {
         const int src = (lane - d) & 63;
 #pragma unroll
@@ -132,6 +108,45 @@ __device__ __forceinline__ int wide_draw(double *wv, const WideLayout &W, double
 #pragma unroll
     for (int t = 0; t < WIDE_MAX_TIERS; ++t)
         if (t == NT - 1) tot = readlane_f64(X[t], 63);
+    return tot;
+}
+
+// scan value of the virtual lane before this one (0 for virtual lane 0): Xt = this tier's values, Xlow = the tier below
+__device__ __forceinline__ double wide_prev(double Xt, double Xlow, bool has_low, int lane)
+{
+    const double a = __shfl(Xt, (lane - 1) & 63, 64);
+    const double b = has_low ? readlane_f64(Xlow, 63) : 0.0;
+    return lane ? a : b;
+}
+
+// Keyed categorical draw over the KP probabilities at wv (overwritten by their per-lane prefix sums): the statements of
+// draw_position<> with the G virtual lanes spread over NT tiers.  Returns the position (wave-uniform) or -1.
+__device__ __forceinline__ int wide_draw(double *wv, const WideLayout &W, double u, int lane)
+{
+    const int T = W.T, G = W.G, NT = W.NT;
+    double X[WIDE_MAX_TIERS];
+    uint32_t pm[WIDE_MAX_TIERS];
+#pragma unroll
+    for (int t = 0; t < WIDE_MAX_TIERS; ++t) {
+        X[t] = 0.0; pm[t] = 0;
+        if (t < NT) {
+            const int gv = t * 64 + lane;
+            double run = 0.0;
+            uint32_t m = 0;
+            for (int c = 0; c < (T >> 2); ++c) {
+                double *p = wv + ((c * G + gv) << 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double v = p[j];
+                    run = (c == 0 && j == 0) ? v : run + v;
+                    p[j] = run;
+                    m |= (v > 0.0 ? 1u : 0u) << (4 * c + j);
+                }
+            }
+            X[t] = run; pm[t] = m;
+        }
+    }
+    const double tot = wide_scan(X, NT, lane);
     const double tt = u * tot;
     int hit = -1, last = -1;
 #pragma unroll
@@ -174,10 +189,96 @@ __device__ __forceinline__ int wide_topic_of(const int32_t *leaf_start, const in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sweep, wide layouts: LabeledLDA.training_iteration (LabeledLDA.py:101-125), one wavefront per document, every site
-// through the exact pipeline.  LDS per wavefront: KP doubles (scores -> probabilities -> prefix sums), the document's
-// n_dk row and the n_k it sees (int32, position order; lane 0 applies the two +-f of a site).
+// Sweep, wide layouts: LabeledLDA.training_iteration (LabeledLDA.py:101-125), one wavefront per document.
+// LDS per wavefront: KP doubles, the document's n_dk row and the n_k it sees (int32, position order; lane 0 applies the
+// two +-f of a site).
+// TIERED (alpha, beta >= 1e-6, V*beta < 2^40, as for the narrow kernels): the draw is DECIDED from unnormalised fp64 prefix
+// sums with the 2^-40 margin of DESIGN.md 4.3 / 4.7 -- score = fac * (n_kw - own + beta) with fac = (n_dk + alpha) * ~1/(n_k +
+// V*beta) cached per position in the KP doubles (lane 0 refreshes the two positions a site changes), lane totals in a first
+// pass over the row, scan over the virtual lanes, then a second pass that recomputes the prefix and compares it with
+// t -+ margin.  A site with any prefix value inside the margin band (or no hit) goes through the exact pipeline below
+// -- the reference's arithmetic bit for bit -- which borrows the KP doubles; the factors are rebuilt afterwards.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wide_factor(int ndk, int nkc, bool allowed, double alpha, double vbeta)
+{
+    return allowed ? ((double)ndk + alpha) * rcp_newton((double)nkc + vbeta) : 0.0;
+}
+
+__device__ __forceinline__ void wide_factors(double *fac, const int *s_ndk, const int *s_nkc, const uint16_t *mrow,
+                                             const WideLayout &W, double alpha, double vbeta, int lane)
+{
+    for (int q = lane; q < (W.KP >> 2); q += 64) {
+        const int c = q / W.G, gv = q - c * W.G;
+        const uint32_t mask = mrow[gv];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pos = (q << 2) | j;
+            fac[pos] = wide_factor(s_ndk[pos], s_nkc[pos], (mask >> (4 * c + j)) & 1u, alpha, vbeta);
+        }
+    }
+}
+
+// the tier's decision for one site: position, or -1 when the margin cannot decide it
+__device__ __forceinline__ int wide_tier(const double *fac, const int4 *xrow, const WideLayout &W, double u, int zo, int f,
+                                         double beta, double margin_rel, int lane)
+{
+    const int T = W.T, G = W.G, NT = W.NT;
+    double X[WIDE_MAX_TIERS];
+#pragma unroll
+    for (int t = 0; t < WIDE_MAX_TIERS; ++t) {
+        X[t] = 0.0;
+        if (t < NT) {
+            const int gv = t * 64 + lane;
+            double run = 0.0;
+            for (int c = 0; c < (T >> 2); ++c) {
+                const int q = c * G + gv;
+                const int4 x4 = xrow[q];
+                const double *p = fac + (q << 2);
+                const int xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    run = run + p[j] * ((double)(xs[j] - ((((q << 2) | j) == zo) ? f : 0)) + beta);
+            }
+            X[t] = run;
+        }
+    }
+    const double tot = wide_scan(X, NT, lane);
+    const double tt = u * tot, m = margin_rel * tot;
+    int hit = -1;
+    bool unsure = !(tot > 0.0);
+#pragma unroll
+    for (int t = 0; t < WIDE_MAX_TIERS; ++t) {
+        if (t < NT) {
+            const double tg = tt - wide_prev(X[t], X[t > 0 ? t - 1 : 0], t > 0, lane);
+            const double lo = tg - m, hi = tg + m;
+            const int gv = t * 64 + lane;
+            double run = 0.0;
+            uint32_t hm = 0, um = 0;
+            for (int c = 0; c < (T >> 2); ++c) {
+                const int q = c * G + gv;
+                const int4 x4 = xrow[q];
+                const double *p = fac + (q << 2);
+                const int xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    run = run + p[j] * ((double)(xs[j] - ((((q << 2) | j) == zo) ? f : 0)) + beta);
+                    hm |= (run > hi ? 1u : 0u) << (4 * c + j);
+                    um |= ((run > lo && !(run > hi)) ? 1u : 0u) << (4 * c + j);
+                }
+            }
+            const uint64_t bh = __ballot(hm != 0);
+            unsure = unsure || __ballot(um != 0) != 0;
+            if (hit < 0 && bh != 0) {
+                const int sl = (int)__ffsll((unsigned long long)bh) - 1;
+                const int ss = __shfl((int)__ffs((int)(hm | 0x10000u)) - 1, sl, 64);
+                hit = pos_of_rt(G, T, t * 64 + sl, ss);
+            }
+        }
+    }
+    return unsure ? -1 : hit;
+}
+
+template <bool TIERED>
 __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
 {
     extern __shared__ double s_wide[];
@@ -186,6 +287,7 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
     const int lane = threadIdx.x, KP = W.KP, G = W.G, T = W.T, NT = W.NT;
     double *wv = s_wide;
     int *s_ndk = reinterpret_cast<int *>(wv + KP), *s_nkc = s_ndk + KP;
+    int n_exact = 0;
 
     for (int64_t idx = blockIdx.x; idx < K.D; idx += gridDim.x) {
         const int64_t d = K.doc_order ? (int64_t)K.doc_order[idx] : idx;
@@ -198,6 +300,7 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
             reinterpret_cast<int4 *>(s_nkc)[q] = reinterpret_cast<const int4 *>(K.n_k)[q];
         }
         const uint16_t *mrow = K.lab_mask + d * G;
+        if (TIERED) wide_factors(wv, s_ndk, s_nkc, mrow, W, K.alpha, K.vbeta, lane);
         const uint32_t gdoc = (uint32_t)(d + K.doc_base);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
 
@@ -205,40 +308,57 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
             const int64_t i = s0 + n;
             const int v = K.word[i], f = K.freq[i], zo = K.z[i];
             const double u = site_uniform<64>(K, n, n == 0, gdoc, lane, r0, r1, r2, r3);
-            if (lane == 0) { s_ndk[zo] -= f; s_nkc[zo] -= f; }          // remove the site (LabeledLDA.py:109-111)
-            const int4 *xrow = reinterpret_cast<const int4 *>(K.n_kw + (int64_t)v * KP);
-            for (int t = 0; t < NT; ++t) {
-                const int gv = t * 64 + lane;
-                const uint32_t mask = mrow[gv];
-                for (int c = 0; c < (T >> 2); ++c) {
-                    const int q = c * G + gv;
-                    const int4 x4 = xrow[q];
-                    const int4 nd4 = reinterpret_cast<const int4 *>(s_ndk)[q];
-                    const int4 nk4 = reinterpret_cast<const int4 *>(s_nkc)[q];
-                    const int xs[4] = {x4.x, x4.y, x4.z, x4.w}, nds[4] = {nd4.x, nd4.y, nd4.z, nd4.w},
-                              nks[4] = {nk4.x, nk4.y, nk4.z, nk4.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int pos = (q << 2) | j;
-                        const double a = (double)nds[j] + K.alpha;
-                        const double num_b = (double)(xs[j] - (pos == zo ? f : 0)) + K.beta;
-                        const double den_b = (double)nks[j] + K.vbeta;
-                        const double ws = a * (num_b / den_b);               // LabeledLDA.py:113-116
-                        wv[pos] = ((mask >> (4 * c + j)) & 1u) ? ws : 0.0;
-                    }
+            if (lane == 0) {                                                 // remove the site (LabeledLDA.py:109-111)
+                const int nd = s_ndk[zo] - f, nk = s_nkc[zo] - f;
+                s_ndk[zo] = nd; s_nkc[zo] = nk;
+                if (TIERED) {
+                    int g0, sl0;
+                    lane_slot_of_rt(G, T, zo, g0, sl0);
+                    wv[zo] = wide_factor(nd, nk, (mrow[g0] >> sl0) & 1u, K.alpha, K.vbeta);
                 }
             }
-            const double S = wide_sum(wv, W, lane);                          // np.sum(prob)
-            wide_div(wv, W, lane, S, 1.0 / S);                               // prob /= np.sum(prob)
-            int zn = wide_draw(wv, W, u, lane);
-            if (zn < 0 || !(S > 0.0)) {
-                zn = zo;
-                if (lane == 0 && K.status) atomicOr(K.status, 1);            // no topic with positive probability
+            const int4 *xrow = reinterpret_cast<const int4 *>(K.n_kw + (int64_t)v * KP);
+            int zn = -1;
+            if (TIERED) zn = wide_tier(wv, xrow, W, u, zo, f, K.beta, K.margin_rel, lane);
+            const bool exact = zn < 0;
+            if (exact) {
+                ++n_exact;
+                for (int t = 0; t < NT; ++t) {
+                    const int gv = t * 64 + lane;
+                    const uint32_t mask = mrow[gv];
+                    for (int c = 0; c < (T >> 2); ++c) {
+                        const int q = c * G + gv;
+                        const int4 x4 = xrow[q];
+                        const int4 nd4 = reinterpret_cast<const int4 *>(s_ndk)[q];
+                        const int4 nk4 = reinterpret_cast<const int4 *>(s_nkc)[q];
+                        const int xs[4] = {x4.x, x4.y, x4.z, x4.w}, nds[4] = {nd4.x, nd4.y, nd4.z, nd4.w},
+                                  nks[4] = {nk4.x, nk4.y, nk4.z, nk4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int pos = (q << 2) | j;
+                            const double a = (double)nds[j] + K.alpha;
+                            const double num_b = (double)(xs[j] - (pos == zo ? f : 0)) + K.beta;
+                            const double den_b = (double)nks[j] + K.vbeta;
+                            const double ws = a * (num_b / den_b);               // LabeledLDA.py:113-116
+                            wv[pos] = ((mask >> (4 * c + j)) & 1u) ? ws : 0.0;
+                        }
+                    }
+                }
+                const double S = wide_sum(wv, W, lane);                          // np.sum(prob)
+                wide_div(wv, W, lane, S, 1.0 / S);                               // prob /= np.sum(prob)
+                zn = wide_draw(wv, W, u, lane);
+                if (zn < 0 || !(S > 0.0)) {
+                    zn = zo;
+                    if (lane == 0 && K.status) atomicOr(K.status, 1);            // no topic with positive probability
+                }
             }
             if (lane == 0) {                                                 // add the site back (LabeledLDA.py:121-125)
-                s_ndk[zn] += f; s_nkc[zn] += f;
+                const int nd = s_ndk[zn] + f, nk = s_nkc[zn] + f;
+                s_ndk[zn] = nd; s_nkc[zn] = nk;
+                if (TIERED && !exact) wv[zn] = wide_factor(nd, nk, true, K.alpha, K.vbeta);
                 commit_site(K, i, v, f, zo, zn, 0, KP);
             }
+            if (TIERED && exact) wide_factors(wv, s_ndk, s_nkc, mrow, W, K.alpha, K.vbeta, lane);
         }
         for (int q = lane; q < (KP >> 2); q += 64) {
             const int4 old = reinterpret_cast<const int4 *>(ndk_row)[q];
@@ -249,6 +369,10 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
                 if (dl[j]) atomicAdd(K.n_k_delta + ((q << 2) | j), dl[j]);
             reinterpret_cast<int4 *>(ndk_row)[q] = cur;
         }
+    }
+    if (TIERED && n_exact && lane == 0 && K.status) {                        // statistics, as the narrow kernels
+        atomicOr(K.status, 2);
+        atomicAdd(K.status + 2, n_exact);
     }
 }
 

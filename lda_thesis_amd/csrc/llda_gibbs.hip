@@ -453,9 +453,10 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         W.k.site_rec = nullptr; W.k.csc_pos = nullptr; W.k.commit_log = nullptr;
         fill_wide(L, W.w);
         const size_t lds = (size_t)L.KP * 16;               // scores (f64) + n_dk + n_k (int32), per wavefront
-        const int rl = allow_lds(llda_sweep_wide_kernel, lds);
+        const int rl = fast ? allow_lds(llda_sweep_wide_kernel<true>, lds) : allow_lds(llda_sweep_wide_kernel<false>, lds);
         if (rl) return rl;
-        hipLaunchKernelGGL(llda_sweep_wide_kernel, dim3(wide_blocks(a->D)), dim3(64), lds, st, W);
+        if (fast) hipLaunchKernelGGL(llda_sweep_wide_kernel<true>, dim3(wide_blocks(a->D)), dim3(64), lds, st, W);
+        else hipLaunchKernelGGL(llda_sweep_wide_kernel<false>, dim3(wide_blocks(a->D)), dim3(64), lds, st, W);
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? LLDA_OK : hip_fail(e);
     }
