@@ -19,7 +19,9 @@ At N = 1 the same JSON line also carries (key "extra"):
   * "hbm_bound"       a cache-hostile variant (uniform words, V = 500 000: n_kw = 1 GB > the 256 MB Infinity Cache)
                       that shows the genuinely HBM-bound regime of the same kernel;
   * "abstracts"       Labeled LDA on the tokenised abstracts_data.csv fixture (configs[0]/[1]) with its own
-                      cpu_baseline -- the >= 50x target of BASELINE.json's north_star.
+                      cpu_baseline -- the >= 50x target of BASELINE.json's north_star;
+  * "sparse_labels", "cascade", "wide_k2048"   the sparse-label kernel on a big corpus, CascadeLDA's ensemble (configs[4])
+                      and the general path for K > 1024 (one wavefront per document).
 and the roofline of the dominant kernel from HBM-side PMC counters collected IN THIS RUN: the script re-runs itself
 for a few sweeps under `rocprofv3 --kernel-trace --pmc ...` (separate passes for FETCH_SIZE, WRITE_SIZE and the SQ
 group; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction of MI355X_MICROARCH.md).
@@ -65,6 +67,9 @@ WORKLOADS = {
     "synth2_sparse": (125000, 300, 100000, 512, 1.0, 15625,
                       "synthetic 125k docs x 300 tokens, K=512, sparse label mask (root + 7 random labels per doc), "
                       "V=100k (secondary variant of BASELINE configs[3])"),
+    "synth_wide": (20000, 100, 20000, 2048, 1.0, 2500,
+                   "synthetic 20k docs x 100 tokens, K=2048 dense mask, V=20k: a 'wide' layout (16 pairwise leaves -> one "
+                   "wavefront per document, DESIGN 4.7) -- the general path for K beyond the tuned kernels' 1024"),
     # real corpus: tokenised abstracts_data.csv, depth 3 (tests/golden/abstracts_d3.npz); sizes read from the file
     "abstracts": (4171, 0, 0, 392, 0.0, 0,
                   "Labeled LDA on abstracts_data.csv, depth 3, K=392 sparse label masks (BASELINE configs[0]/[1]); "
@@ -526,7 +531,8 @@ def main():
         torch.cuda.empty_cache()
         if extras_on:
             for key, wname, st, wu in (("synth1", "synth1", 200, 5), ("hbm_bound", "synth2_hostile", 40, 3),
-                                       ("sparse_labels", "synth2_sparse", 100, 5), ("abstracts", "abstracts", 3000, 20)):
+                                       ("sparse_labels", "synth2_sparse", 100, 5), ("abstracts", "abstracts", 3000, 20),
+                                       ("wide_k2048", "synth_wide", 20, 2)):
                 s2, i2 = build_sampler(wname, dev, 0, 1, False)
                 torch.cuda.synchronize()
                 dt2, k2 = time_sweeps(s2, st, wu)
@@ -548,6 +554,10 @@ def main():
                     e["algorithmic_GBps"] = algorithmic_bytes(s2.S, i2["docs_local"], i2["live_topics"]) / (k2 * 1e-3) / 1e9
                     e["note"] = ("one lane per allowed topic; every 4-byte gather of n_kw[v, pos] costs a 32-byte sector "
                                  "(263 B fetched per site by the counters, profiles/r01v13_synth2_sparse_*), random labels")
+                if wname == "synth_wide":
+                    e["kernel"] = "wide"
+                    e["note"] = ("general path, not tuned: bound by the latency of one wavefront's dependent chain at 5 "
+                                 "wavefronts per CU (LDS: 32 KB each)")
                 extra[key] = e
                 del s2, i2
                 torch.cuda.empty_cache()
