@@ -115,7 +115,8 @@ typedef struct llda_sweep_args {
     int32_t  debug_margin;       /* 0 in production.  Test hook of the two-tier draw: n > 0 widens the
                                     tier-1 safety margin to 2^-n of the total score (more sites take the
                                     exact tier), -1 sends every site through the exact tier, -2 skips only
-                                    the fp32 tier 0                                                  */
+                                    the fp32 tier 0; -3 (wide layouts only) production margins on the kernel
+                                    that keeps nothing of the row in registers                                    */
     double   alpha, beta;        /* priors (LabeledLDA.py:55-56)                               */
     uint64_t seed;               /* RNG key                                                    */
     uint32_t sweep;              /* RNG counter word 3                                         */

@@ -278,13 +278,49 @@ __device__ __forceinline__ int wide_tier(const double *fac, const int4 *xrow, co
     return unsure ? -1 : hit;
 }
 
+// one site through the reference's fp64 pipeline (LabeledLDA.py:113-119): scores into wv, np.sum, prob /= sum, keyed draw
+__device__ inline int wide_exact_site(double *wv, const int *s_ndk, const int *s_nkc, const uint16_t *mrow, const int4 *xrow,
+                                      const WideLayout &W, const KParams &K, int zo, int f, double u, int lane)
+{
+    const int G = W.G, T = W.T, NT = W.NT;
+    for (int t = 0; t < NT; ++t) {
+        const int gv = t * 64 + lane;
+        const uint32_t mask = mrow[gv];
+        for (int c = 0; c < (T >> 2); ++c) {
+            const int q = c * G + gv;
+            const int4 x4 = xrow[q];
+            const int4 nd4 = reinterpret_cast<const int4 *>(s_ndk)[q];
+            const int4 nk4 = reinterpret_cast<const int4 *>(s_nkc)[q];
+            const int xs[4] = {x4.x, x4.y, x4.z, x4.w}, nds[4] = {nd4.x, nd4.y, nd4.z, nd4.w},
+                      nks[4] = {nk4.x, nk4.y, nk4.z, nk4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pos = (q << 2) | j;
+                const double a = (double)nds[j] + K.alpha;
+                const double num_b = (double)(xs[j] - (pos == zo ? f : 0)) + K.beta;
+                const double den_b = (double)nks[j] + K.vbeta;
+                const double ws = a * (num_b / den_b);               // LabeledLDA.py:113-116
+                wv[pos] = ((mask >> (4 * c + j)) & 1u) ? ws : 0.0;
+            }
+        }
+    }
+    const double S = wide_sum(wv, W, lane);                          // np.sum(prob)
+    wide_div(wv, W, lane, S, 1.0 / S);                               // prob /= np.sum(prob)
+    int zn = wide_draw(wv, W, u, lane);
+    if (zn < 0 || !(S > 0.0)) {
+        zn = zo;
+        if (lane == 0 && K.status) atomicOr(K.status, 1);            // no topic with positive probability
+    }
+    return zn;
+}
+
 template <bool TIERED>
 __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
 {
     extern __shared__ double s_wide[];
     const KParams &K = P.k;
     const WideLayout &W = P.w;
-    const int lane = threadIdx.x, KP = W.KP, G = W.G, T = W.T, NT = W.NT;
+    const int lane = threadIdx.x, KP = W.KP, G = W.G, T = W.T;
     double *wv = s_wide;
     int *s_ndk = reinterpret_cast<int *>(wv + KP), *s_nkc = s_ndk + KP;
     int n_exact = 0;
@@ -323,34 +359,7 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
             const bool exact = zn < 0;
             if (exact) {
                 ++n_exact;
-                for (int t = 0; t < NT; ++t) {
-                    const int gv = t * 64 + lane;
-                    const uint32_t mask = mrow[gv];
-                    for (int c = 0; c < (T >> 2); ++c) {
-                        const int q = c * G + gv;
-                        const int4 x4 = xrow[q];
-                        const int4 nd4 = reinterpret_cast<const int4 *>(s_ndk)[q];
-                        const int4 nk4 = reinterpret_cast<const int4 *>(s_nkc)[q];
-                        const int xs[4] = {x4.x, x4.y, x4.z, x4.w}, nds[4] = {nd4.x, nd4.y, nd4.z, nd4.w},
-                                  nks[4] = {nk4.x, nk4.y, nk4.z, nk4.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int pos = (q << 2) | j;
-                            const double a = (double)nds[j] + K.alpha;
-                            const double num_b = (double)(xs[j] - (pos == zo ? f : 0)) + K.beta;
-                            const double den_b = (double)nks[j] + K.vbeta;
-                            const double ws = a * (num_b / den_b);               // LabeledLDA.py:113-116
-                            wv[pos] = ((mask >> (4 * c + j)) & 1u) ? ws : 0.0;
-                        }
-                    }
-                }
-                const double S = wide_sum(wv, W, lane);                          // np.sum(prob)
-                wide_div(wv, W, lane, S, 1.0 / S);                               // prob /= np.sum(prob)
-                zn = wide_draw(wv, W, u, lane);
-                if (zn < 0 || !(S > 0.0)) {
-                    zn = zo;
-                    if (lane == 0 && K.status) atomicOr(K.status, 1);            // no topic with positive probability
-                }
+                zn = wide_exact_site(wv, s_ndk, s_nkc, mrow, xrow, W, K, zo, f, u, lane);
             }
             if (lane == 0) {                                                 // add the site back (LabeledLDA.py:121-125)
                 const int nd = s_ndk[zn] + f, nk = s_nkc[zn] + f;
@@ -371,6 +380,161 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
         }
     }
     if (TIERED && n_exact && lane == 0 && K.status) {                        // statistics, as the narrow kernels
+        atomicOr(K.status, 2);
+        atomicAdd(K.status + 2, n_exact);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The tiered sweep with the row in registers (NT tiers known at compile time): the row of a site is loaded ONCE into
+// registers and serves both passes of the decision, and the scalars of the next two sites run ahead.  The wide path
+// runs 1 - 5 wavefronts per CU (LDS), so a wavefront owns hundreds of VGPRs; what it lacks is latency hiding (the
+// LDS-only kernel above is one dependent chain word -> row -> pass 1 -> scan -> row again -> pass 2 -> next word).
+// Measured (tools/abl_wide.py): K = 2 048 119 -> 217 M sites/s, K = 4 096 37 -> 64, K = 7 688 11 -> 16.  Also prefetching the
+// row of site n+1 into a second register set was tried and is NOT faster (2 tiers: 210, 8 tiers: 9 -- it spills).
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P)
+{
+    extern __shared__ double s_wide[];
+    const KParams &K = P.k;
+    const WideLayout &W = P.w;
+    const int lane = threadIdx.x, KP = W.KP, T = W.T, TC = W.T >> 2;
+    constexpr int G = 64 * NT;
+    double *wv = s_wide;
+    int *s_ndk = reinterpret_cast<int *>(wv + KP), *s_nkc = s_ndk + KP;
+    int n_exact = 0;
+
+    for (int64_t idx = blockIdx.x; idx < K.D; idx += gridDim.x) {
+        const int64_t d = K.doc_order ? (int64_t)K.doc_order[idx] : idx;
+        const int64_t s0 = K.doc_off[d];
+        const int len = (int)(K.doc_off[d + 1] - s0);
+        if (len <= 0) continue;
+        int32_t *ndk_row = K.n_dk + d * KP;
+        for (int q = lane; q < (KP >> 2); q += 64) {
+            reinterpret_cast<int4 *>(s_ndk)[q] = reinterpret_cast<const int4 *>(ndk_row)[q];
+            reinterpret_cast<int4 *>(s_nkc)[q] = reinterpret_cast<const int4 *>(K.n_k)[q];
+        }
+        const uint16_t *mrow = K.lab_mask + d * G;
+        wide_factors(wv, s_ndk, s_nkc, mrow, W, K.alpha, K.vbeta, lane);
+        const uint32_t gdoc = (uint32_t)(d + K.doc_base);
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+
+        int v_c = K.word[s0], f_c = K.freq[s0], zo_c = K.z[s0];
+        const int64_t i1 = s0 + (len > 1 ? 1 : 0);
+        int v_1 = K.word[i1], f_1 = K.freq[i1], zo_1 = K.z[i1];
+
+        for (int n = 0; n < len; ++n) {
+            const int64_t i = s0 + n;
+            const int v = v_c, f = f_c, zo = zo_c;
+            int x[NT][4][4];
+            {
+                const int4 *row = reinterpret_cast<const int4 *>(K.n_kw + (int64_t)v * KP);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < TC) {
+                            const int4 r = row[c * G + t * 64 + lane];
+                            x[t][c][0] = r.x; x[t][c][1] = r.y; x[t][c][2] = r.z; x[t][c][3] = r.w;
+                        }
+                // scalars of site n+2
+                v_c = v_1; f_c = f_1; zo_c = zo_1;
+                const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);
+                v_1 = K.word[i2]; f_1 = K.freq[i2]; zo_1 = K.z[i2];
+            }
+            const double u = site_uniform<64>(K, n, n == 0, gdoc, lane, r0, r1, r2, r3);
+            if (lane == 0) {                                                 // remove the site (LabeledLDA.py:109-111)
+                const int nd = s_ndk[zo] - f, nk = s_nkc[zo] - f;
+                s_ndk[zo] = nd; s_nkc[zo] = nk;
+                int g0, sl0;
+                lane_slot_of_rt(G, T, zo, g0, sl0);
+                wv[zo] = wide_factor(nd, nk, (mrow[g0] >> sl0) & 1u, K.alpha, K.vbeta);
+            }
+            // own count out of the row: position zo belongs to lane (zo >> 2) & 63, tier ((zo >> 2) % G) >> 6, chunk (zo >> 2) / G
+            {
+                const int qz = zo >> 2, cz = qz / G, gz = qz - cz * G;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < TC) {
+                            const bool mine = (gz == t * 64 + lane) && (cz == c);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) x[t][c][j] -= (mine && (zo & 3) == j) ? f : 0;
+                        }
+            }
+            // pass 1: lane totals
+            double X[WIDE_MAX_TIERS];
+#pragma unroll
+            for (int t = 0; t < WIDE_MAX_TIERS; ++t) X[t] = 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double run = 0.0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < TC) {
+                        const double *p = wv + ((c * G + t * 64 + lane) << 2);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) run = run + p[j] * ((double)x[t][c][j] + K.beta);
+                    }
+                X[t] = run;
+            }
+            const double tot = wide_scan(X, NT, lane);
+            const double tt = u * tot, m = K.margin_rel * tot;
+            int zn = -1;
+            bool unsure = !(tot > 0.0);
+            // pass 2: prefix against t -+ margin
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const double tg = tt - wide_prev(X[t], X[t > 0 ? t - 1 : 0], t > 0, lane);
+                const double lo = tg - m, hi = tg + m;
+                double run = 0.0;
+                uint32_t hm = 0, um = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < TC) {
+                        const double *p = wv + ((c * G + t * 64 + lane) << 2);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            run = run + p[j] * ((double)x[t][c][j] + K.beta);
+                            hm |= (run > hi ? 1u : 0u) << (4 * c + j);
+                            um |= ((run > lo && !(run > hi)) ? 1u : 0u) << (4 * c + j);
+                        }
+                    }
+                const uint64_t bh = __ballot(hm != 0);
+                unsure = unsure || __ballot(um != 0) != 0;
+                if (zn < 0 && bh != 0) {
+                    const int sl = (int)__ffsll((unsigned long long)bh) - 1;
+                    const int ss = __shfl((int)__ffs((int)(hm | 0x10000u)) - 1, sl, 64);
+                    zn = pos_of_rt(G, T, t * 64 + sl, ss);
+                }
+            }
+            const bool exact = unsure || zn < 0;
+            if (__builtin_expect(exact, 0)) {
+                ++n_exact;
+                zn = wide_exact_site(wv, s_ndk, s_nkc, mrow, reinterpret_cast<const int4 *>(K.n_kw + (int64_t)v * KP), W, K,
+                                     zo, f, u, lane);
+            }
+            if (lane == 0) {                                                 // add the site back (LabeledLDA.py:121-125)
+                const int nd = s_ndk[zn] + f, nk = s_nkc[zn] + f;
+                s_ndk[zn] = nd; s_nkc[zn] = nk;
+                if (!exact) wv[zn] = wide_factor(nd, nk, true, K.alpha, K.vbeta);
+                commit_site(K, i, v, f, zo, zn, 0, KP);
+            }
+            if (__builtin_expect(exact, 0)) wide_factors(wv, s_ndk, s_nkc, mrow, W, K.alpha, K.vbeta, lane);
+        }
+        for (int q = lane; q < (KP >> 2); q += 64) {
+            const int4 old = reinterpret_cast<const int4 *>(ndk_row)[q];
+            const int4 cur = reinterpret_cast<const int4 *>(s_ndk)[q];
+            const int dl[4] = {cur.x - old.x, cur.y - old.y, cur.z - old.z, cur.w - old.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (dl[j]) atomicAdd(K.n_k_delta + ((q << 2) | j), dl[j]);
+            reinterpret_cast<int4 *>(ndk_row)[q] = cur;
+        }
+    }
+    if (n_exact && lane == 0 && K.status) {                                  // statistics, as the narrow kernels
         atomicOr(K.status, 2);
         atomicAdd(K.status + 2, n_exact);
     }

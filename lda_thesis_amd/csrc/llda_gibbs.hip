@@ -441,7 +441,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     const bool dense = fast && a->dense_mask != 0 && L.K == L.KP;
     // debug_margin: 0 = production margins; n > 0 = 2^-n (wider: more fallbacks); -1 = always exact tier;
     // -2 = no fp32 tier
-    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
+    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 || a->debug_margin == -3 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
     P.margin0_rel = a->debug_margin == 0 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
     hipStream_t st = (hipStream_t)stream;
 
@@ -453,10 +453,30 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         W.k.site_rec = nullptr; W.k.csc_pos = nullptr; W.k.commit_log = nullptr;
         fill_wide(L, W.w);
         const size_t lds = (size_t)L.KP * 16;               // scores (f64) + n_dk + n_k (int32), per wavefront
-        const int rl = fast ? allow_lds(llda_sweep_wide_kernel<true>, lds) : allow_lds(llda_sweep_wide_kernel<false>, lds);
-        if (rl) return rl;
-        if (fast) hipLaunchKernelGGL(llda_sweep_wide_kernel<true>, dim3(wide_blocks(a->D)), dim3(64), lds, st, W);
-        else hipLaunchKernelGGL(llda_sweep_wide_kernel<false>, dim3(wide_blocks(a->D)), dim3(64), lds, st, W);
+        const dim3 grid(wide_blocks(a->D)), block(64);
+        int rl = LLDA_OK;
+#define LLDA_WIDE_REG(NT_)                                                                                   \
+    case NT_:                                                                                                \
+        rl = allow_lds(llda_sweep_wide_reg_kernel<NT_>, lds);                                                \
+        if (rl) return rl;                                                                                   \
+        hipLaunchKernelGGL(llda_sweep_wide_reg_kernel<NT_>, grid, block, lds, st, W);                        \
+        break;
+        if (fast && a->debug_margin != -3) {                // the tiered kernel with the row in registers
+            switch (L.tiers) {
+                LLDA_WIDE_REG(2) LLDA_WIDE_REG(3) LLDA_WIDE_REG(4) LLDA_WIDE_REG(5) LLDA_WIDE_REG(6) LLDA_WIDE_REG(7)
+                LLDA_WIDE_REG(8)
+            default: return LLDA_E_BAD_K;
+            }
+        } else if (fast) {                                  // (debug_margin -3: the same decision on the LDS-only kernel)
+            rl = allow_lds(llda_sweep_wide_kernel<true>, lds);
+            if (rl) return rl;
+            hipLaunchKernelGGL(llda_sweep_wide_kernel<true>, grid, block, lds, st, W);
+        } else {                                            // tiny priors: every site through the exact pipeline
+            rl = allow_lds(llda_sweep_wide_kernel<false>, lds);
+            if (rl) return rl;
+            hipLaunchKernelGGL(llda_sweep_wide_kernel<false>, grid, block, lds, st, W);
+        }
+#undef LLDA_WIDE_REG
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? LLDA_OK : hip_fail(e);
     }

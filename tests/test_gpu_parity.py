@@ -35,6 +35,32 @@ def test_sweeps_match_reference_o3(name, margin):
     s.check_status()
 
 
+@pytest.mark.parametrize("name", [n for n in TINY if int(n.split("k")[-1].rstrip("dense")) > 1024])
+def test_wide_layout_kernels_agree_with_reference(c_oracle, name):
+    """wide layouts (more than 8 pairwise leaves): the LDS-only tiered kernel (debug_margin -3; production runs the one that
+    keeps the row in registers) and the all-exact kernel that tiny priors select -- the fixtures' priors are not tiny, so
+    the latter is checked against the C oracle on the fixture's corpus with alpha = beta = 1e-9."""
+    from lda_thesis_amd.sampler import GibbsSampler
+    g = load_golden(name)
+    s = make_sampler(g)
+    assert s.layout.wide
+    s.debug_margin = -3
+    for i in range(int(g["sweeps"])):
+        s.sweep()
+        assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics(), name)
+    s.check_status()
+    K, V = int(g["K"]), int(g["V"])
+    t = GibbsSampler(g["doc_off"], g["word"], g["freq"], g["init_z"], K, V, 1e-9, 1e-9, labs=g["labs"], seed=5)
+    cs = c_oracle.CState(g["doc_off"], g["word"], g["freq"], g["init_z"], g["labs"], t.n_d_k(), t.n_k_v(), t.n_zk(), V,
+                         1e-9, 1e-9)
+    for i in range(2):
+        t.sweep()
+        cs.sweep(1, 5, i, threads=2)
+        np.testing.assert_array_equal(t.z_topics(), cs.z)
+        np.testing.assert_array_equal(t.n_k_v(), cs.n_k_v)
+    t.check_status()
+
+
 @pytest.mark.parametrize("commit", ["atomics", "log_items_of_16", "log_items_of_3"])
 @pytest.mark.parametrize("name", TINY + ["sublda"])
 def test_commit_paths_agree(name, commit, monkeypatch):
