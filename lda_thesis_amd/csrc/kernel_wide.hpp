@@ -199,6 +199,14 @@ __device__ __forceinline__ int wide_topic_of(const int32_t *leaf_start, const in
 // t -+ margin.  A site with any prefix value inside the margin band (or no hit) goes through the exact pipeline below
 // -- the reference's arithmetic bit for bit -- which borrows the KP doubles; the factors are rebuilt afterwards.
 // ---------------------------------------------------------------------------------------------
+// Where the cached factor of a position lives in the KP doubles: slot-of-chunk major, [pos & 3][pos >> 2], so that the 64
+// lanes of a pass read 64 consecutive doubles (position order -- a lane's four doubles side by side, lanes 32 bytes
+// apart -- made two thirds of the LDS cycles bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.65).
+__device__ __forceinline__ int fac_index(int pos, int KP4)
+{
+    return (pos & 3) * KP4 + (pos >> 2);
+}
+
 __device__ __forceinline__ double wide_factor(int ndk, int nkc, bool allowed, double alpha, double vbeta)
 {
     return allowed ? ((double)ndk + alpha) * rcp_newton((double)nkc + vbeta) : 0.0;
@@ -213,7 +221,7 @@ __device__ __forceinline__ void wide_factors(double *fac, const int *s_ndk, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int pos = (q << 2) | j;
-            fac[pos] = wide_factor(s_ndk[pos], s_nkc[pos], (mask >> (4 * c + j)) & 1u, alpha, vbeta);
+            fac[j * (W.KP >> 2) + q] = wide_factor(s_ndk[pos], s_nkc[pos], (mask >> (4 * c + j)) & 1u, alpha, vbeta);
         }
     }
 }
@@ -222,7 +230,7 @@ __device__ __forceinline__ void wide_factors(double *fac, const int *s_ndk, cons
 __device__ __forceinline__ int wide_tier(const double *fac, const int4 *xrow, const WideLayout &W, double u, int zo, int f,
                                          double beta, double margin_rel, int lane)
 {
-    const int T = W.T, G = W.G, NT = W.NT;
+    const int T = W.T, G = W.G, NT = W.NT, KP4 = W.KP >> 2;
     double X[WIDE_MAX_TIERS];
 #pragma unroll
     for (int t = 0; t < WIDE_MAX_TIERS; ++t) {
@@ -233,11 +241,11 @@ __device__ __forceinline__ int wide_tier(const double *fac, const int4 *xrow, co
             for (int c = 0; c < (T >> 2); ++c) {
                 const int q = c * G + gv;
                 const int4 x4 = xrow[q];
-                const double *p = fac + (q << 2);
+                const double *p = fac + q;
                 const int xs[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    run = run + p[j] * ((double)(xs[j] - ((((q << 2) | j) == zo) ? f : 0)) + beta);
+                    run = run + p[j * KP4] * ((double)(xs[j] - ((((q << 2) | j) == zo) ? f : 0)) + beta);
             }
             X[t] = run;
         }
@@ -257,11 +265,11 @@ __device__ __forceinline__ int wide_tier(const double *fac, const int4 *xrow, co
             for (int c = 0; c < (T >> 2); ++c) {
                 const int q = c * G + gv;
                 const int4 x4 = xrow[q];
-                const double *p = fac + (q << 2);
+                const double *p = fac + q;
                 const int xs[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    run = run + p[j] * ((double)(xs[j] - ((((q << 2) | j) == zo) ? f : 0)) + beta);
+                    run = run + p[j * KP4] * ((double)(xs[j] - ((((q << 2) | j) == zo) ? f : 0)) + beta);
                     hm |= (run > hi ? 1u : 0u) << (4 * c + j);
                     um |= ((run > lo && !(run > hi)) ? 1u : 0u) << (4 * c + j);
                 }
@@ -320,7 +328,7 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
     extern __shared__ double s_wide[];
     const KParams &K = P.k;
     const WideLayout &W = P.w;
-    const int lane = threadIdx.x, KP = W.KP, G = W.G, T = W.T;
+    const int lane = threadIdx.x, KP = W.KP, G = W.G;
     double *wv = s_wide;
     int *s_ndk = reinterpret_cast<int *>(wv + KP), *s_nkc = s_ndk + KP;
     int n_exact = 0;
@@ -347,11 +355,8 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
             if (lane == 0) {                                                 // remove the site (LabeledLDA.py:109-111)
                 const int nd = s_ndk[zo] - f, nk = s_nkc[zo] - f;
                 s_ndk[zo] = nd; s_nkc[zo] = nk;
-                if (TIERED) {
-                    int g0, sl0;
-                    lane_slot_of_rt(G, T, zo, g0, sl0);
-                    wv[zo] = wide_factor(nd, nk, (mrow[g0] >> sl0) & 1u, K.alpha, K.vbeta);
-                }
+                if (TIERED) wv[fac_index(zo, KP >> 2)] = wide_factor(nd, nk, wv[fac_index(zo, KP >> 2)] != 0.0, K.alpha, K.vbeta);   // (a cached factor is 0 exactly
+                                                                                             // where the label mask is)
             }
             const int4 *xrow = reinterpret_cast<const int4 *>(K.n_kw + (int64_t)v * KP);
             int zn = -1;
@@ -364,7 +369,7 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
             if (lane == 0) {                                                 // add the site back (LabeledLDA.py:121-125)
                 const int nd = s_ndk[zn] + f, nk = s_nkc[zn] + f;
                 s_ndk[zn] = nd; s_nkc[zn] = nk;
-                if (TIERED && !exact) wv[zn] = wide_factor(nd, nk, true, K.alpha, K.vbeta);
+                if (TIERED && !exact) wv[fac_index(zn, KP >> 2)] = wide_factor(nd, nk, true, K.alpha, K.vbeta);
                 commit_site(K, i, v, f, zo, zn, 0, KP);
             }
             if (TIERED && exact) wide_factors(wv, s_ndk, s_nkc, mrow, W, K.alpha, K.vbeta, lane);
@@ -399,7 +404,7 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
     extern __shared__ double s_wide[];
     const KParams &K = P.k;
     const WideLayout &W = P.w;
-    const int lane = threadIdx.x, KP = W.KP, T = W.T, TC = W.T >> 2;
+    const int lane = threadIdx.x, KP = W.KP, KP4 = W.KP >> 2, T = W.T, TC = W.T >> 2;
     constexpr int G = 64 * NT;
     double *wv = s_wide;
     int *s_ndk = reinterpret_cast<int *>(wv + KP), *s_nkc = s_ndk + KP;
@@ -447,9 +452,8 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
             if (lane == 0) {                                                 // remove the site (LabeledLDA.py:109-111)
                 const int nd = s_ndk[zo] - f, nk = s_nkc[zo] - f;
                 s_ndk[zo] = nd; s_nkc[zo] = nk;
-                int g0, sl0;
-                lane_slot_of_rt(G, T, zo, g0, sl0);
-                wv[zo] = wide_factor(nd, nk, (mrow[g0] >> sl0) & 1u, K.alpha, K.vbeta);
+                wv[fac_index(zo, KP >> 2)] = wide_factor(nd, nk, wv[fac_index(zo, KP >> 2)] != 0.0, K.alpha, K.vbeta);     // (a cached factor is 0 exactly where the
+                                                                                   // label mask is: no mask load per site)
             }
             // own count out of the row: position zo belongs to lane (zo >> 2) & 63, tier ((zo >> 2) % G) >> 6, chunk (zo >> 2) / G
             {
@@ -474,9 +478,9 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (c < TC) {
-                        const double *p = wv + ((c * G + t * 64 + lane) << 2);
+                        const double *p = wv + (c * G + t * 64 + lane);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) run = run + p[j] * ((double)x[t][c][j] + K.beta);
+                        for (int j = 0; j < 4; ++j) run = run + p[j * KP4] * ((double)x[t][c][j] + K.beta);
                     }
                 X[t] = run;
             }
@@ -494,10 +498,10 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (c < TC) {
-                        const double *p = wv + ((c * G + t * 64 + lane) << 2);
+                        const double *p = wv + (c * G + t * 64 + lane);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            run = run + p[j] * ((double)x[t][c][j] + K.beta);
+                            run = run + p[j * KP4] * ((double)x[t][c][j] + K.beta);
                             hm |= (run > hi ? 1u : 0u) << (4 * c + j);
                             um |= ((run > lo && !(run > hi)) ? 1u : 0u) << (4 * c + j);
                         }
@@ -519,7 +523,7 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
             if (lane == 0) {                                                 // add the site back (LabeledLDA.py:121-125)
                 const int nd = s_ndk[zn] + f, nk = s_nkc[zn] + f;
                 s_ndk[zn] = nd; s_nkc[zn] = nk;
-                if (!exact) wv[zn] = wide_factor(nd, nk, true, K.alpha, K.vbeta);
+                if (!exact) wv[fac_index(zn, KP >> 2)] = wide_factor(nd, nk, true, K.alpha, K.vbeta);
                 commit_site(K, i, v, f, zo, zn, 0, KP);
             }
             if (__builtin_expect(exact, 0)) wide_factors(wv, s_ndk, s_nkc, mrow, W, K.alpha, K.vbeta, lane);
