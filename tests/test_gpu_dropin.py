@@ -346,6 +346,35 @@ def test_cascade_fold_in_against_numpy_oracle():
         np.testing.assert_array_equal(flat["th_hat"], want)
 
 
+def test_cascade_fold_in_wide_layout():
+    """the same two samplers on a label subset with more than 8 pairwise leaves (wide fold-in kernels: beta fallback,
+    both averaging formulas, per-document RNG ids)."""
+    import llda_oracle as orc
+    from lda_thesis_amd.foldin import cascade_fold_in
+    rng = np.random.default_rng(12)
+    K, V = 1031, 16
+    ph = rng.random((K, V))
+    ph[rng.random((K, V)) < 0.7] = 0.0
+    ph[:, 0] += 1e-3                                # (no all-zero row)
+    ph[:, 3] = 0.0                                  # a word no topic loads on: the beta fallback
+    ph /= ph.sum(axis=1, keepdims=True)
+    tups = [[(1, 2), (3, 1), (7, 1)], [(3, 2)], [(0, 1), (2, 1), (3, 1), (9, 3), (15, 1)]]
+    got = cascade_fold_in(ph, 0.2, 0.01, tups, 3, 1, 77, 4242, np.arange(3) + 5)
+    for d, tup in enumerate(tups):
+        ids, fr = zip(*tup)
+        def draw_for_sweep(sw, d=d):
+            k = orc.KeyedDraw(77, 4242)
+            k.sweep, k.doc, k.site = sw, d + 5, 0
+            return k
+        want = orc.cascade_test(ph, 0.2, 0.01, list(ids), list(fr), 3, 1, draw_for_sweep)
+        np.testing.assert_array_equal(got["th_hat"][d], want, err_msg="doc %d" % d)
+    tups = [[(v, f) for v, f in t if v != 3] for t in tups if t != [(3, 2)]]     # (run_test has no fallback: 0/0 raises)
+    flat = cascade_fold_in(ph, 0.2, 0.01, tups, 4, 2, 77, 999, np.arange(2), flat=True)
+    want = orc.cascade_run_test(ph, 0.2, 0.01, [[v for v, _ in t] for t in tups], [[f for _, f in t] for t in tups],
+                                4, 2, orc.keyed_draw_for(77, 999))
+    np.testing.assert_array_equal(flat["th_hat"], want)
+
+
 def _write_csv(path, n=120, seed=3):
     rng = np.random.default_rng(seed)
     codes = ["A11", "A12", "A21", "B11", "B21", "B22", "C31"]
