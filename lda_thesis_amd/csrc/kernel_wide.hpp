@@ -1,5 +1,6 @@
 // kernel_wide.hpp -- "wide" layouts: K with more than 8 pairwise leaves (some K in 969..1023, every K > 1024, up to
-// LLDA_MAX_K): llda_sweep_wide_kernel, llda_loglik_wide_kernel, llda_readout_theta_wide_kernel, llda_foldin_wide_kernel
+// LLDA_MAX_K): llda_sweep_wide_reg_kernel / llda_sweep_wide_kernel, llda_loglik_wide_kernel,
+// llda_readout_theta_wide_kernel, llda_foldin_init_wide_kernel / llda_foldin_wide_kernel
 // Part of the single translation unit llda_gibbs.hip (included in order; see the contents list there).
 #pragma once
 
@@ -10,9 +11,11 @@ namespace {
 // one document and its 64 lanes play G = 64 * NT VIRTUAL lanes, tier by tier: virtual lane gv = 64 * tier + lane, the
 // same position formula pos = ((s >> 2) * G + gv) * 4 + (s & 3) with the larger G (so every 16-byte chunk of the row is
 // still read as one contiguous run per tier), the same (virtual lane, slot) draw order, and the Hillis-Steele scan of
-// the keyed draw over all G virtual lanes (oracle/llda_oracle.py draw_keyed).  Everything is a run-time loop (NT, T from
-// the kernel arguments): this is the GENERAL path -- every site through the reference's exact fp64 pipeline, per-topic
-// scores staged in LDS in position order -- not a tuned one; none of the five BASELINE configs needs it.
+// the keyed draw over all G virtual lanes (oracle/llda_oracle.py draw_keyed).  The exact pipeline (wide_sum, wide_div,
+// wide_draw: run-time loops over NT and T, per-topic values staged in LDS in position order) is what the read-outs, the
+// fold-in and the undecided sites of the sweep run; the sweep itself decides almost every site from unnormalised fp64
+// prefix sums with the 2^-40 margin.  This is the GENERAL path: correct for every K, two to three
+// orders of magnitude faster than a CPU core, not tuned to a roofline; none of the five BASELINE configs needs it.
 struct WideLayout {
     int32_t NT, T, G, KP;              // tiers, slots per virtual lane (8 / 12 / 16), 64 * NT, G * T
     int32_t m, last_leaf, tail, tail_row;
