@@ -556,8 +556,8 @@ def main():
                                  "(263 B fetched per site by the counters, profiles/r01v13_synth2_sparse_*), random labels")
                 if wname == "synth_wide":
                     e["kernel"] = "wide"
-                    e["note"] = ("general path: bound by the latency of one wavefront's dependent chain at 5 wavefronts per CU "
-                                 "(LDS: 32 KB each); SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.5, VALU 22 % busy")
+                    e["note"] = ("general path: bound by the latency of one wavefront's dependent chain at 8 wavefronts per CU "
+                                 "(LDS: 20 KB each -- cached factors + int16 count changes)")
                 extra[key] = e
                 del s2, i2
                 torch.cuda.empty_cache()

@@ -116,7 +116,8 @@ typedef struct llda_sweep_args {
                                     tier-1 safety margin to 2^-n of the total score (more sites take the
                                     exact tier), -1 sends every site through the exact tier, -2 skips only
                                     the fp32 tier 0; -3 (wide layouts only) production margins on the kernel
-                                    that keeps nothing of the row in registers                                    */
+                                    that keeps nothing of the row in registers, -4 on the register kernel with
+                                    LDS copies of the counts whatever max_doc_tokens says                                    */
     double   alpha, beta;        /* priors (LabeledLDA.py:55-56)                               */
     uint64_t seed;               /* RNG key                                                    */
     uint32_t sweep;              /* RNG counter word 3                                         */
@@ -148,6 +149,10 @@ typedef struct llda_sweep_args {
                                     every scalar load touches that many cache lines, which makes the vector-memory
                                     address pipeline the bound.  A call that passes it with such a layout may span at
                                     most 2^28 - 1 sites. */
+    int32_t  max_doc_tokens;     /* (ABI 13) optional hint, 0 = unknown: an upper bound of the tokens (sum of freq) of any
+                                    document of the call.  Wide layouts only: below 32 768 the kernel keeps the document's
+                                    count CHANGES as int16 in LDS instead of copies of the counts (more wavefronts per CU) */
+    int32_t  reserved2;
 } llda_sweep_args;
 
 /* ---- host-only (no device needed) ---- */

@@ -54,7 +54,7 @@ class LldaSweepArgs(ctypes.Structure):
                 ("stream_id", _c_u32), ("doc_base", _c_i64),
                 ("live_off", _c_p), ("live_pos", _c_p), ("resume", _c_p), ("resume_count", _c_p),
                 ("resume_cap", _c_i32), ("live_max", _c_i32), ("csc_pos", _c_p), ("commit_log", _c_p),
-                ("n_sites", _c_i64), ("site_rec", _c_p)]
+                ("n_sites", _c_i64), ("site_rec", _c_p), ("max_doc_tokens", _c_i32), ("reserved2", _c_i32)]
 
 
 class LldaBatchArgs(ctypes.Structure):
@@ -175,7 +175,7 @@ def _launch(ref, fn, what, *args):
 def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
           status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
           dense_mask=False, debug_margin=0, live_off=None, live_pos=None, live_max=0, csc_pos=None, commit_log=None,
-          n_sites=None, site_rec=None):
+          n_sites=None, site_rec=None, max_doc_tokens=0):
     """llda_sweep on the current torch stream.  All array arguments are torch CUDA tensors.  n_sites = the sites
     the D documents span (default: all of ``word``)."""
     a = LldaSweepArgs(_ptr(doc_off), _ptr(doc_order), _ptr(word), _ptr(freq), _ptr(z), _ptr(lab_mask),
@@ -185,7 +185,8 @@ def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta
                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(sweep) & 0xFFFFFFFF,
                       int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), None, None, 0,
                       int(live_max),
-                      _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites), _ptr(site_rec))
+                      _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites), _ptr(site_rec),
+                      int(max_doc_tokens), 0)
     _launch(z, lib().llda_sweep, "llda_sweep", ctypes.byref(a))
 
 

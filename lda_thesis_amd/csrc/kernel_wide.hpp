@@ -215,8 +215,9 @@ __device__ __forceinline__ double wide_factor(int ndk, int nkc, bool allowed, do
     return allowed ? ((double)ndk + alpha) * rcp_newton((double)nkc + vbeta) : 0.0;
 }
 
-__device__ __forceinline__ void wide_factors(double *fac, const int *s_ndk, const int *s_nkc, const uint16_t *mrow,
-                                             const WideLayout &W, double alpha, double vbeta, int lane)
+// (dk: optional per-position change of the document against the start values at s_ndk / s_nkc, see the COMPACT kernel)
+__device__ __forceinline__ void wide_factors(double *fac, const int *s_ndk, const int *s_nkc, const int16_t *dk,
+                                             const uint16_t *mrow, const WideLayout &W, double alpha, double vbeta, int lane)
 {
     for (int q = lane; q < (W.KP >> 2); q += 64) {
         const int c = q / W.G, gv = q - c * W.G;
@@ -224,7 +225,8 @@ __device__ __forceinline__ void wide_factors(double *fac, const int *s_ndk, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int pos = (q << 2) | j;
-            fac[j * (W.KP >> 2) + q] = wide_factor(s_ndk[pos], s_nkc[pos], (mask >> (4 * c + j)) & 1u, alpha, vbeta);
+            const int d = dk ? (int)dk[pos] : 0;
+            fac[j * (W.KP >> 2) + q] = wide_factor(s_ndk[pos] + d, s_nkc[pos] + d, (mask >> (4 * c + j)) & 1u, alpha, vbeta);
         }
     }
 }
@@ -290,8 +292,8 @@ __device__ __forceinline__ int wide_tier(const double *fac, const int4 *xrow, co
 }
 
 // one site through the reference's fp64 pipeline (LabeledLDA.py:113-119): scores into wv, np.sum, prob /= sum, keyed draw
-__device__ inline int wide_exact_site(double *wv, const int *s_ndk, const int *s_nkc, const uint16_t *mrow, const int4 *xrow,
-                                      const WideLayout &W, const KParams &K, int zo, int f, double u, int lane)
+__device__ inline int wide_exact_site(double *wv, const int *s_ndk, const int *s_nkc, const int16_t *dk, const uint16_t *mrow,
+                                      const int4 *xrow, const WideLayout &W, const KParams &K, int zo, int f, double u, int lane)
 {
     const int G = W.G, T = W.T, NT = W.NT;
     for (int t = 0; t < NT; ++t) {
@@ -307,9 +309,10 @@ __device__ inline int wide_exact_site(double *wv, const int *s_ndk, const int *s
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int pos = (q << 2) | j;
-                const double a = (double)nds[j] + K.alpha;
+                const int d = dk ? (int)dk[pos] : 0;
+                const double a = (double)(nds[j] + d) + K.alpha;
                 const double num_b = (double)(xs[j] - (pos == zo ? f : 0)) + K.beta;
-                const double den_b = (double)nks[j] + K.vbeta;
+                const double den_b = (double)(nks[j] + d) + K.vbeta;
                 const double ws = a * (num_b / den_b);               // LabeledLDA.py:113-116
                 wv[pos] = ((mask >> (4 * c + j)) & 1u) ? ws : 0.0;
             }
@@ -347,7 +350,7 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
             reinterpret_cast<int4 *>(s_nkc)[q] = reinterpret_cast<const int4 *>(K.n_k)[q];
         }
         const uint16_t *mrow = K.lab_mask + d * G;
-        if (TIERED) wide_factors(wv, s_ndk, s_nkc, mrow, W, K.alpha, K.vbeta, lane);
+        if (TIERED) wide_factors(wv, s_ndk, s_nkc, nullptr, mrow, W, K.alpha, K.vbeta, lane);
         const uint32_t gdoc = (uint32_t)(d + K.doc_base);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
 
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
             const bool exact = zn < 0;
             if (exact) {
                 ++n_exact;
-                zn = wide_exact_site(wv, s_ndk, s_nkc, mrow, xrow, W, K, zo, f, u, lane);
+                zn = wide_exact_site(wv, s_ndk, s_nkc, nullptr, mrow, xrow, W, K, zo, f, u, lane);
             }
             if (lane == 0) {                                                 // add the site back (LabeledLDA.py:121-125)
                 const int nd = s_ndk[zn] + f, nk = s_nkc[zn] + f;
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
                 if (TIERED && !exact) wv[fac_index(zn, KP >> 2)] = wide_factor(nd, nk, true, K.alpha, K.vbeta);
                 commit_site(K, i, v, f, zo, zn, 0, KP);
             }
-            if (TIERED && exact) wide_factors(wv, s_ndk, s_nkc, mrow, W, K.alpha, K.vbeta, lane);
+            if (TIERED && exact) wide_factors(wv, s_ndk, s_nkc, nullptr, mrow, W, K.alpha, K.vbeta, lane);
         }
         for (int q = lane; q < (KP >> 2); q += 64) {
             const int4 old = reinterpret_cast<const int4 *>(ndk_row)[q];
@@ -401,7 +404,13 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
 // Measured (tools/abl_wide.py): K = 2 048 119 -> 217 M sites/s, K = 4 096 37 -> 64, K = 7 688 11 -> 16.  Also prefetching the
 // row of site n+1 into a second register set was tried and is NOT faster (2 tiers: 210, 8 tiers: 9 -- it spills).
 // ---------------------------------------------------------------------------------------------
-template <int NT>
+// COMPACT (the caller vouches that no document holds 32 768 tokens or more, llda_sweep_args.max_doc_tokens): the
+// document's counts are not copied to LDS at all -- they are the start values in HBM (its n_dk row, n_k: both constant
+// while the document is sampled) plus ONE int16 change per position in LDS (a topic of the document changes n_dk and the
+// n_k it sees by the same amount).  10 bytes of LDS per position instead of 16: 8 wavefronts per CU instead of 5 at K = 2 048,
+// 4 instead of 2 at K = 4 096, 2 instead of 1 at K = 7 688 -- and this path is bound by exactly that.  Lane 0 fetches the two
+// start values of the old topic one site ahead and those of the new topic after the draw (L2 hits).
+template <int NT, bool COMPACT>
 __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P)
 {
     extern __shared__ double s_wide[];
@@ -410,7 +419,8 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
     const int lane = threadIdx.x, KP = W.KP, KP4 = W.KP >> 2, T = W.T, TC = W.T >> 2;
     constexpr int G = 64 * NT;
     double *wv = s_wide;
-    int *s_ndk = reinterpret_cast<int *>(wv + KP), *s_nkc = s_ndk + KP;
+    int *s_ndk = reinterpret_cast<int *>(wv + KP), *s_nkc = s_ndk + KP;          // (!COMPACT)
+    int16_t *s_dk = reinterpret_cast<int16_t *>(wv + KP);                        // (COMPACT)
     int n_exact = 0;
 
     for (int64_t idx = blockIdx.x; idx < K.D; idx += gridDim.x) {
@@ -420,21 +430,30 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
         if (len <= 0) continue;
         int32_t *ndk_row = K.n_dk + d * KP;
         for (int q = lane; q < (KP >> 2); q += 64) {
-            reinterpret_cast<int4 *>(s_ndk)[q] = reinterpret_cast<const int4 *>(ndk_row)[q];
-            reinterpret_cast<int4 *>(s_nkc)[q] = reinterpret_cast<const int4 *>(K.n_k)[q];
+            if (COMPACT) {
+                reinterpret_cast<int2 *>(s_dk)[q] = make_int2(0, 0);
+            } else {
+                reinterpret_cast<int4 *>(s_ndk)[q] = reinterpret_cast<const int4 *>(ndk_row)[q];
+                reinterpret_cast<int4 *>(s_nkc)[q] = reinterpret_cast<const int4 *>(K.n_k)[q];
+            }
         }
+        // where the counts are read: start values (HBM) + change (LDS), or the LDS copies
+        const int *c_ndk = COMPACT ? ndk_row : s_ndk, *c_nk = COMPACT ? K.n_k : s_nkc;
+        const int16_t *c_dk = COMPACT ? s_dk : nullptr;
         const uint16_t *mrow = K.lab_mask + d * G;
-        wide_factors(wv, s_ndk, s_nkc, mrow, W, K.alpha, K.vbeta, lane);
+        wide_factors(wv, c_ndk, c_nk, c_dk, mrow, W, K.alpha, K.vbeta, lane);
         const uint32_t gdoc = (uint32_t)(d + K.doc_base);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
 
         int v_c = K.word[s0], f_c = K.freq[s0], zo_c = K.z[s0];
         const int64_t i1 = s0 + (len > 1 ? 1 : 0);
         int v_1 = K.word[i1], f_1 = K.freq[i1], zo_1 = K.z[i1];
+        int nd0_c = 0, nk0_c = 0;                                                // COMPACT: start counts of the old topic
+        if (COMPACT) { nd0_c = ndk_row[zo_c]; nk0_c = K.n_k[zo_c]; }
 
         for (int n = 0; n < len; ++n) {
             const int64_t i = s0 + n;
-            const int v = v_c, f = f_c, zo = zo_c;
+            const int v = v_c, f = f_c, zo = zo_c, nd0 = nd0_c, nk0 = nk0_c;
             int x[NT][4][4];
             {
                 const int4 *row = reinterpret_cast<const int4 *>(K.n_kw + (int64_t)v * KP);
@@ -448,13 +467,21 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
                         }
                 // scalars of site n+2
                 v_c = v_1; f_c = f_1; zo_c = zo_1;
+                if (COMPACT) { nd0_c = ndk_row[zo_c]; nk0_c = K.n_k[zo_c]; }     // (for site n+1; zo_c arrived a site ago)
                 const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);
                 v_1 = K.word[i2]; f_1 = K.freq[i2]; zo_1 = K.z[i2];
             }
             const double u = site_uniform<64>(K, n, n == 0, gdoc, lane, r0, r1, r2, r3);
             if (lane == 0) {                                                 // remove the site (LabeledLDA.py:109-111)
-                const int nd = s_ndk[zo] - f, nk = s_nkc[zo] - f;
-                s_ndk[zo] = nd; s_nkc[zo] = nk;
+                int nd, nk;
+                if (COMPACT) {
+                    const int dz = (int)s_dk[zo] - f;
+                    s_dk[zo] = (int16_t)dz;
+                    nd = nd0 + dz; nk = nk0 + dz;
+                } else {
+                    nd = s_ndk[zo] - f; nk = s_nkc[zo] - f;
+                    s_ndk[zo] = nd; s_nkc[zo] = nk;
+                }
                 wv[fac_index(zo, KP >> 2)] = wide_factor(nd, nk, wv[fac_index(zo, KP >> 2)] != 0.0, K.alpha, K.vbeta);     // (a cached factor is 0 exactly where the
                                                                                    // label mask is: no mask load per site)
             }
@@ -520,25 +547,45 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
             const bool exact = unsure || zn < 0;
             if (__builtin_expect(exact, 0)) {
                 ++n_exact;
-                zn = wide_exact_site(wv, s_ndk, s_nkc, mrow, reinterpret_cast<const int4 *>(K.n_kw + (int64_t)v * KP), W, K,
+                zn = wide_exact_site(wv, c_ndk, c_nk, c_dk, mrow, reinterpret_cast<const int4 *>(K.n_kw + (int64_t)v * KP), W, K,
                                      zo, f, u, lane);
             }
             if (lane == 0) {                                                 // add the site back (LabeledLDA.py:121-125)
-                const int nd = s_ndk[zn] + f, nk = s_nkc[zn] + f;
-                s_ndk[zn] = nd; s_nkc[zn] = nk;
+                int nd, nk;
+                if (COMPACT) {
+                    const int dz = (int)s_dk[zn] + f;
+                    s_dk[zn] = (int16_t)dz;
+                    nd = ndk_row[zn] + dz; nk = K.n_k[zn] + dz;
+                } else {
+                    nd = s_ndk[zn] + f; nk = s_nkc[zn] + f;
+                    s_ndk[zn] = nd; s_nkc[zn] = nk;
+                }
                 if (!exact) wv[fac_index(zn, KP >> 2)] = wide_factor(nd, nk, true, K.alpha, K.vbeta);
                 commit_site(K, i, v, f, zo, zn, 0, KP);
             }
-            if (__builtin_expect(exact, 0)) wide_factors(wv, s_ndk, s_nkc, mrow, W, K.alpha, K.vbeta, lane);
+            if (__builtin_expect(exact, 0)) wide_factors(wv, c_ndk, c_nk, c_dk, mrow, W, K.alpha, K.vbeta, lane);
         }
         for (int q = lane; q < (KP >> 2); q += 64) {
-            const int4 old = reinterpret_cast<const int4 *>(ndk_row)[q];
-            const int4 cur = reinterpret_cast<const int4 *>(s_ndk)[q];
-            const int dl[4] = {cur.x - old.x, cur.y - old.y, cur.z - old.z, cur.w - old.w};
+            if (COMPACT) {
+                const int2 pk = reinterpret_cast<const int2 *>(s_dk)[q];
+                if (pk.x | pk.y) {
+                    const int dl[4] = {(int)(int16_t)(pk.x & 0xFFFF), pk.x >> 16, (int)(int16_t)(pk.y & 0xFFFF), pk.y >> 16};
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (dl[j]) atomicAdd(K.n_k_delta + ((q << 2) | j), dl[j]);
-            reinterpret_cast<int4 *>(ndk_row)[q] = cur;
+                    for (int j = 0; j < 4; ++j)
+                        if (dl[j]) {
+                            atomicAdd(K.n_k_delta + ((q << 2) | j), dl[j]);
+                            ndk_row[(q << 2) | j] += dl[j];
+                        }
+                }
+            } else {
+                const int4 old = reinterpret_cast<const int4 *>(ndk_row)[q];
+                const int4 cur = reinterpret_cast<const int4 *>(s_ndk)[q];
+                const int dl[4] = {cur.x - old.x, cur.y - old.y, cur.z - old.z, cur.w - old.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (dl[j]) atomicAdd(K.n_k_delta + ((q << 2) | j), dl[j]);
+                reinterpret_cast<int4 *>(ndk_row)[q] = cur;
+            }
         }
     }
     if (n_exact && lane == 0 && K.status) {                                  // statistics, as the narrow kernels

@@ -441,7 +441,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     const bool dense = fast && a->dense_mask != 0 && L.K == L.KP;
     // debug_margin: 0 = production margins; n > 0 = 2^-n (wider: more fallbacks); -1 = always exact tier;
     // -2 = no fp32 tier
-    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 || a->debug_margin == -3 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
+    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 || a->debug_margin == -3 || a->debug_margin == -4 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
     P.margin0_rel = a->debug_margin == 0 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
     hipStream_t st = (hipStream_t)stream;
 
@@ -455,16 +455,26 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         const size_t lds = (size_t)L.KP * 16;               // scores (f64) + n_dk + n_k (int32), per wavefront
         const dim3 grid(wide_blocks(a->D)), block(64);
         int rl = LLDA_OK;
-#define LLDA_WIDE_REG(NT_)                                                                                   \
+#define LLDA_WIDE_REG(NT_, C_)                                                                               \
     case NT_:                                                                                                \
-        rl = allow_lds(llda_sweep_wide_reg_kernel<NT_>, lds);                                                \
+        rl = allow_lds(llda_sweep_wide_reg_kernel<NT_, C_>, lds_reg);                                        \
         if (rl) return rl;                                                                                   \
-        hipLaunchKernelGGL(llda_sweep_wide_reg_kernel<NT_>, grid, block, lds, st, W);                        \
+        hipLaunchKernelGGL((llda_sweep_wide_reg_kernel<NT_, C_>), grid, block, lds_reg, st, W);              \
         break;
-        if (fast && a->debug_margin != -3) {                // the tiered kernel with the row in registers
+        // counts as start values + int16 changes (no document may then hold 2^15 tokens): 10 instead of 16 bytes of LDS
+        // per position
+        const bool compact = a->max_doc_tokens > 0 && a->max_doc_tokens < 32768 && a->debug_margin != -4;
+        const size_t lds_reg = compact ? (size_t)L.KP * 10 : lds;
+        if (fast && a->debug_margin != -3 && compact) {     // the tiered kernel with the row in registers
             switch (L.tiers) {
-                LLDA_WIDE_REG(2) LLDA_WIDE_REG(3) LLDA_WIDE_REG(4) LLDA_WIDE_REG(5) LLDA_WIDE_REG(6) LLDA_WIDE_REG(7)
-                LLDA_WIDE_REG(8)
+                LLDA_WIDE_REG(2, true) LLDA_WIDE_REG(3, true) LLDA_WIDE_REG(4, true) LLDA_WIDE_REG(5, true)
+                LLDA_WIDE_REG(6, true) LLDA_WIDE_REG(7, true) LLDA_WIDE_REG(8, true)
+            default: return LLDA_E_BAD_K;
+            }
+        } else if (fast && a->debug_margin != -3) {
+            switch (L.tiers) {
+                LLDA_WIDE_REG(2, false) LLDA_WIDE_REG(3, false) LLDA_WIDE_REG(4, false) LLDA_WIDE_REG(5, false)
+                LLDA_WIDE_REG(6, false) LLDA_WIDE_REG(7, false) LLDA_WIDE_REG(8, false)
             default: return LLDA_E_BAD_K;
             }
         } else if (fast) {                                  // (debug_margin -3: the same decision on the LDS-only kernel)

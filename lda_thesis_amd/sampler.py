@@ -121,6 +121,13 @@ class GibbsSampler(object):
             wmin, wmax = int(self.word.min()), int(self.word.max())
             if wmin < 0 or wmax >= self.V:
                 raise IndexError("word id %d is out of bounds for a vocabulary of %d" % (wmax if wmax >= self.V else wmin, self.V))
+        # wide layouts: the most tokens any document holds (llda_sweep_args.max_doc_tokens: below 2^15 the kernel keeps
+        # int16 count changes in LDS instead of copies of the counts)
+        self.max_doc_tokens = 0
+        if lay.wide and self.S:
+            pre = torch.zeros((self.S + 1,), dtype=torch.int64, device=dev)
+            torch.cumsum(self.freq, 0, out=pre[1:])
+            self.max_doc_tokens = int(min((pre[self.doc_off[1:]] - pre[self.doc_off[:-1]]).max().item(), 2 ** 31 - 1))
         self._topic_pos = torch.from_numpy(lay.topic_pos.astype(np.int64)).to(dev)
         self._pos_topic = torch.from_numpy(lay.pos_topic.astype(np.int64)).to(dev)
         self.z = self._topic_pos[as_dev(z, torch.int64)].to(torch.int32)
@@ -378,7 +385,7 @@ class GibbsSampler(object):
                                    live_off=None if self.live_off is None else self.live_off[lo:hi + 1],
                                    live_pos=self.live_pos,
                                    live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
-                                   n_sites=s1 - s0, site_rec=self.site_rec)
+                                   n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens)
             if pipelined:
                 # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
                 # collective's stream (ordered after the fold) while the next range is sampled on this one

@@ -42,13 +42,14 @@ def test_wide_layout_kernels_agree_with_reference(c_oracle, name):
     the latter is checked against the C oracle on the fixture's corpus with alpha = beta = 1e-9."""
     from lda_thesis_amd.sampler import GibbsSampler
     g = load_golden(name)
-    s = make_sampler(g)
-    assert s.layout.wide
-    s.debug_margin = -3
-    for i in range(int(g["sweeps"])):
-        s.sweep()
-        assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics(), name)
-    s.check_status()
+    for margin in (-3, -4):           # -4: row in registers, LDS copies of the counts (production: int16 changes)
+        s = make_sampler(g)
+        assert s.layout.wide and 0 < s.max_doc_tokens < 32768
+        s.debug_margin = margin
+        for i in range(int(g["sweeps"])):
+            s.sweep()
+            assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics(), name)
+        s.check_status()
     K, V = int(g["K"]), int(g["V"])
     t = GibbsSampler(g["doc_off"], g["word"], g["freq"], g["init_z"], K, V, 1e-9, 1e-9, labs=g["labs"], seed=5)
     cs = c_oracle.CState(g["doc_off"], g["word"], g["freq"], g["init_z"], g["labs"], t.n_d_k(), t.n_k_v(), t.n_zk(), V,
@@ -59,6 +60,26 @@ def test_wide_layout_kernels_agree_with_reference(c_oracle, name):
         np.testing.assert_array_equal(t.z_topics(), cs.z)
         np.testing.assert_array_equal(t.n_k_v(), cs.n_k_v)
     t.check_status()
+
+
+def test_wide_layout_documents_too_heavy_for_int16_changes(c_oracle):
+    """a document of 2^15 tokens or more: the sampler's max_doc_tokens hint keeps the wide kernel on full-width counts."""
+    from lda_thesis_amd.sampler import GibbsSampler
+    rng = np.random.default_rng(3)
+    K, D, V = 1500, 12, 200
+    doc_off, word, freq, labs, z = synth(rng, D, V, K, 1, 40, True)
+    freq = freq.copy()
+    freq[doc_off[3]:doc_off[4]] = 9000                  # document 3: tens of thousands of tokens
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=8)
+    assert s.layout.wide and s.max_doc_tokens >= 32768
+    cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
+    for i in range(3):
+        s.sweep()
+        cs.sweep(1, 8, i, threads=2)
+        np.testing.assert_array_equal(s.z_topics(), cs.z)
+        np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+        np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+    s.check_status()
 
 
 @pytest.mark.parametrize("commit", ["atomics", "log_items_of_16", "log_items_of_3"])

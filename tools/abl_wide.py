@@ -1,5 +1,6 @@
 """Wide layouts (K with more than 8 pairwise leaves): kernel time of the sweep for the kernel variants llda_sweep's
-debug_margin selects -- 0 production (row in registers), -3 LDS-only kernel.
+debug_margin selects -- 0 production (row in registers, int16 count changes in LDS), -4 row in registers with LDS
+copies of the counts, -3 LDS-only kernel.
 python tools/abl_wide.py K [N V docs]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +12,7 @@ bench.WORKLOADS["abl"] = (docs, N, V, K, 1.0, 1000, "ablation")
 dev = torch.device("cuda", 0)
 s, info = bench.build_sampler("abl", dev, 0, 1, False)
 out = []
-for dm in (0, -3):
+for dm in (0, -4, -3):
     s.debug_margin = dm
     for _ in range(2):
         s.sweep()
