@@ -20,8 +20,9 @@ At N = 1 the same JSON line also carries (key "extra"):
                       that shows the genuinely HBM-bound regime of the same kernel;
   * "abstracts"       Labeled LDA on the tokenised abstracts_data.csv fixture (configs[0]/[1]) with its own
                       cpu_baseline -- the >= 50x target of BASELINE.json's north_star;
-  * "sparse_labels", "cascade", "wide_k2048"   the sparse-label kernel on a big corpus, CascadeLDA's ensemble (configs[4])
-                      and the general path for K > 1024 (one wavefront per document).
+  * "sparse_labels", "cascade", "wide_k2048", "wide_sparse_k2048"   the sparse-label kernel on a big corpus, CascadeLDA's
+                      ensemble (configs[4]) and the paths for K > 1024 (dense mask: one wavefront per document; sparse label
+                      sets: the sparse-label kernel with the wide exact tier).
 and the roofline of the dominant kernel from HBM-side PMC counters collected IN THIS RUN: the script re-runs itself
 for a few sweeps under `rocprofv3 --kernel-trace --pmc ...` (separate passes for FETCH_SIZE, WRITE_SIZE and the SQ
 group; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction of MI355X_MICROARCH.md).
@@ -67,6 +68,10 @@ WORKLOADS = {
     "synth2_sparse": (125000, 300, 100000, 512, 1.0, 15625,
                       "synthetic 125k docs x 300 tokens, K=512, sparse label mask (root + 7 random labels per doc), "
                       "V=100k (secondary variant of BASELINE configs[3])"),
+    "synth_wide_sparse": (125000, 300, 100000, 2048, 1.0, 15625,
+                          "synthetic 125k docs x 300 tokens, K=2048 (a 'wide' layout), sparse label mask (root + 7 random "
+                          "labels per doc), V=100k: Labeled LDA proper with thousands of labels -- the sparse-label kernel "
+                          "with the wide exact tier"),
     "synth_wide": (20000, 100, 20000, 2048, 1.0, 2500,
                    "synthetic 20k docs x 100 tokens, K=2048 dense mask, V=20k: a 'wide' layout (16 pairwise leaves -> one "
                    "wavefront per document, DESIGN 4.7) -- the general path for K beyond the tuned kernels' 1024"),
@@ -111,7 +116,7 @@ def build_sampler(name, dev, rank, world, dist_on, docs_total=0, docs_per_group=
     doc_off, word, freq, z = synthetic_corpus_blocks(lo, hi, N, V, K, 1234, dev, zipf_s=zs, block=block)
     Dg = hi - lo
     info["docs_local"] = Dg
-    if name == "synth2_sparse":
+    if name in ("synth2_sparse", "synth_wide_sparse"):
         gen = torch.Generator(device=dev)
         gen.manual_seed(99 + rank)
         # root + 7 distinct random labels per document: sort 7 draws, bump duplicates (still <= K-1)
@@ -532,7 +537,7 @@ def main():
         if extras_on:
             for key, wname, st, wu in (("synth1", "synth1", 200, 5), ("hbm_bound", "synth2_hostile", 40, 3),
                                        ("sparse_labels", "synth2_sparse", 100, 5), ("abstracts", "abstracts", 3000, 20),
-                                       ("wide_k2048", "synth_wide", 20, 2)):
+                                       ("wide_k2048", "synth_wide", 20, 2), ("wide_sparse_k2048", "synth_wide_sparse", 50, 3)):
                 s2, i2 = build_sampler(wname, dev, 0, 1, False)
                 torch.cuda.synchronize()
                 dt2, k2 = time_sweeps(s2, st, wu)
@@ -549,6 +554,9 @@ def main():
                     if not args.no_cpu:
                         e["cpu_baseline"], e["speedup_vs_cpu_port"] = cpu_baseline_json(s2, i2, wname, v2)
                         e["target_speedup"] = 50.0
+                if wname == "synth_wide_sparse":
+                    e["live_topics_per_doc"] = i2["live_topics"]
+                    e["note"] = "the sparse-label kernel (one lane per allowed topic) on a layout with 16 pairwise leaves"
                 if wname == "synth2_sparse":
                     e["live_topics_per_doc"] = i2["live_topics"]
                     e["algorithmic_GBps"] = algorithmic_bytes(s2.S, i2["docs_local"], i2["live_topics"]) / (k2 * 1e-3) / 1e9

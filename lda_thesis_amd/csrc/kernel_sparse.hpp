@@ -171,14 +171,24 @@ __device__ __forceinline__ void sparse_site(const PT &P, int layK, int layKP, in
 }
 
 
-template <int GS>
-__global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
+__device__ void sparse_wide_init();
+
+// PT = KParams (narrow layouts) or WSParams (kernel_wide.hpp: layouts with more than 8 pairwise leaves -- the arithmetic
+// of the decided sites does not know the layout at all; what differs is the exact tier an undecided site takes and that the
+// n_k changes go straight to global atomics instead of a workgroup accumulator of KP ints)
+template <class PT> struct sparse_is_wide { static constexpr bool value = false; };
+
+template <int GS, class PT = KParams>
+__global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const PT P)
 {
     constexpr int GPB = 256 / GS;
-    __shared__ int s_nk[LLDA_NARROW_KP];      // workgroup accumulator of the n_k changes (narrow layouts only)
+    constexpr bool WIDE = sparse_is_wide<PT>::value;
+    __shared__ int s_nk[WIDE ? 1 : LLDA_NARROW_KP];      // workgroup accumulator of the n_k changes (narrow layouts)
     const int tid = threadIdx.x;
     const int KP = P.KP;
-    for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
+    if (!WIDE)
+        for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
+    if (WIDE && tid == 0) sparse_wide_init();             // (the lock of the workgroup's exact-tier buffer)
     __syncthreads();
     const int lane = tid & 63;
     const int lig = tid & (GS - 1);
@@ -278,13 +288,18 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const KParams P)
         }
         if (live) {
             *ndk_p = ndk;
-            if (ndk != ndk0) atomicAdd(&s_nk[pos], ndk - ndk0);
+            if (ndk != ndk0) {
+                if (WIDE) atomicAdd(P.n_k_delta + pos, ndk - ndk0);
+                else atomicAdd(&s_nk[pos], ndk - ndk0);
+            }
         }
     }
-    __syncthreads();
-    for (int i = tid; i < KP; i += 256) {
-        const int dl = s_nk[i];
-        if (dl) atomicAdd(P.n_k_delta + i, dl);
+    if (!WIDE) {
+        __syncthreads();
+        for (int i = tid; i < KP; i += 256) {
+            const int dl = s_nk[i];
+            if (dl) atomicAdd(P.n_k_delta + i, dl);
+        }
     }
 }
 

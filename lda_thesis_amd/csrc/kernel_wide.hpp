@@ -182,6 +182,52 @@ __device__ __forceinline__ int wide_draw(double *wv, const WideLayout &W, double
     return hit >= 0 ? hit : last;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sparse label sets on a wide layout (Labeled LDA proper with thousands of labels, a handful per document): the sparse
+// kernel of kernel_sparse.hpp -- one lane per ALLOWED topic; its decided sites never see the layout -- with this exact tier
+// for the ~1e-11 of the sites the margin cannot decide: the wavefront scatters the document's exact scores into the
+// workgroup's KP doubles (zeros elsewhere: adding an exact zero never changes a partial sum) and runs wide_sum / wide_div /
+// wide_draw on them.  One buffer per workgroup, taken with an LDS lock by the wavefront that needs it.
+// ---------------------------------------------------------------------------------------------
+struct WSParams : KParams {
+    WideLayout w;
+};
+template <> struct sparse_is_wide<WSParams> { static constexpr bool value = true; };
+
+// dynamic LDS of the wide sparse kernel: [KP] doubles, then the lock word
+__device__ void sparse_wide_init()
+{
+    extern __shared__ double s_wide[];
+    const WSParams *K = (const WSParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    *reinterpret_cast<int *>(s_wide + K->w.KP) = 0;
+}
+
+__device__ __noinline__ int exact_call(const WSParams *K, int, int, double wx, int pos, int base, int A, double u, int lane)
+{
+    extern __shared__ double s_wide[];
+    const WideLayout &W = K->w;
+    double *wv = s_wide;
+    int *lock = reinterpret_cast<int *>(s_wide + W.KP);
+    base = __builtin_amdgcn_readfirstlane(base);
+    A = __builtin_amdgcn_readfirstlane(A);
+    if (lane == 0)
+        while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int q = lane; q < (W.KP >> 2); q += 64) {
+        double *p = wv + (q << 2);
+        p[0] = 0.0; p[1] = 0.0; p[2] = 0.0; p[3] = 0.0;
+    }
+    if (lane >= base && lane < base + A) wv[pos] = wx;            // (ordered after the zeros: LDS runs a wavefront's
+                                                                  // instructions in order)
+    const double S = wide_sum(wv, W, lane);                       // np.sum(prob)
+    wide_div(wv, W, lane, S, 1.0 / S);                            // prob /= np.sum(prob)
+    int r = wide_draw(wv, W, u, lane);
+    if (!(S > 0.0)) r = -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicExch(lock, 0);
+    return r;
+}
+
 // topic held by a position of a wide row (-1: padding)
 __device__ __forceinline__ int wide_topic_of(const int32_t *leaf_start, const int32_t *leaf_len, int G, int T, int pos)
 {

@@ -445,6 +445,36 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     P.margin0_rel = a->debug_margin == 0 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
     hipStream_t st = (hipStream_t)stream;
 
+    if (L.wide && !logged && fast && a->dense_mask == 0 && a->live_off && a->live_pos && a->live_max >= 1 &&
+        a->live_max <= LLDA_MAX_LIVE) {
+        // sparse label sets on a wide layout: one lane per allowed topic, the wide exact tier for undecided sites
+        WSParams W;
+        memset(&W, 0, sizeof W);
+        static_cast<KParams &>(W) = P;
+        W.site_rec = nullptr; W.csc_pos = nullptr; W.commit_log = nullptr;
+        W.live_off = a->live_off; W.live_pos = a->live_pos;
+        if (a->debug_margin < 0) W.margin_rel = 2.0;        // test hook: every site goes through the exact pipeline
+        fill_wide(L, W.w);
+        const int GS = a->live_max <= 8 ? 8 : a->live_max <= 16 ? 16 : a->live_max <= 32 ? 32 : 64;
+        int dpg = a->docs_per_group < 1 ? 1 : a->docs_per_group;
+        W.dpg = dpg;
+        const int64_t per_block = (int64_t)(256 / GS) * dpg;
+        const int64_t blocks = (a->D + per_block - 1) / per_block;
+        if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
+        const size_t lds = (size_t)L.KP * 8 + 16;
+        const dim3 grid((unsigned)blocks), block(256);
+        int rl;
+#define LLDA_SPARSE_WIDE(GS_)                                                                       \
+    case GS_:                                                                                       \
+        rl = allow_lds(llda_sweep_sparse_kernel<GS_, WSParams>, lds);                               \
+        if (rl) return rl;                                                                          \
+        hipLaunchKernelGGL((llda_sweep_sparse_kernel<GS_, WSParams>), grid, block, lds, st, W);     \
+        break;
+        switch (GS) { LLDA_SPARSE_WIDE(8) LLDA_SPARSE_WIDE(16) LLDA_SPARSE_WIDE(32) LLDA_SPARSE_WIDE(64) }
+#undef LLDA_SPARSE_WIDE
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? LLDA_OK : hip_fail(e);
+    }
     if (L.wide) {                                           // more than 8 pairwise leaves: the general path
         if (logged) return LLDA_E_BAD_ARG;                  // (atomics commit path only)
         WParams W;

@@ -138,7 +138,7 @@ class GibbsSampler(object):
         # the library then runs one lane per ALLOWED topic (llda_sweep_sparse_kernel)
         self.live_off = self.live_pos = None
         self.live_max = 0
-        if sparse_labels and labs is not None and self.D > 0 and not lay.wide:
+        if sparse_labels and labs is not None and self.D > 0:
             self._make_live()
         self.csc_pos = self.commit_log = self.site_rec = None
         self._ranges = self._make_ranges()
@@ -253,19 +253,24 @@ class GibbsSampler(object):
 
     def _make_live(self):
         lay, dev = self.layout, self.device
-        bits = (self.lab_mask.to(torch.int32) & 0xFFFF)                       # (D, G) lane masks
         shifts = torch.arange(lay.T, device=dev, dtype=torch.int32)
-        allowed = ((bits.unsqueeze(-1) >> shifts) & 1).reshape(self.D, lay.KP)  # (lane, slot) order = draw order
-        counts = allowed.sum(dim=1)
-        live_max = int(counts.max().item())
-        if live_max > 64 or live_max * 4 > self.K:
-            return                                                             # dense kernel is the better fit
-        rows, lm = torch.nonzero(allowed, as_tuple=True)                       # row-major => draw order ascending
-        pos = torch.from_numpy(lay.lm_pos.astype(np.int64)).to(dev)[lm]        # ... as memory positions
+        lm_pos = torch.from_numpy(lay.lm_pos.astype(np.int64)).to(dev)
+        counts, pos = [], []
+        step = max(1, (1 << 26) // lay.KP)                 # documents per chunk: the (chunk, KP) 0/1 matrix stays small
+        for d0 in range(0, self.D, step):
+            bits = (self.lab_mask[d0:d0 + step].to(torch.int32) & 0xFFFF)          # (chunk, G) lane masks
+            allowed = ((bits.unsqueeze(-1) >> shifts) & 1).reshape(bits.shape[0], lay.KP)   # (lane, slot) order = draw order
+            c = allowed.sum(dim=1)
+            if int(c.max().item()) > 64 or int(c.max().item()) * 4 > self.K:
+                return                                                         # dense kernel is the better fit
+            _, lm = torch.nonzero(allowed, as_tuple=True)                      # row-major => draw order ascending
+            counts.append(c)
+            pos.append(lm_pos[lm])                                             # ... as memory positions
+        counts = torch.cat(counts)
         self.live_off = torch.zeros((self.D + 1,), dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=self.live_off[1:])
-        self.live_pos = pos.to(torch.int32).contiguous()
-        self.live_max = live_max
+        self.live_pos = torch.cat(pos).to(torch.int32).contiguous()
+        self.live_max = int(counts.max().item())
 
     def _make_ranges(self):
         """document bounds of the overlap ranges (contiguous, balanced by site count); one range = no overlap."""

@@ -377,7 +377,7 @@ def test_edge_tiny_priors_take_the_exact_kernel(c_oracle):
 
 # ---- sparse-label kernel (one lane per allowed topic) -------------------------------------------------
 @pytest.mark.parametrize("margin", [0, 6, -1])
-@pytest.mark.parametrize("name", ["tiny_k40", "tiny_k392", "tiny_k200", "sublda"])
+@pytest.mark.parametrize("name", ["tiny_k40", "tiny_k392", "tiny_k200", "sublda", "tiny_k1100"])
 def test_sparse_kernel_matches_reference_o3(name, margin):
     """fixtures whose documents allow few topics run through llda_sweep_sparse_kernel; margin 6 sends many sites
     through the in-kernel exact tier (exact_site_wave), -1 every site."""
@@ -393,7 +393,8 @@ def test_sparse_kernel_matches_reference_o3(name, margin):
 
 
 @pytest.mark.parametrize("margin", [-1, 6])
-@pytest.mark.parametrize("K", [9, 40, 100, 129, 190, 257, 392, 640, 777, 900, 968, 1024])
+@pytest.mark.parametrize("K", [9, 40, 100, 129, 190, 257, 392, 640, 777, 900, 968, 1024,
+                               1031, 1500, 2100, 3000, 7688])      # the last five: wide layouts (wide exact tier, LDS lock)
 def test_sparse_kernel_exact_tier_on_every_layout_shape(c_oracle, K, margin):
     """exact_site_wave (the reference's fp64 pipeline run by a whole wavefront in the dense layout, with G, T, tail and
     the leaf-combine schedule as run-time values): every site (margin -1) or a mixture with decided sites inside one
@@ -432,7 +433,7 @@ def test_sparse_and_dense_kernels_agree_on_a_large_sparse_workload(c_oracle):
     D, N, V = 3000, 120, 5000
     off, w, f, _ = synthetic_corpus(D, N, V, 8, seed=2, device="cuda")
     rng = np.random.default_rng(0)
-    for K, nlab in ((392, 7), (512, 15), (100, 20)):
+    for K, nlab in ((392, 7), (512, 15), (100, 20), (2048, 7)):        # (the last: a wide layout)
         labs = np.zeros((D, K), dtype=np.uint8)
         labs[:, 0] = 1
         for d in range(D):
