@@ -59,9 +59,8 @@ enum {
  * per wavefront.  Wide layouts (wide = 1; ABI 13): G = 8 * (leaves rounded up to a multiple of 8) = 64 * tiers; the G
  * "lanes" of the formulas above are VIRTUAL lanes, virtual lane gv = 64 * tier + physical lane of the one wavefront that
  * walks the document; T is 8, 12 or 16.  The leaf totals of a wide layout are combined along numpy's recursion tree by
- * n_leaves - 1 in-place adds  total[comb_dst[i]] += total[comb_src[i]]  (post-order; total[0] is the sum).  Wide layouts
- * are served by llda_sweep (atomics commit path; with the sparse-label list: the sparse kernel), llda_count_init, llda_apply_delta, llda_loglik,
- * llda_readout_phi / _theta and llda_foldin; llda_commit_log, llda_apply_rows and llda_sweep_batch return LLDA_E_BAD_K. */
+ * n_leaves - 1 in-place adds  total[comb_dst[i]] += total[comb_src[i]]  (post-order; total[0] is the sum).  Every entry
+ * point takes wide layouts except llda_sweep_batch (its problems have at most 128 topics). */
 typedef struct llda_layout {
     int32_t K;                       /* number of topics (labels incl. 'root')                */
     int32_t n_leaves;                /* numpy pairwise-sum leaves                             */

@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_kernel(const WParams P)
                 const int nd = s_ndk[zn] + f, nk = s_nkc[zn] + f;
                 s_ndk[zn] = nd; s_nkc[zn] = nk;
                 if (TIERED && !exact) wv[fac_index(zn, KP >> 2)] = wide_factor(nd, nk, true, K.alpha, K.vbeta);
-                commit_site(K, i, v, f, zo, zn, 0, KP);
+                commit_site(K, i, v, f, zo, zn, K.csc_pos ? K.csc_pos[i] : 0, KP);
             }
             if (TIERED && exact) wide_factors(wv, s_ndk, s_nkc, nullptr, mrow, W, K.alpha, K.vbeta, lane);
         }
@@ -494,12 +494,13 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
         int v_c = K.word[s0], f_c = K.freq[s0], zo_c = K.z[s0];
         const int64_t i1 = s0 + (len > 1 ? 1 : 0);
         int v_1 = K.word[i1], f_1 = K.freq[i1], zo_1 = K.z[i1];
+        int c_c = K.csc_pos ? K.csc_pos[s0] : 0, c_1 = K.csc_pos ? K.csc_pos[i1] : 0;       // (commit-log positions)
         int nd0_c = 0, nk0_c = 0;                                                // COMPACT: start counts of the old topic
         if (COMPACT) { nd0_c = ndk_row[zo_c]; nk0_c = K.n_k[zo_c]; }
 
         for (int n = 0; n < len; ++n) {
             const int64_t i = s0 + n;
-            const int v = v_c, f = f_c, zo = zo_c, nd0 = nd0_c, nk0 = nk0_c;
+            const int v = v_c, f = f_c, zo = zo_c, cpos = c_c, nd0 = nd0_c, nk0 = nk0_c;
             int x[NT][4][4];
             {
                 const int4 *row = reinterpret_cast<const int4 *>(K.n_kw + (int64_t)v * KP);
@@ -512,10 +513,11 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
                             x[t][c][0] = r.x; x[t][c][1] = r.y; x[t][c][2] = r.z; x[t][c][3] = r.w;
                         }
                 // scalars of site n+2
-                v_c = v_1; f_c = f_1; zo_c = zo_1;
+                v_c = v_1; f_c = f_1; zo_c = zo_1; c_c = c_1;
                 if (COMPACT) { nd0_c = ndk_row[zo_c]; nk0_c = K.n_k[zo_c]; }     // (for site n+1; zo_c arrived a site ago)
                 const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);
                 v_1 = K.word[i2]; f_1 = K.freq[i2]; zo_1 = K.z[i2];
+                if (K.csc_pos) c_1 = K.csc_pos[i2];
             }
             const double u = site_uniform<64>(K, n, n == 0, gdoc, lane, r0, r1, r2, r3);
             if (lane == 0) {                                                 // remove the site (LabeledLDA.py:109-111)
@@ -607,7 +609,7 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
                     s_ndk[zn] = nd; s_nkc[zn] = nk;
                 }
                 if (!exact) wv[fac_index(zn, KP >> 2)] = wide_factor(nd, nk, true, K.alpha, K.vbeta);
-                commit_site(K, i, v, f, zo, zn, 0, KP);
+                commit_site(K, i, v, f, zo, zn, cpos, KP);
             }
             if (__builtin_expect(exact, 0)) wide_factors(wv, c_ndk, c_nk, c_dk, mrow, W, K.alpha, K.vbeta, lane);
         }

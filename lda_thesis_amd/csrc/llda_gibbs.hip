@@ -445,13 +445,13 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     P.margin0_rel = a->debug_margin == 0 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
     hipStream_t st = (hipStream_t)stream;
 
-    if (L.wide && !logged && fast && a->dense_mask == 0 && a->live_off && a->live_pos && a->live_max >= 1 &&
+    if (L.wide && fast && a->dense_mask == 0 && a->live_off && a->live_pos && a->live_max >= 1 &&
         a->live_max <= LLDA_MAX_LIVE) {
         // sparse label sets on a wide layout: one lane per allowed topic, the wide exact tier for undecided sites
         WSParams W;
         memset(&W, 0, sizeof W);
         static_cast<KParams &>(W) = P;
-        W.site_rec = nullptr; W.csc_pos = nullptr; W.commit_log = nullptr;
+        W.site_rec = nullptr;
         W.live_off = a->live_off; W.live_pos = a->live_pos;
         if (a->debug_margin < 0) W.margin_rel = 2.0;        // test hook: every site goes through the exact pipeline
         fill_wide(L, W.w);
@@ -476,11 +476,10 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         return e == hipSuccess ? LLDA_OK : hip_fail(e);
     }
     if (L.wide) {                                           // more than 8 pairwise leaves: the general path
-        if (logged) return LLDA_E_BAD_ARG;                  // (atomics commit path only)
         WParams W;
         memset(&W, 0, sizeof W);
         W.k = P;
-        W.k.site_rec = nullptr; W.k.csc_pos = nullptr; W.k.commit_log = nullptr;
+        W.k.site_rec = nullptr;
         fill_wide(L, W.w);
         const size_t lds = (size_t)L.KP * 16;               // scores (f64) + n_dk + n_k (int32), per wavefront
         const dim3 grid(wide_blocks(a->D)), block(64);
@@ -603,7 +602,6 @@ int llda_commit_log(const int64_t *item_begin, const int32_t *item_len, const in
     const llda_layout *Lp = layout_of(K, &rc);
     if (rc) return rc;
     const llda_layout &L = *Lp;
-    if (L.wide) return LLDA_E_BAD_K;                        // wide layouts keep the atomics commit path
     if (n_items > 0 && (!item_begin || !item_len || !item_word || !commit_log || !freq_csc || !target)) return LLDA_E_BAD_ARG;
     if (n_items == 0 && !n_k) return LLDA_OK;
     CParams P;
@@ -613,6 +611,8 @@ int llda_commit_log(const int64_t *item_begin, const int32_t *item_len, const in
     int64_t blocks = (n_items + 3) / 4;
     if (blocks < 1) blocks = 1;
     if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
+    const int rl = allow_lds(llda_commit_log_kernel, 4 * L.KP * sizeof(int));      // (above 64 KB from KP = 4 096 on)
+    if (rl) return rl;
     hipLaunchKernelGGL(llda_commit_log_kernel, dim3((unsigned)blocks), dim3(256), 4 * L.KP * sizeof(int), (hipStream_t)stream, P);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
@@ -625,7 +625,6 @@ int llda_apply_rows(const int64_t *row_off, int32_t *rows, int64_t n_rows, int32
     const llda_layout *Lp = layout_of(K, &rc);
     if (rc) return rc;
     const llda_layout &L = *Lp;
-    if (L.wide) return LLDA_E_BAD_K;
     if (n_rows == 0) return LLDA_OK;
     if (!row_off || !rows || !counts) return LLDA_E_BAD_ARG;
     const int64_t blocks = (n_rows + 3) / 4;

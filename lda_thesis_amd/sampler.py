@@ -144,8 +144,6 @@ class GibbsSampler(object):
         self._ranges = self._make_ranges()
         if commit_log is None:
             commit_log = self.S >= (1 << 20)
-        if lay.wide:
-            commit_log = False                      # wide layouts (more than 8 pairwise leaves): atomics commit path
         if self.S >= (1 << 31):
             commit_log = False                      # log positions are int32
         if commit_log and self.S > 0:

@@ -48,7 +48,7 @@ def _worker(rank, world, port, name, counts_mode, overlap, q):
                      counts=counts, seed=int(g["seed"]), doc_base=lo, device="cpu",
                      backend=OracleBackend(c_oracle), commit_log=counts_mode == "built",   # both commit paths
                      overlap_ranges=overlap)
-    ok = (s.rows is not None) == (counts_mode == "built" and not s.layout.wide)   # every rank logs -> packed exchange rows
+    ok = (s.rows is not None) == (counts_mode == "built")       # every rank logs -> packed exchange rows
     if overlap > 1 and counts_mode == "built":                   # pipelined exchange: one set of rows per document range
         ok &= len(s._rows_list) == overlap and len(s._calls) >= 2 and len(s._item_bounds) == overlap + 1
     if name == "tiny_k12":
@@ -74,7 +74,7 @@ def test_two_rank_sharded_sweeps_match_single_process_golden(name, counts_mode, 
     """overlap > 1: the exchange is pipelined over document ranges (the rows of range i are all-reduced
     asynchronously while range i+1 is sampled) -- same state, bit for bit; ("given", 2): ranks that commit with
     atomics ignore the ranges; ("tiny_k1024", 16): more ranges than a rank has documents; k1031 / k2100: wide layouts
-    (more than 8 pairwise leaves) always commit with atomics and exchange the int32 delta buffer."""
+    (more than 8 pairwise leaves), both commit paths."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
