@@ -15,6 +15,10 @@ One sweep = ``llda_sweep`` (HIP, include/llda_gibbs.h) under per-document snapsh
 then -- when the documents are sharded over several GPUs -- one RCCL all-reduce (SUM, int32) of the
 n_kw / n_k deltas over xGMI, then ``llda_apply_delta``.  Integer sums are exact and order
 independent, so the state after a sweep is bit-identical for any number of GPUs.
+
+Any K up to 7 688 (``layout.MAX_K``): up to 8 of numpy's pairwise-sum leaves the tuned "narrow" kernels run; beyond
+that ``layout.wide`` is set, G counts the virtual lanes of one wavefront, and ``llda_sweep`` picks the wide kernels
+ -- nothing in this class differs except the ``max_doc_tokens`` hint it hands them.
 """
 import numpy as np
 import torch
