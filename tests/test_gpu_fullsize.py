@@ -21,7 +21,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = {"synth1": (100_000, 200, 50_000, 128), "synth2_shard": (125_000, 300, 100_000, 512)}
+CONFIGS = {"synth1": (100_000, 200, 50_000, 128), "synth2_shard": (125_000, 300, 100_000, 512),
+           "wide_k2048": (20_000, 100, 20_000, 2048)}      # (a wide layout: bench.py's extra.wide_k2048)
 
 
 def corpus(name):
@@ -115,7 +116,7 @@ def test_full_size_properties(name):
         s0, s1 = int(off[lo]), int(off[hi])
         # exchange path without a process group: every half folds its own rows (int16 pairs for all but the hot words)
         h = make(doc_off[lo:hi + 1] - doc_off[lo], word[s0:s1], freq[s0:s1], z[s0:s1], K, V, doc_base=lo,
-                 exchange_always=True)
+                 exchange_always=True, commit_log=True)
         assert h.rows is not None and int((h.row_off < 0).sum()) > V // 2
         halves.append(h)
     counts = start.clone()
@@ -131,7 +132,7 @@ def test_full_size_properties(name):
     assert torch.equal(torch.cat([h.n_dk for h in halves]), s.n_dk)
 
 
-@pytest.mark.parametrize("name,n_docs", [("synth1", 3000), ("synth2_shard", 2000), ("synth2_1M", 2000)])
+@pytest.mark.parametrize("name,n_docs", [("synth1", 3000), ("synth2_shard", 2000), ("synth2_1M", 2000), ("wide_k2048", 600)])
 def test_full_size_sampled_documents_vs_c_oracle(c_oracle, name, n_docs):
     """the oracle at full size, by sampling (see the module docstring): two sweeps, a fresh sample each."""
     doc_off, word, freq, z, K, V = corpus(name)
