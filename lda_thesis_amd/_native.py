@@ -135,6 +135,13 @@ def lib():
     return L
 
 
+def require_device():
+    """Raise unless a HIP device is visible (the product has no CPU path)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise NativeError("no HIP device visible: the sampler has no CPU fallback")
+
+
 def check(rc, what):
     if rc != 0:
         L = lib()

@@ -61,17 +61,12 @@ def draw_initial_topics(allowed, n_allowed, inst_of_site, uniforms):
 class Ensemble(object):
     """Device state of a set of sub-problems (``plans``: see CascadeLDA.plan_subproblems) and the sweep driver."""
 
-    def __init__(self, plans, z_local, doc_off, word, freq, V, alpha, beta, seed, device=None, streams=None,
-                 backend=None):
+    def __init__(self, plans, z_local, doc_off, word, freq, V, alpha, beta, seed, device=None, streams=None):
         """streams[i] = RNG stream of plans[i] (default i).  plans[i]: dict(K, docs (member document ids), allowed (D_p, A_max) local topics ascending, padded
         with -1, n_allowed (D_p,)); z_local[i]: initial local topic of every site of plan i (instance order)."""
-        self.backend = backend if backend is not None else _native     # (tests inject a CPU checker, as GibbsSampler)
-        if backend is None:
-            _native.lib()
-            if not torch.cuda.is_available():
-                raise _native.NativeError("no HIP device visible: the sampler has no CPU fallback")
-        self.device = dev = torch.device(device if device is not None else
-                                         ("cuda:%d" % torch.cuda.current_device() if backend is None else "cpu"))
+        _native.lib()
+        _native.require_device()
+        self.device = dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.V, self.alpha, self.beta, self.seed = int(V), float(alpha), float(beta), int(seed)
         self.plans = plans
         self.sweeps_done = 0
@@ -176,13 +171,13 @@ class Ensemble(object):
     def sweep(self):
         """one Gibbs sweep of every sub-problem (SubLDA.training_iteration, CascadeLDA.py:397-421)."""
         for lanes, order in self.orders:
-            self.backend.sweep_batch(inst_off=self.inst_off, order=order, word=self.word, freq=self.freq, z=self.z,
+            _native.sweep_batch(inst_off=self.inst_off, order=order, word=self.word, freq=self.freq, z=self.z,
                                 inst_prob=self.inst_prob, inst_doc=self.inst_doc, live_off=self.live_off,
                                 live_pos=self.live_pos, ndk_off=self.ndk_off, n_dk=self.n_dk, kw_off=self.kw_off,
                                 nk_off=self.nk_off, kp=self.kp, prob_stream=self.prob_stream, k=self.prob_k, counts=self.counts, delta=self.delta,
                                 status=self.status, V=self.V, lanes=lanes, alpha=self.alpha, beta=self.beta,
                                 seed=self.seed, sweep=self.sweeps_done, debug_margin=self.debug_margin)
-        self.backend.apply_delta(self.counts, self.delta)
+        _native.apply_delta(self.counts, self.delta)
         self.sweeps_done += 1
 
     def check_status(self):

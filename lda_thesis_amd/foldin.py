@@ -59,8 +59,7 @@ def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, see
     """ph (K, V) float64; init_rows (R, K) float64; init_idx[S] row per site.  doc_ids: RNG id per document (any
     values: the whole batch is one launch).  Enqueues on ``stream`` (default: the current one), returns Pending."""
     _native.lib()
-    if not torch.cuda.is_available():
-        raise _native.NativeError("no HIP device visible: the fold-in sampler has no CPU fallback")
+    _native.require_device()
     dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
     stream = stream if stream is not None else torch.cuda.current_stream(dev)
     K, V = (ph.shape[1], ph.shape[0]) if isinstance(ph, torch.Tensor) else ph.shape     # device form: (V, KP) rows
@@ -118,8 +117,7 @@ def fold_in(ph_hat, alpha, doc_tups, it, thinning, seed, stream_id=TEST_STREAM, 
     axis 0 of a C-contiguous matrix row by row, i.e. sequentially over the topics, which K in-place row additions
     reproduce bit for bit; the division is IEEE on both sides."""
     _native.lib()
-    if not torch.cuda.is_available():
-        raise _native.NativeError("no HIP device visible: the fold-in sampler has no CPU fallback")
+    _native.require_device()
     dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
     ph = ph_hat.to(device=dev, dtype=torch.float64) if isinstance(ph_hat, torch.Tensor) else \
         torch.from_numpy(np.ascontiguousarray(ph_hat, dtype=np.float64)).to(dev)

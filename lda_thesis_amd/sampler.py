@@ -74,21 +74,15 @@ class GibbsSampler(object):
                all-reduced (asynchronously, on the collective's own stream) while range i+1 is still being sampled.
                Every range exchanges its own dense rows, so C ranges move C times the bytes -- see DESIGN.md section 7
                for when that pays.  Needs the commit-log exchange rows on every rank (else it is ignored).
-    backend  : module with the _native entry points (tests inject a CPU checker here; the product
-               always uses the HIP library).
     """
 
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
-                 stream_id=0, doc_base=0, device=None, group=None, backend=None, sort_docs=True,
+                 stream_id=0, doc_base=0, device=None, group=None, sort_docs=True,
                  docs_per_group=0, sharded=True, sparse_labels=True, commit_log=None, exchange_always=False,
                  overlap_ranges=1):
-        self.backend = backend if backend is not None else _native
-        if backend is None:
-            _native.lib()                                   # fail loudly when the extension is missing
-            if not torch.cuda.is_available():
-                raise _native.NativeError("no HIP device visible: the sampler has no CPU fallback")
-        self.device = torch.device(device if device is not None else
-                                   ("cuda:%d" % torch.cuda.current_device() if backend is None else "cpu"))
+        _native.lib()                                       # fail loudly when the extension is missing
+        _native.require_device()                            # ... or when no GPU is visible: there is no CPU fallback
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.K, self.V = int(K), int(V)
         self.alpha, self.beta = float(alpha), float(beta)
         self.seed, self.stream_id, self.doc_base = int(seed), int(stream_id), int(doc_base)
@@ -170,7 +164,7 @@ class GibbsSampler(object):
         self.n_k_delta = self._delta[self.V * KP:]
         self.status = torch.zeros((4,), dtype=torch.int32, device=dev)   # [flags, tier-0 unsure, exact tier, -]
         if counts is None:
-            self.backend.count_init(self.doc_off, self.word, self.freq, self.z, self.D, self.K,
+            _native.count_init(self.doc_off, self.word, self.freq, self.z, self.D, self.K,
                                     self.n_dk, self.n_kw, self.n_k)
             if self.sharded and _dist_active(self.group):
                 import torch.distributed as dist
@@ -296,7 +290,7 @@ class GibbsSampler(object):
         if self.S <= self._call_limit and len(self._ranges) == 2:
             return [(0, self.D, order(0, self.D))]
         off = self._off_host
-        if int(np.diff(off).max()) > self._call_limit:
+        if self.D and int(np.diff(off).max()) > self._call_limit:
             raise ValueError("a document has more than %d sites" % self._call_limit)
         calls = []
         for r in range(len(self._ranges) - 1):
@@ -306,7 +300,7 @@ class GibbsSampler(object):
                 hi = max(min(hi, end), lo + 1)
                 calls.append((lo, hi, order(lo, hi)))
                 lo = hi
-        return calls
+        return calls or [(0, 0, None)]                       # (a rank without documents)
 
     def _make_commit_log(self):
         """word-major (CSC) view of the sites -- range by range when the exchange is pipelined over document ranges
@@ -370,7 +364,9 @@ class GibbsSampler(object):
         have_group = dist.is_available() and dist.is_initialized()
         exchange = self.sharded and (_dist_active(self.group) or self.exchange_always)
         n_ranges = len(self._ranges) - 1
-        pipelined = exchange and self.rows is not None and n_ranges > 1 and logged
+        # decided from values every rank agrees on (a rank with an empty shard logs nothing but must still issue
+        # one collective per range)
+        pipelined = exchange and self.rows is not None and n_ranges > 1
         if len(self._calls) == 1:
             self._calls[0] = (0, self.D, self.doc_order)
         works, call = [], 0
@@ -381,7 +377,7 @@ class GibbsSampler(object):
                 call += 1
                 s0 = 0 if len(self._calls) == 1 else int(self._off_host[lo])
                 s1 = self.S if len(self._calls) == 1 else int(self._off_host[hi])
-                self.backend.sweep(doc_off=self.doc_off[lo:hi + 1], doc_order=order, word=self.word, freq=self.freq,
+                _native.sweep(doc_off=self.doc_off[lo:hi + 1], doc_order=order, word=self.word, freq=self.freq,
                                    z=self.z, lab_mask=self.lab_mask[lo:hi], n_dk=self.n_dk[lo:hi], n_kw=self.n_kw,
                                    n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=nk_delta,
                                    status=self.status, D=hi - lo, V=self.V, K=self.K, alpha=self.alpha,
@@ -396,9 +392,9 @@ class GibbsSampler(object):
             if pipelined:
                 # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
                 # collective's stream (ordered after the fold) while the next range is sampled on this one
-                i0, i1 = self._item_bounds[r], self._item_bounds[r + 1]
+                i0, i1 = (self._item_bounds[r], self._item_bounds[r + 1]) if logged else (0, 0)
                 if i1 > i0:
-                    self.backend.commit_log(self.item_begin[i0:i1], self.item_len[i0:i1], self.item_word[i0:i1],
+                    _native.commit_log(self.item_begin[i0:i1], self.item_len[i0:i1], self.item_word[i0:i1],
                                             self.commit_log, self.freq_csc, self.K, self._rows_list[r],
                                             row_off=self.row_off)
                 if have_group:
@@ -409,30 +405,30 @@ class GibbsSampler(object):
         if not exchange:
             if logged:
                 # single device: the log is folded straight into n_kw (and n_k += its delta) -- no delta pass
-                self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
+                _native.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
                                         self.freq_csc, self.K, self.n_kw, self.n_k, self.n_k_delta)
             else:
-                self.backend.apply_delta(self._counts, self._delta)
+                _native.apply_delta(self._counts, self._delta)
         elif pipelined:
             self._timed(lambda: [w.wait() for w in works])
             for r in range(n_ranges):
-                self.backend.apply_rows(self.row_off, self._rows_list[r], self.K, self._counts)
+                _native.apply_rows(self.row_off, self._rows_list[r], self.K, self._counts)
         elif self.rows is not None:
             # every rank folds its log into the exchange rows (int16 pairs for all but the hot words), ONE int32
             # all-reduce over xGMI, then the rows are decoded into [n_kw | n_k]
             if logged:
-                self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
+                _native.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
                                         self.freq_csc, self.K, self.rows, row_off=self.row_off)
             if have_group:
                 self._timed(lambda: dist.all_reduce(self.rows, group=self.group))
-            self.backend.apply_rows(self.row_off, self.rows, self.K, self._counts)
+            _native.apply_rows(self.row_off, self.rows, self.K, self._counts)
         else:
             if logged:
-                self.backend.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
+                _native.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
                                         self.freq_csc, self.K, self.n_kw_delta)
             if have_group:
                 self._timed(lambda: dist.all_reduce(self._delta, group=self.group))   # RCCL over xGMI: SUM int32, one collective
-            self.backend.apply_delta(self._counts, self._delta)
+            _native.apply_delta(self._counts, self._delta)
         self.sweeps_done += 1
 
     def comm_stats(self):
@@ -465,7 +461,7 @@ class GibbsSampler(object):
     def loglik_sum(self):
         """sum over local sites of -log(phi[:, w] . theta_d)  (LabeledLDA.py:256-265), on device."""
         out = torch.zeros((self.D,), dtype=torch.float64, device=self.device)
-        self.backend.loglik(self.doc_off, self.word, self.lab_mask, self.n_dk, self.n_kw, self.n_k,
+        _native.loglik(self.doc_off, self.word, self.lab_mask, self.n_dk, self.n_kw, self.n_k,
                             self.D, self.V, self.K, self.alpha, self.beta, out)
         return float(out.sum().item())
 
@@ -485,7 +481,7 @@ class GibbsSampler(object):
         """get_phi: (n_k_v + beta) / (n_zk[:, None] + V*beta), reference LabeledLDA.py:231-234."""
         if out is None:
             out = torch.empty((self.K, self.V), dtype=torch.float64, device=self.device)
-        self.backend.readout_phi(self.n_kw, self.n_k, None, self.V, self.K, self.beta, out, flags, keep, share)
+        _native.readout_phi(self.n_kw, self.n_k, None, self.V, self.K, self.beta, out, flags, keep, share)
         return out
 
     def ph_rows(self, out=None, keep=None, share=None):
@@ -494,14 +490,14 @@ class GibbsSampler(object):
         if out is None:
             out = torch.empty((self.K, self.V), dtype=torch.float64, device=self.device)
         den = self.n_kw.sum(dim=0, dtype=torch.int64).to(torch.float64)
-        self.backend.readout_phi(self.n_kw, None, den, self.V, self.K, 0.0, out, None, keep, share)
+        _native.readout_phi(self.n_kw, None, den, self.V, self.K, 0.0, out, None, keep, share)
         return out
 
     def theta(self, out=None, keep=None, share=None):
         """get_theta of the LOCAL documents: (n_d_k + labs*alpha) / row sums, reference LabeledLDA.py:236-239."""
         if out is None:
             out = torch.empty((self.D, self.K), dtype=torch.float64, device=self.device)
-        self.backend.readout_theta(self.n_dk, self.lab_mask, self.D, self.K, self.alpha, out, keep, share)
+        _native.readout_theta(self.n_dk, self.lab_mask, self.D, self.K, self.alpha, out, keep, share)
         return out
 
     # ------------------------------------------------------------------ reference-layout views

@@ -37,11 +37,31 @@ def assert_state_equal(g, key, n_k_v, n_d_k, n_zk, z, what=""):
 # ------------------------------------------------------------------------------------------------
 # CPU stand-in for lda_thesis_amd._native, for HOST-LOGIC tests only (sharding, exchange, layout
 # conversions): the device entry points are replaced by the C oracle working on CPU torch tensors.
-# The product never takes this path: GibbsSampler(backend=None) requires the HIP library + a GPU.
+# The product never takes this path: it has no seam for it.  Tests swap the module attribute
+# (``use_oracle_backend``); the real ``_native.require_device`` raises without a GPU.
 # ------------------------------------------------------------------------------------------------
+def use_oracle_backend(co, *modules):
+    """replace ``_native`` in the given lda_thesis_amd modules (default: sampler and ensemble) by the C-oracle stand-in."""
+    import lda_thesis_amd.ensemble as E
+    import lda_thesis_amd.sampler as S
+    b = OracleBackend(co)
+    for m in (modules or (S, E)):
+        m._native = b
+    return b
+
+
 class OracleBackend(object):
+    class NativeError(RuntimeError):
+        pass
+
     def __init__(self, co):
         self.co = co
+
+    def lib(self):
+        return None
+
+    def require_device(self):
+        return None
 
     @staticmethod
     def _lay(K):

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, counts_mode, overlap, q):
+def _worker(rank, world, port, name, counts_mode, overlap, q, empty_last=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -31,13 +31,16 @@ def _worker(rank, world, port, name, counts_mode, overlap, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import c_oracle
-    from helpers import OracleBackend
+    from helpers import use_oracle_backend
     from lda_thesis_amd.sampler import GibbsSampler, shard_documents
+    use_oracle_backend(c_oracle)
     g = load_golden(name)
     if name == "tiny_k12":
         GibbsSampler.PAIR_LIMIT = 20        # mix of int16-pair rows and int32 rows (hot words) in the exchange
     off = g["doc_off"]
     b = shard_documents(off, world)
+    if empty_last:                              # the last rank holds no document at all
+        b = shard_documents(off, world - 1) + [int(g["D"])]
     lo, hi = b[rank], b[rank + 1]
     s0, s1 = int(off[lo]), int(off[hi])
     counts = None
@@ -46,11 +49,13 @@ def _worker(rank, world, port, name, counts_mode, overlap, q):
     s = GibbsSampler(off[lo:hi + 1] - off[lo], g["word"][s0:s1], g["freq"][s0:s1], g["init_z"][s0:s1],
                      int(g["K"]), int(g["V"]), float(g["alpha"]), float(g["beta"]), labs=g["labs"][lo:hi],
                      counts=counts, seed=int(g["seed"]), doc_base=lo, device="cpu",
-                     backend=OracleBackend(c_oracle), commit_log=counts_mode == "built",   # both commit paths
+                     commit_log=counts_mode == "built",   # both commit paths
                      overlap_ranges=overlap)
     ok = (s.rows is not None) == (counts_mode == "built")       # every rank logs -> packed exchange rows
     if overlap > 1 and counts_mode == "built":                   # pipelined exchange: one set of rows per document range
-        ok &= len(s._rows_list) == overlap and len(s._calls) >= 2 and len(s._item_bounds) == overlap + 1
+        ok &= len(s._rows_list) == overlap
+        if hi > lo:
+            ok &= len(s._calls) >= 2 and len(s._item_bounds) == overlap + 1
     if name == "tiny_k12":
         ok &= 0 < int((s.row_off < 0).sum()) < s.V
     for i in range(int(g["sweeps"])):
@@ -89,14 +94,34 @@ def test_two_rank_sharded_sweeps_match_single_process_golden(name, counts_mode, 
     assert sum(n for _, _, n in res) == int(load_golden(name)["D"])
 
 
-def test_single_process_oracle_backend_matches_golden(c_oracle):
+@pytest.mark.parametrize("overlap", [1, 2])
+def test_rank_with_an_empty_shard_issues_the_same_collectives(overlap):
+    """three ranks, the last one without documents: it logs nothing, yet it must build the exchange rows and issue
+    one all-reduce per overlap range like the others (else the job hangs or sums the wrong buffers)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, "tiny_k40", "built", overlap, q, True)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert sorted(n for _, _, n in res)[0] == 0
+
+
+def test_single_process_oracle_backend_matches_golden(c_oracle, monkeypatch):
     """sanity of the stand-in itself (world size 1, no process group)."""
     from helpers import OracleBackend, assert_state_equal
+    import lda_thesis_amd.sampler as S
     from lda_thesis_amd.sampler import GibbsSampler
+    monkeypatch.setattr(S, "_native", OracleBackend(c_oracle))
     g = load_golden("tiny_k130")
     s = GibbsSampler(g["doc_off"], g["word"], g["freq"], g["init_z"], int(g["K"]), int(g["V"]),
                      float(g["alpha"]), float(g["beta"]), labs=g["labs"], seed=int(g["seed"]), device="cpu",
-                     backend=OracleBackend(c_oracle), commit_log=True)
+                     commit_log=True)
     assert s.commit_log is not None and int(s.item_len.sum()) == s.S
     np.testing.assert_array_equal(s.n_k_v(), g["init_n_k_v"])
     for i in range(int(g["sweeps"])):
@@ -113,21 +138,22 @@ def _cascade_worker(rank, world, port, batched, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import c_oracle
     from fixture_corpora import cascade_corpus
-    from helpers import OracleBackend
+    from helpers import use_oracle_backend
     import lda_thesis_amd.CascadeLDA as C
     from lda_thesis_amd.sampler import GibbsSampler
     from lda_thesis_amd.text import Dictionary
+    use_oracle_backend(c_oracle)               # test stand-in: C oracle instead of the HIP library
 
-    class CpuSampler(GibbsSampler):            # test stand-in: C oracle instead of the HIP library
+    class CpuSampler(GibbsSampler):
         def __init__(self, *a, **k):
-            k.update(device="cpu", backend=OracleBackend(c_oracle))
+            k.update(device="cpu")
             super().__init__(*a, **k)
     C.GibbsSampler = CpuSampler
     import lda_thesis_amd.ensemble as E
 
     class CpuEnsemble(E.Ensemble):             # the batched ensemble, same stand-in
         def __init__(self, plans, z_local, *a, **k):
-            k.update(device="cpu", backend=OracleBackend(c_oracle))
+            k.update(device="cpu")
             super().__init__(plans, z_local, *a, **k)
     E.Ensemble = CpuEnsemble
     g = load_golden("cascade_toy")
@@ -176,14 +202,15 @@ def _llda_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import c_oracle
     from fixture_corpora import tiny_corpus
-    from helpers import OracleBackend
+    from helpers import use_oracle_backend
     import lda_thesis_amd.LabeledLDA as L
     from lda_thesis_amd.sampler import GibbsSampler
     from lda_thesis_amd.text import Dictionary
+    use_oracle_backend(c_oracle)
 
     class CpuSampler(GibbsSampler):
         def __init__(self, *a, **k):
-            k.update(device="cpu", backend=OracleBackend(c_oracle))
+            k.update(device="cpu")
             super().__init__(*a, **k)
     L.GibbsSampler = CpuSampler
     g = load_golden("tiny_k40")
