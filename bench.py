@@ -137,6 +137,39 @@ def build_sampler(name, dev, rank, world, dist_on, docs_total=0, docs_per_group=
     return s, info
 
 
+CHECKSUM_FILE = os.path.join(ROOT, "profiles", "state_checksums.json")
+
+
+def state_checksums(sampler):
+    """digests of the shared counts in TOPIC order (independent of the device permutation): weighted sums of n_k and
+    of the whole n_kw (int64, wrapping).  The state after s sweeps is the same for every number of GPUs, so an
+    N > 1 run can be checked against the N = 1 values stored in profiles/state_checksums.json."""
+    dev, K, V = sampler.device, sampler.K, sampler.V
+    nk = sampler.n_k[sampler._topic_pos].to(torch.int64)
+    c_k = int((nk * torch.arange(1, K + 1, device=dev)).sum().item())
+    c_kw = 0
+    step = max(1, (1 << 24) // K)
+    wk = torch.arange(K, device=dev, dtype=torch.int64)
+    for v0 in range(0, V, step):
+        blk = sampler.n_kw[v0:v0 + step][:, sampler._topic_pos].to(torch.int64)
+        idx = (torch.arange(v0, v0 + blk.shape[0], device=dev, dtype=torch.int64)[:, None] * K + wk[None, :]) % 1000003 + 1
+        c_kw = (c_kw + int((blk * idx).sum().item())) & 0x7FFFFFFFFFFFFFFF
+    return {"n_k": c_k, "n_kw": c_kw}
+
+
+def checksum_verdict(name, docs_total, sweeps, got):
+    """compare with the stored N = 1 digests -> (True / False / None, note)"""
+    try:
+        table = json.load(open(CHECKSUM_FILE))
+    except Exception:                                   # noqa: BLE001
+        return None, "profiles/state_checksums.json not found"
+    t = table.get("%s:%d" % (name, docs_total))
+    if not t or sweeps > len(t["n_k"]) or sweeps < 1:
+        return None, "no stored N = 1 digest for %s with %d documents after %d sweeps" % (name, docs_total, sweeps)
+    want = {"n_k": t["n_k"][sweeps - 1], "n_kw": t["n_kw"][sweeps - 1]}
+    return (got == want), "N = 1 digests after %d sweeps (%s): %r" % (sweeps, t.get("source", "stored"), want)
+
+
 def time_sweeps(sampler, steps, warmup, dist=None, dev=None):
     """warmup untimed sweeps, then exactly `steps` sweeps between barrier + synchronize; MAX over ranks.
     -> (seconds, mean sweep-kernel ms from HIP events on the launch stream, tier counters)"""
@@ -421,6 +454,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
     ap.add_argument("--pmc-keep", default="", help="directory to keep the raw counter CSVs of the in-run passes in")
     ap.add_argument("--pmc-inner", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--make-checksums", type=int, default=0,
+                    help="N = 1: run this many sweeps, print the digests after each (the content of one entry of "
+                         "profiles/state_checksums.json) and exit")
     ap.add_argument("--force-exchange", action="store_true",
                     help="diagnostic: take the multi-GPU path (exchange rows, all-reduce if a group exists) on one GPU")
     ap.add_argument("--overlap", type=int, default=-1, help="document ranges per sweep for the overlapped exchange")
@@ -459,10 +495,25 @@ def main():
                                   overlap=None if args.overlap < 0 else args.overlap)
     sites_local = sampler.S
     torch.cuda.synchronize()
+    if args.make_checksums:
+        if world != 1:
+            raise SystemExit("--make-checksums is a single-GPU run")
+        out = {"n_k": [], "n_kw": [], "source": "python bench.py --workload %s%s --make-checksums %d on one MI355X" %
+               (name, " --docs %d" % args.docs if args.docs else "", args.make_checksums)}
+        for _ in range(args.make_checksums):
+            sampler.sweep()
+            c = state_checksums(sampler)
+            out["n_k"].append(c["n_k"])
+            out["n_kw"].append(c["n_kw"])
+        sampler.check_status()
+        print(json.dumps({"%s:%d" % (name, info["docs_total"]): out}))
+        return
     dt, kavg = time_sweeps(sampler, args.steps, args.warmup, dist, dev)
     tier = sampler.status.cpu().numpy().astype(np.int64)
     total_sites = sites_local
-    checksum = int((sampler.n_k[sampler._topic_pos].to(torch.int64) * torch.arange(1, sampler.K + 1, device=dev)).sum().item())   # topic order
+    sums = state_checksums(sampler)
+    checksum = sums["n_k"]
+    sweeps_done = sampler.sweeps_done
     comm = sampler.comm_stats() if hasattr(sampler, "comm_stats") else None
     if dist is not None and comm is not None and sampler.rows is not None:
         # the collective alone (no sweep beside it), outside the timed region: what an ideal overlap could hide
@@ -491,8 +542,10 @@ def main():
         dt2, k2 = time_sweeps(sampler, max(5, args.steps // 4), 2, dist, dev)
         probe = {"overlap_ranges": 2, "steps": max(5, args.steps // 4), "ms_per_step": dt2 / max(5, args.steps // 4) * 1e3,
                  "exchange_ms": sampler.comm_stats(),
-                 "state_checksum_n_k_after_probe": int((sampler.n_k[sampler._topic_pos].to(torch.int64) *
-                                                        torch.arange(1, sampler.K + 1, device=dev)).sum().item())}
+                 "sweeps": sampler.sweeps_done}
+        psums = state_checksums(sampler)
+        probe["state_checksum_n_k_after_probe"] = psums["n_k"]
+        probe["checksum_matches_n1"], _ = checksum_verdict(name, info["docs_total"], sampler.sweeps_done, psums)
 
     if rank == 0:
         K, V, N = info["K"], info["V"], info["N"]
@@ -519,10 +572,15 @@ def main():
                        "semantics": "per-document snapshot (bit-exact vs the reference under O3)",
                        "draw": "tiered: fp32 decision with a proven margin, fp64 / exact fp64 pipeline otherwise; "
                                "the result is the exact fp64 pipeline's",
-                       "state_checksum_n_k": checksum},
+                       "state_checksum_n_k": checksum, "state_checksum_n_kw": sums["n_kw"],
+                       "sweeps_behind_checksum": sweeps_done},
             "draw_tiers": {"sites": int(sites_local) * (args.steps + args.warmup),
                            "fp32_tier_unsure": int(tier[1]), "exact_tier": int(tier[2])},
         }
+        if world > 1:
+            # the state after s sweeps is identical for every N: compare with the stored single-GPU digests
+            line["checksum_matches_n1"], line["checksum_note"] = checksum_verdict(name, line["config"]["docs_total"],
+                                                                                  sweeps_done, sums)
         if comm is not None:
             line["exchange_ms"] = comm
         if probe is not None:

@@ -1,7 +1,10 @@
 """N > 1 host path on CPU: two gloo ranks, documents sharded by site count, per-sweep all-reduce of
 the integer deltas, fold.  The device entry points are replaced by the C oracle (tests/helpers.py
 OracleBackend) -- this checks the sharding / exchange / layout logic of GibbsSampler, not the kernel.
-The state after every sweep must equal the single-process O3 golden of the reference."""
+The state after every sweep must equal the single-process O3 golden of the reference.
+
+The workers take ``hip=True`` from tests/test_gpu_multirank.py: the same checks with the REAL HIP kernels, every
+rank on cuda:0, the gloo group reducing CUDA tensors."""
 import os
 import socket
 import sys
@@ -23,17 +26,33 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, counts_mode, overlap, q, empty_last=False):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def _setup(rank, world, port, hip):
+    """process-group + backend of one worker: the C-oracle stand-in on CPU tensors, or (hip) the real library on
+    cuda:0.  -> device string"""
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if hip:
+        torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if hip:
+        from lda_thesis_amd import _native
+        import lda_thesis_amd.ensemble as E
+        import lda_thesis_amd.sampler as S
+        _native.lib()
+        assert S._native is _native and E._native is _native      # nothing stands in for the HIP library
+        return "cuda:0"
     import c_oracle
     from helpers import use_oracle_backend
-    from lda_thesis_amd.sampler import GibbsSampler, shard_documents
     use_oracle_backend(c_oracle)
+    return "cpu"
+
+
+def _worker(rank, world, port, name, counts_mode, overlap, q, empty_last=False, hip=False):
+    dev = _setup(rank, world, port, hip)
+    from lda_thesis_amd.sampler import GibbsSampler, shard_documents
     g = load_golden(name)
     if name == "tiny_k12":
         GibbsSampler.PAIR_LIMIT = 20        # mix of int16-pair rows and int32 rows (hot words) in the exchange
@@ -48,7 +67,7 @@ def _worker(rank, world, port, name, counts_mode, overlap, q, empty_last=False):
         counts = dict(n_d_k=g["init_n_d_k"][lo:hi], n_k_v=g["init_n_k_v"], n_zk=g["init_n_zk"])
     s = GibbsSampler(off[lo:hi + 1] - off[lo], g["word"][s0:s1], g["freq"][s0:s1], g["init_z"][s0:s1],
                      int(g["K"]), int(g["V"]), float(g["alpha"]), float(g["beta"]), labs=g["labs"][lo:hi],
-                     counts=counts, seed=int(g["seed"]), doc_base=lo, device="cpu",
+                     counts=counts, seed=int(g["seed"]), doc_base=lo, device=dev,
                      commit_log=counts_mode == "built",   # both commit paths
                      overlap_ranges=overlap)
     ok = (s.rows is not None) == (counts_mode == "built")       # every rank logs -> packed exchange rows
@@ -129,33 +148,25 @@ def test_single_process_oracle_backend_matches_golden(c_oracle, monkeypatch):
         assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics())
 
 
-def _cascade_worker(rank, world, port, batched, q):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import c_oracle
+def _cascade_worker(rank, world, port, batched, q, hip=False):
+    dev = _setup(rank, world, port, hip)
     from fixture_corpora import cascade_corpus
-    from helpers import use_oracle_backend
     import lda_thesis_amd.CascadeLDA as C
     from lda_thesis_amd.sampler import GibbsSampler
     from lda_thesis_amd.text import Dictionary
-    use_oracle_backend(c_oracle)               # test stand-in: C oracle instead of the HIP library
 
-    class CpuSampler(GibbsSampler):
+    class DevSampler(GibbsSampler):            # (the stand-in works on CPU tensors)
         def __init__(self, *a, **k):
-            k.update(device="cpu")
+            k.update(device=dev)
             super().__init__(*a, **k)
-    C.GibbsSampler = CpuSampler
+    C.GibbsSampler = DevSampler
     import lda_thesis_amd.ensemble as E
 
-    class CpuEnsemble(E.Ensemble):             # the batched ensemble, same stand-in
+    class DevEnsemble(E.Ensemble):             # the batched ensemble, same
         def __init__(self, plans, z_local, *a, **k):
-            k.update(device="cpu")
+            k.update(device=dev)
             super().__init__(plans, z_local, *a, **k)
-    E.Ensemble = CpuEnsemble
+    E.Ensemble = DevEnsemble
     g = load_golden("cascade_toy")
     docs, labs, labelset = cascade_corpus()
     np.random.seed(int(g["np_seed"]))
@@ -193,26 +204,18 @@ def test_cascade_subproblems_spread_over_two_ranks(batched):
     assert res[0][2] == [0, 1]                      # both ranks own some sub-problems
 
 
-def _llda_worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import c_oracle
+def _llda_worker(rank, world, port, q, hip=False):
+    dev = _setup(rank, world, port, hip)
     from fixture_corpora import tiny_corpus
-    from helpers import use_oracle_backend
     import lda_thesis_amd.LabeledLDA as L
     from lda_thesis_amd.sampler import GibbsSampler
     from lda_thesis_amd.text import Dictionary
-    use_oracle_backend(c_oracle)
 
-    class CpuSampler(GibbsSampler):
+    class DevSampler(GibbsSampler):
         def __init__(self, *a, **k):
-            k.update(device="cpu")
+            k.update(device=dev)
             super().__init__(*a, **k)
-    L.GibbsSampler = CpuSampler
+    L.GibbsSampler = DevSampler
     g = load_golden("tiny_k40")
     docs, labs, labelset, alpha, beta, sweeps, npseed = tiny_corpus("k40")
     np.random.seed(npseed)

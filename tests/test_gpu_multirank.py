@@ -1,0 +1,161 @@
+"""N > 1 on hardware: several processes, each with its own HIP context on cuda:0, one gloo process group reducing
+CUDA tensors -- the REAL ``llda_sweep`` + ``llda_commit_log`` -> exchange rows -> ``all_reduce`` -> ``llda_apply_rows``
+(tests/test_distributed_gloo.py runs the same host logic with the C oracle standing in for the kernels; RCCL refuses
+two ranks on one device, and the GPU box has one).  What the collective sums are the shared-count updates of the
+reference (/root/reference/LabeledLDA.py:109-111,123-125).
+
+(i)  goldens: the state of every rank after every sweep == the reference's O3 golden (2 and 4 ranks, one exchange
+     per sweep and pipelined over 2 document ranges, narrow / wide layouts, both commit paths);
+(ii) a 200 000-document slice of BASELINE configs[3] (K = 512, V = 100 000, 300 sites per document): every rank's
+     [n_kw | n_k] replica, and the concatenation of the ranks' z / n_dk, equal the ONE-process run bit for bit;
+(iii) the drop-in classes (LabeledLDA sharded over the ranks, CascadeLDA's sub-problems spread over them).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden
+from test_distributed_gloo import _cascade_worker, _free_port, _llda_worker, _setup, _worker
+
+pytestmark = pytest.mark.gpu
+
+
+def _spawn(world, target, args, timeout=600):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=timeout) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for p in procs:
+        assert p.exitcode == 0
+    return res
+
+
+def _golden(rank, world, port, name, counts_mode, overlap, q):
+    _worker(rank, world, port, name, counts_mode, overlap, q, hip=True)
+
+
+@pytest.mark.parametrize("world,name,counts_mode,overlap", [
+    (2, "tiny_k40", "built", 1), (2, "tiny_k40", "built", 2), (4, "tiny_k40", "built", 1), (4, "tiny_k40", "built", 2),
+    (2, "tiny_k12", "built", 1), (4, "tiny_k12", "built", 2),            # int16-pair rows and int32 rows mixed
+    (2, "tiny_k392", "given", 1), (4, "tiny_k392", "given", 2),         # atomics commit path: int32 delta buffer
+    (2, "tiny_k512", "built", 2), (4, "tiny_k1024", "built", 1),        # the dense tiered kernel
+    (2, "tiny_k1031", "built", 1), (2, "tiny_k2100", "built", 2),       # wide layouts
+])
+def test_hip_kernels_with_a_real_reduction_match_the_reference_golden(world, name, counts_mode, overlap):
+    res = _spawn(world, _golden, (name, counts_mode, overlap))
+    assert all(ok for _, ok, _ in res), res
+    assert sum(n for _, _, n in res) == int(load_golden(name)["D"])
+
+
+def _golden_empty(rank, world, port, overlap, q):
+    _worker(rank, world, port, "tiny_k40", "built", overlap, q, empty_last=True, hip=True)
+
+
+@pytest.mark.parametrize("overlap", [1, 2])
+def test_hip_rank_without_documents(overlap):
+    res = _spawn(3, _golden_empty, (overlap,))
+    assert all(ok for _, ok, _ in res), res
+
+
+# ------------------------------------------------------------------------------------------------ (ii) configs[3] slice
+SLICE_DOCS, SLICE_BLOCK, SLICE_N, SLICE_V, SLICE_K, SLICE_SWEEPS = 200000, 12500, 300, 100000, 512, 3
+
+
+def _digest(t):
+    return hashlib.sha256(t.contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+def _slice_worker(rank, world, port, overlap, q):
+    from lda_thesis_amd.corpus import synthetic_corpus_blocks
+    from lda_thesis_amd.sampler import GibbsSampler
+    if world > 1:
+        dev = _setup(rank, world, port, True)
+    else:                                           # the single-process run: no process group at all
+        _setup_paths_only()
+        torch.cuda.set_device(0)
+        dev = "cuda:0"
+    lo, hi = SLICE_DOCS // world * rank, SLICE_DOCS // world * (rank + 1)
+    doc_off, word, freq, z = synthetic_corpus_blocks(lo, hi, SLICE_N, SLICE_V, SLICE_K, 1234, dev, zipf_s=1.0,
+                                                     block=SLICE_BLOCK)
+    s = GibbsSampler(doc_off, word, freq, z, SLICE_K, SLICE_V, 0.1, 0.01, labs=None, seed=42, doc_base=lo, device=dev,
+                     overlap_ranges=overlap)
+    facts = dict(rows=s.rows is not None, logged=s.commit_log is not None,
+                 pair_rows=int((s.row_off[:-1] < 0).sum()) if s.row_off is not None else -1,
+                 collectives=len(s._rows_list) if s._rows_list is not None else 0)
+    for _ in range(SLICE_SWEEPS):
+        s.sweep()
+    s.check_status()
+    torch.cuda.synchronize()
+    nb = SLICE_BLOCK * SLICE_N
+    blocks = [(lo // SLICE_BLOCK + b, _digest(s.z[b * nb:(b + 1) * nb]),
+               _digest(s.n_dk[b * SLICE_BLOCK:(b + 1) * SLICE_BLOCK])) for b in range((hi - lo) // SLICE_BLOCK)]
+    q.put((rank, _digest(s._counts), blocks, facts, int(s.n_k.sum(dtype=torch.int64))))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _setup_paths_only():
+    import os
+    import sys
+    from conftest import ROOT
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+@pytest.fixture(scope="module")
+def one_rank_slice():
+    (rank, counts, blocks, facts, tokens), = _spawn(1, _slice_worker, (1,))
+    assert facts["logged"] and not facts["rows"]        # one process: the log is folded straight into n_kw
+    assert tokens == SLICE_DOCS * SLICE_N
+    return counts, blocks
+
+
+@pytest.mark.parametrize("world,overlap", [(2, 1), (2, 2), (4, 1), (4, 2)])
+def test_configs3_slice_sharded_over_ranks_equals_the_one_rank_run(one_rank_slice, world, overlap):
+    counts1, blocks1 = one_rank_slice
+    res = _spawn(world, _slice_worker, (overlap,), timeout=900)
+    for rank, counts, blocks, facts, tokens in res:
+        assert counts == counts1, "rank %d: [n_kw | n_k] differs from the one-rank run" % rank
+        assert tokens == SLICE_DOCS * SLICE_N
+        # the path under test: every rank logs, the exchange travels as packed rows (int16 pairs for most words,
+        # int32 for the hot ones), one collective per document range
+        assert facts["rows"] and facts["logged"] and 0 < facts["pair_rows"] < SLICE_V
+        assert facts["collectives"] == overlap
+    got = sorted(b for _, _, blocks, _, _ in res for b in blocks)
+    assert got == sorted(blocks1), "z / n_dk of the shards differ from the one-rank run"
+
+
+# ------------------------------------------------------------------------------------------------ (iii) drop-in classes
+def _llda(rank, world, port, q):
+    _llda_worker(rank, world, port, q, hip=True)
+
+
+def test_hip_dropin_labeledlda_sharded_over_two_ranks():
+    res = _spawn(2, _llda, ())
+    assert all(ok for _, ok in res), res
+
+
+def _cascade(rank, world, port, batched, q):
+    _cascade_worker(rank, world, port, batched, q, hip=True)
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_hip_cascade_subproblems_over_two_ranks(batched):
+    res = _spawn(2, _cascade, (batched,))
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == [0, 1]

@@ -14,6 +14,10 @@ pass c SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VALU SQ_INS
 pass d TCC_HIT_sum TCC_MISS_sum
 pass e TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum
 pass f GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum
+pass g TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum
+pass h TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_ATOMIC_sum
+pass i FETCH_SIZE
+pass j WRITE_SIZE TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum
 python - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)
@@ -21,6 +25,7 @@ for f in glob.glob("$P/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "llda_sweep" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg["kernel_ns (under counters)"].append(float(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 for k in sorted(agg):
     v = agg[k]
     print("%-34s %.6g  (n=%d)" % (k, sum(v) / len(v), len(v)))
