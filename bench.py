@@ -311,15 +311,219 @@ def cascade_extra():
             "made tests/golden/cascade_abstracts.npz)"}
 
 
+# ------------------------------------------------------------------------------------------------ (f) rows: the harness steps
+def _abstracts_tokens(g, off_key, word_key, freq_key, lab_off_key, lab_idx_key, names):
+    """token lists (word id v with frequency f = f copies of 'w%05d' % v) and label-string lists of the fixture."""
+    off, w, f = g[off_key], g[word_key], g[freq_key]
+    lo, li = g[lab_off_key], g[lab_idx_key]
+    docs, labs = [], []
+    for d in range(len(off) - 1):
+        toks = []
+        for v, n in zip(w[off[d]:off[d + 1]], f[off[d]:off[d + 1]]):
+            toks += ["w%05d" % v] * int(n)
+        docs.append(toks)
+        labs.append([names[k] for k in li[lo[d]:lo[d + 1]] if k != 0])
+    return docs, labs
+
+
+def _quiet(fn, *a, **k):
+    import io
+    from contextlib import redirect_stdout
+    with redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def pipeline_extra(with_cpu=True):
+    """SURVEY 8(f) rows 1, 3, 4 as the harness runs them (evaluate_LabeledLDA.py:110-180 of the reference): Labeled LDA on the
+    abstracts fixture -- run_training(200, 25) with the thinning read-outs on the device, run_test of the 464 held-out
+    documents (150 sweeps, thinning 25: one llda_foldin launch), the report's metrics -- each timed, with the CPU port
+    of the same step (oracle/, bounded samples) beside it."""
+    from lda_thesis_amd import evaluate as ev
+    from lda_thesis_amd.LabeledLDA import LabeledLDA
+    from lda_thesis_amd.text import Dictionary
+    g = np.load(os.path.join(ROOT, "tests", "golden", "abstracts_d3.npz"))
+    names = [str(x) for x in g["labelset"]]
+    docs, labs = _abstracts_tokens(g, "doc_off", "word", "freq", "lab_off", "lab_idx", names)
+    tdocs, tlabs = _abstracts_tokens(g, "test_doc_off", "test_word", "test_freq", "test_lab_off", "test_lab_idx", names)
+    keep = [i for i, t in enumerate(tdocs) if t]
+    tdocs, tlabs = [tdocs[i] for i in keep], [tlabs[i] for i in keep]
+    dicti = Dictionary(docs)
+    IT, THIN, T_IT, T_THIN = 200, 25, 150, 25
+    out = {"workload": "Labeled LDA on the tokenised abstracts_data.csv fixture: run_training(%d, %d) + run_test of %d held-out "
+                       "documents (%d sweeps, thinning %d) + the report's metrics (reference evaluate_LabeledLDA.py:110-180)"
+                       % (IT, THIN, len(tdocs), T_IT, T_THIN), "unit": "s", "higher_is_better": False}
+    best = None
+    for rep in range(2):                                   # first pass cold (code objects, allocator), second timed
+        np.random.seed(0)
+        model = LabeledLDA(docs, labs, names[1:], dicti, ALPHA, BETA, seed=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _quiet(model.run_training, IT, THIN)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        th = model.run_test(tdocs, T_IT, T_THIN)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        th4 = np.round(np.asarray(th), 4)                  # test_it rounds to 4 decimals before the metrics
+        y_bin = ev.binary_yreal(tlabs, model.labelmap)[:, 1:]
+        thr = th4[:, 1:]
+        nz = np.where(thr.sum(axis=1) != 0)[0]
+        y_bin, thr = y_bin[nz, :], thr[nz, :]
+        tps, tns, fps, fns, fprs, tprs = ev.rates(thr, y_bin)
+        metrics = {"auc_roc": float(ev.macro_auc_roc(fprs, tprs)), "one_error": float(ev.n_error(thr, y_bin, 1)),
+                   "two_error": float(ev.n_error(thr, y_bin, 2)), "f1_macro": float(ev.get_f1(tps, fps, tns, fns))}
+        t3 = time.perf_counter()
+        best = dict(train_s=t1 - t0, test_s=t2 - t1, metrics_s=t3 - t2)
+        if rep == 0:
+            out["cold_first_pass_s"] = dict(best)
+    sites_train = int(sum(len(t) for t in model.doc_tups))
+    ttups = [dicti.doc2bow(x) for x in tdocs]
+    sites_test = int(sum(len(t) for t in ttups))
+    out.update(value=best["train_s"] + best["test_s"] + best["metrics_s"], stages_s=best, metrics=metrics,
+               train={"sweeps": IT, "thinning": THIN, "sites_per_sweep": sites_train,
+                      "Msite_draws_per_s": sites_train * IT / best["train_s"] / 1e6,
+                      "perplexity_trace_last": float(model.cur_perplx[-1])},
+               test={"documents": len(tdocs), "sites": sites_test, "sweeps": T_IT,
+                     "Msite_draws_per_s": sites_test * T_IT / best["test_s"] / 1e6})
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import llda_oracle as orc
+        # training: one sweep of the numpy per-site loop + one perplexity() read-out of the same model state
+        st = orc.State([list(x) for x in model.docs], [list(x) for x in model.freqs], model.labs.astype(np.float64), model.V,
+                       ALPHA, BETA, [z.copy() for z in model.z_dn])
+        st.n_k_v, st.n_zk, st.n_d_k = model.n_k_v.copy(), model.n_zk.copy(), model.n_d_k.copy()
+        np.random.seed(1)
+        t0 = time.perf_counter()
+        orc.sweep_sequential(st, None)
+        t1 = time.perf_counter()
+        orc.perplexity(st)
+        orc.get_phi(st)
+        orc.get_theta(st)
+        t2 = time.perf_counter()
+        # test: the first documents of the held-out set through the restated run_test, same keyed draws as the device
+        n_s = min(12, len(ttups))
+        ph_hat = model.ph_hat
+        ids = [[v for v, _ in t] for t in ttups[:n_s]]
+        frs = [[f for _, f in t] for t in ttups[:n_s]]
+        from lda_thesis_amd.foldin import TEST_STREAM
+        t3 = time.perf_counter()
+        want = orc.run_test(ph_hat, ALPHA, ids, frs, T_IT, T_THIN, orc.keyed_draw_for(model.seed, TEST_STREAM))
+        t4 = time.perf_counter()
+        s_sample = sum(len(x) for x in ids)
+        cpu_train = IT * (t1 - t0) + (IT // THIN) * (t2 - t1)
+        cpu_test = (t4 - t3) * sites_test / s_sample
+        out["cpu_baseline"] = {
+            "kind": "port", "cores": 1, "unit": "s", "value": cpu_train + cpu_test,
+            "train_s": cpu_train, "test_s": cpu_test,
+            "sample": "training: 1 sweep of the numpy per-site loop (%.2f s) x %d + 1 thinning read-out (perplexity, phi, theta: "
+                      "%.2f s) x %d; test: run_test of the first %d held-out documents (%d of %d sites, %.2f s) scaled by sites"
+                      % (t1 - t0, IT, t2 - t1, IT // THIN, n_s, s_sample, sites_test, t4 - t3),
+            "test_sample_identical_to_device": bool(np.array_equal(np.asarray(th)[:n_s], want))}
+        out["speedup_vs_cpu_port"] = out["cpu_baseline"]["value"] / out["value"]
+    return out
+
+
+def cascade_test_extra(with_cpu=True):
+    """SURVEY 8(f) row 1, Cascade side: test_down_tree (reference CascadeLDA.py:249-297) for every held-out document of the
+    abstracts fixture (150 sweeps, thinning 25, threshold 0.95) after go_down_tree(4, 2) -- all documents that reach the
+    same node of the label tree in one llda_foldin launch -- with the CPU port of the same walk (oracle cascade_test,
+    same keyed draws) on a bounded sample beside it."""
+    from lda_thesis_amd.CascadeLDA import CascadeLDA
+    from lda_thesis_amd.corpus import cascade_corpus_from_csr
+    from lda_thesis_amd.foldin import doc_key
+    from lda_thesis_amd.text import Dictionary
+    g = np.load(os.path.join(ROOT, "tests", "golden", "abstracts_d3.npz"))
+    names = [str(x) for x in g["labelset"]]
+    docs, labs, labelset = cascade_corpus_from_csr(g["doc_off"], g["word"], g["freq"], g["lab_off"], g["lab_idx"], names)
+    held, _ = _abstracts_tokens(g, "test_doc_off", "test_word", "test_freq", "test_lab_off", "test_lab_idx", names)
+    held = [t for t in held if t]
+    dicti = Dictionary(docs)
+    np.random.seed(0)
+    model = CascadeLDA(docs, labs, list(labelset), dicti, alpha=ALPHA, beta=BETA, seed=1)
+    _quiet(model.go_down_tree, it=4, s=2)
+    model.ph = np.nan_to_num(model.ph)                     # (the never-trained '' row)
+    IT, THIN, THR = 150, 25, 0.95
+    walls = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        trees = model.test_down_tree_batch(held, IT, THIN, THR)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+    nodes = sum(1 + len(t[1]) + len(t[2]) for t in trees)
+    bows = [dicti.doc2bow(x) for x in held]
+    out = {"workload": "CascadeLDA.test_down_tree for the %d held-out documents of the abstracts fixture (%d sweeps, thinning %d, "
+                       "threshold %.2f) after go_down_tree(4, 2); documents at the same tree node share a launch"
+                       % (len(held), IT, THIN, THR),
+           "value": min(walls[1:]), "unit": "s", "higher_is_better": False, "cold_first_call_s": walls[0],
+           "warm_calls_s": walls[1:], "documents": len(held), "node_visits": nodes,
+           "site_sweeps": int(sum(len(bows[d]) * (1 + len(t[1]) + len(t[2])) for d, t in enumerate(trees))) * IT}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import re
+        import llda_oracle as orc
+
+        def node(tup, labels):
+            ids_, fr_ = zip(*tup)
+            rows = [model.labelmap[x] for x in labels]
+            stream, key = model._test_stream(labels), doc_key(tup)
+
+            def draw_for_sweep(sw):
+                k = orc.KeyedDraw(model.seed, stream)
+                k.sweep, k.doc, k.site = sw, key, 0
+                return k
+            return orc.cascade_test(model.ph[rows, :], ALPHA, BETA, list(ids_), list(fr_), IT, THIN, draw_for_sweep)
+
+        def walk(tup):                                    # the visiting order of the reference's test_down_tree
+            kids = lambda p: [p] + list(filter(re.compile("^" + p + "[0-9]{1}$").match, model.lablist))
+            labels = model.lablist_l1
+            keep, loads = model._head(node(tup, labels), labels, THR)
+            l1, l2, l3 = list(zip(keep, loads)), [], []
+            for parent in [x for x in keep if x != "root"]:
+                labels = kids(parent)
+                keep2, loads2 = model._head(node(tup, labels), labels, THR)
+                l2.append(list(zip(keep2, loads2)))
+                for parent2 in [x for x in keep2 if x != parent]:
+                    labels = kids(parent2)
+                    keep3, loads3 = model._head(node(tup, labels), labels, THR)
+                    l3.append(list(zip(keep3, loads3)))
+            return l1, l2, l3
+        n_s = min(8, len(held))
+        t0 = time.perf_counter()
+        ported = [walk(bows[d]) for d in range(n_s)]
+        dt = time.perf_counter() - t0
+        work = lambda d, t: len(bows[d]) * (1 + len(t[1]) + len(t[2]))
+        w_s = sum(work(d, trees[d]) for d in range(n_s))
+        w_all = sum(work(d, t) for d, t in enumerate(trees))
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "unit": "s", "value": dt * w_all / w_s,
+                               "sample": "the walk of the first %d held-out documents through oracle cascade_test (%.2f s), scaled by "
+                                         "sites x node visits (%d of %d)" % (n_s, dt, w_s, w_all),
+                               "sample_identical_to_device": all(str(a) == str(b) for a, b in zip(trees[:n_s], ported))}
+        out["speedup_vs_cpu_port"] = out["cpu_baseline"]["value"] / out["value"]
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ PMC passes
-PMC_WORKLOADS = ("synth2", "synth1", "synth2_hostile")     # dense kernels, in the order the inner run sweeps them
+# every workload whose sweep is ONE kernel launch per sweep, in the order the inner run sweeps them
+PMC_WORKLOADS = ("synth2", "synth1", "synth2_hostile", "synth2_sparse", "synth_wide_sparse", "synth_wide", "abstracts")
 PMC_SWEEPS = 3                                              # per workload in the inner run (all are measured)
+# one rocprofv3 run per group (kernel trace only, as the guide prescribes).  TCC holds 4 counters per pass
+# (FETCH_SIZE costs 3, WRITE_SIZE 2); SQ / TA / TCP / GRBM are separate blocks.
 PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
-              ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]))
+              ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
+                      "GRBM_GUI_ACTIVE"]),
+              ("l2", ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum"]),
+              ("ta", ["TA_BUSY_avr", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCC_READ_REQ_sum"]))
+MALL_BYTES = 256 * 2 ** 20                                  # Infinity Cache (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0                                 # measured streaming ceiling of the guide
+
+
+def is_sweep_kernel(name):
+    return "llda_sweep" in name
 
 
 def pmc_inner(dev, workloads):
-    """the process rocprofv3 wraps: PMC_SWEEPS sweeps of each dense workload, nothing else."""
+    """the process rocprofv3 wraps: PMC_SWEEPS sweeps of each workload, nothing else."""
     for name in workloads:
         s, info = build_sampler(name, dev, 0, 1, False)
         for _ in range(PMC_SWEEPS):
@@ -329,13 +533,14 @@ def pmc_inner(dev, workloads):
         torch.cuda.empty_cache()
 
 
-def pmc_collect(workloads, keep_dir=None, timeout=240):
-    """Run this script under rocprofv3, one --pmc group per pass (kernel trace only, as the guide prescribes), and
-    return {workload: {counter: mean per sweep-kernel launch}}.  Any failure returns {} (traffic is then null)."""
+def pmc_collect(workloads, keep_dir=None, timeout=300):
+    """Run this script under rocprofv3, one --pmc group per pass, and return
+    ({workload: {counter: mean per sweep-kernel launch}}, note).  A pass that fails only loses its own counters."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {}, "rocprofv3 not found"
     out = {w: {} for w in workloads}
+    problems = []
     tmp = tempfile.mkdtemp(prefix="llda_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -354,79 +559,134 @@ def pmc_collect(workloads, keep_dir=None, timeout=240):
             except subprocess.TimeoutExpired:
                 os.killpg(proc.pid, 9)
                 proc.communicate()
-                return {}, "rocprofv3 pass %s did not finish in %d s" % (tag, timeout)
+                problems.append("pass %s did not finish in %d s" % (tag, timeout))
+                continue
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if proc.returncode != 0 or not files:
-                return {}, "rocprofv3 pass %s failed (rc %d): %s" % (tag, proc.returncode, out_text.decode(errors="replace")[-300:])
-            rows = []
+                problems.append("pass %s failed (rc %d): %s" % (tag, proc.returncode, out_text.decode(errors="replace")[-200:]))
+                continue
+            rows, names = [], {}
             for r_ in csv.DictReader(open(files[0])):
                 nm = r_["Kernel_Name"]
-                if "llda_sweep_kernel" in nm or "llda_sweep_exact_kernel" in nm:
-                    rows.append((int(r_["Dispatch_Id"]), r_["Counter_Name"], float(r_["Counter_Value"])))
+                if is_sweep_kernel(nm):
+                    did = int(r_["Dispatch_Id"])
+                    names[did] = nm
+                    rows.append((did, r_["Counter_Name"], float(r_["Counter_Value"])))
                     if r_["Counter_Name"] == counters[0]:      # the launch's duration under this pass
-                        rows.append((int(r_["Dispatch_Id"]), tag + "_pass_kernel_ns",
+                        rows.append((did, tag + "_pass_kernel_ns",
                                      float(int(r_["End_Timestamp"]) - int(r_["Start_Timestamp"]))))
             disp = sorted(set(x[0] for x in rows))
             if len(disp) != PMC_SWEEPS * len(workloads):
-                return {}, "unexpected number of sweep-kernel dispatches in pass %s: %d" % (tag, len(disp))
+                problems.append("pass %s: %d sweep-kernel dispatches, expected %d" % (tag, len(disp), PMC_SWEEPS * len(workloads)))
+                continue
             which = {d_: workloads[i // PMC_SWEEPS] for i, d_ in enumerate(disp)}
             agg = collections.defaultdict(list)
             for d_, c, v in rows:
                 agg[(which[d_], c)].append(v)
             for (w, c), v in agg.items():
                 out[w][c] = sum(v) / PMC_SWEEPS          # a counter may be reported in several rows per dispatch
+            for d_, nm in names.items():
+                out[which[d_]]["kernel_name"] = nm.split("(")[0]
             if keep_dir:
                 os.makedirs(keep_dir, exist_ok=True)
                 shutil.copy(files[0], os.path.join(keep_dir, "pmc_%s_counter_collection.csv" % tag))
     except Exception as e:                                # noqa: BLE001 -- the bench line must survive a profiler problem
-        return {}, "pmc collection failed: %r" % (e,)
+        problems.append("pmc collection failed: %r" % (e,))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return out, "in-run rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group), %d launches each" % PMC_SWEEPS
+    note = "in-run rocprofv3 --kernel-trace --pmc passes (%s), %d launches each" % (" | ".join(t for t, _ in PMC_PASSES), PMC_SWEEPS)
+    if problems:
+        note += "; PROBLEMS: " + "; ".join(problems)
+    return out, note
 
 
-def roofline_json(kernel_ms, sites, docs, live_topics, pmc, source, stored_key=None):
-    """roofline of the sweep kernel.  `hbm`: HBM-side bytes from the PMC counters over the kernel's mean duration
-    (HIP events in the timed region) against 8 TB/s.  `valu_issue`: VALU instructions issued x 4 cycles against
-    1024 SIMDs x clock.  Algorithmic bytes are reported separately: hot n_kw rows are served by the
-    L2s / Infinity Cache, so algorithmic bytes over time is NOT an HBM rate."""
+def roofline_json(kernel_ms, sites, docs, live_topics, pmc, source, stored_key=None, shared_bytes=0, kernel="llda_sweep_kernel"):
+    """Roofline block of one sweep kernel.
+
+    achieved / frac / traffic: bytes that crossed the L2 <-> fabric interface per launch, from the PMC counters
+    ((2 x FETCH_SIZE + WRITE_SIZE) x 1024: L2 line fills are 128-byte requests tallied as 64, MI355X_MICROARCH.md),
+    over the kernel's mean duration (HIP events in the timed region), against the 8 TB/s HBM peak.  These requests
+    INCLUDE hits in the 256 MiB Infinity Cache -- gfx950 exposes no counter behind it (TCC_EA0_RDREQ_DRAM_sum equals
+    TCC_EA0_RDREQ_sum on every workload) -- so the figure is an UPPER bound of the HBM rate; `hbm_estimate` brackets it.
+    `valu_issue`: wave64 VALU instructions x 4 cycles against 1024 SIMDs x clock.  `binding_roof` names the ceiling the
+    evidence points at.  Algorithmic bytes are reported separately: rows served by L1 / L2 never reach the
+    fabric, so algorithmic bytes over time is not a memory rate at all."""
     alg = algorithmic_bytes(sites, docs, live_topics)
     ks = kernel_ms * 1e-3
-    traffic = None
+    traffic, kind = None, None
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-        traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        traffic, kind = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0, "measured"
     elif stored_key:
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             per_site = json.load(open(tpath)).get(stored_key)
             if per_site:
-                traffic = per_site * sites
-                source = "stored PMC figure (profiles/pmc_traffic.json: %.1f HBM bytes per site) x local sites" % per_site
-    r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "llda_sweep_kernel", "kernel_ms": kernel_ms,
+                traffic, kind = per_site * sites, "stored"
+                source = ("STORED, not measured in this run: profiles/pmc_traffic.json holds %.1f fabric bytes per site from "
+                          "the single-GPU counter passes; x local sites" % per_site)
+    r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": (pmc or {}).get("kernel_name", kernel),
+         "kernel_ms": kernel_ms,
          "algorithmic_bytes_per_launch": alg, "algorithmic_GBps": alg / ks / 1e9,
-         "algorithmic_note": "SURVEY 8(d) bytes / kernel time; includes rows served by L2 / Infinity Cache, so it may "
+         "algorithmic_note": "SURVEY 8(d) bytes / kernel time; includes rows served by L1 / L2 / Infinity Cache, so it may "
                              "exceed the HBM peak and is not the roofline fraction"}
+    cands = {}
     if traffic is not None:
-        r.update(achieved=traffic / ks / 1e9, frac=traffic / ks / 1e9 / HBM_PEAK_GBS, traffic=traffic,
-                 traffic_source=source, traffic_over_algorithmic=traffic / alg)
+        fabric = traffic / ks / 1e9
+        # what HBM itself must at least move: the state that is streamed once per sweep and cannot stay in the 256 MiB
+        # cache from one sweep to the next (sites: word, freq, z read + write, log word; documents: n_dk read + write of
+        # the live entries) -- plus the shared counts when they do not fit either
+        floor = sites * 24.0 + docs * 8.0 * live_topics + (shared_bytes if shared_bytes > MALL_BYTES else 0)
+        r.update(achieved=fabric, frac=fabric / HBM_PEAK_GBS, traffic=traffic, traffic_kind=kind, traffic_source=source,
+                 traffic_over_algorithmic=traffic / alg,
+                 achieved_is="fabric_GBps: L2 <-> fabric bytes (L2 line fills + write-backs), Infinity-Cache hits included",
+                 fabric_GBps=fabric,
+                 hbm_estimate={"lower_GBps": floor / ks / 1e9, "upper_GBps": min(fabric, HBM_ACHIEVABLE_GBS),
+                               "note": "lower = bytes streamed once per sweep that no cache can hold; upper = the fabric "
+                                       "rate capped at the %.1f TB/s a streaming copy achieves; shared counts %.0f MB %s "
+                                       "the 256 MiB Infinity Cache" % (HBM_ACHIEVABLE_GBS / 1e3, shared_bytes / 1e6,
+                                                                       "exceed" if shared_bytes > MALL_BYTES else "fit")})
+        cands["hbm" if shared_bytes > MALL_BYTES else "fabric (L2 fills, mostly Infinity-Cache hits)"] = fabric / HBM_PEAK_GBS
     else:
-        r.update(achieved=None, frac=None, traffic=None, traffic_source=source)
+        r.update(achieved=None, frac=None, traffic=None, traffic_kind=None, traffic_source=source)
+    if pmc and pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
+        r["l2"] = {"hit_rate": pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]),
+                   "requests_per_site": (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]) / sites,
+                   "fabric_read_requests_per_site": pmc.get("TCC_EA0_RDREQ_sum", float("nan")) / sites,
+                   "fabric_write_requests_per_site": pmc.get("TCC_EA0_WRREQ_sum", float("nan")) / sites}
+    cycles = None
+    if pmc and pmc.get("GRBM_GUI_ACTIVE"):
+        cycles = pmc["GRBM_GUI_ACTIVE"] / N_XCD                       # shader cycles of the profiled launch
+    if pmc and cycles and pmc.get("TA_BUSY_avr") is not None:
+        r["ta_busy_frac"] = pmc["TA_BUSY_avr"] / cycles
+        if pmc.get("TCP_PENDING_STALL_CYCLES_sum") is not None:
+            r["tcp_pending_stall_frac"] = pmc["TCP_PENDING_STALL_CYCLES_sum"] / 256.0 / cycles
     if pmc and "SQ_INSTS_VALU" in pmc:
         insts = pmc["SQ_INSTS_VALU"]
         peak_ips = N_SIMD * MAX_CLOCK_HZ / VALU_CYCLES_PER_INST
         v = {"achieved": insts / ks, "peak": peak_ips, "unit": "wave64 VALU instructions/s",
              "frac": insts / ks / peak_ips, "valu_insts_per_site": insts / sites,
              "model": "SQ_INSTS_VALU x %d cycles / (%d SIMDs x %.1f GHz)" % (VALU_CYCLES_PER_INST, N_SIMD, MAX_CLOCK_HZ / 1e9)}
-        if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("SQ_ACTIVE_INST_VALU"):
-            cycles = pmc["GRBM_GUI_ACTIVE"] / N_XCD                       # shader cycles of the profiled launch
+        if cycles and pmc.get("SQ_ACTIVE_INST_VALU"):
             v["valu_busy_frac"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * N_SIMD)
             v["valu_busy_note"] = ("SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share "
                                    "of the profiled launch's own cycles in which a SIMD issues VALU")
             if pmc.get("sq_pass_kernel_ns"):
                 v["effective_clock_GHz"] = cycles / pmc["sq_pass_kernel_ns"]
+        if pmc.get("SQ_WAIT_INST_ANY") and pmc.get("SQ_WAVE_CYCLES"):
+            v["wave_cycles_waiting_frac"] = pmc["SQ_WAIT_INST_ANY"] / pmc["SQ_WAVE_CYCLES"]
+            if cycles:
+                v["waves_per_simd_avg"] = pmc["SQ_WAVE_CYCLES"] * 4.0 / (cycles * N_SIMD)
         r["valu_issue"] = v
-        if traffic is not None:
-            r["binding_roof"] = "valu_issue" if v["frac"] > r["frac"] else "hbm"
+        cands["valu_issue"] = v["frac"]
+    if cands:
+        best = max(cands, key=cands.get)
+        r["binding_roof"] = best
+        r["roof_fractions"] = cands
+        r["headroom"] = 1.0 - cands[best]
+        r["binding_note"] = ("the larger of: fabric bytes / time / 8 TB/s (called 'hbm' only when the shared counts exceed the "
+                             "Infinity Cache) and VALU instructions x 4 cycles / time / (1024 SIMDs x 2.4 GHz); a kernel far "
+                             "below both is bound by the latency of its dependent chain at its occupancy "
+                             "(valu_issue.wave_cycles_waiting_frac)")
     return r
 
 
@@ -587,7 +847,8 @@ def main():
             line["overlap_probe"] = probe
         # ---- extras (N = 1, default workload): the other configurations, timed in this run ----
         extra = {}
-        measured = {name: dict(kernel_ms=kavg, sites=sites_local, docs=info["docs_local"], live=live)}
+        measured = {name: dict(kernel_ms=kavg, sites=sites_local, docs=info["docs_local"], live=live,
+                               shared=sampler._counts.numel() * 4)}
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"], line["speedup_vs_cpu_port"] = cpu_baseline_json(sampler, info, name, value)
         del sampler, info
@@ -604,7 +865,8 @@ def main():
                      "ms_per_step": dt2 / st * 1e3, "timed_seconds": dt2, "docs": i2["docs_local"], "sites_per_sweep": s2.S,
                      "K": i2["K"], "V": i2["V"], "kernel": "sparse" if s2.live_off is not None else "dense",
                      "kernel_ms": k2}
-                measured[wname] = dict(kernel_ms=k2, sites=s2.S, docs=i2["docs_local"], live=i2["live_topics"])
+                measured[wname] = dict(kernel_ms=k2, sites=s2.S, docs=i2["docs_local"], live=i2["live_topics"],
+                                       shared=s2._counts.numel() * 4)
                 if wname == "abstracts":
                     e["live_topics_per_doc"] = i2["live_topics"]
                     e["algorithmic_GBps"] = algorithmic_bytes(s2.S, i2["docs_local"], i2["live_topics"]) / (k2 * 1e-3) / 1e9
@@ -618,8 +880,8 @@ def main():
                 if wname == "synth2_sparse":
                     e["live_topics_per_doc"] = i2["live_topics"]
                     e["algorithmic_GBps"] = algorithmic_bytes(s2.S, i2["docs_local"], i2["live_topics"]) / (k2 * 1e-3) / 1e9
-                    e["note"] = ("one lane per allowed topic; every 4-byte gather of n_kw[v, pos] costs a 32-byte sector "
-                                 "(263 B fetched per site by the counters, profiles/r01v13_synth2_sparse_*), random labels")
+                    e["note"] = ("one lane per allowed topic; every 4-byte gather of n_kw[v, pos] that misses the L2 costs a "
+                                 "128-byte line fill (roofline.l2: fabric requests per site), random labels")
                 if wname == "synth_wide":
                     e["kernel"] = "wide"
                     e["note"] = ("general path: bound by the latency of one wavefront's dependent chain at 8 wavefronts per CU "
@@ -628,18 +890,21 @@ def main():
                 del s2, i2
                 torch.cuda.empty_cache()
             extra["cascade"] = cascade_extra()
+            extra["pipeline_abstracts"] = pipeline_extra(with_cpu=not args.no_cpu)
+            extra["cascade_test"] = cascade_test_extra(with_cpu=not args.no_cpu)
         # ---- roofline: HBM-side counters collected in this run (separate rocprofv3 passes) ----
         pmc, source = ({}, "not collected (N > 1 or --no-pmc)")
         if pmc_names:
             pmc, source = pmc_collect(pmc_names, keep_dir=args.pmc_keep or None)
         m = measured[name]
         line["roofline"] = roofline_json(m["kernel_ms"], m["sites"], m["docs"], m["live"], pmc.get(name), source,
-                                         stored_key=name)
-        for key, wname in (("synth1", "synth1"), ("hbm_bound", "synth2_hostile")):
+                                         stored_key=name, shared_bytes=m["shared"])
+        for key, wname in (("synth1", "synth1"), ("hbm_bound", "synth2_hostile"), ("sparse_labels", "synth2_sparse"),
+                           ("wide_sparse_k2048", "synth_wide_sparse"), ("wide_k2048", "synth_wide"), ("abstracts", "abstracts")):
             if key in extra:
                 m = measured[wname]
                 extra[key]["roofline"] = roofline_json(m["kernel_ms"], m["sites"], m["docs"], m["live"], pmc.get(wname),
-                                                       source, stored_key=wname)
+                                                       source, stored_key=wname, shared_bytes=m["shared"])
         if extra:
             line["extra"] = extra
         print(json.dumps(line))

@@ -125,7 +125,9 @@ typedef struct llda_sweep_args {
     /* optional sparse-label path (live_off, live_pos non-NULL and live_max <= 64): one lane per allowed
      * topic instead of one lane per 16 topics */
     const int64_t *live_off;     /* [dev] [D+1] offsets into live_pos                              */
-    const int32_t *live_pos;     /* [dev] device positions of the topics every document allows, ascending */
+    const int32_t *live_pos;     /* [dev] device positions of the topics every document allows, in DRAW order:
+                                  * ascending (lane, slot) of the layout -- llda_layout.pos_lane / pos_slot --,
+                                  * which for layouts with T >= 8 is not ascending memory position          */
     int32_t       *resume;       /* unused since ABI 10 (pass NULL): a site the sparse kernel cannot decide is now   */
     int32_t       *resume_count; /* resolved inside the kernel by the exact pipeline instead of being handed to a    */
     int32_t  resume_cap;         /* second launch; the fields keep the struct layout                                 */
@@ -191,7 +193,8 @@ typedef struct llda_batch_args {
     const int32_t *inst_prob;    /* [dev] [I] problem of every instance                               */
     const int32_t *inst_doc;     /* [dev] [I] index of the document inside its problem (RNG word 1)   */
     const int64_t *live_off;     /* [dev] [I+1] offsets into live_pos                                 */
-    const int32_t *live_pos;     /* [dev] allowed device positions of every instance, ascending       */
+    const int32_t *live_pos;     /* [dev] allowed device positions of every instance, in DRAW order
+                                  * (ascending (lane, slot) of the instance's layout, see llda_sweep_args) */
     const int64_t *ndk_off;      /* [dev] [I] offset of the instance's n_dk row (KP_p entries) in n_dk */
     int32_t       *n_dk;         /* [dev] in/out                                                      */
     const int64_t *kw_off;       /* [dev] [P] offset of problem p's n_kw in counts / delta            */

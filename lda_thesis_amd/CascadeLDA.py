@@ -527,8 +527,10 @@ class CascadeLDA(object):
         (reference CascadeLDA.py:135-184).  Sub-problem i (visiting order) uses RNG stream id i.
 
         batched=True: all sub-problems of this rank are trained TOGETHER (lda_thesis_amd/ensemble.py: a sweep of
-        the whole ensemble is a handful of launches).  Priors below 1e-6 or a sub-problem of more than 128 topics --
-        outside what llda_sweep_batch covers -- take the one-by-one path instead, which gives the same result.
+        the whole ensemble is a handful of launches).  Priors below 1e-6, a sub-problem of more than 128 topics or a
+        document that allows more than 64 of them -- outside what llda_sweep_batch covers -- take the one-by-one path
+        instead, which gives the same result.  A rank that is assigned no sub-problem (more ranks than sub-problems)
+        trains nothing and only takes part in the final all-reduce.
         keep_state=True keeps the trained ensemble in ``self._ensemble`` (tests)."""
         import torch.distributed as dist
         world, rank = 1, 0
@@ -585,9 +587,14 @@ class CascadeLDA(object):
         z_local = np.split(z_all, np.cumsum(sites)[:-1])
         owner = lpt_assign(sites, world)
         mine = [i for i in range(len(plans)) if owner[i] == rank]
-        from .ensemble import MAX_BATCH_K
-        if any(pl["K"] > MAX_BATCH_K for pl in plans):
+        from .ensemble import MAX_BATCH_K, MAX_BATCH_ALLOWED
+        # decided from ALL plans, so that every rank takes the same path
+        if any(pl["K"] > MAX_BATCH_K or (len(pl["docs"]) and int(pl["n_allowed"].max()) > MAX_BATCH_ALLOWED) for pl in plans):
             return owner, False
+        if not mine:                                   # more ranks than sub-problems: nothing to train here
+            self._owned_rows = np.zeros(0, dtype=np.int64)
+            self._ensemble = None
+            return owner, True
         ens = Ensemble([plans[i] for i in mine], [z_local[i] for i in mine], doc_off, word, freq,
                        self.V, self.alpha, self.beta, self.seed, device=self._device, streams=mine)
         ens.debug_margin = self._batch_debug_margin

@@ -26,7 +26,7 @@ struct BParams {
     const int32_t *inst_prob;    // [I] problem of the instance
     const int32_t *inst_doc;     // [I] index of the document inside its problem (RNG counter word 1)
     const int64_t *live_off;     // [I+1]
-    const int32_t *live_pos;     // allowed positions, ascending
+    const int32_t *live_pos;     // allowed positions in draw order: ascending (lane, slot), not memory position
     const int64_t *ndk_off;      // [I] offset of the instance's n_dk row
     int32_t *n_dk;
     const int64_t *kw_off;       // [P] offset of the problem's n_kw (V x KP) in counts / delta

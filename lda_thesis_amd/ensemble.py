@@ -32,6 +32,7 @@ from . import _native
 from .layout import group_layout
 
 MAX_BATCH_K = 128            # llda_sweep_batch: every problem is one numpy pairwise leaf (8 lanes)
+MAX_BATCH_ALLOWED = 64       # ... and a document has one lane per allowed topic
 
 
 def choice_cdf_table(a_max):
@@ -127,8 +128,9 @@ class Ensemble(object):
         live_off = np.concatenate(([0], np.cumsum(n_allowed)))
         live_pos = apos[apos != big]
         self.n_allowed_max = int(n_allowed.max()) if self.I else 0
-        if self.n_allowed_max > 64:
-            raise ValueError("a document allows %d topics; the batched ensemble handles at most 64" % self.n_allowed_max)
+        if self.n_allowed_max > MAX_BATCH_ALLOWED:
+            raise ValueError("a document allows %d topics; the batched ensemble handles at most %d (CascadeLDA.go_down_tree "
+                             "takes the one-by-one path for such corpora)" % (self.n_allowed_max, MAX_BATCH_ALLOWED))
 
         def up(a, dtype):
             return torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dtype)

@@ -113,9 +113,9 @@ def fold_in(ph_hat, alpha, doc_tups, it, thinning, seed, stream_id=TEST_STREAM, 
     n_dk (D, K), z).
 
     prep4test's column normalisation (LabeledLDA.py:159-167: ``probs = ph_hat[:, doc]; probs /= probs.sum(axis=0)``,
-    uniform 1/K for a document that holds a column which cannot be normalised) runs on the device: numpy reduces
-    axis 0 of a C-contiguous matrix row by row, i.e. sequentially over the topics, which K in-place row additions
-    reproduce bit for bit; the division is IEEE on both sides."""
+    uniform 1/K for a document that holds a column which cannot be normalised) runs on the device: the fancy-indexed
+    ``ph_hat[:, doc]`` is F-contiguous, so numpy reduces every column with its pairwise sum (``numpy_column_sums``
+    restates that order); the division is IEEE on both sides."""
     _native.lib()
     _native.require_device()
     dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
@@ -126,9 +126,7 @@ def fold_in(ph_hat, alpha, doc_tups, it, thinning, seed, stream_id=TEST_STREAM, 
         if not doc:
             raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
     lay = group_layout(K)
-    colsum = ph[0].clone()
-    for k in range(1, K):
-        colsum += ph[k]                                              # sequential over k, as numpy's axis-0 sum
+    colsum = numpy_column_sums(ph)
     phn = ph / colsum                                                # 0/0 -> nan, x/0 -> inf as numpy (errstate ignore)
     bad = ~torch.isfinite(phn).all(dim=0) | (colsum == 0)
     lm = torch.from_numpy(lay.lm_topic_pos.astype(np.int64)).to(dev)
@@ -168,16 +166,38 @@ def cascade_init_rows(ph, beta, doc_tups):
     return rows, np.arange(rows.shape[0])
 
 
+def numpy_column_sums(m):
+    """``a.sum(axis=0)`` of numpy for an F-contiguous (K, n) float64 matrix -- what ``ph[:, ids]`` is -- on a torch
+    tensor ``m`` (K, n): numpy reduces every column (contiguous, length K) with its pairwise sum: fewer than 8 terms
+    sequentially; up to 128 terms eight strided accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the
+    tail sequentially; beyond that split at n/2 rounded down to a multiple of 8 (the same
+    order the sweep kernels use for the score sum).  Bit-identical to numpy: IEEE fp64 additions in the same order."""
+    K = m.shape[0]
+    if K < 8:
+        res = m[0].clone()
+        for k in range(1, K):
+            res += m[k]
+        return res
+    if K <= 128:
+        nb = K - K % 8
+        r = m[0:8].clone()
+        for i in range(8, nb, 8):
+            r += m[i:i + 8]
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        for k in range(nb, K):
+            res = res + m[k]
+        return res
+    n2 = K // 2
+    n2 -= n2 % 8
+    return numpy_column_sums(m[:n2]) + numpy_column_sums(m[n2:])
+
+
 def cascade_init_rows_device(ph, beta, doc_off, word_dev, lay):
     """cascade_init_rows on the device for loadings ``ph`` (K, V) that live there: the same elementwise expressions
-    (CascadeLDA.py:193-198); ``probs.sum(axis=0)`` of the (K, n) matrix is numpy's sequential sum over the K rows.
-    -> (S, KP) lane-major rows."""
-    K = ph.shape[0]
+    (CascadeLDA.py:193-198); ``probs.sum(axis=0)`` of the F-contiguous (K, n) matrix in numpy's pairwise order
+    (``numpy_column_sums``).  -> (S, KP) lane-major rows, row d bitwise what ``cascade_init_rows`` gives."""
     probs = ph[:, word_dev] + beta                                   # (K, S): probs = ph[:, ids]; probs += beta
-    colsum = probs[0].clone()
-    for k in range(1, K):
-        colsum += probs[k]
-    probs /= colsum
+    probs /= numpy_column_sums(probs)
     lens = np.diff(doc_off)
     inv_len = np.repeat(1 / lens.astype(np.float64), lens)           # probs[0, :] = 1 / len(ids)
     probs[0] = torch.from_numpy(inv_len).to(ph.device)

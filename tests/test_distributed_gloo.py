@@ -148,7 +148,7 @@ def test_single_process_oracle_backend_matches_golden(c_oracle, monkeypatch):
         assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics())
 
 
-def _cascade_worker(rank, world, port, batched, q, hip=False):
+def _cascade_worker(rank, world, port, batched, q, hip=False, all_on_rank0=False):
     dev = _setup(rank, world, port, hip)
     from fixture_corpora import cascade_corpus
     import lda_thesis_amd.CascadeLDA as C
@@ -167,12 +167,14 @@ def _cascade_worker(rank, world, port, batched, q, hip=False):
             k.update(device=dev)
             super().__init__(plans, z_local, *a, **k)
     E.Ensemble = DevEnsemble
+    if all_on_rank0:                           # as if there were more ranks than sub-problems: rank 1 trains nothing
+        C.lpt_assign = lambda costs, n_workers: [0] * len(costs)
     g = load_golden("cascade_toy")
     docs, labs, labelset = cascade_corpus()
     np.random.seed(int(g["np_seed"]))
     c = C.CascadeLDA(docs, labs, list(labelset), Dictionary(docs), float(g["alpha"]), float(g["beta"]), seed=int(g["seed"]))
     owner = c.go_down_tree(it=int(g["it"]), s=int(g["s"]), batched=batched, keep_state=True)
-    ok = bool(np.array_equal(c.ph, g["ph"])) and (c._ensemble is not None) == batched
+    ok = bool(np.array_equal(c.ph, g["ph"])) and (c._ensemble is not None) == (batched and not (all_on_rank0 and rank > 0))
     # a second call must not add the rows of the first call in again (the all-reduce sums only the owned rows)
     ph1 = c.ph.copy()
     np.random.seed(int(g["np_seed"]))
@@ -202,6 +204,27 @@ def test_cascade_subproblems_spread_over_two_ranks(batched):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == [0, 1]                      # both ranks own some sub-problems
+
+
+def _cascade_idle(rank, world, port, batched, q):
+    _cascade_worker(rank, world, port, batched, q, all_on_rank0=True)
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_cascade_rank_without_subproblems(batched):
+    """a rank that owns no sub-problem builds no ensemble, takes part in the all-reduce and ends with the full ph."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cascade_idle, args=(r, 2, port, batched, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == [0]
 
 
 def _llda_worker(rank, world, port, q, hip=False):

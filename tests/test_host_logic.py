@@ -221,3 +221,26 @@ def test_plan_subproblems_equals_the_list_based_enumeration():
         z = draw_initial_topics(pl["allowed"], pl["n_allowed"], np.repeat(np.arange(len(pl["docs"])), n_sites), u)
         np.testing.assert_array_equal(z, sub._z0)
         t["labset"].remove("root")
+
+
+@pytest.mark.parametrize("K", [2, 7, 8, 9, 20, 40, 127, 128, 129, 130, 300, 1031])
+def test_device_column_normalisation_is_numpys_pairwise_order(K):
+    """``ph[:, ids]`` is F-contiguous, so the reference's ``probs.sum(axis=0)`` (LabeledLDA.py:161, CascadeLDA.py:195)
+    reduces every column with numpy's pairwise sum -- for K >= 8 not the sequential sum over the rows.  The torch
+    statements that prepare the fold-in on the device must give the same bits as the numpy expressions."""
+    import torch
+    from lda_thesis_amd.foldin import cascade_init_rows, cascade_init_rows_device, numpy_column_sums
+    from lda_thesis_amd.layout import group_layout
+    rng = np.random.default_rng(K)
+    V = 37
+    ph = rng.random((K, V)) ** 6
+    ph[rng.random((K, V)) < 0.3] = 0.0
+    ids = [0, 3, 4, 11, 36, 20, 7]
+    np.testing.assert_array_equal(numpy_column_sums(torch.from_numpy(ph)).numpy()[ids], ph[:, ids].sum(axis=0))
+    tups = [[(3, 1), (4, 2), (20, 1)], [(0, 5)], [(7, 1), (11, 1), (36, 2), (3, 1)]]
+    want, _ = cascade_init_rows(ph.copy(), 0.01, tups)
+    lay = group_layout(K)
+    doc_off = np.array([0, 3, 4, 8])
+    word = torch.tensor([3, 4, 20, 0, 7, 11, 36, 3])
+    got = cascade_init_rows_device(torch.from_numpy(ph.copy()), 0.01, doc_off, word, lay)
+    np.testing.assert_array_equal(got[:, torch.from_numpy(lay.lm_topic_pos.astype(np.int64))].numpy(), want)
