@@ -33,6 +33,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import socket
 import subprocess
@@ -488,7 +489,7 @@ def cascade_test_extra(with_cpu=True):
                     keep3, loads3 = model._head(node(tup, labels), labels, THR)
                     l3.append(list(zip(keep3, loads3)))
             return l1, l2, l3
-        n_s = min(8, len(held))
+        n_s = min(3, len(held))
         t0 = time.perf_counter()
         ported = [walk(bows[d]) for d in range(n_s)]
         dt = time.perf_counter() - t0
@@ -520,6 +521,12 @@ HBM_ACHIEVABLE_GBS = 6300.0                                 # measured streaming
 
 def is_sweep_kernel(name):
     return "llda_sweep" in name
+
+
+def short_kernel_name(name):
+    """'void (anonymous namespace)::llda_sweep_kernel<32, 16, false, true, true, false>(KParams)' -> the template-id"""
+    m = re.search(r"llda_\w+(<[^()]*>)?", name.replace("(anonymous namespace)::", ""))
+    return m.group(0) if m else name
 
 
 def pmc_inner(dev, workloads):
@@ -586,10 +593,18 @@ def pmc_collect(workloads, keep_dir=None, timeout=300):
             for (w, c), v in agg.items():
                 out[w][c] = sum(v) / PMC_SWEEPS          # a counter may be reported in several rows per dispatch
             for d_, nm in names.items():
-                out[which[d_]]["kernel_name"] = nm.split("(")[0]
+                out[which[d_]]["kernel_name"] = short_kernel_name(nm)
             if keep_dir:
+                # the raw file has one row per counter INSTANCE (XCD / SE / channel) per dispatch -- tens of MB; what is
+                # kept is one row per sweep-kernel dispatch and counter: the sum over the instances
                 os.makedirs(keep_dir, exist_ok=True)
-                shutil.copy(files[0], os.path.join(keep_dir, "pmc_%s_counter_collection.csv" % tag))
+                tot = collections.OrderedDict()
+                for d_, c, v in rows:
+                    tot[(d_, c)] = tot.get((d_, c), 0.0) + v
+                with open(os.path.join(keep_dir, "pmc_%s.csv" % tag), "w") as fh:
+                    fh.write("Dispatch_Id,Workload,Kernel_Name,Counter_Name,Counter_Value_summed_over_instances\n")
+                    for (d_, c), v in tot.items():
+                        fh.write('%d,%s,"%s",%s,%.6f\n' % (d_, which[d_], short_kernel_name(names[d_]), c, v))
     except Exception as e:                                # noqa: BLE001 -- the bench line must survive a profiler problem
         problems.append("pmc collection failed: %r" % (e,))
     finally:

@@ -71,6 +71,18 @@ __device__ __forceinline__ uint32_t opaque_u32(uint32_t x)
     asm("" : "+v"(x));
     return x;
 }
+// The kernel-argument segment as a FRESH pointer (constant address space: loads through it are s_load from the scalar
+// cache).  The empty asm makes the pointer opaque, so a field read through it is re-loaded where the read is written
+// instead of being hoisted out of every loop and kept -- or spilled to VGPR lanes -- for the whole kernel.  For fields
+// that are needed once per document or once per batch of sites this trades a v_readlane reload for an s_load.
+#define LLDA_CONSTANT __attribute__((address_space(4)))
+template <class PT>
+__device__ __forceinline__ const LLDA_CONSTANT PT *kernarg_fresh()
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const LLDA_CONSTANT PT *)p;
+}
 __device__ __forceinline__ int gload_i32(const int32_t *base, uint32_t byte_off)
 {
     return *(const LLDA_GLOBAL int32_t *)((const LLDA_GLOBAL char *)base + byte_off);

@@ -303,11 +303,13 @@ __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, co
 
 // store the new assignment of a site and move its count in n_kw_delta (int32 atomics, no return value)
 // (c = the site's position in the commit log when there is one; v, f are only needed without a log)
-__device__ __forceinline__ void commit_site(const KParams &P, int64_t i, int v, int f, int zo, int zn, int c, int KP)
+template <class PR>      // PR: const KParams & or a reference into the kernel-argument segment (kernarg_fresh)
+__device__ __forceinline__ void commit_site(PR &P, int64_t i, int v, int f, int zo, int zn, int c, int KP)
 {
     P.z[i] = zn;
-    if (P.commit_log) {
-        P.commit_log[c] = (uint32_t)zo | ((uint32_t)zn << 16);
+    uint32_t *log = P.commit_log;
+    if (log) {
+        log[c] = (uint32_t)zo | ((uint32_t)zn << 16);
     } else if (zn != zo) {
         int32_t *row = P.n_kw_delta + (int64_t)v * KP;
         atomicAdd(row + zo, -f);

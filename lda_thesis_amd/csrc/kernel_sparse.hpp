@@ -139,7 +139,8 @@ __device__ __forceinline__ void sparse_site(const PT &P, int layK, int layKP, in
     const double Q = scan_any_f64<GS>(w, lig);
     const double tot = allsum_any_f64<GS>(w, lane);
     const double t = u * tot, margin = tot * P.margin_rel;
-    const bool unsure = active && ((live && !(fabs(Q - t) > margin)) || !(tot > 0.0) || !(margin < tot));
+    // (bitwise on purpose: the short-circuit forms compile to exec-mask branches around single compares)
+    const bool unsure = (active != 0) & ((live & !(fabs(Q - t) > margin)) | !(tot > 0.0) | !(margin < tot));
     const uint64_t gf = (__ballot(live && Q > t) >> gbase) & gmask;
     const int sel = gf ? (int)__ffsll((unsigned long long)gf) - 1 : A - 1;          // none: last allowed topic
     int zn = allor_i32<GS>((lig == sel) ? pos : 0, lane);
@@ -166,7 +167,8 @@ __device__ __forceinline__ void sparse_site(const PT &P, int layK, int layKP, in
     // add the site back (LabeledLDA.py:121-125)
     const int back = active & f & ((pos == zn) ? -1 : 0);
     ndk += back; nk += back;
-    my_zn = (active & ((lig == J) ? -1 : 0)) ? zn : my_zn;
+    // (lig through an opaque move: the eight loop-invariant masks lig == J would otherwise live in 16 SGPRs)
+    my_zn = (active & (((int)opaque_u32((uint32_t)lig) == J) ? -1 : 0)) ? zn : my_zn;
     done -= active;                                                                 // active is 0 or -1
 }
 
@@ -198,22 +200,28 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const PT P)
 
     // The document loops are WAVE-UNIFORM (a lane group whose document is shorter, empty or past the end of the shard
     // idles through flags, it does not leave the loop): the exact tier of sparse_site() needs all 64 lanes.
-    for (int it = 0; it < P.dpg; ++it) {
-        const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * GPB + grp;
-        const bool valid = idx < P.D;
+    const int dpg = P.dpg;
+    for (int it = 0; it < dpg; ++it) {
+        // (fields needed once per document are read through a fresh kernel-argument pointer: an s_load here instead of
+        // a register -- or a spill slot -- held across the site loop)
+        const LLDA_CONSTANT PT *Q = kernarg_fresh<PT>();
+        const int64_t idx = ((int64_t)blockIdx.x * Q->dpg + it) * GPB + grp;
+        const bool valid = idx < Q->D;
         if (!__any(valid)) break;
-        const int64_t d = valid ? (P.doc_order ? (int64_t)P.doc_order[idx] : idx) : 0;
-        const int64_t s0 = P.doc_off[d];
-        const int len = valid ? (int)(P.doc_off[d + 1] - s0) : 0;
-        const int64_t l0 = P.live_off[d];
-        const int A = (int)(P.live_off[d + 1] - l0);
+        const int32_t *order = Q->doc_order;
+        const int64_t d = valid ? (order ? (int64_t)order[idx] : idx) : 0;
+        const int64_t *doc_off = Q->doc_off, *live_off = Q->live_off;
+        const int64_t s0 = doc_off[d];
+        const int len = valid ? (int)(doc_off[d + 1] - s0) : 0;
+        const int64_t l0 = live_off[d];
+        const int A = (int)(live_off[d + 1] - l0);
         const bool live = valid && len > 0 && lig < A;
-        const int pos = live ? P.live_pos[l0 + lig] : -1;
-        int32_t *ndk_p = P.n_dk + d * KP + (live ? pos : 0);
+        const int pos = live ? Q->live_pos[l0 + lig] : -1;
+        int32_t *ndk_p = Q->n_dk + d * KP + (live ? pos : 0);
         int ndk = live ? *ndk_p : 0;
         const int ndk0 = ndk;
-        int nk = live ? P.n_k[pos] : 0;
-        const uint32_t gdoc = (uint32_t)(d + P.doc_base);
+        int nk = live ? Q->n_k[pos] : 0;
+        const uint32_t gdoc = (uint32_t)(d + Q->doc_base);
         int max_len = len;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) max_len = max(max_len, __shfl_xor(max_len, o, 64));
@@ -231,8 +239,10 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const PT P)
             const int nbb = max(0, min(8, len - n0b));
             S.v = S.f = S.z = S.c = 0;
             if (nbb > 0) {
+                const LLDA_CONSTANT PT *B = kernarg_fresh<PT>();     // (once per batch of 8 sites)
                 const int64_t si = s0 + n0b + (jj < nbb ? jj : nbb - 1);
-                S.v = P.word[si]; S.f = P.freq[si]; S.z = P.z[si]; S.c = P.csc_pos ? P.csc_pos[si] : 0;
+                const int32_t *cp = B->csc_pos;
+                S.v = B->word[si]; S.f = B->freq[si]; S.z = B->z[si]; S.c = cp ? cp[si] : 0;
             }
         };
         auto gather = [&](const int n0b, const int sv, int (&xg)[8]) {
@@ -281,7 +291,7 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const PT P)
             LLDA_SPARSE_SITE(4) LLDA_SPARSE_SITE(5) LLDA_SPARSE_SITE(6) LLDA_SPARSE_SITE(7)
 #undef LLDA_SPARSE_SITE
             // commit the sites of the batch: lane j handles site n0+j
-            if (lig < 8 && lig < done) commit_site(P, s0 + n0 + lig, sv, sf, sz, my_zn, sc, KP);
+            if (lig < 8 && lig < done) commit_site(*kernarg_fresh<PT>(), s0 + n0 + lig, sv, sf, sz, my_zn, sc, KP);
             Sc = Sn; Sn = Sf;
 #pragma unroll
             for (int j = 0; j < 8; ++j) xg[j] = xg_next[j];

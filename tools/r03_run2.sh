@@ -27,4 +27,4 @@ open("%s/gather_one_%s_%s.fetch.txt" % (out, fp, w), "w").write("\n".join("FETCH
 PY
 done
 timeout 600 python bench.py --make-checksums 64 > $OUT/checksums_synth2.json 2> $OUT/checksums.err
-ls -la $OUT $OUT/pmc
+du -sh $OUT; ls -la $OUT $OUT/pmc
