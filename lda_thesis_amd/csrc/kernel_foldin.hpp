@@ -54,15 +54,48 @@ __device__ __forceinline__ void load_row_f64(const double *__restrict__ p, doubl
     }
 }
 
-// `while prob.sum() > 1: prob /= c`  (LabeledLDA.py:170-171, 192-193); c_rcp = RN(1/c)
+// `while prob.sum() > 1: prob /= c`  (LabeledLDA.py:170-171, 192-193); c_rcp = RN(1/c).
+// The reference evaluates the sum before every division; CascadeLDA's prep4test rows sum to 1 - p_0 + 1/len(doc) and
+// c = 1.0000005, so one site can take tens of thousands of steps, and the numpy-ordered sum (a cross-lane reduction) is
+// by far the dearest part of a step.  Most of those sums can be skipped WITHOUT changing the result: every element is
+// non-increasing under p <- RN(p / c) (c > 1, rounding is monotone) and a tree of floating-point additions is monotone
+// in each of its non-negative leaves, so the computed sum S(k) after k steps is non-increasing in k; the reference
+// stops at the first k with S(k) <= 1, hence if S(k0) > 1 it has not stopped at any k <= k0.  So: run k0 division
+// steps on a copy without looking at the sum (k0 from log(S)/log(c), taken short), then compute S(k0); when it is
+// still > 1 the copy is where the reference is after k0 steps and the loop goes on from there; when it is not (the
+// estimate was too long -- never seen) the copy is dropped and the steps are taken one by one as the reference does.
 template <int G, int T, bool HAS_TAIL>
 __device__ __forceinline__ void shrink_to_one(double (&p)[T], double c, double c_rcp, const KParams &K, int lig, int lane)
 {
-    for (int guard = 0; guard < (1 << 28); ++guard) {   // the reference loops until the sum is <= 1
-        const double s = group_sum<G, T, HAS_TAIL>(p, K, lig, lane);
-        if (!(s > 1.0)) break;                     // group-uniform: every lane holds the same s
+    double s = group_sum<G, T, HAS_TAIL>(p, K, lig, lane);     // group-uniform: every lane holds the same s
+    bool may_jump = true;
+    int steps = 0;
+    while (s > 1.0 && steps < (1 << 28)) {                     // (the reference loops until the sum is <= 1)
+        if (may_jump) {
+            const double est = log(s) / log(c);                // real-arithmetic distance to sum = 1, in steps
+            const int k0 = (est > 96.0 && est < 2.0e8) ? (int)(est * 0.998) - 16 : 0;
+            if (k0 > 0) {
+                double q[T];
+#pragma unroll
+                for (int k = 0; k < T; ++k) q[k] = p[k];
+                for (int i = 0; i < k0; ++i) {
+#pragma unroll
+                    for (int k = 0; k < T; ++k) q[k] = div_by(q[k], c, c_rcp);
+                }
+                const double sq = group_sum<G, T, HAS_TAIL>(q, K, lig, lane);
+                if (sq > 1.0) {
+#pragma unroll
+                    for (int k = 0; k < T; ++k) p[k] = q[k];
+                    s = sq; steps += k0;
+                    continue;
+                }
+                may_jump = false;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < T; ++k) p[k] = div_by(p[k], c, c_rcp);
+        s = group_sum<G, T, HAS_TAIL>(p, K, lig, lane);
+        ++steps;
     }
 }
 

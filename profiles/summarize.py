@@ -1,17 +1,17 @@
-"""Summarise gpurun_out/prof_<tag>/ (written by tools/profile.sh on the GPU box) into profiles/:
+"""Summarise one profiling run (gpurun_out/<dir>/, written by tools/r03_run2.sh / tools/profile.sh on the GPU box) into profiles/:
 
-    profiles/<tag>_bench_default.json       the bench line of the default run (roofline from in-run PMC passes)
-    profiles/<tag>_kernel_stats.csv         rocprofv3 --kernel-trace --stats of the same command (kernels >= 0.05 %)
-    profiles/<tag>_pmc_*.csv                the sweep-kernel rows of the raw counter CSVs of the in-run passes
-    profiles/<tag>_summary.md               kernel table + counters per launch + the derived roofline numbers
-    profiles/pmc_traffic.json               HBM bytes per site per workload (bench.py's fallback when it cannot profile)
+    profiles/<tag>_bench_default.json       the bench line of the default run (rooflines from in-run PMC passes, all extras)
+    profiles/<tag>_kernel_stats.csv         rocprofv3 --kernel-trace --stats of the same command (kernels >= 0.02 %)
+    profiles/<tag>_pmc_<pass>.csv           the counter passes bench.py ran on itself: one row per sweep-kernel dispatch and
+                                            counter (summed over the counter's instances), passes fetch | write | sq | l2 | ta
+    profiles/<tag>_summary.md               kernel table + per workload: counters per launch and the derived roofline numbers
+    profiles/pmc_traffic.json               fabric bytes per site per workload (bench.py's labelled fallback at N > 1)
 
-HBM traffic per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes: FETCH_SIZE / WRITE_SIZE are in KiB, collected in
-separate --pmc passes, and on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads
-(MI355X_MICROARCH.md, section HBM) -- the kernel reads n_kw rows as 16 B/lane global_load_dwordx4.  WRITE_SIZE is
-uncalibrated on gfx950 (same section) and is taken as is.
+Fabric traffic per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes: FETCH_SIZE / WRITE_SIZE are in KiB, collected in
+separate --pmc passes; FETCH_SIZE tallies every L2 line fill (a 128-byte request) as 64 bytes (MI355X_MICROARCH.md, section
+HBM, for wide reads; tools/gather_ubench.hip for 4-byte gathers).  The requests include Infinity-Cache hits.
 
-usage: python profiles/summarize.py <tag>
+usage: python profiles/summarize.py <tag> [<dir under gpurun_out, default prof_<tag>>]
 """
 import csv
 import json
@@ -20,84 +20,102 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXTRAS = (("synth1", "synth1"), ("hbm_bound", "synth2_hostile"), ("sparse_labels", "synth2_sparse"),
+          ("wide_sparse_k2048", "synth_wide_sparse"), ("wide_k2048", "synth_wide"), ("abstracts", "abstracts"))
 
 
-def main(tag):
-    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+def main(tag, sub=None):
+    src = os.path.join(ROOT, "gpurun_out", sub or ("prof_" + tag))
     prof = os.path.join(ROOT, "profiles")
-    line = json.load(open(os.path.join(src, "bench_default.json")))
+    text = open(os.path.join(src, "bench_default.json")).read().strip().split("\n")[-1]
+    line = json.loads(text)
     json.dump(line, open(os.path.join(prof, "%s_bench_default.json" % tag), "w"), indent=1)
-    out = ["# rocprofv3 summary %s" % tag, "", "Command: `python bench.py` (default: the 1M-document corpus on one GPU).", ""]
+    out = ["# rocprofv3 summary %s" % tag, "", "Command: `python bench.py` (default: the 1M-document corpus on one GPU, all extras).", ""]
     stats = os.path.join(src, "stats_kernel_stats.csv")
     if os.path.exists(stats):
-        out += ["## kernel stats (`rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu --no-pmc --no-extras`)", "",
+        out += ["## kernel stats (`rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu --no-pmc`: every workload of the line)", "",
                 "| kernel | calls | avg ms | % |", "|---|---|---|---|"]
         keep = []
         rows = list(csv.DictReader(open(stats)))
         for r in rows:
-            if float(r["Percentage"]) >= 0.05:
+            if float(r["Percentage"]) >= 0.02:
                 keep.append(r)
-                out.append("| `%s` | %s | %.4f | %s |" % (r["Name"][:100], r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"]))
+                name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+                out.append("| `%s` | %s | %.4f | %s |" % (name[:110], r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"]))
         with open(os.path.join(prof, "%s_kernel_stats.csv" % tag), "w", newline="") as fh:
             w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
             w.writeheader()
             w.writerows(keep)
-    # counters: the sweep-kernel rows of the in-run passes
-    out += ["", "## PMC counters of llda_sweep_kernel, per launch (in-run passes of bench.py, 3 launches per workload)", ""]
-    for tagp in ("fetch", "write", "sq"):
-        f = os.path.join(src, "pmc", "pmc_%s_counter_collection.csv" % tagp)
+    counters = {}
+    for tagp in ("fetch", "write", "sq", "l2", "ta"):
+        f = os.path.join(src, "pmc", "pmc_%s.csv" % tagp)
         if not os.path.exists(f):
             continue
-        rows = [r for r in csv.DictReader(open(f)) if "llda_sweep_kernel" in r["Kernel_Name"]]
-        with open(os.path.join(prof, "%s_pmc_%s.csv" % (tag, tagp)), "w", newline="") as fh:
-            cols = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
-                    "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
-            w = csv.DictWriter(fh, fieldnames=cols, extrasaction="ignore")
-            w.writeheader()
-            for r in rows:
-                r["Kernel_Name"] = r["Kernel_Name"][:80]
-                w.writerow(r)
+        shutil.copy(f, os.path.join(prof, "%s_pmc_%s.csv" % (tag, tagp)))
+        for r in csv.DictReader(open(f)):
+            counters.setdefault(r["Workload"], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value_summed_over_instances"]))
+    out += ["", "## sweep kernels: PMC counters per launch (in-run passes of bench.py, 3 launches per workload) and what follows from them", ""]
     traffic = {}
 
     def block(name, key, sites):
         r = key.get("roofline")
         if not r:
             return
-        out.append("### %s" % name)
+        out.append("### %s -- `%s`" % (name, r.get("kernel", "?")))
         out.append("")
         out.append("| quantity | value |")
         out.append("|---|---|")
+        out.append("| sites per launch | %d |" % sites)
         out.append("| kernel ms (HIP events, timed region) | %.4f |" % r["kernel_ms"])
+        for c, v in sorted(counters.get(name, {}).items()):
+            out.append("| %s (mean per launch) | %.6g |" % (c, sum(v) / len(v)))
         if r.get("traffic"):
-            out.append("| HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) x 1024 | %.4g (%.1f B/site) |" % (r["traffic"], r["traffic"] / sites))
-            out.append("| HBM GB/s achieved / 8000 | %.0f / frac %.3f |" % (r["achieved"], r["frac"]))
+            out.append("| fabric bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) x 1024 | %.4g (%.1f B/site, %.2f x algorithmic) |" %
+                       (r["traffic"], r["traffic"] / sites, r["traffic_over_algorithmic"]))
+            out.append("| fabric GB/s / 8000 (`achieved`, `frac`) | %.0f / %.3f |" % (r["achieved"], r["frac"]))
+            h = r.get("hbm_estimate")
+            if h:
+                out.append("| HBM estimate GB/s (lower .. upper) | %.0f .. %.0f |" % (h["lower_GBps"], h["upper_GBps"]))
             traffic[name] = r["traffic"] / sites
         out.append("| algorithmic bytes per launch (SURVEY 8d) | %.4g (%.0f GB/s over the kernel time) |" % (r["algorithmic_bytes_per_launch"], r["algorithmic_GBps"]))
+        if r.get("l2"):
+            out.append("| L2 hit rate; fabric read requests per site | %.3f; %.2f |" % (r["l2"]["hit_rate"], r["l2"]["fabric_read_requests_per_site"]))
+        if "ta_busy_frac" in r:
+            out.append("| TA busy; TCP pending-stall share | %.3f; %.3f |" % (r["ta_busy_frac"], r.get("tcp_pending_stall_frac", float("nan"))))
         v = r.get("valu_issue")
         if v:
             out.append("| VALU instructions per site | %.1f |" % v["valu_insts_per_site"])
             out.append("| VALU issue frac (x 4 cycles / 1024 SIMDs x 2.4 GHz) | %.3f |" % v["frac"])
             if "valu_busy_frac" in v:
                 out.append("| VALU busy share of the profiled launch's cycles | %.3f (clock %.2f GHz) |" % (v["valu_busy_frac"], v.get("effective_clock_GHz", float("nan"))))
-        out.append("| binding roof | %s |" % r.get("binding_roof", "-"))
+            if "wave_cycles_waiting_frac" in v:
+                out.append("| wave cycles waiting on an instruction; waves per SIMD | %.3f; %.2f |" % (v["wave_cycles_waiting_frac"], v.get("waves_per_simd_avg", float("nan"))))
+        out.append("| binding roof (headroom) | %s (%.2f) |" % (r.get("binding_roof", "-"), r.get("headroom", float("nan"))))
         out.append("")
     block("synth2", line, line["config"]["sites_per_sweep"])
-    for k, nm in (("synth1", "synth1"), ("hbm_bound", "synth2_hostile")):
+    for k, nm in EXTRAS:
         e = line.get("extra", {}).get(k)
         if e:
             block(nm, e, e["sites_per_sweep"])
+    out += ["## the harness steps (SURVEY 8f rows), timed in the same run", ""]
+    for k in ("cascade", "pipeline_abstracts", "cascade_test"):
+        e = line.get("extra", {}).get(k)
+        if e:
+            cb = e.get("cpu_baseline", {})
+            out.append("* `%s`: %.4f s%s" % (k, e["value"], (" -- CPU port %.1f s (%s)" % (cb["value"], cb.get("sample", ""))) if cb else ""))
     if traffic:
         tpath = os.path.join(prof, "pmc_traffic.json")
         t = json.load(open(tpath)) if os.path.exists(tpath) else {}
         t.update(traffic)
-        t["_unit"] = "HBM bytes per site of llda_sweep_kernel: (2*FETCH_SIZE+WRITE_SIZE)*1024 / sites, rocprofv3 --pmc passes (profiles/%s_summary.md)" % tag
+        t["_unit"] = ("fabric bytes per site of the sweep kernel: (2*FETCH_SIZE+WRITE_SIZE)*1024 / sites, rocprofv3 --pmc passes on ONE GPU "
+                      "(profiles/%s_summary.md); bench.py uses it, labelled 'stored', where it cannot profile (N > 1)" % tag)
         json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
-    for extra in ("bench_synth2_sparse.json", "bench_cascade.json", "bench_cascade_one_by_one.json"):
-        if os.path.exists(os.path.join(src, extra)):
+    for extra in os.listdir(src):
+        if extra.startswith(("bench_", "gather_")) and extra != "bench_default.json" and not extra.endswith(".err"):
             shutil.copy(os.path.join(src, extra), os.path.join(prof, "%s_%s" % (tag, extra)))
     open(os.path.join(prof, "%s_summary.md" % tag), "w").write("\n".join(out) + "\n")
     print("\n".join(out))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
