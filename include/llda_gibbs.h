@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 13
+#define LLDA_ABI_VERSION 14
 #define LLDA_MAX_K 7688          /* every K up to here splits into <= 64 pairwise leaves                       */
 #define LLDA_MAX_KP 8192         /* longest padded row: 64 leaves x 128                                        */
 #define LLDA_MAX_LEAVES 8        /* "narrow" layouts: one lane group of <= 64 lanes x <= 16 slots per document  */
@@ -116,7 +116,8 @@ typedef struct llda_sweep_args {
                                     exact tier), -1 sends every site through the exact tier, -2 skips only
                                     the fp32 tier 0; -3 (wide layouts only) production margins on the kernel
                                     that keeps nothing of the row in registers, -4 on the register kernel with
-                                    LDS copies of the counts whatever max_doc_tokens says                                    */
+                                    LDS copies of the counts whatever max_doc_tokens says, -5 on the fp64 register
+                                    kernel without its fp32 tier                                                              */
     double   alpha, beta;        /* priors (LabeledLDA.py:55-56)                               */
     uint64_t seed;               /* RNG key                                                    */
     uint32_t sweep;              /* RNG counter word 3                                         */
@@ -128,10 +129,10 @@ typedef struct llda_sweep_args {
     const int32_t *live_pos;     /* [dev] device positions of the topics every document allows, in DRAW order:
                                   * ascending (lane, slot) of the layout -- llda_layout.pos_lane / pos_slot --,
                                   * which for layouts with T >= 8 is not ascending memory position          */
-    int32_t       *resume;       /* unused since ABI 10 (pass NULL): a site the sparse kernel cannot decide is now   */
-    int32_t       *resume_count; /* resolved inside the kernel by the exact pipeline instead of being handed to a    */
-    int32_t  resume_cap;         /* second launch; the fields keep the struct layout                                 */
     int32_t  live_max;           /* largest number of allowed topics of any document                  */
+    int32_t  max_doc_tokens;     /* (ABI 13) optional hint, 0 = unknown: an upper bound of the tokens (sum of freq) of any
+                                    document of the call.  Wide layouts only: below 32 768 the kernel keeps the document's
+                                    count CHANGES as int16 in LDS instead of copies of the counts (more wavefronts per CU) */
     /* optional commit log (both non-NULL): instead of two int32 atomics on n_kw_delta per changed site the
      * kernels store ONE word (old position | new position << 16) at the site's place in WORD-major order;
      * llda_commit_log then folds the log into the counts word by word without global atomics.  (No-return
@@ -150,10 +151,6 @@ typedef struct llda_sweep_args {
                                     every scalar load touches that many cache lines, which makes the vector-memory
                                     address pipeline the bound.  A call that passes it with such a layout may span at
                                     most 2^28 - 1 sites. */
-    int32_t  max_doc_tokens;     /* (ABI 13) optional hint, 0 = unknown: an upper bound of the tokens (sum of freq) of any
-                                    document of the call.  Wide layouts only: below 32 768 the kernel keeps the document's
-                                    count CHANGES as int16 in LDS instead of copies of the counts (more wavefronts per CU) */
-    int32_t  reserved2;
 } llda_sweep_args;
 
 /* ---- host-only (no device needed) ---- */

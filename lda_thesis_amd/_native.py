@@ -16,7 +16,7 @@ MAX_KP = 8192
 MAX_LEAVES = 8          # narrow layouts
 MAX_WIDE_LEAVES = 64
 MAX_ROUNDS = 4
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -52,9 +52,9 @@ class LldaSweepArgs(ctypes.Structure):
                 ("D", _c_i64), ("V", _c_i64), ("K", _c_i32), ("docs_per_group", _c_i32),
                 ("dense_mask", _c_i32), ("debug_margin", _c_i32), ("alpha", _c_d), ("beta", _c_d), ("seed", _c_u64), ("sweep", _c_u32),
                 ("stream_id", _c_u32), ("doc_base", _c_i64),
-                ("live_off", _c_p), ("live_pos", _c_p), ("resume", _c_p), ("resume_count", _c_p),
-                ("resume_cap", _c_i32), ("live_max", _c_i32), ("csc_pos", _c_p), ("commit_log", _c_p),
-                ("n_sites", _c_i64), ("site_rec", _c_p), ("max_doc_tokens", _c_i32), ("reserved2", _c_i32)]
+                ("live_off", _c_p), ("live_pos", _c_p),
+                ("live_max", _c_i32), ("max_doc_tokens", _c_i32), ("csc_pos", _c_p), ("commit_log", _c_p),
+                ("n_sites", _c_i64), ("site_rec", _c_p)]
 
 
 class LldaBatchArgs(ctypes.Structure):
@@ -68,6 +68,7 @@ class LldaBatchArgs(ctypes.Structure):
 
 
 EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_struct_size", "llda_layout_init",
+
            "llda_sweep", "llda_sweep_batch", "llda_commit_log", "llda_apply_rows", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
            "llda_readout_phi", "llda_readout_theta", "llda_selftest_div")
 
@@ -190,10 +191,8 @@ def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta
                       int(D), int(V), int(K), int(docs_per_group), 1 if dense_mask else 0, int(debug_margin),
                       float(alpha), float(beta),
                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(sweep) & 0xFFFFFFFF,
-                      int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), None, None, 0,
-                      int(live_max),
-                      _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites), _ptr(site_rec),
-                      int(max_doc_tokens), 0)
+                      int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), int(live_max), int(max_doc_tokens),
+                      _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites), _ptr(site_rec))
     _launch(z, lib().llda_sweep, "llda_sweep", ctypes.byref(a))
 
 

@@ -71,7 +71,7 @@ __device__ __forceinline__ void shrink_to_one(double (&p)[T], double c, double c
     bool may_jump = true;
     int steps = 0;
     while (s > 1.0 && steps < (1 << 28)) {                     // (the reference loops until the sum is <= 1)
-        if (may_jump) {
+        if (may_jump && s > 1.0 + 128.0 * (c - 1.0)) {         // (far enough from 1 for a jump to pay: the logs are dear)
             const double est = log(s) / log(c);                // real-arithmetic distance to sum = 1, in steps
             const int k0 = (est > 96.0 && est < 2.0e8) ? (int)(est * 0.998) - 16 : 0;
             if (k0 > 0) {
@@ -132,64 +132,8 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
         for (int n = 0; n < len; ++n) ntot += P.freq[s0 + n];
     }
 
-    // sweep = -1: prep4test (initial assignments from the normalised loadings), then `iters` sweeps
-    for (int sweep = pre ? 0 : -1; sweep < P.iters; ++sweep) {
-        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        for (int n = 0; n < len; ++n) {
-            const int v = P.word[s0 + n], f = P.freq[s0 + n];
-            if ((n & (2 * G - 1)) == 0) {
-                r0 = (uint32_t)(n >> 1) + (uint32_t)lig; r1 = gdoc; r2 = stream_id; r3 = (uint32_t)sweep;
-                philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
-            }
-            const int holder = (n >> 1) & (G - 1);
-            const uint32_t ra = (uint32_t)__shfl((int)((n & 1) ? r2 : r0), holder, G);
-            const uint32_t rb = (uint32_t)__shfl((int)((n & 1) ? r3 : r1), holder, G);
-            const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
-
-            double w[T];
-            int zo = -1;
-            if (sweep < 0) {
-                load_row_f64<T>(P.phn + (int64_t)P.init_idx[s0 + n] * KP + lig * T, w);
-                shrink_to_one<G, T, HAS_TAIL>(w, c0, c0r, K, lig, lane);
-                ntot += f;
-            } else {
-                zo = P.z[s0 + n];
-                {
-                    int lo, so;
-                    lane_slot_of<G, T>(zo, lo, so);
-                    onehot_add1<T>(ndk, (lig == lo) ? (1u << so) : 0u, f);       // n_dk[z] -= f
-                }
-                double b[T];
-                load_row_f64<T>(ph + (int64_t)v * KP + lig * T, b);
-#pragma unroll
-                for (int s = 0; s < T; ++s) w[s] = ((double)ndk[s] + P.alpha) * b[s];   // num_a * b
-                double S = group_sum<G, T, HAS_TAIL>(w, K, lig, lane);
-                if (P.beta_fallback && S == 0.0) {     // 0/0 raises in the reference (CascadeLDA.py:225-230)
-#pragma unroll
-                    for (int s = 0; s < T; ++s) {
-                        const bool real = P.slot_valid[lig * T + s] != 0;
-                        w[s] = real ? ((double)ndk[s] + P.alpha) * (b[s] + P.beta) : 0.0;
-                    }
-                    S = group_sum<G, T, HAS_TAIL>(w, K, lig, lane);
-                }
-                const double y = 1.0 / S;
-#pragma unroll
-                for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);                  // prob /= prob.sum()
-                shrink_to_one<G, T, HAS_TAIL>(w, c1, c1r, K, lig, lane);
-            }
-            int zn = draw_position<G, T, false>(w, u, 0u, true, lig, lane);
-            if (zn < 0) {                         // all-zero / NaN probabilities: the reference would raise
-                zn = zo < 0 ? 0 : zo;
-                if (lig == 0 && P.status) atomicOr(P.status, 1);
-            }
-            {
-                int ln, sn;
-                lane_slot_of<G, T>(zn, ln, sn);
-                onehot_add1<T>(ndk, (lig == ln) ? (1u << sn) : 0u, -f);          // n_dk[new_z] += f
-            }
-            if (lig == 0) P.z[s0 + n] = zn;
-        }
-        // thinned running average of the document-topic state (LabeledLDA.py:199-211)
+    // thinned running average of the document-topic state (LabeledLDA.py:199-211)
+    auto thin = [&](const int sweep) {
         if (sweep >= 0 && (sweep + 1) % P.thinning == 0) {
             const int s2 = (sweep + 1) / P.thinning;
             const double tot = (double)ntot;
@@ -214,6 +158,124 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
                 }
             }
         }
+    };
+    // one site of a sweep >= 0 given its scalars and its row of loadings; returns the new position
+    auto sample = [&](const int n, const int sweep, const int f, const int zo, const double (&b)[T], uint32_t &r0, uint32_t &r1,
+                      uint32_t &r2, uint32_t &r3) {
+        if ((n & (2 * G - 1)) == 0) {
+            r0 = (uint32_t)(n >> 1) + (uint32_t)lig; r1 = gdoc; r2 = stream_id; r3 = (uint32_t)sweep;
+            philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
+        }
+        const int holder = (n >> 1) & (G - 1);
+        const uint32_t ra = (uint32_t)__shfl((int)((n & 1) ? r2 : r0), holder, G);
+        const uint32_t rb = (uint32_t)__shfl((int)((n & 1) ? r3 : r1), holder, G);
+        const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+        {
+            int lo, so;
+            lane_slot_of<G, T>(zo, lo, so);
+            onehot_add1<T>(ndk, (lig == lo) ? (1u << so) : 0u, f);               // n_dk[z] -= f
+        }
+        double w[T];
+#pragma unroll
+        for (int s = 0; s < T; ++s) w[s] = ((double)ndk[s] + P.alpha) * b[s];   // num_a * b
+        double S = group_sum<G, T, HAS_TAIL>(w, K, lig, lane);
+        if (P.beta_fallback && S == 0.0) {     // 0/0 raises in the reference (CascadeLDA.py:225-230)
+#pragma unroll
+            for (int s = 0; s < T; ++s) {
+                const bool real = P.slot_valid[lig * T + s] != 0;
+                w[s] = real ? ((double)ndk[s] + P.alpha) * (b[s] + P.beta) : 0.0;
+            }
+            S = group_sum<G, T, HAS_TAIL>(w, K, lig, lane);
+        }
+        const double y = 1.0 / S;
+#pragma unroll
+        for (int s = 0; s < T; ++s) w[s] = div_by(w[s], S, y);                  // prob /= prob.sum()
+        shrink_to_one<G, T, HAS_TAIL>(w, c1, c1r, K, lig, lane);
+        int zn = draw_position<G, T, false>(w, u, 0u, true, lig, lane);
+        if (zn < 0) {                         // all-zero / NaN probabilities: the reference would raise
+            zn = zo < 0 ? 0 : zo;
+            if (lig == 0 && P.status) atomicOr(P.status, 1);
+        }
+        {
+            int ln, sn;
+            lane_slot_of<G, T>(zn, ln, sn);
+            onehot_add1<T>(ndk, (lig == ln) ? (1u << sn) : 0u, -f);          // n_dk[new_z] += f
+        }
+        return zn;
+    };
+
+    if (pre) {
+        // The start state was drawn by llda_foldin_init_kernel: `iters` sweeps with the memory operations software-pipelined --
+        // a site's row of loadings depends on its word, so a plain loop is two dependent memory round trips per site and
+        // the kernel (one short chain per document, the chip mostly idle) is bound by exactly that latency: the word and
+        // frequency of the site after the next and the row + old topic of the next site are in flight while a site is
+        // sampled.  The sites of a document are walked cyclically (site len of a sweep is site 0 of the next one).
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        if (len > 0 && P.iters > 0) {
+            int v_1 = P.word[s0], f_1 = P.freq[s0];                     // site "next"
+            const int n2 = len > 1 ? 1 : 0;
+            int v_2 = P.word[s0 + n2], f_2 = P.freq[s0 + n2];           // site "after next"
+            double b_1[T];
+            load_row_f64<T>(ph + (int64_t)v_1 * KP + lig * T, b_1);
+            int zo_1 = P.z[s0];
+            int nn = n2;                                                 // index of the site whose scalars are in ._2
+            for (int sweep = 0; sweep < P.iters; ++sweep) {
+                for (int n = 0; n < len; ++n) {
+                    const int f = f_1, zo = zo_1;
+                    double b[T];
+#pragma unroll
+                    for (int s = 0; s < T; ++s) b[s] = b_1[s];
+                    // next site: its row and its old topic (written one sweep ago -- or just now when the document has one site)
+                    v_1 = v_2; f_1 = f_2;
+                    load_row_f64<T>(ph + (int64_t)v_1 * KP + lig * T, b_1);
+                    if (len > 1) zo_1 = P.z[s0 + nn];
+                    // the site after the next: word and frequency
+                    nn = nn + 1 < len ? nn + 1 : 0;
+                    v_2 = P.word[s0 + nn]; f_2 = P.freq[s0 + nn];
+                    const int zn = sample(n, sweep, f, zo, b, r0, r1, r2, r3);
+                    if (lig == 0) P.z[s0 + n] = zn;
+                    if (len == 1) zo_1 = zn;
+                }
+                thin(sweep);
+            }
+        }
+    } else {
+    // sweep = -1: prep4test (initial assignments from the normalised loadings), then `iters` sweeps
+    for (int sweep = -1; sweep < P.iters; ++sweep) {
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        for (int n = 0; n < len; ++n) {
+            const int v = P.word[s0 + n], f = P.freq[s0 + n];
+            if (sweep < 0) {
+                if ((n & (2 * G - 1)) == 0) {
+                    r0 = (uint32_t)(n >> 1) + (uint32_t)lig; r1 = gdoc; r2 = stream_id; r3 = (uint32_t)sweep;
+                    philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
+                }
+                const int holder = (n >> 1) & (G - 1);
+                const uint32_t ra = (uint32_t)__shfl((int)((n & 1) ? r2 : r0), holder, G);
+                const uint32_t rb = (uint32_t)__shfl((int)((n & 1) ? r3 : r1), holder, G);
+                const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+                double w[T];
+                load_row_f64<T>(P.phn + (int64_t)P.init_idx[s0 + n] * KP + lig * T, w);
+                shrink_to_one<G, T, HAS_TAIL>(w, c0, c0r, K, lig, lane);
+                ntot += f;
+                int zn = draw_position<G, T, false>(w, u, 0u, true, lig, lane);
+                if (zn < 0) {
+                    zn = 0;
+                    if (lig == 0 && P.status) atomicOr(P.status, 1);
+                }
+                int ln, sn;
+                lane_slot_of<G, T>(zn, ln, sn);
+                onehot_add1<T>(ndk, (lig == ln) ? (1u << sn) : 0u, -f);
+                if (lig == 0) P.z[s0 + n] = zn;
+            } else {
+                double b[T];
+                load_row_f64<T>(ph + (int64_t)v * KP + lig * T, b);
+                const int zn = sample(n, sweep, f, P.z[s0 + n], b, r0, r1, r2, r3);
+                if (lig == 0) P.z[s0 + n] = zn;
+            }
+        }
+        thin(sweep);
+    }
     }
     store_row<T>(P.n_dk + d * KP + lig * T, ndk);
 #pragma unroll

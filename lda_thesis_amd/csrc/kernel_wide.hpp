@@ -643,6 +643,270 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tier 0 for wide layouts: the fp32 decision of the narrow kernels in front of the fp64 decision of the
+// register kernel above, with the G = 64 * NT virtual lanes of one wavefront.  Same LDS state as that kernel in its COMPACT
+// form (one fp64 factor (n_dk + alpha) * ~1/(n_k + V*beta) and one int16 count change per position), so the rare tiers
+// need nothing rebuilt; what changes is the work per site:
+//   * ONE pass in fp32: the row (registers) times the factors (rounded to fp32 as they are read) gives the T fp32 prefix
+//     values of each of the lane's NT virtual lanes (packed fp32), which stay in registers; lane totals are scanned over the
+//     wavefront (DPP) tier by tier with a sequential carry over the tiers; per virtual lane the count of prefix values below
+//     the target and the "no value inside the margin band" test are the branch-free search of the narrow kernel
+//     (~350 VALU instructions per site at K = 2 048 instead of 660 fp64 ones);
+//   * the site's own count leaves the row through ONE indexed register write (zo is uniform: the index goes through M0);
+//   * the row of site n + 1 is in flight while site n is decided (two register sets), scalars two sites ahead, the start
+//     counts of the next site's old topic one site ahead.
+// Error bound (v = 2^-24, total score 1; as DESIGN.md 4.3 with fp64-accurate factors and the longer scan): a factor
+// rounded from fp64 is within 0.5v, (float)x + beta32 within 1.5v, the score within 3v, a virtual lane's prefix within 18v;
+// the wavefront scan adds 6v, the carry over <= 7 tiers 7v and the add of the carry 1v: X within 32v, the total within 31v,
+// t = fl(u~ * total) within 33.2v, the target fl(t - X[g-1]) within 66.2v, its margin bounds one more v: every compared
+// difference is within 18v + 67.2v < 86v of its real value (the exact pipeline: 2^-44).  Margin: 112v (LLDA_MARGIN0_WIDE),
+// so a "sure" decision has the signs of the exact pipeline.  An unsure site -- 2 * margin * (topics with a score above the
+// margin): ~3 % at K = 2 048 -- takes the fp64 two-pass decision on the same registers and factors and, if that is unsure
+// too (~1e-9), the exact pipeline; the topic is always the exact pipeline's.  Needs max_doc_tokens < 2^15 (int16 changes).
+// ---------------------------------------------------------------------------------------------
+#ifndef LLDA_MARGIN0_WIDE
+#define LLDA_MARGIN0_WIDE (112.0f * 0x1p-24f)
+#endif
+
+// TC = slots per virtual lane / 4 (3 or 4: the only values wide layouts have).  (Registers: two rows, the prefix values and
+// the fp64 tier's temporaries want more than the 168 VGPRs of three wavefronts per SIMD -- with that cap the allocator
+// spilled the PREFETCHED row, i.e. waited for it on the spot; LDS allows 8 wavefronts per CU at K = 2 048 anyway.)
+template <int NT, int TC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NT <= 4 ? 2 : 1)))
+llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel)
+{
+    extern __shared__ double s_wide[];
+    const KParams &K = P.k;
+    const WideLayout &W = P.w;
+    constexpr int G = 64 * NT, T = 4 * TC;
+    typedef int v16i __attribute__((ext_vector_type(16)));
+    const int lane = threadIdx.x, KP = W.KP, KP4 = W.KP >> 2;
+    double *wv = s_wide;                                          // factor of position p at (p & 3) * KP4 + (p >> 2)
+    int16_t *s_dk = reinterpret_cast<int16_t *>(wv + KP);        // change of n_dk (= of the n_k the document sees), position order
+    const float beta32 = (float)K.beta;
+    int n_unsure = 0, n_exact = 0;
+
+    for (int64_t idx = blockIdx.x; idx < K.D; idx += gridDim.x) {
+        const int64_t d = K.doc_order ? (int64_t)K.doc_order[idx] : idx;
+        const int64_t s0 = K.doc_off[d];
+        const int len = (int)(K.doc_off[d + 1] - s0);
+        if (len <= 0) continue;
+        int32_t *ndk_row = K.n_dk + d * KP;
+        const uint16_t *mrow = K.lab_mask + d * G;
+        for (int q = lane; q < KP4; q += 64) reinterpret_cast<int2 *>(s_dk)[q] = make_int2(0, 0);
+        wide_factors(wv, ndk_row, K.n_k, s_dk, mrow, W, K.alpha, K.vbeta, lane);
+        uint32_t mk[NT];                                          // allowed slots of this lane's virtual lanes
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mk[t] = mrow[t * 64 + lane];
+        const uint32_t gdoc = (uint32_t)(d + K.doc_base);
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+
+        auto load_row = [&](const int v, v16i (&x)[NT]) {
+            const int4 *row = reinterpret_cast<const int4 *>(K.n_kw + (int64_t)v * KP);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int c = 0; c < TC; ++c) {
+#ifdef ABL_WIDE_NOROW                                           // ablation: no n_kw traffic
+                    const int4 r = make_int4(v & 7, c, t, lane & 3);
+#else
+                    const int4 r = row[c * G + t * 64 + lane];
+#endif
+                    x[t][4 * c] = r.x; x[t][4 * c + 1] = r.y; x[t][4 * c + 2] = r.z; x[t][4 * c + 3] = r.w;
+                }
+        };
+        // scalars of the sites n (._c) and n + 1 (._1) are in registers at the top of site n; the row of site n too
+        int v_c = K.word[s0], f_c = K.freq[s0], zo_c = K.z[s0];
+        const int64_t i1 = s0 + (len > 1 ? 1 : 0);
+        int v_1 = K.word[i1], f_1 = K.freq[i1], zo_1 = K.z[i1];
+        int c_c = K.csc_pos ? K.csc_pos[s0] : 0, c_1 = K.csc_pos ? K.csc_pos[i1] : 0;       // (commit-log positions)
+        v16i xa[NT], xb[NT];
+        load_row(__builtin_amdgcn_readfirstlane(v_c), xa);
+        // a topic count of the document changes by df (lane 0): the int16 change and the cached factor; nd0, nk0 = the
+        // start values of the position (HBM; fetched ahead of time where the position is known ahead of time)
+        auto count_change = [&](const int pos, const int df, const int nd0, const int nk0) {
+            const int dz = (int)s_dk[pos] + df;
+            s_dk[pos] = (int16_t)dz;
+            double *pf = wv + fac_index(pos, KP4);
+            // (a cached factor is 0 exactly where the label mask is: no mask load per site)
+            *pf = wide_factor(nd0 + dz, nk0 + dz, *pf != 0.0, K.alpha, K.vbeta);
+        };
+        if (lane == 0) count_change(zo_c, -f_c, ndk_row[zo_c], K.n_k[zo_c]);    // site 0 leaves its topic (LabeledLDA.py:109-111)
+
+        auto site = [&](const int n, v16i (&x)[NT], v16i (&xnext)[NT]) {
+            const int64_t i = s0 + n;
+            const int v = __builtin_amdgcn_readfirstlane(v_c), f = __builtin_amdgcn_readfirstlane(f_c),
+                      zo = __builtin_amdgcn_readfirstlane(zo_c), cpos = c_c;
+            uint32_t ra, rb;
+            site_random_bits<64>(K, n, n == 0, gdoc, lane, r0, r1, r2, r3, ra, rb);
+            // row of site n + 1, scalars of site n + 2, start counts of site n + 1's old topic (needed at the end of this site)
+            load_row(__builtin_amdgcn_readfirstlane(v_1), xnext);
+            v_c = v_1; f_c = f_1; zo_c = zo_1; c_c = c_1;
+            const int nd0_n = ndk_row[zo_c], nk0_n = K.n_k[zo_c];
+            {
+                const int64_t i2 = s0 + (n + 2 < len ? n + 2 : len - 1);
+                v_1 = K.word[i2]; f_1 = K.freq[i2]; zo_1 = K.z[i2];
+                if (K.csc_pos) c_1 = K.csc_pos[i2];
+            }
+            // own count out of the row: position zo is slot 4 * chunk + (zo & 3) of virtual lane (zo >> 2) % G -- all uniform,
+            // so it is ONE indexed register write in the lane that owns it
+            {
+                const int qz = zo >> 2, cz = qz / G, gz = qz - cz * G, tz = gz >> 6, lz = gz & 63, sz = 4 * cz + (zo & 3);
+                const int fm = (lane == lz) ? f : 0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (tz == t) {
+                        v16i xv = x[t];                              // (a local tuple: the index goes through M0)
+                        xv[sz & 15] -= fm;
+                        x[t] = xv;
+                    }
+            }
+            // ---- tier 0: fp32 prefix values, lane totals, scan ----
+            int zn = -1;
+            bool decided = false;
+            if (margin0_rel < 1.0f) {
+                float q[NT][T], Y[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    int xs[T];
+                    float pa[T];
+#pragma unroll
+                    for (int c = 0; c < TC; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pa[4 * c + j] = (float)wv[j * KP4 + c * G + t * 64 + lane];
+#pragma unroll
+                    for (int s = 0; s < T; ++s) xs[s] = x[t][s];
+                    prefix_scores_f32<T, true>(q[t], xs, pa, 0xFFFFu, beta32);
+                    Y[t] = group_scan_f32<64>(q[t][T - 1], lane);
+                }
+                float carry[NT + 1];
+                carry[0] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    carry[t + 1] = carry[t] + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Y[t]), 63));
+                const float tot = carry[NT];
+                const float u32 = (float)(ra >> 5) * 0x1p-27f;   // fp32 image of the uniform: its top 27 bits
+                const float tt = u32 * tot, margin = tot * margin0_rel;
+                bool dirty = !(tot > 0.0f) || !(margin < tot) || !(tot < 3.0e38f);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float prev = dpp_f32<DPP_WAVE_SHR1>(Y[t]);
+                    const float before = lane ? prev + carry[t] : carry[t];       // X of the virtual lane before this one
+                    const float tg = tt - before;
+                    int cnt;
+                    bool clean;
+                    count_sorted_f32<T>(q[t], tg - margin, tg + margin, cnt, clean);
+                    dirty = dirty || !clean;
+                    const uint32_t fmk = mk[t] & (0xFFFFu << cnt);
+                    const uint64_t bh = __ballot(fmk != 0);
+                    if (zn < 0 && bh != 0) {
+                        const int sl = (int)__builtin_ctzll(bh);
+                        const int ss = __builtin_amdgcn_readlane((int)__ffs((int)(fmk | 0x10000u)) - 1, sl);
+                        zn = pos_of_rt(G, T, t * 64 + sl, ss);
+                    }
+                }
+                // (a clean site always has a prefix value above its target -- the last allowed one is the total, and u < 1 --
+                // so "no hit" goes the way of the unsure sites)
+                decided = __ballot(dirty) == 0 && zn >= 0;
+            }
+            bool exact = false;
+            if (__builtin_expect(!decided, 0)) {
+                // ---- tier 1: the fp64 two-pass decision of the register kernel on the same row and factors ----
+                ++n_unsure;
+                const double u = uniform53(ra, rb);
+                double X[WIDE_MAX_TIERS];
+#pragma unroll
+                for (int t = 0; t < WIDE_MAX_TIERS; ++t) X[t] = 0.0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    double run = 0.0;
+#pragma unroll
+                    for (int c = 0; c < TC; ++c) {
+                        const double *p = wv + (c * G + t * 64 + lane);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) run = run + p[j * KP4] * ((double)x[t][4 * c + j] + K.beta);
+                    }
+                    X[t] = run;
+                }
+                const double tot = wide_scan(X, NT, lane);
+                const double tt = u * tot, m = K.margin_rel * tot;
+                zn = -1;
+                bool unsure = !(tot > 0.0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const double tg = tt - wide_prev(X[t], X[t > 0 ? t - 1 : 0], t > 0, lane);
+                    const double lo = tg - m, hi = tg + m;
+                    double run = 0.0;
+                    uint32_t hm = 0, um = 0;
+#pragma unroll
+                    for (int c = 0; c < TC; ++c) {
+                        const double *p = wv + (c * G + t * 64 + lane);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            run = run + p[j * KP4] * ((double)x[t][4 * c + j] + K.beta);
+                            hm |= (run > hi ? 1u : 0u) << (4 * c + j);
+                            um |= ((run > lo && !(run > hi)) ? 1u : 0u) << (4 * c + j);
+                        }
+                    }
+                    const uint64_t bh = __ballot(hm != 0);
+                    unsure = unsure || __ballot(um != 0) != 0;
+                    if (zn < 0 && bh != 0) {
+                        const int sl = (int)__ffsll((unsigned long long)bh) - 1;
+                        const int ss = __shfl((int)__ffs((int)(hm | 0x10000u)) - 1, sl, 64);
+                        zn = pos_of_rt(G, T, t * 64 + sl, ss);
+                    }
+                }
+                exact = unsure || zn < 0;
+                if (__builtin_expect(exact, 0)) {
+                    ++n_exact;
+                    // (the parameters through the kernel-argument segment: wide_sum indexes the layout's tables dynamically,
+                    // and on the by-value copy that would put ALL of P into scratch memory -- and every pointer of the hot
+                    // loop behind a scratch load)
+                    const WParams *Pk = (const WParams *)__builtin_amdgcn_kernarg_segment_ptr();
+                    zn = wide_exact_site(wv, ndk_row, Pk->k.n_k, s_dk, mrow,
+                                         reinterpret_cast<const int4 *>(Pk->k.n_kw + (int64_t)v * KP), Pk->w, Pk->k, zo, f, u, lane);
+                    wide_factors(wv, ndk_row, Pk->k.n_k, s_dk, mrow, Pk->w, Pk->k.alpha, Pk->k.vbeta, lane);   // (the exact pipeline borrowed the doubles)
+                }
+            }
+            if (lane == 0) {
+#ifdef ABL_WIDE_NOADDLOAD                                        // ablation (tools/abl_wide.py): no start-value loads behind the draw
+                count_change(zn, f, 0, 1000);
+#else
+                count_change(zn, f, ndk_row[zn], K.n_k[zn]);     // add the site back (LabeledLDA.py:121-125)
+#endif
+                if (n + 1 < len) count_change(zo_c, -f_c, nd0_n, nk0_n);   // ... and take the next site out of its topic already
+                commit_site(K, i, v, f, zo, zn, cpos, KP);
+            }
+        };
+        for (int n = 0;; n += 2) {
+            site(n, xa, xb);
+            if (n + 1 >= len) break;
+            site(n + 1, xb, xa);
+            if (n + 2 >= len) break;
+        }
+        for (int q = lane; q < KP4; q += 64) {
+            const int2 pk = reinterpret_cast<const int2 *>(s_dk)[q];
+            if (pk.x | pk.y) {
+                const int dl[4] = {(int)(int16_t)(pk.x & 0xFFFF), pk.x >> 16, (int)(int16_t)(pk.y & 0xFFFF), pk.y >> 16};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (dl[j]) {
+                        atomicAdd(K.n_k_delta + ((q << 2) | j), dl[j]);
+                        ndk_row[(q << 2) | j] += dl[j];
+                    }
+            }
+        }
+    }
+    if (lane == 0 && K.status) {                                 // statistics, as the narrow kernels
+        if (n_unsure) atomicAdd(K.status + 1, n_unsure);
+        if (n_exact) {
+            atomicOr(K.status, 2);
+            atomicAdd(K.status + 2, n_exact);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Read-outs, wide layouts
 // ---------------------------------------------------------------------------------------------
 struct WLParams {

@@ -441,7 +441,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     const bool dense = fast && a->dense_mask != 0 && L.K == L.KP;
     // debug_margin: 0 = production margins; n > 0 = 2^-n (wider: more fallbacks); -1 = always exact tier;
     // -2 = no fp32 tier
-    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 || a->debug_margin == -3 || a->debug_margin == -4 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
+    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 || a->debug_margin == -3 || a->debug_margin == -4 || a->debug_margin == -5 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
     P.margin0_rel = a->debug_margin == 0 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
     hipStream_t st = (hipStream_t)stream;
 
@@ -494,7 +494,23 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         // per position
         const bool compact = a->max_doc_tokens > 0 && a->max_doc_tokens < 32768 && a->debug_margin != -4;
         const size_t lds_reg = compact ? (size_t)L.KP * 10 : lds;
-        if (fast && a->debug_margin != -3 && compact) {     // the tiered kernel with the row in registers
+        // fp32 tier 0 in front of the fp64 decision (needs the int16 count changes): production
+        const bool tier0 = fast && compact && a->debug_margin != -2 && a->debug_margin != -3 && a->debug_margin != -5 &&
+                           a->debug_margin >= -1;
+        if (tier0) {
+            // margins: production, or the test hook's (n > 0: 2^-n for tier 0 below 16, else tier 0 off; -1: everything exact)
+            const float m0 = a->debug_margin == 0 ? LLDA_MARGIN0_WIDE : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
+#define LLDA_WIDE_F32(NT_, TC_)                                                                              \
+    if (L.tiers == NT_ && L.T == 4 * TC_) {                                                                  \
+        rl = allow_lds(llda_sweep_wide_f32_kernel<NT_, TC_>, lds_reg);                                       \
+        if (rl) return rl;                                                                                   \
+        hipLaunchKernelGGL((llda_sweep_wide_f32_kernel<NT_, TC_>), grid, block, lds_reg, st, W, m0);         \
+    } else
+            LLDA_WIDE_F32(2, 3) LLDA_WIDE_F32(2, 4) LLDA_WIDE_F32(3, 4) LLDA_WIDE_F32(4, 3) LLDA_WIDE_F32(4, 4) LLDA_WIDE_F32(5, 4)
+            LLDA_WIDE_F32(6, 4) LLDA_WIDE_F32(7, 4) LLDA_WIDE_F32(8, 3) LLDA_WIDE_F32(8, 4)
+                return LLDA_E_BAD_K;
+#undef LLDA_WIDE_F32
+        } else if (fast && a->debug_margin != -3 && compact) {     // the tiered kernel with the row in registers
             switch (L.tiers) {
                 LLDA_WIDE_REG(2, true) LLDA_WIDE_REG(3, true) LLDA_WIDE_REG(4, true) LLDA_WIDE_REG(5, true)
                 LLDA_WIDE_REG(6, true) LLDA_WIDE_REG(7, true) LLDA_WIDE_REG(8, true)

@@ -42,7 +42,9 @@ def test_wide_layout_kernels_agree_with_reference(c_oracle, name):
     the latter is checked against the C oracle on the fixture's corpus with alpha = beta = 1e-9."""
     from lda_thesis_amd.sampler import GibbsSampler
     g = load_golden(name)
-    for margin in (-3, -4):           # -4: row in registers, LDS copies of the counts (production: int16 changes)
+    # production (0) runs the fp32-tiered kernel (rare tiers on the scratch row); -5: the fp64 kernel with the row in
+    # registers and int16 changes; -4: the same with LDS copies of the counts; -3: the LDS-only kernel
+    for margin in (0, -5, -3, -4):
         s = make_sampler(g)
         assert s.layout.wide and 0 < s.max_doc_tokens < 32768
         s.debug_margin = margin
@@ -494,7 +496,9 @@ def test_exchange_path_on_one_rank(commit, monkeypatch):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K,dense", [(1024, True), (512, True), (128, True), (777, False), (257, False), (40, False)])
+@pytest.mark.parametrize("K,dense", [(1024, True), (512, True), (128, True), (777, False), (257, False), (40, False),
+                                     # wide layouts: the fp32 tier of kernel_wide.hpp (margin 160 * 2^-24, bound 116 * 2^-24)
+                                     (2048, True), (1088, True), (1031, False), (3000, False), (4296, True)])
 def test_adversarial_near_ties_for_the_fp32_tier(c_oracle, K, dense):
     """tests/neartie.py: the last site of every document has its keyed threshold within 2^-24 of a prefix-sum
     boundary (far below fp32 resolution), all other sites are at least 2^-14 away.  The fp32 tier (margin 2^-17,
@@ -504,7 +508,7 @@ def test_adversarial_near_ties_for_the_fp32_tier(c_oracle, K, dense):
     (/root/reference/LabeledLDA.py:113-119)."""
     import neartie
     from lda_thesis_amd.sampler import GibbsSampler
-    st = neartie.make_neartie_state(K, 1500, dense, seed=4242, rng=np.random.default_rng(K), doc_base=7)
+    st = neartie.make_neartie_state(K, 1500 if K <= 1024 else 400, dense, seed=4242, rng=np.random.default_rng(K), doc_base=7)
     assert st["tuned_gap_max"] < 2.0 ** -23 and st["safe_gap_min"] > 2.0 ** -14.5
     counts = dict(n_d_k=st["n_d_k"], n_k_v=st["n_k_v"], n_zk=st["n_zk"])
     labs = None if dense else st["labs"]

@@ -1,6 +1,7 @@
 """Wide layouts (K with more than 8 pairwise leaves): kernel time of the sweep for the kernel variants llda_sweep's
-debug_margin selects -- 0 production (row in registers, int16 count changes in LDS), -4 row in registers with LDS
-copies of the counts, -3 LDS-only kernel.
+debug_margin selects -- 0 production (fp32 tier 0: float factors + int16 count changes in LDS, rare tiers on a scratch
+row), -5 the fp64 kernel with the row in registers and int16 count changes, -4 the same with LDS copies of the counts,
+-3 LDS-only kernel.
 python tools/abl_wide.py K [N V docs]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +13,7 @@ bench.WORKLOADS["abl"] = (docs, N, V, K, 1.0, 1000, "ablation")
 dev = torch.device("cuda", 0)
 s, info = bench.build_sampler("abl", dev, 0, 1, False)
 out = []
-for dm in (0, -4, -3):
+for dm in (0, -5, -4, -3):
     s.debug_margin = dm
     for _ in range(2):
         s.sweep()
@@ -21,5 +22,7 @@ for dm in (0, -4, -3):
         s.sweep()
     torch.cuda.synchronize()
     ms = [a.elapsed_time(b) for a, b in s.kernel_events]
-    out.append("%d: %.2f ms %.0f M/s" % (dm, sum(ms) / len(ms), s.S / (sum(ms) / len(ms)) / 1e3))
+    st = s.status.cpu().numpy()
+    out.append("%d: %.2f ms %.0f M/s (unsure %d exact %d)" % (dm, sum(ms) / len(ms), s.S / (sum(ms) / len(ms)) / 1e3, int(st[1]), int(st[2])))
+    s.status.zero_()
 print("K %d tiers %d T %d | " % (K, s.layout.NT, s.layout.T) + " | ".join(out))
