@@ -304,7 +304,10 @@ typedef struct llda_foldin_args {
     int32_t *status;            /* [dev] optional: bit 0 = a site had no positive probability    */
     int64_t D;
     int64_t doc_base;           /* RNG counter word 1 of document 0                              */
-    int32_t K, iters, thinning, beta_fallback, avg_mode, reserved;
+    int32_t K, iters, thinning, beta_fallback, avg_mode;
+    int32_t exact_only;         /* 0 in production.  Test hook: 1 = every site through the reference's pipeline (numpy-ordered
+                                   sum, IEEE divisions, shrink loop, keyed inverse-CDF draw) instead of deciding the draw from
+                                   unnormalised prefix sums with a 2^-40 margin where that is provably the same topic */
     double alpha, beta, c_init, c_loop;
     uint64_t seed;
     uint32_t stream_id, reserved2;

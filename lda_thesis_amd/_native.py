@@ -38,7 +38,7 @@ class LldaFoldinArgs(ctypes.Structure):
     _fields_ = [("doc_off", _c_p), ("word", _c_p), ("init_idx", _c_p), ("freq", _c_p), ("ph", _c_p),
                 ("init_rows", _c_p), ("slot_valid", _c_p), ("z", _c_p), ("n_dk", _c_p), ("th", _c_p),
                 ("status", _c_p), ("D", _c_i64), ("doc_base", _c_i64), ("K", _c_i32), ("iters", _c_i32),
-                ("thinning", _c_i32), ("beta_fallback", _c_i32), ("avg_mode", _c_i32), ("reserved", _c_i32),
+                ("thinning", _c_i32), ("beta_fallback", _c_i32), ("avg_mode", _c_i32), ("exact_only", _c_i32),
                 ("alpha", _c_d), ("beta", _c_d), ("c_init", _c_d), ("c_loop", _c_d), ("seed", _c_u64),
                 ("stream_id", _c_u32), ("reserved2", _c_u32), ("doc_ids", _c_p), ("n_sites", _c_i64),
                 ("ph_base", _c_p), ("doc_stream", _c_p)]
@@ -266,10 +266,10 @@ def selftest_div(n, seed=1):
 
 def foldin(*, doc_off, word, init_idx, freq, ph, init_rows, slot_valid, z, n_dk, th, status, D, K, iters, thinning,
            alpha, beta, c_init, c_loop, seed, stream_id, doc_base=0, beta_fallback=False, avg_mode=0, doc_ids=None,
-           ph_base=None, doc_stream=None):
+           ph_base=None, doc_stream=None, exact_only=False):
     a = LldaFoldinArgs(_ptr(doc_off), _ptr(word), _ptr(init_idx), _ptr(freq), _ptr(ph), _ptr(init_rows),
                        _ptr(slot_valid), _ptr(z), _ptr(n_dk), _ptr(th), _ptr(status), int(D), int(doc_base), int(K),
-                       int(iters), int(thinning), 1 if beta_fallback else 0, int(avg_mode), 0, float(alpha),
+                       int(iters), int(thinning), 1 if beta_fallback else 0, int(avg_mode), 1 if exact_only else 0, float(alpha),
                        float(beta), float(c_init), float(c_loop), int(seed) & 0xFFFFFFFFFFFFFFFF,
                        int(stream_id) & 0xFFFFFFFF, 0, _ptr(doc_ids), int(word.numel()), _ptr(ph_base), _ptr(doc_stream))
     _launch(z, lib().llda_foldin, "llda_foldin", ctypes.byref(a))

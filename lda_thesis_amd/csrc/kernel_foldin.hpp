@@ -32,6 +32,7 @@ struct FParams {
     int32_t iters, thinning;
     int32_t beta_fallback;   // CascadeLDA.cascade_test: prob.sum() == 0 -> prob = num_a * (b + beta)
     int32_t avg_mode;        // 0: (s-1)/s*avg + (1/s)*cur   1: m*avg + (1-m)*cur with m = (s-1)/s
+    int32_t exact_only;      // test hook: every site through the reference's pipeline (no decided tier)
     int32_t last_leaf, tail, tail_row, n_rounds, xor_tree;
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];
     int64_t n_sites;         // > 0: the initial assignments were drawn by llda_foldin_init_kernel (one lane group per SITE)
@@ -178,6 +179,50 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
         double w[T];
 #pragma unroll
         for (int s = 0; s < T; ++s) w[s] = ((double)ndk[s] + P.alpha) * b[s];   // num_a * b
+        // ---- decided tier (DESIGN.md 4.3 applied to this pipeline): the reference normalises the scores, divides them by c
+        // while their sum exceeds 1 -- after `prob /= prob.sum()` the sum is within (K + 2) * 2^-53 of 1 and c - 1 >= 5e-7,
+        // so that is at most ONE division -- and draws by inverse CDF; all of it is a common positive scale on every score
+        // plus a few roundings (relative 2^-51 at most), so WHICH topic is drawn is decided by the signs of
+        // prefix - u * total of the UNNORMALISED scores wherever those differences exceed 2^-40 of the total.  A site with
+        // a difference inside that band, a zero / non-finite total or no hit takes the reference's pipeline below -- the
+        // topic is the reference's either way; the per-site cost drops from ~600 dependent fp64 instructions (numpy-ordered
+        // sum, IEEE divisions, second sum, scan) to ~60, and this kernel is one dependent chain per document.
+        if (!P.exact_only) {
+            double q[T];
+            uint32_t pm = 0;
+            double run = 0.0;
+#pragma unroll
+            for (int s = 0; s < T; ++s) {
+                run = run + w[s];
+                q[s] = run;
+                pm |= (w[s] > 0.0 ? 1u : 0u) << s;
+            }
+            const double X = group_scan<G>(run, lig);
+            const double tot = bcast_last<G>(X, lane);
+            const double prev = dpp_f64<DPP_WAVE_SHR1>(X);
+            const double tg = u * tot - (lig ? prev : 0.0);
+            const double margin = tot * 0x1p-40;
+            int cnt_lo = 0, cnt_hi = 0;
+#pragma unroll
+            for (int s = 0; s < T; ++s) {
+                cnt_lo += (q[s] <= tg - margin) ? 1 : 0;
+                cnt_hi += (q[s] <= tg + margin) ? 1 : 0;
+            }
+            const uint32_t fm = pm & (0xFFFFu << cnt_lo);
+            const int gbase = lane & ~(G - 1);
+            const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull);
+            const bool unsure = (cnt_lo != cnt_hi) || !(tot > 0.0) || !(margin < tot) || !(tot < 1.0e300);
+            const uint64_t gu = (__ballot(unsure) >> gbase) & gmask, gf = (__ballot(fm != 0) >> gbase) & gmask;
+            if (gu == 0 && gf != 0) {
+                const int sl = (int)__ffsll((unsigned long long)gf) - 1;
+                const int my = (int)__ffs((int)(fm | 0x10000u)) - 1;
+                const int zn = pos_of<G, T>(sl, __shfl(my, sl, G));
+                int ln, sn;
+                lane_slot_of<G, T>(zn, ln, sn);
+                onehot_add1<T>(ndk, (lig == ln) ? (1u << sn) : 0u, -f);      // n_dk[new_z] += f
+                return zn;
+            }
+        }
         double S = group_sum<G, T, HAS_TAIL>(w, K, lig, lane);
         if (P.beta_fallback && S == 0.0) {     // 0/0 raises in the reference (CascadeLDA.py:225-230)
 #pragma unroll

@@ -720,8 +720,11 @@ llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel)
         const int64_t i1 = s0 + (len > 1 ? 1 : 0);
         int v_1 = K.word[i1], f_1 = K.freq[i1], zo_1 = K.z[i1];
         int c_c = K.csc_pos ? K.csc_pos[s0] : 0, c_1 = K.csc_pos ? K.csc_pos[i1] : 0;       // (commit-log positions)
-        v16i xa[NT], xb[NT];
-        load_row(__builtin_amdgcn_readfirstlane(v_c), xa);
+        // (two row buffers need 32 * NT registers: beyond two tiers the allocator keeps them in scratch memory, so there the
+        // row of a site is loaded at its top and only the scalars run ahead)
+        constexpr bool PREFETCH = NT <= 2;
+        v16i xa[NT], xb[PREFETCH ? NT : 1];
+        if constexpr (PREFETCH) load_row(__builtin_amdgcn_readfirstlane(v_c), xa);
         // a topic count of the document changes by df (lane 0): the int16 change and the cached factor; nd0, nk0 = the
         // start values of the position (HBM; fetched ahead of time where the position is known ahead of time)
         auto count_change = [&](const int pos, const int df, const int nd0, const int nk0) {
@@ -733,14 +736,15 @@ llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel)
         };
         if (lane == 0) count_change(zo_c, -f_c, ndk_row[zo_c], K.n_k[zo_c]);    // site 0 leaves its topic (LabeledLDA.py:109-111)
 
-        auto site = [&](const int n, v16i (&x)[NT], v16i (&xnext)[NT]) {
+        auto site = [&](const int n, v16i (&x)[NT], v16i (&xnext)[PREFETCH ? NT : 1]) {
             const int64_t i = s0 + n;
             const int v = __builtin_amdgcn_readfirstlane(v_c), f = __builtin_amdgcn_readfirstlane(f_c),
                       zo = __builtin_amdgcn_readfirstlane(zo_c), cpos = c_c;
             uint32_t ra, rb;
             site_random_bits<64>(K, n, n == 0, gdoc, lane, r0, r1, r2, r3, ra, rb);
             // row of site n + 1, scalars of site n + 2, start counts of site n + 1's old topic (needed at the end of this site)
-            load_row(__builtin_amdgcn_readfirstlane(v_1), xnext);
+            if constexpr (PREFETCH) load_row(__builtin_amdgcn_readfirstlane(v_1), xnext);
+            else load_row(v, x);
             v_c = v_1; f_c = f_1; zo_c = zo_1; c_c = c_1;
             const int nd0_n = ndk_row[zo_c], nk0_n = K.n_k[zo_c];
             {
@@ -870,19 +874,28 @@ llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel)
             }
             if (lane == 0) {
 #ifdef ABL_WIDE_NOADDLOAD                                        // ablation (tools/abl_wide.py): no start-value loads behind the draw
-                count_change(zn, f, 0, 1000);
+                const int nd0_z = 0, nk0_z = 1000;
 #else
-                count_change(zn, f, ndk_row[zn], K.n_k[zn]);     // add the site back (LabeledLDA.py:121-125)
+                const int nd0_z = ndk_row[zn], nk0_z = K.n_k[zn];   // (issued first: everything below up to their use overlaps them)
 #endif
-                if (n + 1 < len) count_change(zo_c, -f_c, nd0_n, nk0_n);   // ... and take the next site out of its topic already
                 commit_site(K, i, v, f, zo, zn, cpos, KP);
+                const bool more = n + 1 < len;
+                // take the next site out of its topic already; when that is the topic just drawn the two changes must be
+                // applied in order (the factor is computed from the final count)
+                if (more && zo_c != zn) count_change(zo_c, -f_c, nd0_n, nk0_n);
+                count_change(zn, f, nd0_z, nk0_z);               // add the site back (LabeledLDA.py:121-125)
+                if (more && zo_c == zn) count_change(zo_c, -f_c, nd0_n, nk0_n);
             }
         };
-        for (int n = 0;; n += 2) {
-            site(n, xa, xb);
-            if (n + 1 >= len) break;
-            site(n + 1, xb, xa);
-            if (n + 2 >= len) break;
+        if constexpr (PREFETCH) {
+            for (int n = 0;; n += 2) {
+                site(n, xa, xb);
+                if (n + 1 >= len) break;
+                site(n + 1, xb, xa);
+                if (n + 2 >= len) break;
+            }
+        } else {
+            for (int n = 0; n < len; ++n) site(n, xa, xb);
         }
         for (int q = lane; q < KP4; q += 64) {
             const int2 pk = reinterpret_cast<const int2 *>(s_dk)[q];

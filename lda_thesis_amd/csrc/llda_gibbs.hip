@@ -806,6 +806,8 @@ int llda_foldin(const llda_foldin_args *a, void *stream)
     P.c_init = a->c_init; P.c_loop = a->c_loop;
     P.key0 = (uint32_t)a->seed; P.key1 = (uint32_t)(a->seed >> 32); P.stream_id = a->stream_id;
     P.iters = a->iters; P.thinning = a->thinning; P.beta_fallback = a->beta_fallback; P.avg_mode = a->avg_mode;
+    // the decided tier needs non-negative scores and a divisor c whose distance from 1 dwarfs the rounding of a normalised sum
+    P.exact_only = (a->exact_only != 0 || !(a->alpha >= 0.0) || !(a->c_loop - 1.0 >= 1e-9)) ? 1 : 0;
     P.n_sites = a->n_sites > 0 ? a->n_sites : 0;
     P.ph_base = a->ph_base; P.doc_stream = a->doc_stream;
     fill_schedule(L, P.last_leaf, P.tail, P.tail_row, P.n_rounds, P.xor_tree, P.rounds_pk);

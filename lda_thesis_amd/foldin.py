@@ -32,6 +32,9 @@ def doc_key(doc_tup):
     return zlib.crc32(np.asarray(list(ids) + list(freqs), dtype=np.int32).tobytes())
 
 
+EXACT_ONLY = False      # test hook (llda_foldin_args.exact_only): every site through the reference's pipeline
+
+
 class Pending(object):
     """An enqueued llda_foldin launch; ``result()`` waits for it (on its stream) and brings the outputs to the host."""
 
@@ -96,7 +99,7 @@ def _launch(ph, init_rows, init_idx, doc_tups, *, alpha, beta, it, thinning, see
             _native.foldin(doc_off=d_off, n_dk=n_dk, th=th, D=D, doc_ids=d_ids, word=d_word, init_idx=d_idx, freq=d_freq,
                            ph=d_ph, init_rows=d_init, slot_valid=valid, z=z, status=status, K=K, iters=it,
                            thinning=thinning, alpha=alpha, beta=beta, c_init=c_init, c_loop=c_loop, seed=seed,
-                           stream_id=stream_id, beta_fallback=beta_fallback, avg_mode=avg_mode)
+                           stream_id=stream_id, beta_fallback=beta_fallback, avg_mode=avg_mode, exact_only=EXACT_ONLY)
         return Pending(stream, lay, doc_off, z, n_dk, th, status, (d_off, d_word, d_freq, d_idx, d_ph, d_init, valid, d_ids))
     # hold=True: everything is uploaded and prepared, the kernels are enqueued when the caller calls the returned
     # function -- a synchronous host-to-device copy waits for kernels that are already running, so a caller with many
@@ -286,7 +289,8 @@ def cascade_fold_in_many(jobs, alpha, beta, it, thinning, seed, stream=None):
             _native.foldin(doc_off=d_off, n_dk=n_dk, th=th, D=D, doc_ids=d_ids, word=d_word, init_idx=d_idx, freq=d_freq,
                            ph=d_ph, init_rows=d_init, slot_valid=valid, z=z, status=status, K=K, iters=it,
                            thinning=thinning, alpha=alpha, beta=beta, c_init=1.0000005, c_loop=1.000005, seed=seed,
-                           stream_id=0, beta_fallback=True, avg_mode=0, ph_base=d_base, doc_stream=d_stream)
+                           stream_id=0, beta_fallback=True, avg_mode=0, ph_base=d_base, doc_stream=d_stream,
+                           exact_only=EXACT_ONLY)
         keep = [(d_off, d_word, d_freq, d_idx, d_ids, d_base, d_stream, d_ph, d_init, valid)]   # alive until it has run
 
         def result():

@@ -246,6 +246,43 @@ def test_fold_in_against_numpy_oracle_on_seeded_inputs():
         np.testing.assert_array_equal(got["th_hat"], want)
 
 
+@pytest.mark.parametrize("K,V,dense", [(5, 60, True), (20, 80, False), (64, 90, True), (392, 70, False), (512, 50, True),
+                                       (1000, 40, False)])
+def test_fold_in_decided_tier_equals_the_reference_pipeline(K, V, dense):
+    """The fold-in kernel decides a site from unnormalised fp64 prefix sums when every |prefix - u * total| exceeds 2^-40 of
+    the total (DESIGN.md 4.3 applied to LabeledLDA.py:183-197 / CascadeLDA.py:216-236) and runs the reference's pipeline
+    (normalise, shrink, inverse-CDF draw) otherwise; ``exact_only`` forces the latter for every site.  Same z, n_dk, th_hat,
+    bit for bit, on loadings with a wide dynamic range, exact zeros, all-zero columns (the beta fall-back) and tiny alpha."""
+    import lda_thesis_amd.foldin as F
+    rng = np.random.default_rng(K + V)
+    ph = rng.random((K, V)) ** 12                                   # 12 decades between the loadings of a word
+    if not dense:
+        ph[rng.random((K, V)) < 0.5] = 0.0
+        ph[:, 3] = 0.0                                              # a word no topic loads on
+        ph[0, :] += 1e-9                                            # (no all-zero row)
+    ph /= ph.sum(axis=1, keepdims=True)
+    tups = []
+    for d in range(40):
+        ids = np.sort(rng.choice(V, size=int(rng.integers(1, 30)), replace=False)).tolist()
+        tups.append(list(zip(ids, rng.integers(1, 5, size=len(ids)).tolist())))
+    runs = {}
+    for mode in (False, True):
+        F.EXACT_ONLY = mode
+        try:
+            a = F.cascade_fold_in(ph, 1e-3, 0.01, tups, 40, 5, 77, 4242, np.arange(len(tups)) + 3)
+            b = None if not dense else F.fold_in(ph, 0.2, tups, 40, 5, 78, stream_id=9, doc_base=2)
+        finally:
+            F.EXACT_ONLY = False
+        runs[mode] = (a, b)
+    for got, want in zip(runs[False], runs[True]):
+        if got is None:
+            continue
+        np.testing.assert_array_equal(got["th_hat"], want["th_hat"])
+        np.testing.assert_array_equal(got["n_dk"], want["n_dk"])
+        for zg, zw in zip(got["z"], want["z"]):
+            np.testing.assert_array_equal(zg, zw)
+
+
 def test_labeledlda_run_test_method():
     g = load_golden("runtest_k12")
     m, _, _ = build_model("k12", seed=12345)
