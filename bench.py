@@ -899,8 +899,9 @@ def main():
                                  "128-byte line fill (roofline.l2: fabric requests per site), random labels")
                 if wname == "synth_wide":
                     e["kernel"] = "wide"
-                    e["note"] = ("general path: bound by the latency of one wavefront's dependent chain at 8 wavefronts per CU "
-                                 "(LDS: 20 KB each -- cached factors + int16 count changes)")
+                    e["note"] = ("general path (one wavefront per document, fp32 tier 0 in front of the fp64 decision): bound by the "
+                                 "latency of one wavefront's dependent chain at 8 wavefronts per CU (LDS: 20 KB each -- cached fp64 "
+                                 "factors + int16 count changes)")
                 extra[key] = e
                 del s2, i2
                 torch.cuda.empty_cache()

@@ -309,6 +309,18 @@ class CascadeLDA(object):
         order = np.argsort(th_hat)[::-1][:n]
         return [labels[i] for i in order], loads[:n]
 
+    @staticmethod
+    def _head_many(th, labels, threshold):
+        """``_head`` for every row of a (documents, labels) matrix with the sorts and cumulative sums done once for the
+        whole matrix (numpy sorts / accumulates each row exactly as it does a 1-D array)."""
+        th = np.asarray(th)
+        if th.shape[0] == 0:
+            return []
+        loads = np.sort(th, axis=1)[:, ::-1]
+        n = (np.cumsum(loads, axis=1) < threshold).sum(axis=1) + 1
+        order = np.argsort(th, axis=1)[:, ::-1]
+        return [([labels[i] for i in order[r, :n[r]]], loads[r, :n[r]]) for r in range(th.shape[0])]
+
     def test_down_tree(self, doc, it, thinning, threshold, seed=None, doc_id=None):
         """walk the label tree: level 1 over all one-character labels, then the children of every label
         kept at the level above (CascadeLDA.py:249-297).  Returns (level_1, level_2, level_3)."""
@@ -408,8 +420,7 @@ class CascadeLDA(object):
         labels = self.lablist_l1
         th = self.cascade_test_batch(None, it, thinning, labels, seed=seed, bows=bows, doc_ids=keys, ph_dev=ph_dev)
         todo2 = {}                                      # parent -> documents that kept it, in visiting order
-        for d in range(len(docs)):
-            keep, loads = self._head(th[d], labels, threshold)
+        for d, (keep, loads) in enumerate(self._head_many(th, labels, threshold)):
             out[d][0] = list(zip(keep, loads))
             if "root" in keep:
                 keep.remove("root")
@@ -418,8 +429,7 @@ class CascadeLDA(object):
         # level 2, then level 3: one launch per node that some document reached
         res2, todo3 = {}, {}
         for parent, (labels, th) in level(todo2).items():
-            for row, d in zip(th, todo2[parent]):
-                keep2, loads2 = self._head(row, labels, threshold)
+            for (keep2, loads2), d in zip(self._head_many(th, labels, threshold), todo2[parent]):
                 res2[(d, parent)] = list(zip(keep2, loads2))
                 if parent in keep2:
                     keep2.remove(parent)
@@ -427,8 +437,7 @@ class CascadeLDA(object):
                     todo3.setdefault(parent2, []).append(d)
         res3 = {}
         for parent2, (labels, th) in level(todo3).items():
-            for row, d in zip(th, todo3[parent2]):
-                keep3, loads3 = self._head(row, labels, threshold)
+            for (keep3, loads3), d in zip(self._head_many(th, labels, threshold), todo3[parent2]):
                 res3[(d, parent2)] = list(zip(keep3, loads3))
         # assemble in the order test_down_tree visits the nodes
         for d in range(len(docs)):

@@ -197,8 +197,25 @@ __global__ void __launch_bounds__(256) llda_foldin_kernel(const FParams P)
                 q[s] = run;
                 pm |= (w[s] > 0.0 ? 1u : 0u) << s;
             }
-            const double X = group_scan<G>(run, lig);
-            const double tot = bcast_last<G>(X, lane);
+            double X = group_scan<G>(run, lig);
+            double tot = bcast_last<G>(X, lane);
+            if (P.beta_fallback && tot == 0.0) {
+                // every score is an exact zero (the word loads on none of these topics -- common in CascadeLDA's label subsets):
+                // the reference's sum is 0 too, its 0/0 raises, and it takes prob = num_a * (b + beta) (CascadeLDA.py:225-230)
+                // -- the same scores here, then the same decision
+                pm = 0;
+                run = 0.0;
+#pragma unroll
+                for (int s = 0; s < T; ++s) {
+                    const bool real = P.slot_valid[lig * T + s] != 0;
+                    const double ws = real ? ((double)ndk[s] + P.alpha) * (b[s] + P.beta) : 0.0;
+                    run = run + ws;
+                    q[s] = run;
+                    pm |= (ws > 0.0 ? 1u : 0u) << s;
+                }
+                X = group_scan<G>(run, lig);
+                tot = bcast_last<G>(X, lane);
+            }
             const double prev = dpp_f64<DPP_WAVE_SHR1>(X);
             const double tg = u * tot - (lig ? prev : 0.0);
             const double margin = tot * 0x1p-40;

@@ -240,8 +240,9 @@ class Dictionary(object):
         return [(i, self.id2token[i]) for i in self.keys()]
 
     def doc2bow(self, document):
-        counter = Counter(t for t in document if t in self.token2id)
-        return sorted((self.token2id[t], c) for t, c in counter.items())
+        counter = Counter(map(self.token2id.get, document))     # (ids counted at C speed; unknown tokens map to None)
+        counter.pop(None, None)
+        return sorted(counter.items())
 
     def filter_extremes(self, no_below=5, no_above=0.5, keep_n=100000):
         no_above_abs = int(no_above * self.num_docs)
