@@ -4,13 +4,13 @@
 set -u
 export TMPDIR=/tmp
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/r03b
+OUT=$REPO/gpurun_out/${TAG:-r03b}
 mkdir -p $OUT
 timeout 1500 python bench.py --pmc-keep $OUT/pmc > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "bench rc=$?"; tail -c 600 $OUT/bench_default.err
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r03b_stats -o default -- \
-    python $REPO/bench.py --steps 10 --warmup 2 --no-cpu --no-pmc > /tmp/r03b_stats.log 2>&1)
-for f in $(find /tmp/r03b_stats -name "*_kernel_stats.csv"); do cp $f $OUT/stats_kernel_stats.csv; done
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${TAG:-r03b}_stats -o default -- \
+    python $REPO/bench.py --steps 10 --warmup 2 --no-cpu --no-pmc > /tmp/${TAG:-r03b}_stats.log 2>&1)
+for f in $(find /tmp/${TAG:-r03b}_stats -name "*_kernel_stats.csv"); do cp $f $OUT/stats_kernel_stats.csv; done
 tools/bin/gather_ubench > $OUT/gather_ubench.txt 2>&1
 for cfg in "8192 1" "205 1" "8192 16"; do
   set -- $cfg
