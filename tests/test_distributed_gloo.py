@@ -34,16 +34,20 @@ def _setup(rank, world, port, hip):
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    if hip:
-        torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if hip == "nccl":                           # one GPU per rank, RCCL (only where the box has several GPUs)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        if hip:
+            torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     if hip:
         from lda_thesis_amd import _native
         import lda_thesis_amd.ensemble as E
         import lda_thesis_amd.sampler as S
         _native.lib()
         assert S._native is _native and E._native is _native      # nothing stands in for the HIP library
-        return "cuda:0"
+        return "cuda:%d" % (rank if hip == "nccl" else 0)
     import c_oracle
     from helpers import use_oracle_backend
     use_oracle_backend(c_oracle)

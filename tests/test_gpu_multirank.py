@@ -70,6 +70,21 @@ def test_hip_rank_without_documents(overlap):
     assert all(ok for _, ok, _ in res), res
 
 
+def _golden_nccl(rank, world, port, name, counts_mode, overlap, q):
+    _worker(rank, world, port, name, counts_mode, overlap, q, hip="nccl")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device "
+                                                          "('Duplicate GPU detected')")
+@pytest.mark.parametrize("name,counts_mode,overlap", [("tiny_k40", "built", 1), ("tiny_k12", "built", 2),
+                                                      ("tiny_k392", "given", 1), ("tiny_k1031", "built", 1)])
+def test_rccl_one_rank_per_gpu_matches_the_reference_golden(name, counts_mode, overlap):
+    """the same check over RCCL with one GPU per rank -- runs only where the box has at least two GPUs"""
+    world = min(4, torch.cuda.device_count())
+    res = _spawn(world, _golden_nccl, (name, counts_mode, overlap))
+    assert all(ok for _, ok, _ in res), res
+
+
 # ------------------------------------------------------------------------------------------------ (ii) configs[3] slice
 SLICE_DOCS, SLICE_BLOCK, SLICE_N, SLICE_V, SLICE_K, SLICE_SWEEPS = 200000, 12500, 300, 100000, 512, 3
 
