@@ -117,7 +117,8 @@ typedef struct llda_sweep_args {
                                     the fp32 tier 0; -3 (wide layouts only) production margins on the kernel
                                     that keeps nothing of the row in registers, -4 on the register kernel with
                                     LDS copies of the counts whatever max_doc_tokens says, -5 on the fp64 register
-                                    kernel without its fp32 tier                                                              */
+                                    kernel without its fp32 tier, -6 the fp32 tier with fp64 factors in LDS even when
+                                    scratch is there, -7 with fp32 factors only whenever scratch is there                     */
     double   alpha, beta;        /* priors (LabeledLDA.py:55-56)                               */
     uint64_t seed;               /* RNG key                                                    */
     uint32_t sweep;              /* RNG counter word 3                                         */
@@ -129,6 +130,12 @@ typedef struct llda_sweep_args {
     const int32_t *live_pos;     /* [dev] device positions of the topics every document allows, in DRAW order:
                                   * ascending (lane, slot) of the layout -- llda_layout.pos_lane / pos_slot --,
                                   * which for layouts with T >= 8 is not ascending memory position          */
+    void          *scratch;      /* [dev] optional (ABI 14) work space: llda_sweep_scratch_bytes(K, D) bytes, contents irrelevant.
+                                    Wide layouts of three or four tiers (K = 1 929 ... 3 848) with a dense or general label mask
+                                    keep fp32 factors only in LDS when it is there (more wavefronts per CU) and run the rare
+                                    fp64 / exact tiers on it.  NULL or too small: the same result from the kernel that keeps
+                                    fp64 factors in LDS (14 % slower there)                                                 */
+    int64_t  scratch_bytes;      /* size of scratch                                                        */
     int32_t  live_max;           /* largest number of allowed topics of any document                  */
     int32_t  max_doc_tokens;     /* (ABI 13) optional hint, 0 = unknown: an upper bound of the tokens (sum of freq) of any
                                     document of the call.  Wide layouts only: below 32 768 the kernel keeps the document's
@@ -162,6 +169,10 @@ int         llda_last_hip_error(void);
 int         llda_struct_size(int which);
 /* Fill *out for K topics.  Mirrors numpy's pairwise-sum recursion (np.sum at LabeledLDA.py:117). */
 int         llda_layout_init(int32_t K, llda_layout *out);
+
+/* Bytes of llda_sweep_args.scratch that let llda_sweep(K, D documents per call) run its fastest kernel (0 for layouts that
+ * need none: every narrow layout).  Host only. */
+int64_t     llda_sweep_scratch_bytes(int32_t K, int64_t D);
 
 /* ---- device entry points (enqueue on `stream`) ---- */
 /* One Gibbs sweep over the shard: LabeledLDA.py:101-125 / CascadeLDA.py:397-421. */

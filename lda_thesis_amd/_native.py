@@ -52,7 +52,7 @@ class LldaSweepArgs(ctypes.Structure):
                 ("D", _c_i64), ("V", _c_i64), ("K", _c_i32), ("docs_per_group", _c_i32),
                 ("dense_mask", _c_i32), ("debug_margin", _c_i32), ("alpha", _c_d), ("beta", _c_d), ("seed", _c_u64), ("sweep", _c_u32),
                 ("stream_id", _c_u32), ("doc_base", _c_i64),
-                ("live_off", _c_p), ("live_pos", _c_p),
+                ("live_off", _c_p), ("live_pos", _c_p), ("scratch", _c_p), ("scratch_bytes", _c_i64),
                 ("live_max", _c_i32), ("max_doc_tokens", _c_i32), ("csc_pos", _c_p), ("commit_log", _c_p),
                 ("n_sites", _c_i64), ("site_rec", _c_p)]
 
@@ -68,6 +68,7 @@ class LldaBatchArgs(ctypes.Structure):
 
 
 EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_struct_size", "llda_layout_init",
+           "llda_sweep_scratch_bytes",
 
            "llda_sweep", "llda_sweep_batch", "llda_commit_log", "llda_apply_rows", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
            "llda_readout_phi", "llda_readout_theta", "llda_selftest_div")
@@ -103,6 +104,8 @@ def lib():
     L.llda_layout_init.argtypes = [_c_i32, ctypes.POINTER(LldaLayout)]
     L.llda_sweep.restype = ctypes.c_int
     L.llda_sweep.argtypes = [ctypes.POINTER(LldaSweepArgs), _c_p]
+    L.llda_sweep_scratch_bytes.restype = _c_i64
+    L.llda_sweep_scratch_bytes.argtypes = [_c_i32, _c_i64]
     L.llda_sweep_batch.restype = ctypes.c_int
     L.llda_sweep_batch.argtypes = [ctypes.POINTER(LldaBatchArgs), _c_p]
     L.llda_commit_log.restype = ctypes.c_int
@@ -183,17 +186,24 @@ def _launch(ref, fn, what, *args):
 def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
           status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
           dense_mask=False, debug_margin=0, live_off=None, live_pos=None, live_max=0, csc_pos=None, commit_log=None,
-          n_sites=None, site_rec=None, max_doc_tokens=0):
+          n_sites=None, site_rec=None, max_doc_tokens=0, scratch=None):
     """llda_sweep on the current torch stream.  All array arguments are torch CUDA tensors.  n_sites = the sites
-    the D documents span (default: all of ``word``)."""
+    the D documents span (default: all of ``word``); scratch = a uint8 tensor of sweep_scratch_bytes(K, D) bytes (wide
+    layouts) or None."""
     a = LldaSweepArgs(_ptr(doc_off), _ptr(doc_order), _ptr(word), _ptr(freq), _ptr(z), _ptr(lab_mask),
                       _ptr(n_dk), _ptr(n_kw), _ptr(n_kw_delta), _ptr(n_k), _ptr(n_k_delta), _ptr(status),
                       int(D), int(V), int(K), int(docs_per_group), 1 if dense_mask else 0, int(debug_margin),
                       float(alpha), float(beta),
                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(sweep) & 0xFFFFFFFF,
-                      int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), int(live_max), int(max_doc_tokens),
+                      int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), _ptr(scratch),
+                      0 if scratch is None else int(scratch.numel() * scratch.element_size()), int(live_max), int(max_doc_tokens),
                       _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites), _ptr(site_rec))
     _launch(z, lib().llda_sweep, "llda_sweep", ctypes.byref(a))
+
+
+def sweep_scratch_bytes(K, D):
+    """llda_sweep_scratch_bytes: bytes of work space that let llda_sweep take its fastest kernel (0: none needed)."""
+    return int(lib().llda_sweep_scratch_bytes(int(K), int(D)))
 
 
 def sweep_batch(*, inst_off, order, word, freq, z, inst_prob, inst_doc, live_off, live_pos, ndk_off, n_dk, kw_off,

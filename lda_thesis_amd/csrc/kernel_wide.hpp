@@ -664,6 +664,42 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
 // margin): ~3 % at K = 2 048 -- takes the fp64 two-pass decision on the same registers and factors and, if that is unsure
 // too (~1e-9), the exact pipeline; the topic is always the exact pipeline's.  Needs max_doc_tokens < 2^15 (int16 changes).
 // ---------------------------------------------------------------------------------------------
+// fp32 image of the fp64 factors (SLIM form of the kernel below): computed in fp64, rounded once
+__device__ __forceinline__ void wide_factors32(float *fac, const int *s_ndk, const int *s_nkc, const uint16_t *mrow,
+                                               const WideLayout &W, double alpha, double vbeta, int lane)
+{
+    for (int q = lane; q < (W.KP >> 2); q += 64) {
+        const int c = q / W.G, gv = q - c * W.G;
+        const uint32_t mask = mrow[gv];
+        const int4 nd = reinterpret_cast<const int4 *>(s_ndk)[q], nk = reinterpret_cast<const int4 *>(s_nkc)[q];
+        const int nds[4] = {nd.x, nd.y, nd.z, nd.w}, nks[4] = {nk.x, nk.y, nk.z, nk.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            fac[j * (W.KP >> 2) + q] = (float)wide_factor(nds[j], nks[j], (mask >> (4 * c + j)) & 1u, alpha, vbeta);
+    }
+}
+
+// The rare tiers of a site of the SLIM kernel, out of line (a real call: their registers are not part of the hot loop's
+// allocation) and on a scratch row of KP doubles in HBM: fp64 factors from the start counts + the int16 changes, the fp64
+// two-pass decision (the row is read again), then the exact pipeline.  Returns the position; *exact tells whether the exact
+// pipeline ran.  (Parameters through the kernel-argument segment: see the note at the exact tier of the kernel below.)
+__device__ __noinline__ int wide_rare_tiers(const WParams *Pk, double *scr, const int32_t *ndk_row, const int16_t *s_dk,
+                                            const uint16_t *mrow, int v, int zo, int f, uint32_t ra, uint32_t rb, int lane, int *exact)
+{
+    const KParams &K = Pk->k;
+    const WideLayout &W = Pk->w;
+    const double u = uniform53(ra, rb);
+    const int4 *xrow = reinterpret_cast<const int4 *>(K.n_kw + (int64_t)v * W.KP);
+    wide_factors(scr, ndk_row, K.n_k, s_dk, mrow, W, K.alpha, K.vbeta, lane);
+    int zn = wide_tier(scr, xrow, W, u, zo, f, K.beta, K.margin_rel, lane);
+    *exact = 0;
+    if (zn < 0) {
+        *exact = 1;
+        zn = wide_exact_site(scr, ndk_row, K.n_k, s_dk, mrow, xrow, W, K, zo, f, u, lane);
+    }
+    return zn;
+}
+
 #ifndef LLDA_MARGIN0_WIDE
 #define LLDA_MARGIN0_WIDE (112.0f * 0x1p-24f)
 #endif
@@ -671,18 +707,29 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
 // TC = slots per virtual lane / 4 (3 or 4: the only values wide layouts have).  (Registers: two rows, the prefix values and
 // the fp64 tier's temporaries want more than the 168 VGPRs of three wavefronts per SIMD -- with that cap the allocator
 // spilled the PREFETCHED row, i.e. waited for it on the spot; LDS allows 8 wavefronts per CU at K = 2 048 anyway.)
-template <int NT, int TC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NT <= 4 ? 2 : 1)))
-llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel)
+// SLIM (the caller passes llda_sweep_args.scratch): the factors live in LDS as fp32 only -- 6 instead of 10 bytes per position: 13
+// instead of 8 wavefronts per CU at K = 2 048 -- rounded once from the fp64 value (the error bound above is unchanged); the sites
+// tier 0 is unsure about take wide_rare_tiers() on a scratch row in HBM.  With a third wavefront per SIMD the row is NOT double-
+// buffered (two rows + prefix values + a call do not fit 168 VGPRs: the allocator spilled the prefetched row, i.e. waited for it on
+// the spot).  Measured (tools/abl_wide.py, M sites/s, SLIM vs fp64 factors in LDS): K = 1 088 841 / 838, K = 2 048 669 / 830,
+// K = 3 000 384 / 337, K = 4 296 78 / 90, K = 7 688 57 / 84 -- three wavefronts without the row prefetch are no better than two
+// with it, and beyond four tiers the dearer fall-back (7 % of the sites at K = 7 688) costs more than the occupancy buys.
+// llda_sweep therefore takes SLIM only for three and four tiers (debug_margin -7 forces it, -6 forbids it).
+template <int NT, int TC, bool SLIM>
+__global__ void __launch_bounds__(64)
+    __attribute__((amdgpu_waves_per_eu(SLIM ? (NT <= 2 ? 3 : NT <= 4 ? 2 : 1) : (NT <= 4 ? 2 : 1))))
+llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel, double *scratch)
 {
     extern __shared__ double s_wide[];
     const KParams &K = P.k;
     const WideLayout &W = P.w;
     constexpr int G = 64 * NT, T = 4 * TC;
     typedef int v16i __attribute__((ext_vector_type(16)));
+    typedef typename std::conditional<SLIM, float, double>::type fac_t;
     const int lane = threadIdx.x, KP = W.KP, KP4 = W.KP >> 2;
-    double *wv = s_wide;                                          // factor of position p at (p & 3) * KP4 + (p >> 2)
+    fac_t *wv = reinterpret_cast<fac_t *>(s_wide);              // factor of position p at (p & 3) * KP4 + (p >> 2)
     int16_t *s_dk = reinterpret_cast<int16_t *>(wv + KP);        // change of n_dk (= of the n_k the document sees), position order
+    double *scr = SLIM ? scratch + (size_t)blockIdx.x * KP : nullptr;    // the rare tiers' row of doubles
     const float beta32 = (float)K.beta;
     int n_unsure = 0, n_exact = 0;
 
@@ -694,7 +741,8 @@ llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel)
         int32_t *ndk_row = K.n_dk + d * KP;
         const uint16_t *mrow = K.lab_mask + d * G;
         for (int q = lane; q < KP4; q += 64) reinterpret_cast<int2 *>(s_dk)[q] = make_int2(0, 0);
-        wide_factors(wv, ndk_row, K.n_k, s_dk, mrow, W, K.alpha, K.vbeta, lane);
+        if constexpr (SLIM) wide_factors32(wv, ndk_row, K.n_k, mrow, W, K.alpha, K.vbeta, lane);
+        else wide_factors(wv, ndk_row, K.n_k, s_dk, mrow, W, K.alpha, K.vbeta, lane);
         uint32_t mk[NT];                                          // allowed slots of this lane's virtual lanes
 #pragma unroll
         for (int t = 0; t < NT; ++t) mk[t] = mrow[t * 64 + lane];
@@ -722,7 +770,7 @@ llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel)
         int c_c = K.csc_pos ? K.csc_pos[s0] : 0, c_1 = K.csc_pos ? K.csc_pos[i1] : 0;       // (commit-log positions)
         // (two row buffers need 32 * NT registers: beyond two tiers the allocator keeps them in scratch memory, so there the
         // row of a site is loaded at its top and only the scalars run ahead)
-        constexpr bool PREFETCH = NT <= 2;
+        constexpr bool PREFETCH = NT <= 2 && !SLIM;
         v16i xa[NT], xb[PREFETCH ? NT : 1];
         if constexpr (PREFETCH) load_row(__builtin_amdgcn_readfirstlane(v_c), xa);
         // a topic count of the document changes by df (lane 0): the int16 change and the cached factor; nd0, nk0 = the
@@ -730,9 +778,9 @@ llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel)
         auto count_change = [&](const int pos, const int df, const int nd0, const int nk0) {
             const int dz = (int)s_dk[pos] + df;
             s_dk[pos] = (int16_t)dz;
-            double *pf = wv + fac_index(pos, KP4);
+            fac_t *pf = wv + fac_index(pos, KP4);
             // (a cached factor is 0 exactly where the label mask is: no mask load per site)
-            *pf = wide_factor(nd0 + dz, nk0 + dz, *pf != 0.0, K.alpha, K.vbeta);
+            *pf = (fac_t)wide_factor(nd0 + dz, nk0 + dz, *pf != (fac_t)0, K.alpha, K.vbeta);
         };
         if (lane == 0) count_change(zo_c, -f_c, ndk_row[zo_c], K.n_k[zo_c]);    // site 0 leaves its topic (LabeledLDA.py:109-111)
 
@@ -815,8 +863,14 @@ llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel)
             }
             bool exact = false;
             if (__builtin_expect(!decided, 0)) {
+              ++n_unsure;
+              if constexpr (SLIM) {
+                int ex = 0;
+                zn = wide_rare_tiers((const WParams *)__builtin_amdgcn_kernarg_segment_ptr(), scr, ndk_row, s_dk, mrow, v, zo, f, ra, rb,
+                                     lane, &ex);
+                n_exact += ex;
+              } else {
                 // ---- tier 1: the fp64 two-pass decision of the register kernel on the same row and factors ----
-                ++n_unsure;
                 const double u = uniform53(ra, rb);
                 double X[WIDE_MAX_TIERS];
 #pragma unroll
@@ -871,6 +925,7 @@ llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel)
                                          reinterpret_cast<const int4 *>(Pk->k.n_kw + (int64_t)v * KP), Pk->w, Pk->k, zo, f, u, lane);
                     wide_factors(wv, ndk_row, Pk->k.n_k, s_dk, mrow, Pk->w, Pk->k.alpha, Pk->k.vbeta, lane);   // (the exact pipeline borrowed the doubles)
                 }
+              }
             }
             if (lane == 0) {
 #ifdef ABL_WIDE_NOADDLOAD                                        // ablation (tools/abl_wide.py): no start-value loads behind the draw

@@ -38,6 +38,7 @@
 #include <string.h>
 #include <map>
 #include <memory>
+#include <type_traits>
 
 #include "llda_gibbs.h"
 
@@ -403,6 +404,14 @@ int llda_layout_init(int32_t K, llda_layout *L)
     return LLDA_OK;
 }
 
+int64_t llda_sweep_scratch_bytes(int32_t K, int64_t D)
+{
+    int rc;
+    const llda_layout *Lp = layout_of(K, &rc);
+    if (rc || !Lp->wide) return 0;
+    return (int64_t)wide_blocks(D) * Lp->KP * 8;          // one row of doubles per workgroup of the wide sweep
+}
+
 int llda_sweep(const llda_sweep_args *a, void *stream)
 {
     if (!a || a->D < 0 || a->V < 1) return LLDA_E_BAD_ARG;
@@ -441,7 +450,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     const bool dense = fast && a->dense_mask != 0 && L.K == L.KP;
     // debug_margin: 0 = production margins; n > 0 = 2^-n (wider: more fallbacks); -1 = always exact tier;
     // -2 = no fp32 tier
-    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 || a->debug_margin == -3 || a->debug_margin == -4 || a->debug_margin == -5 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
+    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 || a->debug_margin == -3 || a->debug_margin == -4 || a->debug_margin == -5 || a->debug_margin == -6 || a->debug_margin == -7 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
     P.margin0_rel = a->debug_margin == 0 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
     hipStream_t st = (hipStream_t)stream;
 
@@ -496,15 +505,28 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         const size_t lds_reg = compact ? (size_t)L.KP * 10 : lds;
         // fp32 tier 0 in front of the fp64 decision (needs the int16 count changes): production
         const bool tier0 = fast && compact && a->debug_margin != -2 && a->debug_margin != -3 && a->debug_margin != -5 &&
-                           a->debug_margin >= -1;
+                           (a->debug_margin >= -1 || a->debug_margin == -6 || a->debug_margin == -7);
         if (tier0) {
             // margins: production, or the test hook's (n > 0: 2^-n for tier 0 below 16, else tier 0 off; -1: everything exact)
-            const float m0 = a->debug_margin == 0 ? LLDA_MARGIN0_WIDE : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
+            const float m0 = a->debug_margin == 0 || a->debug_margin == -6 || a->debug_margin == -7 ? LLDA_MARGIN0_WIDE
+                             : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
+            // fp32 factors only in LDS (6 bytes per position) when the caller brought the scratch rows of the rare tiers
+            // (measured faster only for three and four tiers: see the note at the kernel; -7 forces it for tests and ablations)
+            const bool slim = a->scratch && a->scratch_bytes >= llda_sweep_scratch_bytes(a->K, a->D) && a->debug_margin != -6 &&
+                              (a->debug_margin == -7 || L.tiers == 3 || L.tiers == 4);
+            const size_t lds32 = slim ? (size_t)L.KP * 6 : lds_reg;
+            double *scr = slim ? static_cast<double *>(a->scratch) : nullptr;
 #define LLDA_WIDE_F32(NT_, TC_)                                                                              \
     if (L.tiers == NT_ && L.T == 4 * TC_) {                                                                  \
-        rl = allow_lds(llda_sweep_wide_f32_kernel<NT_, TC_>, lds_reg);                                       \
-        if (rl) return rl;                                                                                   \
-        hipLaunchKernelGGL((llda_sweep_wide_f32_kernel<NT_, TC_>), grid, block, lds_reg, st, W, m0);         \
+        if (slim) {                                                                                          \
+            rl = allow_lds(llda_sweep_wide_f32_kernel<NT_, TC_, true>, lds32);                               \
+            if (rl) return rl;                                                                               \
+            hipLaunchKernelGGL((llda_sweep_wide_f32_kernel<NT_, TC_, true>), grid, block, lds32, st, W, m0, scr);  \
+        } else {                                                                                             \
+            rl = allow_lds(llda_sweep_wide_f32_kernel<NT_, TC_, false>, lds32);                              \
+            if (rl) return rl;                                                                               \
+            hipLaunchKernelGGL((llda_sweep_wide_f32_kernel<NT_, TC_, false>), grid, block, lds32, st, W, m0, scr); \
+        }                                                                                                    \
     } else
             LLDA_WIDE_F32(2, 3) LLDA_WIDE_F32(2, 4) LLDA_WIDE_F32(3, 4) LLDA_WIDE_F32(4, 3) LLDA_WIDE_F32(4, 4) LLDA_WIDE_F32(5, 4)
             LLDA_WIDE_F32(6, 4) LLDA_WIDE_F32(7, 4) LLDA_WIDE_F32(8, 3) LLDA_WIDE_F32(8, 4)

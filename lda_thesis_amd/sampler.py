@@ -173,6 +173,13 @@ class GibbsSampler(object):
             self.n_dk[:, self._topic_pos] = as_dev(counts["n_d_k"], torch.int32)
             self.n_kw[:, self._topic_pos] = as_dev(np.asarray(counts["n_k_v"]).T, torch.int32)
             self.n_k[self._topic_pos] = as_dev(counts["n_zk"], torch.int32)
+        # wide layouts, dense or general label masks: work space that lets the sweep keep fp32 factors only in LDS
+        # (llda_sweep_args.scratch)
+        self._scratch = None
+        if lay.wide and self.live_off is None and self.D > 0:
+            nbytes = _native.sweep_scratch_bytes(self.K, max(hi - lo for lo, hi, _ in self._calls))
+            if nbytes:
+                self._scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         self.row_off = self.rows = self._rows_list = None
         if self.sharded and (_dist_active(self.group) or exchange_always):
             self._make_exchange_rows()
@@ -388,7 +395,8 @@ class GibbsSampler(object):
                                    live_off=None if self.live_off is None else self.live_off[lo:hi + 1],
                                    live_pos=self.live_pos,
                                    live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
-                                   n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens)
+                                   n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens,
+                                   scratch=self._scratch)
             if pipelined:
                 # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
                 # collective's stream (ordered after the fold) while the next range is sampled on this one

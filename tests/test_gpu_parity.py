@@ -42,11 +42,12 @@ def test_wide_layout_kernels_agree_with_reference(c_oracle, name):
     the latter is checked against the C oracle on the fixture's corpus with alpha = beta = 1e-9."""
     from lda_thesis_amd.sampler import GibbsSampler
     g = load_golden(name)
-    # production (0) runs the fp32-tiered kernel (rare tiers on the scratch row); -5: the fp64 kernel with the row in
-    # registers and int16 changes; -4: the same with LDS copies of the counts; -3: the LDS-only kernel
-    for margin in (0, -5, -3, -4):
+    # production (0) runs the fp32-tiered kernel; -7: with fp32 factors only in LDS (rare tiers on the scratch row); -6: with
+    # fp64 factors in LDS; -5: the fp64 kernel with the row in registers and int16 changes; -4: the same with LDS copies of
+    # the counts; -3: the LDS-only kernel
+    for margin in (0, -7, -6, -5, -3, -4):
         s = make_sampler(g)
-        assert s.layout.wide and 0 < s.max_doc_tokens < 32768
+        assert s.layout.wide and 0 < s.max_doc_tokens < 32768 and (s._scratch is not None) == (s.live_off is None)
         s.debug_margin = margin
         for i in range(int(g["sweeps"])):
             s.sweep()
@@ -513,7 +514,8 @@ def test_adversarial_near_ties_for_the_fp32_tier(c_oracle, K, dense):
     counts = dict(n_d_k=st["n_d_k"], n_k_v=st["n_k_v"], n_zk=st["n_zk"])
     labs = None if dense else st["labs"]
     runs = {}
-    for margin in (0, -1):
+    margins = (0, -1) + ((-6, -7) if K > 1024 else ())     # wide layouts: the fp32 tier in both of its LDS forms
+    for margin in margins:
         s = GibbsSampler(st["doc_off"], st["word"], st["freq"], st["z"], K, st["V"], st["alpha"], st["beta"],
                          labs=labs, counts=counts, seed=4242, doc_base=7, sparse_labels=False)
         s.debug_margin = margin
@@ -523,7 +525,7 @@ def test_adversarial_near_ties_for_the_fp32_tier(c_oracle, K, dense):
     cs = c_oracle.CState(st["doc_off"], st["word"], st["freq"], st["z"], st["labs"], st["n_d_k"], st["n_k_v"],
                          st["n_zk"], st["V"], st["alpha"], st["beta"])
     cs.sweep(1, 4242, 0, doc_base=7, threads=4)
-    for margin in (0, -1):
+    for margin in margins:
         z, ndk, nkv, nzk, _ = runs[margin]
         np.testing.assert_array_equal(z, cs.z)
         np.testing.assert_array_equal(ndk, cs.n_d_k)
@@ -531,3 +533,6 @@ def test_adversarial_near_ties_for_the_fp32_tier(c_oracle, K, dense):
         np.testing.assert_array_equal(nzk, cs.n_zk)
     # production run: the fp32 tier gave up on every tuned site and on no other
     assert int(runs[0][4][1]) == st["n_tuned"]
+    for m in (-6, -7):
+        if m in runs:
+            assert int(runs[m][4][1]) == st["n_tuned"]

@@ -1,6 +1,6 @@
 """Wide layouts (K with more than 8 pairwise leaves): kernel time of the sweep for the kernel variants llda_sweep's
 debug_margin selects -- 0 production (fp32 tier 0: float factors + int16 count changes in LDS, rare tiers on a scratch
-row), -5 the fp64 kernel with the row in registers and int16 count changes, -4 the same with LDS copies of the counts,
+row), -7 the fp32 tier with fp32 factors only in LDS (rare tiers on the scratch row), -6 with fp64 factors in LDS, -5 the fp64 kernel with the row in registers and int16 count changes, -4 the same with LDS copies of the counts,
 -3 LDS-only kernel.
 python tools/abl_wide.py K [N V docs]"""
 import os, sys
@@ -13,7 +13,7 @@ bench.WORKLOADS["abl"] = (docs, N, V, K, 1.0, 1000, "ablation")
 dev = torch.device("cuda", 0)
 s, info = bench.build_sampler("abl", dev, 0, 1, False)
 out = []
-for dm in (0, -5, -4, -3):
+for dm in (0, -7, -6, -5, -4, -3):
     s.debug_margin = dm
     for _ in range(2):
         s.sweep()

@@ -4,7 +4,7 @@
 set -u
 export TMPDIR=/tmp
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/r03h
+OUT=$REPO/gpurun_out/${TAG:-r03h}
 mkdir -p $OUT
 timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -k "wide or near_ties or seeded_inputs or sweeps_match" > $OUT/widetest.log 2>&1; echo "widetest rc=$?" >> $OUT/widetest.log
 tail -3 $OUT/widetest.log
