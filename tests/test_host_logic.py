@@ -244,3 +244,36 @@ def test_device_column_normalisation_is_numpys_pairwise_order(K):
     word = torch.tensor([3, 4, 20, 0, 7, 11, 36, 3])
     got = cascade_init_rows_device(torch.from_numpy(ph.copy()), 0.01, doc_off, word, lay)
     np.testing.assert_array_equal(got[:, torch.from_numpy(lay.lm_topic_pos.astype(np.int64))].numpy(), want)
+
+
+def test_head_many_equals_head_row_by_row():
+    """CascadeLDA._head_many (the batched tree walk) selects what _head -- the statements of test_down_tree,
+    /root/reference/CascadeLDA.py:253-258 -- selects for every row, ties and exactly uniform rows included."""
+    from lda_thesis_amd.CascadeLDA import CascadeLDA
+    rng = np.random.default_rng(0)
+    for K in (2, 5, 20, 27):
+        th = rng.dirichlet(np.ones(K) * 0.3, size=200)
+        th[5] = th[6]
+        th[7, :] = 1.0 / K
+        th[8, :2] = th[8, 0]
+        if K == 5:
+            th = np.round(th, 3)
+        labels = ["L%d" % i for i in range(K)]
+        many = CascadeLDA._head_many(th, labels, 0.95)
+        assert len(many) == th.shape[0]
+        for r in range(th.shape[0]):
+            keep, loads = CascadeLDA._head(th[r], labels, 0.95)
+            assert keep == many[r][0]
+            np.testing.assert_array_equal(loads, many[r][1])
+    assert CascadeLDA._head_many(np.zeros((0, 4)), ["a", "b", "c", "d"], 0.9) == []
+
+
+def test_doc2bow_counts_known_tokens_in_id_order():
+    """Dictionary.doc2bow: sorted (id, count) pairs of the in-vocabulary tokens (gensim's contract, which
+    /root/reference/LabeledLDA.py:64,156 relies on: ids unique and ascending inside a document)."""
+    from lda_thesis_amd.text import Dictionary
+    d = Dictionary([["b", "a", "c"], ["c", "d"]])
+    ids = d.token2id
+    bow = d.doc2bow(["c", "zzz", "a", "c", "c", "d", "a", "nope"])
+    assert bow == sorted([(ids["a"], 2), (ids["c"], 3), (ids["d"], 1)])
+    assert d.doc2bow([]) == [] and d.doc2bow(["zzz"]) == []
