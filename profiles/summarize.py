@@ -1,4 +1,4 @@
-"""Summarise one profiling run (gpurun_out/<dir>/, written by tools/r03_run2.sh / tools/profile.sh on the GPU box) into profiles/:
+"""Summarise one profiling run (gpurun_out/<dir>/, written by tools/profile.sh on the GPU box) into profiles/:
 
     profiles/<tag>_bench_default.json       the bench line of the default run (rooflines from in-run PMC passes, all extras)
     profiles/<tag>_kernel_stats.csv         rocprofv3 --kernel-trace --stats of the same command (kernels >= 0.02 %)
@@ -111,7 +111,7 @@ def main(tag, sub=None):
                       "(profiles/%s_summary.md); bench.py uses it, labelled 'stored', where it cannot profile (N > 1)" % tag)
         json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
     for extra in os.listdir(src):
-        if extra.startswith(("bench_", "gather_")) and extra != "bench_default.json" and not extra.endswith(".err"):
+        if extra.startswith(("bench_", "gather_", "abl_")) and extra != "bench_default.json" and not extra.endswith(".err"):
             shutil.copy(os.path.join(src, extra), os.path.join(prof, "%s_%s" % (tag, extra)))
     open(os.path.join(prof, "%s_summary.md" % tag), "w").write("\n".join(out) + "\n")
     print("\n".join(out))
