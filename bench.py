@@ -69,6 +69,10 @@ WORKLOADS = {
     "synth2_sparse": (125000, 300, 100000, 512, 1.0, 15625,
                       "synthetic 125k docs x 300 tokens, K=512, sparse label mask (root + 7 random labels per doc), "
                       "V=100k (secondary variant of BASELINE configs[3])"),
+    "synth2_sparse_hier": (125000, 300, 100000, 512, 1.0, 15625,
+                           "synthetic 125k docs x 300 tokens, K=512, sparse label mask with CO-LOCATED labels: root + 7 labels drawn "
+                           "from ONE block of 32 consecutive topic ids per document (a label hierarchy whose siblings have "
+                           "neighbouring ids: 32 consecutive topics share a 128-byte line of every n_kw row), V=100k"),
     "synth_wide_sparse": (125000, 300, 100000, 2048, 1.0, 15625,
                           "synthetic 125k docs x 300 tokens, K=2048 (a 'wide' layout), sparse label mask (root + 7 random "
                           "labels per doc), V=100k: Labeled LDA proper with thousands of labels -- the sparse-label kernel "
@@ -117,12 +121,18 @@ def build_sampler(name, dev, rank, world, dist_on, docs_total=0, docs_per_group=
     doc_off, word, freq, z = synthetic_corpus_blocks(lo, hi, N, V, K, 1234, dev, zipf_s=zs, block=block)
     Dg = hi - lo
     info["docs_local"] = Dg
-    if name in ("synth2_sparse", "synth_wide_sparse"):
+    if name in ("synth2_sparse", "synth_wide_sparse", "synth2_sparse_hier"):
         gen = torch.Generator(device=dev)
         gen.manual_seed(99 + rank)
-        # root + 7 distinct random labels per document: sort 7 draws, bump duplicates (still <= K-1)
-        lab = torch.sort(torch.randint(1, K - 8, (Dg, 7), device=dev, generator=gen), dim=1).values
-        lab = lab + torch.arange(7, device=dev)              # strictly increasing => distinct
+        if name == "synth2_sparse_hier":
+            # 7 distinct labels inside one block of 32 consecutive topic ids (block 0 without the root's id 0)
+            blk = torch.randint(0, K // 32, (Dg, 1), device=dev, generator=gen)
+            inner = torch.argsort(torch.rand((Dg, 31), device=dev, generator=gen), dim=1)[:, :7] + 1     # 7 of 1..31
+            lab = torch.sort(blk * 32 + inner, dim=1).values
+        else:
+            # root + 7 distinct random labels per document: sort 7 draws, bump duplicates (still <= K-1)
+            lab = torch.sort(torch.randint(1, K - 8, (Dg, 7), device=dev, generator=gen), dim=1).values
+            lab = lab + torch.arange(7, device=dev)          # strictly increasing => distinct
         lab = torch.cat([torch.zeros((Dg, 1), dtype=lab.dtype, device=dev), lab], dim=1)
         pick = torch.randint(0, 8, (Dg * N,), device=dev, generator=gen)
         z = lab.repeat_interleave(N, dim=0)[torch.arange(Dg * N, device=dev), pick]
@@ -246,7 +256,7 @@ def cpu_baseline_json(sampler, info, name, value):
     Dg = info["docs_local"]
     n_py = n_c = min(Dg, 3000)                         # ~10 s of single-core numpy work at K=512
     labs_h = None
-    if name == "synth2_sparse":
+    if name in ("synth2_sparse", "synth2_sparse_hier"):
         labs_h = np.zeros((n_py, K), dtype=np.uint8)
         lh = info["lab"][:n_py].cpu().numpy()
         labs_h[np.repeat(np.arange(lh.shape[0]), 8), lh.reshape(-1)] = 1
@@ -506,7 +516,8 @@ def cascade_test_extra(with_cpu=True):
 
 # ------------------------------------------------------------------------------------------------ PMC passes
 # every workload whose sweep is ONE kernel launch per sweep, in the order the inner run sweeps them
-PMC_WORKLOADS = ("synth2", "synth1", "synth2_hostile", "synth2_sparse", "synth_wide_sparse", "synth_wide", "abstracts")
+PMC_WORKLOADS = ("synth2", "synth1", "synth2_hostile", "synth2_sparse", "synth2_sparse_hier", "synth_wide_sparse", "synth_wide",
+                 "abstracts")
 PMC_SWEEPS = 3                                              # per workload in the inner run (all are measured)
 # one rocprofv3 run per group (kernel trace only, as the guide prescribes).  TCC holds 4 counters per pass
 # (FETCH_SIZE costs 3, WRITE_SIZE 2); SQ / TA / TCP / GRBM are separate blocks.
@@ -870,7 +881,8 @@ def main():
         torch.cuda.empty_cache()
         if extras_on:
             for key, wname, st, wu in (("synth1", "synth1", 200, 5), ("hbm_bound", "synth2_hostile", 40, 3),
-                                       ("sparse_labels", "synth2_sparse", 100, 5), ("abstracts", "abstracts", 3000, 20),
+                                       ("sparse_labels", "synth2_sparse", 100, 5),
+                                       ("sparse_labels_colocated", "synth2_sparse_hier", 100, 5), ("abstracts", "abstracts", 3000, 20),
                                        ("wide_k2048", "synth_wide", 20, 2), ("wide_sparse_k2048", "synth_wide_sparse", 50, 3)):
                 s2, i2 = build_sampler(wname, dev, 0, 1, False)
                 torch.cuda.synchronize()
@@ -892,6 +904,11 @@ def main():
                 if wname == "synth_wide_sparse":
                     e["live_topics_per_doc"] = i2["live_topics"]
                     e["note"] = "the sparse-label kernel (one lane per allowed topic) on a layout with 16 pairwise leaves"
+                if wname == "synth2_sparse_hier":
+                    e["live_topics_per_doc"] = i2["live_topics"]
+                    e["note"] = ("the same kernel and arithmetic as sparse_labels; only WHICH labels a document carries differs: "
+                                 "siblings with neighbouring topic ids share cache lines (a caller gets this by ordering a "
+                                 "hierarchical labelset by code before handing it to LabeledLDA)")
                 if wname == "synth2_sparse":
                     e["live_topics_per_doc"] = i2["live_topics"]
                     e["algorithmic_GBps"] = algorithmic_bytes(s2.S, i2["docs_local"], i2["live_topics"]) / (k2 * 1e-3) / 1e9
@@ -916,7 +933,7 @@ def main():
         line["roofline"] = roofline_json(m["kernel_ms"], m["sites"], m["docs"], m["live"], pmc.get(name), source,
                                          stored_key=name, shared_bytes=m["shared"])
         for key, wname in (("synth1", "synth1"), ("hbm_bound", "synth2_hostile"), ("sparse_labels", "synth2_sparse"),
-                           ("wide_sparse_k2048", "synth_wide_sparse"), ("wide_k2048", "synth_wide"), ("abstracts", "abstracts")):
+                           ("sparse_labels_colocated", "synth2_sparse_hier"), ("wide_sparse_k2048", "synth_wide_sparse"), ("wide_k2048", "synth_wide"), ("abstracts", "abstracts")):
             if key in extra:
                 m = measured[wname]
                 extra[key]["roofline"] = roofline_json(m["kernel_ms"], m["sites"], m["docs"], m["live"], pmc.get(wname),

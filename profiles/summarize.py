@@ -21,6 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXTRAS = (("synth1", "synth1"), ("hbm_bound", "synth2_hostile"), ("sparse_labels", "synth2_sparse"),
+          ("sparse_labels_colocated", "synth2_sparse_hier"),
           ("wide_sparse_k2048", "synth_wide_sparse"), ("wide_k2048", "synth_wide"), ("abstracts", "abstracts"))
 
 
