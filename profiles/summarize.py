@@ -1,7 +1,8 @@
 """Summarise one profiling run (gpurun_out/<dir>/, written by tools/profile.sh on the GPU box) into profiles/:
 
     profiles/<tag>_bench_default.json       the bench line of the default run (rooflines from in-run PMC passes, all extras)
-    profiles/<tag>_kernel_stats.csv         rocprofv3 --kernel-trace --stats of the same command (kernels >= 0.02 %)
+    profiles/<tag>_kernel_stats.csv         rocprofv3 --kernel-trace --stats of the timed line alone (kernels >= 0.02 %)
+    profiles/<tag>_kernel_stats_extras.csv  ... and of the same command with the extras
     profiles/<tag>_pmc_<pass>.csv           the counter passes bench.py ran on itself: one row per sweep-kernel dispatch and
                                             counter (summed over the counter's instances), passes fetch | write | sq | l2 | ta
     profiles/<tag>_summary.md               kernel table + per workload: counters per launch and the derived roofline numbers
@@ -32,18 +33,26 @@ def main(tag, sub=None):
     line = json.loads(text)
     json.dump(line, open(os.path.join(prof, "%s_bench_default.json" % tag), "w"), indent=1)
     out = ["# rocprofv3 summary %s" % tag, "", "Command: `python bench.py` (default: the 1M-document corpus on one GPU, all extras).", ""]
-    stats = os.path.join(src, "stats_kernel_stats.csv")
-    if os.path.exists(stats):
-        out += ["## kernel stats (`rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu --no-pmc`: every workload of the line)", "",
-                "| kernel | calls | avg ms | % |", "|---|---|---|---|"]
+    for fname, dest, title in (("stats_kernel_stats.csv", "%s_kernel_stats.csv",
+                                "## kernel stats of the timed line (`rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 "
+                                "--no-cpu --no-pmc --no-extras`): the sweep kernel's average is what `roofline.kernel_ms` must agree with"),
+                               ("stats_extras_kernel_stats.csv", "%s_kernel_stats_extras.csv",
+                                "## kernel stats with the extras (`... --no-cpu --no-pmc`): every kernel of the library; an instantiation "
+                                "shared by two workloads shows their mixed average")):
+        stats = os.path.join(src, fname)
+        if not os.path.exists(stats):
+            continue
+        out += [title, "", "| kernel | calls | avg ms | % |", "|---|---|---|---|"]
         keep = []
         rows = list(csv.DictReader(open(stats)))
         for r in rows:
             if float(r["Percentage"]) >= 0.02:
                 keep.append(r)
                 name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-                out.append("| `%s` | %s | %.4f | %s |" % (name[:110], r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"]))
-        with open(os.path.join(prof, "%s_kernel_stats.csv" % tag), "w", newline="") as fh:
+                if name.startswith("llda_") or float(r["Percentage"]) >= 0.5:
+                    out.append("| `%s` | %s | %.4f | %s |" % (name[:110], r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"]))
+        out.append("")
+        with open(os.path.join(prof, dest % tag), "w", newline="") as fh:
             w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
             w.writeheader()
             w.writerows(keep)

@@ -3,8 +3,8 @@
 #   gpurun -- 'bash tools/profile.sh <tag>'      (writes gpurun_out/prof_<tag>/)
 # then, back in the container:  python profiles/summarize.py <tag>
 # bench.py collects the PMC counters itself (separate rocprofv3 --pmc passes, kernel trace only: fetch | write | sq | l2 | ta) and
-# keeps one row per sweep-kernel dispatch and counter with --pmc-keep.  The --stats pass times the same command (all extras)
-# without counters.  The gather micro-benchmark (tools/gather_ubench.hip -> tools/bin/gather_ubench, built in the container)
+# keeps one row per sweep-kernel dispatch and counter with --pmc-keep.  The --stats passes time the same command without
+# counters: the timed line alone, then with the extras.  The gather micro-benchmark (tools/gather_ubench.hip -> tools/bin/gather_ubench, built in the container)
 # calibrates FETCH_SIZE for 4-byte gathers.
 set -u
 TAG=${1:?tag}
@@ -15,9 +15,14 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT $P
 timeout 1500 python bench.py --pmc-keep $OUT/pmc > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "bench rc=$?"; tail -c 400 $OUT/bench_default.err
+# (i) the timed line alone: the dominant kernel's average here must agree with roofline.kernel_ms of the bench line
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o default -- \
-    python $REPO/bench.py --steps 10 --warmup 2 --no-cpu --no-pmc > $P/stats.log 2>&1)
+    python $REPO/bench.py --steps 10 --warmup 2 --no-cpu --no-pmc --no-extras > $P/stats.log 2>&1)
 for f in $(find $P/stats -name "*_kernel_stats.csv"); do cp $f $OUT/stats_kernel_stats.csv; done
+# (ii) the same command with the extras: every other kernel of the library (the hot kernel's average then mixes workloads)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_x -o extras -- \
+    python $REPO/bench.py --steps 10 --warmup 2 --no-cpu --no-pmc > $P/stats_x.log 2>&1)
+for f in $(find $P/stats_x -name "*_kernel_stats.csv"); do cp $f $OUT/stats_extras_kernel_stats.csv; done
 if [ -x tools/bin/gather_ubench ]; then
   tools/bin/gather_ubench > $OUT/gather_ubench.txt 2>&1
   for cfg in "8192 1" "8192 2" "205 1"; do
