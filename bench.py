@@ -672,6 +672,18 @@ def roofline_json(kernel_ms, sites, docs, live_topics, pmc, source, stored_key=N
                                        "the 256 MiB Infinity Cache" % (HBM_ACHIEVABLE_GBS / 1e3, shared_bytes / 1e6,
                                                                        "exceed" if shared_bytes > MALL_BYTES else "fit")})
         cands["hbm" if shared_bytes > MALL_BYTES else "fabric (L2 fills, mostly Infinity-Cache hits)"] = fabric / HBM_PEAK_GBS
+        # the measured ceiling of RANDOM line fills for a footprint of this size (tools/gather_ubench.hip, stored): what the
+        # fabric rate can be compared with when the counts do not stream
+        try:
+            fc = json.load(open(os.path.join(ROOT, "profiles", "fabric_ceiling.json")))
+            mib = shared_bytes / 2.0 ** 20
+            i = min(range(len(fc["footprint_MiB"])), key=lambda j: abs(np.log(max(mib, 1.0) / fc["footprint_MiB"][j])))
+            r["fabric_ceiling"] = {"line_fill_GBps": fc["line_fill_GBps"][i], "at_footprint_MiB": fc["footprint_MiB"][i],
+                                   "frac": fabric / fc["line_fill_GBps"][i],
+                                   "note": "random 128-byte line fills sustained by the gather micro-benchmark over the nearest "
+                                           "measured footprint (profiles/fabric_ceiling.json); stored, not measured in this run"}
+        except Exception:                                   # noqa: BLE001
+            pass
     else:
         r.update(achieved=None, frac=None, traffic=None, traffic_kind=None, traffic_source=source)
     if pmc and pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
