@@ -655,11 +655,12 @@ __global__ void __launch_bounds__(64) llda_sweep_wide_reg_kernel(const WParams P
 //   * the site's own count leaves the row through ONE indexed register write (zo is uniform: the index goes through M0);
 //   * the row of site n + 1 is in flight while site n is decided (two register sets), scalars two sites ahead, the start
 //     counts of the next site's old topic one site ahead.
-// Error bound (v = 2^-24, total score 1; as DESIGN.md 4.3 with fp64-accurate factors and the longer scan): a factor
-// rounded from fp64 is within 0.5v, (float)x + beta32 within 1.5v, the score within 3v, a virtual lane's prefix within 18v;
-// the wavefront scan adds 6v, the carry over <= 7 tiers 7v and the add of the carry 1v: X within 32v, the total within 31v,
-// t = fl(u~ * total) within 33.2v, the target fl(t - X[g-1]) within 66.2v, its margin bounds one more v: every compared
-// difference is within 18v + 67.2v < 86v of its real value (the exact pipeline: 2^-44).  Margin: 112v (LLDA_MARGIN0_WIDE),
+// Error bound (v = 2^-24 per fp32 rounding, total score 1; as DESIGN.md 4.3 with fp64-accurate factors and the longer scan): a
+// factor rounded from fp64 is within 1v; (float)x + beta32 within 3v (x >= 2^24 rounds, beta32 is rounded, the sum rounds); the
+// score within 5v; a virtual lane's prefix adds <= 15v: 20v; the wavefront scan adds 6v, the carry over <= 7 tiers 7v and the add
+// of the carry 1v: X within 34v, the total within 33v; t = fl(u~ * total) within 35.2v (u~: the uniform's top 27 bits rounded to
+// fp32); the target fl(t - X[g-1]) within 70.2v, its margin bounds one more v: every compared
+// difference is within 20v + 71.2v < 92v of its real value (the exact pipeline: 2^-44).  Margin: 112v (LLDA_MARGIN0_WIDE),
 // so a "sure" decision has the signs of the exact pipeline.  An unsure site -- 2 * margin * (topics with a score above the
 // margin): ~3 % at K = 2 048 -- takes the fp64 two-pass decision on the same registers and factors and, if that is unsure
 // too (~1e-9), the exact pipeline; the topic is always the exact pipeline's.  Needs max_doc_tokens < 2^15 (int16 changes).

@@ -498,7 +498,7 @@ def test_exchange_path_on_one_rank(commit, monkeypatch):
 
 
 @pytest.mark.parametrize("K,dense", [(1024, True), (512, True), (128, True), (777, False), (257, False), (40, False),
-                                     # wide layouts: the fp32 tier of kernel_wide.hpp (margin 160 * 2^-24, bound 116 * 2^-24)
+                                     # wide layouts: the fp32 tier of kernel_wide.hpp (margin 112 * 2^-24, bound 92 * 2^-24)
                                      (2048, True), (1088, True), (1031, False), (3000, False), (4296, True)])
 def test_adversarial_near_ties_for_the_fp32_tier(c_oracle, K, dense):
     """tests/neartie.py: the last site of every document has its keyed threshold within 2^-24 of a prefix-sum
