@@ -120,3 +120,26 @@ def test_ensemble_refuses_to_run_without_gpu():
     with pytest.raises(_native.NativeError):
         Ensemble([plan], [np.array([0])], np.array([0, 1]), np.array([0], dtype=np.int32), np.array([1], dtype=np.int32),
                  3, 0.1, 0.01, 1)
+
+
+def test_integration_md_stub_struct_definitions_match_the_library():
+    """the ctypes stub printed in INTEGRATION.md declares llda_layout / llda_sweep_args itself and checks them against
+    llda_struct_size when it is imported: executing its definitions needs no GPU (the sweep through it runs in
+    tests/test_gpu_dropin.py)."""
+    import os
+    import re
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n# llda_gpu.py.*?```", text, flags=re.S).group(0)
+    code = code[len("```python\n"):-3].replace('ctypes.CDLL("lda_thesis_amd/libllda_gibbs.so")',
+                                               'ctypes.CDLL(%r)' % os.path.join(ROOT, "lda_thesis_amd", "libllda_gibbs.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)          # runs the stub's own assert on the struct sizes
+    assert ns["lib"].llda_abi_version() == _native_abi()
+    names = [n for n, _ in ns["SweepArgs"]._fields_]
+    assert "scratch" in names and "resume" not in names        # ABI 14
+
+
+def _native_abi():
+    from lda_thesis_amd import _native
+    return _native.ABI_VERSION
