@@ -681,7 +681,8 @@ def roofline_json(kernel_ms, sites, docs, live_topics, pmc, source, stored_key=N
             r["fabric_ceiling"] = {"line_fill_GBps": fc["line_fill_GBps"][i], "at_footprint_MiB": fc["footprint_MiB"][i],
                                    "frac": fabric / fc["line_fill_GBps"][i],
                                    "note": "random 128-byte line fills sustained by the gather micro-benchmark over the nearest "
-                                           "measured footprint (profiles/fabric_ceiling.json); stored, not measured in this run"}
+                                           "measured footprint (profiles/fabric_ceiling.json); stored, not measured in this run.  A kernel that reads "
+                                           "16 consecutive lines per row can exceed the purely random figure by a few per cent"}
         except Exception:                                   # noqa: BLE001
             pass
     else:
