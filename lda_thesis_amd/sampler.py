@@ -165,7 +165,7 @@ class GibbsSampler(object):
         self.status = torch.zeros((4,), dtype=torch.int32, device=dev)   # [flags, tier-0 unsure, exact tier, -]
         if counts is None:
             _native.count_init(self.doc_off, self.word, self.freq, self.z, self.D, self.K,
-                                    self.n_dk, self.n_kw, self.n_k)
+                               self.n_dk, self.n_kw, self.n_k)
             if self.sharded and _dist_active(self.group):
                 import torch.distributed as dist
                 dist.all_reduce(self._counts, group=self.group)
@@ -385,26 +385,26 @@ class GibbsSampler(object):
                 s0 = 0 if len(self._calls) == 1 else int(self._off_host[lo])
                 s1 = self.S if len(self._calls) == 1 else int(self._off_host[hi])
                 _native.sweep(doc_off=self.doc_off[lo:hi + 1], doc_order=order, word=self.word, freq=self.freq,
-                                   z=self.z, lab_mask=self.lab_mask[lo:hi], n_dk=self.n_dk[lo:hi], n_kw=self.n_kw,
-                                   n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=nk_delta,
-                                   status=self.status, D=hi - lo, V=self.V, K=self.K, alpha=self.alpha,
-                                   beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
-                                   stream_id=self.stream_id, doc_base=self.doc_base + lo,
-                                   docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
-                                   debug_margin=self.debug_margin,
-                                   live_off=None if self.live_off is None else self.live_off[lo:hi + 1],
-                                   live_pos=self.live_pos,
-                                   live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
-                                   n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens,
-                                   scratch=self._scratch)
+                              z=self.z, lab_mask=self.lab_mask[lo:hi], n_dk=self.n_dk[lo:hi], n_kw=self.n_kw,
+                              n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=nk_delta,
+                              status=self.status, D=hi - lo, V=self.V, K=self.K, alpha=self.alpha,
+                              beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
+                              stream_id=self.stream_id, doc_base=self.doc_base + lo,
+                              docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
+                              debug_margin=self.debug_margin,
+                              live_off=None if self.live_off is None else self.live_off[lo:hi + 1],
+                              live_pos=self.live_pos,
+                              live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
+                              n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens,
+                              scratch=self._scratch)
             if pipelined:
                 # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
                 # collective's stream (ordered after the fold) while the next range is sampled on this one
                 i0, i1 = (self._item_bounds[r], self._item_bounds[r + 1]) if logged else (0, 0)
                 if i1 > i0:
                     _native.commit_log(self.item_begin[i0:i1], self.item_len[i0:i1], self.item_word[i0:i1],
-                                            self.commit_log, self.freq_csc, self.K, self._rows_list[r],
-                                            row_off=self.row_off)
+                                       self.commit_log, self.freq_csc, self.K, self._rows_list[r],
+                                       row_off=self.row_off)
                 if have_group:
                     works.append(dist.all_reduce(self._rows_list[r], group=self.group, async_op=True))
         if ev is not None:
@@ -414,7 +414,7 @@ class GibbsSampler(object):
             if logged:
                 # single device: the log is folded straight into n_kw (and n_k += its delta) -- no delta pass
                 _native.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
-                                        self.freq_csc, self.K, self.n_kw, self.n_k, self.n_k_delta)
+                                   self.freq_csc, self.K, self.n_kw, self.n_k, self.n_k_delta)
             else:
                 _native.apply_delta(self._counts, self._delta)
         elif pipelined:
@@ -426,14 +426,14 @@ class GibbsSampler(object):
             # all-reduce over xGMI, then the rows are decoded into [n_kw | n_k]
             if logged:
                 _native.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
-                                        self.freq_csc, self.K, self.rows, row_off=self.row_off)
+                                   self.freq_csc, self.K, self.rows, row_off=self.row_off)
             if have_group:
                 self._timed(lambda: dist.all_reduce(self.rows, group=self.group))
             _native.apply_rows(self.row_off, self.rows, self.K, self._counts)
         else:
             if logged:
                 _native.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
-                                        self.freq_csc, self.K, self.n_kw_delta)
+                                   self.freq_csc, self.K, self.n_kw_delta)
             if have_group:
                 self._timed(lambda: dist.all_reduce(self._delta, group=self.group))   # RCCL over xGMI: SUM int32, one collective
             _native.apply_delta(self._counts, self._delta)
@@ -470,7 +470,7 @@ class GibbsSampler(object):
         """sum over local sites of -log(phi[:, w] . theta_d)  (LabeledLDA.py:256-265), on device."""
         out = torch.zeros((self.D,), dtype=torch.float64, device=self.device)
         _native.loglik(self.doc_off, self.word, self.lab_mask, self.n_dk, self.n_kw, self.n_k,
-                            self.D, self.V, self.K, self.alpha, self.beta, out)
+                       self.D, self.V, self.K, self.alpha, self.beta, out)
         return float(out.sum().item())
 
     def perplexity(self):
