@@ -95,13 +95,15 @@ def algorithmic_bytes(sites, docs, A):
 
 # ------------------------------------------------------------------------------------------------ workloads
 def build_sampler(name, dev, rank, world, dist_on, docs_total=0, docs_per_group=0, force_exchange=False,
-                  overlap=None):
+                  overlap=None, rows16=None):
     """-> (sampler, info dict).  Inputs are generated on the device."""
     Dt, N, V, K, zs, block, desc = WORKLOADS[name]
     if docs_total:
         Dt = docs_total
     info = dict(desc=desc, K=K, V=V, N=N, live_topics=float(K), docs_total=Dt)
     kw = {} if overlap is None else dict(overlap_ranges=overlap)
+    if rows16 is not None:
+        kw["rows16"] = rows16
     if name == "abstracts":
         g = np.load(os.path.join(ROOT, "tests", "golden", "abstracts_d3.npz"))
         Dg, V, K = int(g["D"]), int(g["V"]), int(g["K"])

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 14
+#define LLDA_ABI_VERSION 15
 #define LLDA_MAX_K 7688          /* every K up to here splits into <= 64 pairwise leaves                       */
 #define LLDA_MAX_KP 8192         /* longest padded row: 64 leaves x 128                                        */
 #define LLDA_MAX_LEAVES 8        /* "narrow" layouts: one lane group of <= 64 lanes x <= 16 slots per document  */
@@ -103,6 +103,7 @@ typedef struct llda_sweep_args {
     int32_t        *status;      /* [dev] optional (may be NULL), int32[4]: word 0 bit 0 is set when a site had no
                                     topic with positive probability (the reference would raise);
                                     bit 1 (informational) when some site took the exact tier;
+                                    bit 2 when llda_pack_rows16 met a count outside 0 .. 65535 in a flagged row;
                                     word 1 += sites the fp32 tier was unsure about, word 2 += sites that
                                     reached the exact tier (statistics)                           */
     int64_t  D;                  /* local documents                                            */
@@ -158,6 +159,12 @@ typedef struct llda_sweep_args {
                                     every scalar load touches that many cache lines, which makes the vector-memory
                                     address pipeline the bound.  A call that passes it with such a layout may span at
                                     most 2^28 - 1 sites. */
+    const uint16_t *n_kw16;      /* [dev] [V*KP] optional (ABI 15): the 16-bit image of n_kw written by llda_pack_rows16 for THIS
+                                    sweep's n_kw.  Sites whose csc_pos has bit 31 set read their word's row from it (half the
+                                    bytes for the rows that miss the L2); the caller sets the bit for the sites of flagged
+                                    words only.  Taken by the dense 16-slot kernel with the commit log (llda_rows16_ok(K),
+                                    dense_mask = 1, alpha, beta >= 1e-6); LLDA_E_BAD_ARG on any other path.  Results do
+                                    not depend on it. */
 } llda_sweep_args;
 
 /* ---- host-only (no device needed) ---- */
@@ -173,6 +180,9 @@ int         llda_layout_init(int32_t K, llda_layout *out);
 /* Bytes of llda_sweep_args.scratch that let llda_sweep(K, D documents per call) run its fastest kernel (0 for layouts that
  * need none: every narrow layout).  Host only. */
 int64_t     llda_sweep_scratch_bytes(int32_t K, int64_t D);
+/* 1 when llda_sweep can read 16-bit rows for K topics (narrow layout, 16 slots per lane, 32 or 64 lanes, no padded slot:
+ * K = 512 and K = 1024).  Host only. */
+int         llda_rows16_ok(int32_t K);
 
 /* ---- device entry points (enqueue on `stream`) ---- */
 /* One Gibbs sweep over the shard: LabeledLDA.py:101-125 / CascadeLDA.py:397-421. */
@@ -246,6 +256,15 @@ int llda_commit_log(const int64_t *item_begin, const int32_t *item_len, const in
  * llda_apply_rows: counts[r*KP ..] += row r (pairs decoded), row zeroed, for r < n_rows.  With n_rows = V + 1
  * and counts = the fused [n_kw | n_k] buffer, row V is the n_k delta the sweep kernels wrote. */
 int llda_apply_rows(const int64_t *row_off, int32_t *rows, int64_t n_rows, int32_t K, int32_t *counts, void *stream);
+
+/* The 16-bit image of n_kw for llda_sweep_args.n_kw16 (ABI 15; K with llda_rows16_ok).  row16[v] != 0 flags the words whose
+ * rows are packed: those whose counts can never leave 0 .. 65535 -- e.g. the words whose total over all topics, which Gibbs
+ * sampling conserves, is at most 65535 (the reference's counts, LabeledLDA.py:109-111,123-125, only move a site's frequency
+ * between two topics of one word).  Call it once per sweep, after the counts of the previous sweep were folded in and before
+ * the first llda_sweep; unflagged rows of n_kw16 are not written.  A flagged row with a count outside the range sets bit 2
+ * of status word 0. */
+int llda_pack_rows16(const int32_t *n_kw, const uint8_t *row16, int64_t V, int32_t K, uint16_t *n_kw16, int32_t *status,
+                     void *stream);
 
 /* Count initialisation from assignments: LabeledLDA.py:89-92.  n_dk, n_kw, n_k must be zeroed by the
  * caller; z holds device positions.  (The SubLDA phantom-column quirk, CascadeLDA.py:382-385, is a

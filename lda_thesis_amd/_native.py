@@ -16,7 +16,7 @@ MAX_KP = 8192
 MAX_LEAVES = 8          # narrow layouts
 MAX_WIDE_LEAVES = 64
 MAX_ROUNDS = 4
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -54,7 +54,7 @@ class LldaSweepArgs(ctypes.Structure):
                 ("stream_id", _c_u32), ("doc_base", _c_i64),
                 ("live_off", _c_p), ("live_pos", _c_p), ("scratch", _c_p), ("scratch_bytes", _c_i64),
                 ("live_max", _c_i32), ("max_doc_tokens", _c_i32), ("csc_pos", _c_p), ("commit_log", _c_p),
-                ("n_sites", _c_i64), ("site_rec", _c_p)]
+                ("n_sites", _c_i64), ("site_rec", _c_p), ("n_kw16", _c_p)]
 
 
 class LldaBatchArgs(ctypes.Structure):
@@ -68,7 +68,7 @@ class LldaBatchArgs(ctypes.Structure):
 
 
 EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_struct_size", "llda_layout_init",
-           "llda_sweep_scratch_bytes",
+           "llda_sweep_scratch_bytes", "llda_rows16_ok", "llda_pack_rows16",
 
            "llda_sweep", "llda_sweep_batch", "llda_commit_log", "llda_apply_rows", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
            "llda_readout_phi", "llda_readout_theta", "llda_selftest_div")
@@ -106,6 +106,10 @@ def lib():
     L.llda_sweep.argtypes = [ctypes.POINTER(LldaSweepArgs), _c_p]
     L.llda_sweep_scratch_bytes.restype = _c_i64
     L.llda_sweep_scratch_bytes.argtypes = [_c_i32, _c_i64]
+    L.llda_rows16_ok.restype = ctypes.c_int
+    L.llda_rows16_ok.argtypes = [_c_i32]
+    L.llda_pack_rows16.restype = ctypes.c_int
+    L.llda_pack_rows16.argtypes = [_c_p, _c_p, _c_i64, _c_i32, _c_p, _c_p, _c_p]
     L.llda_sweep_batch.restype = ctypes.c_int
     L.llda_sweep_batch.argtypes = [ctypes.POINTER(LldaBatchArgs), _c_p]
     L.llda_commit_log.restype = ctypes.c_int
@@ -186,10 +190,10 @@ def _launch(ref, fn, what, *args):
 def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
           status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
           dense_mask=False, debug_margin=0, live_off=None, live_pos=None, live_max=0, csc_pos=None, commit_log=None,
-          n_sites=None, site_rec=None, max_doc_tokens=0, scratch=None):
+          n_sites=None, site_rec=None, max_doc_tokens=0, scratch=None, n_kw16=None):
     """llda_sweep on the current torch stream.  All array arguments are torch CUDA tensors.  n_sites = the sites
     the D documents span (default: all of ``word``); scratch = a uint8 tensor of sweep_scratch_bytes(K, D) bytes (wide
-    layouts) or None."""
+    layouts) or None; n_kw16 = the 16-bit image written by pack_rows16 (then csc_pos carries the row flags in bit 31) or None."""
     a = LldaSweepArgs(_ptr(doc_off), _ptr(doc_order), _ptr(word), _ptr(freq), _ptr(z), _ptr(lab_mask),
                       _ptr(n_dk), _ptr(n_kw), _ptr(n_kw_delta), _ptr(n_k), _ptr(n_k_delta), _ptr(status),
                       int(D), int(V), int(K), int(docs_per_group), 1 if dense_mask else 0, int(debug_margin),
@@ -197,13 +201,25 @@ def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta
                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(sweep) & 0xFFFFFFFF,
                       int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), _ptr(scratch),
                       0 if scratch is None else int(scratch.numel() * scratch.element_size()), int(live_max), int(max_doc_tokens),
-                      _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites), _ptr(site_rec))
+                      _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites), _ptr(site_rec),
+                      _ptr(n_kw16))
     _launch(z, lib().llda_sweep, "llda_sweep", ctypes.byref(a))
 
 
 def sweep_scratch_bytes(K, D):
     """llda_sweep_scratch_bytes: bytes of work space that let llda_sweep take its fastest kernel (0: none needed)."""
     return int(lib().llda_sweep_scratch_bytes(int(K), int(D)))
+
+
+def rows16_ok(K):
+    """llda_rows16_ok: can llda_sweep read 16-bit rows for K topics?"""
+    return bool(lib().llda_rows16_ok(int(K)))
+
+
+def pack_rows16(n_kw, row16, K, n_kw16, status):
+    """llda_pack_rows16 on the current torch stream: the 16-bit image of the rows of n_kw flagged in row16 (uint8 [V])."""
+    _launch(n_kw, lib().llda_pack_rows16, "llda_pack_rows16", _ptr(n_kw), _ptr(row16), int(row16.numel()), int(K),
+            _ptr(n_kw16), _ptr(status))
 
 
 def sweep_batch(*, inst_off, order, word, freq, z, inst_prob, inst_doc, live_off, live_pos, ndk_off, n_dk, kw_off,

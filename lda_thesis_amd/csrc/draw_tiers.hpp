@@ -29,8 +29,9 @@ __device__ __forceinline__ float dpp_f32(float x)
 
 // pa = the lane's cached tier-0 factors (s_pa[.][tid]), read by the caller at the top of the site so that their LDS
 // latency is covered by the wait for the row
-template <int T, bool DENSE, int S = 0>
-__device__ __forceinline__ void prefix_scores_f32(float (&qw)[T], const int (&x)[T], const float (&pa)[T], uint32_t mask, float beta)
+// (XT: the counts as int32, or already converted -- exactly -- to fp32 by the caller)
+template <int T, bool DENSE, int S = 0, class XT = int>
+__device__ __forceinline__ void prefix_scores_f32(float (&qw)[T], const XT (&x)[T], const float (&pa)[T], uint32_t mask, float beta)
 {
     if constexpr (DENSE && T % 2 == 0 && S + 1 < T) {
         // two slots per instruction: (x + beta) * factor as packed fp32 (v_pk_add_f32, v_pk_mul_f32); a wave64

@@ -1,8 +1,35 @@
-// kernel_counts.hpp -- llda_commit_log_kernel, llda_apply_delta_kernel, llda_count_init_kernel, division self test
+// kernel_counts.hpp -- llda_pack_rows16_kernel, llda_commit_log_kernel, llda_apply_delta_kernel, llda_count_init_kernel, division self test
 // Part of the single translation unit llda_gibbs.hip (included in order; see the contents list there).
 #pragma once
 
 namespace {
+
+// ---------------------------------------------------------------------------------------------
+// llda_pack_rows16: the 16-bit image of the n_kw rows flagged in row16 (16 slots per lane only).  A packed row keeps the
+// slots 8j .. 8j+7 of ALL lanes contiguous (16 bytes per lane and chunk j = 0, 1), the even slot in the low half of its
+// register -- the form llda_sweep_kernel<.., R16> loads with two global_load_dwordx4 per lane.  One thread per 16-byte
+// chunk.  A flagged row with a count outside 0 .. 65535 sets bit 2 of status word 0 (the caller flags only rows whose total
+// -- which Gibbs sampling conserves -- fits).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) llda_pack_rows16_kernel(const int32_t *__restrict__ n_kw, const uint8_t *__restrict__ row16,
+                                                               uint16_t *__restrict__ out, int64_t V, int G, int32_t *status)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = 2 * G;
+    const int64_t w = t / per_row;
+    if (w >= V || !row16[w]) return;
+    const int c = (int)(t - w * per_row), j = c / G, g = c - j * G;
+    const int4 *src = reinterpret_cast<const int4 *>(n_kw + w * (int64_t)(G * 16));
+    const int4 a = src[(2 * j) * G + g], b = src[(2 * j + 1) * G + g];
+    const int m = a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w;
+    if ((unsigned)m > 0xffffu && status) atomicOr(status, 4);
+    uint4 o;
+    o.x = ((uint32_t)a.x & 0xffffu) | ((uint32_t)a.y << 16);
+    o.y = ((uint32_t)a.z & 0xffffu) | ((uint32_t)a.w << 16);
+    o.z = ((uint32_t)b.x & 0xffffu) | ((uint32_t)b.y << 16);
+    o.w = ((uint32_t)b.z & 0xffffu) | ((uint32_t)b.w << 16);
+    reinterpret_cast<uint4 *>(out + w * (int64_t)(G * 16))[j * G + g] = o;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Fold of the commit log into word-major counts (llda_commit_log, include/llda_gibbs.h): one wavefront per

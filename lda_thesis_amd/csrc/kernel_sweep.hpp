@@ -152,9 +152,15 @@ __device__ __forceinline__ void count_update(int (*s_ndk)[256], int (*s_nkc)[256
 // REC: the scalars of a site come from llda_sweep_args.site_rec -- a compile-time fact too: as a run-time pointer test the two
 // load paths met in a phi, the record's fields had to be COPIED into the registers of the other path, the copy needs the
 // value, and the compiler put s_waitcnt vmcnt(0) right behind the load -- i.e. behind the row prefetch issued just before.
-template <int G, int T, bool HAS_TAIL, bool DENSE, bool LOGGED, bool REC = false>
+// R16: rows of n_kw whose counts fit 16 bits are read from their 16-bit image P.n_kw16 (llda_pack_rows16) -- half the
+// bytes through the fabric for exactly the rows that miss the L2 (the rare words); which sites do so is bit 31 of their
+// csc_pos, so the choice is known when the row is prefetched.  A 16-bit row arrives as two 16-byte chunks per lane
+// (slots 0..7, 8..15, two per register); the site's own count is removed from the packed register, and the
+// conversion to fp32 reads the halves directly (SDWA), so a 16-bit site costs no instruction more than a 32-bit one.
+template <int G, int T, bool HAS_TAIL, bool DENSE, bool LOGGED, bool REC = false, bool R16 = false>
 __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : LLDA_WAVES) llda_sweep_kernel(const KParams P)
 {
+    static_assert(!R16 || (G >= 32 && T == 16 && DENSE && LOGGED && !REC), "16-bit rows: the dense 16-slot kernel with the commit log");
     constexpr int KP = G * T;
     constexpr int GPB = 256 / G;              // lane groups (documents in flight) per workgroup
     __shared__ int s_nk[KP];                  // workgroup accumulator of the n_k changes
@@ -248,7 +254,31 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         // three scalar sets).
         constexpr bool INDEXED = G >= 32 && T == 16;
         int xn[T], xm[INDEXED ? T : 1];
-        gload_lane_row<G, T>(P.n_kw, (int64_t)R0.v * KP, lig, xn);
+        // the row of word v into xl; c = the site's csc_pos (bit 31: 16-bit row, slots 8j .. 8j+7 of all lanes contiguous)
+        auto load_word_row = [&](int (&xl)[T], const int v, const int c) {
+            if constexpr (R16) {
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                const bool h = c < 0;
+                const LLDA_GLOBAL char *q = (h ? (const LLDA_GLOBAL char *)P.n_kw16 : (const LLDA_GLOBAL char *)P.n_kw) +
+                                            (int64_t)v * (h ? KP * 2 : KP * 4) + lig * 16;
+                const v4i a0 = *(const LLDA_GLOBAL v4i *)q, a1 = *(const LLDA_GLOBAL v4i *)(q + G * 16);
+                xl[0] = a0.x; xl[1] = a0.y; xl[2] = a0.z; xl[3] = a0.w;
+                xl[4] = a1.x; xl[5] = a1.y; xl[6] = a1.z; xl[7] = a1.w;
+                // (the upper half of the tuple is DEFINED here, by no instruction: were it merely left alone by 16-bit sites, the
+                // values of the previous load would have to survive and the in-place update below would work on a copy)
+                v4i a2, a3;
+                asm volatile("" : "=v"(a2), "=v"(a3));
+                if (!h) {
+                    a2 = *(const LLDA_GLOBAL v4i *)(q + 2 * G * 16);
+                    a3 = *(const LLDA_GLOBAL v4i *)(q + 3 * G * 16);
+                }
+                xl[8] = a2.x; xl[9] = a2.y; xl[10] = a2.z; xl[11] = a2.w;
+                xl[12] = a3.x; xl[13] = a3.y; xl[14] = a3.z; xl[15] = a3.w;
+            } else {
+                gload_lane_row<G, T>(P.n_kw, (int64_t)v * KP, lig, xl);
+            }
+        };
+        load_word_row(xn, R0.v, R0.c);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the previous site
             lane_slot_of<G, T>(R0.zo, R0.lo, R0.so);
@@ -271,7 +301,31 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
             __builtin_amdgcn_sched_barrier(0);
             // the fetched row minus the site's own count (n_dk / n_k were updated already)
             int x[T];
-            if constexpr (INDEXED) {
+            [[maybe_unused]] float xf[R16 ? T : 1];                   // R16: the counts as fp32 (exact: 16-bit rows hold < 2^16)
+            if constexpr (R16) {
+                typedef int v16i __attribute__((ext_vector_type(16)));
+                v16i xv;
+#pragma unroll
+                for (int s = 0; s < T; ++s) xv[s] = xc[s];
+#pragma unroll
+                for (int g = 0; g < 64 / G; ++g) {
+                    int lo_g, so_g;                                   // scalar: zo, csc_pos are the same in every lane of a group
+                    lane_slot_of<G, T>(__builtin_amdgcn_readlane(zo, g * G), lo_g, so_g);
+                    const bool h_g = __builtin_amdgcn_readlane(cur.c, g * G) < 0;
+                    // a packed row: register so >> 1, upper half for odd slots (no borrow: the count includes f)
+                    const int reg = h_g ? so_g >> 1 : so_g, sh = h_g ? (so_g & 1) << 4 : 0;
+                    xv[reg & (T - 1)] -= (lane == g * G + lo_g) ? f << sh : 0;
+                }
+#pragma unroll
+                for (int s = 0; s < T; ++s) x[s] = xv[s];
+                if (cur.c < 0) {
+#pragma unroll
+                    for (int s = 0; s < T; ++s) xf[s] = (float)((s & 1) ? (uint32_t)x[s >> 1] >> 16 : (uint32_t)x[s >> 1] & 0xffffu);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < T; ++s) xf[s] = (float)x[s];
+                }
+            } else if constexpr (INDEXED) {
                 typedef int v16i __attribute__((ext_vector_type(16)));
                 v16i xv;
 #pragma unroll
@@ -291,10 +345,11 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
             int (&xl)[T] = *(int (*)[T])(INDEXED ? (void *)&xnx : (void *)&xc);     // where the next row goes
 #ifndef ABL_NOCOMMIT
             if (lig == 0 && n > n0)
-                commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn, prv.c, KP);
+                commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn,
+                                        R16 ? prv.c & 0x7fffffff : prv.c, KP);
 #endif
 #ifndef ABL_NOLOAD
-            gload_lane_row<G, T>(P.n_kw, (int64_t)nxt.v * KP, lig, xl);   // row of site n+1 (clamped)
+            load_word_row(xl, nxt.v, nxt.c);                              // row of site n+1 (clamped)
 #else
 #pragma unroll
             for (int s = 0; s < T; ++s) xl[s] = (nxt.v + s) & 7;          // ablation: no n_kw traffic
@@ -308,7 +363,8 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
             bool decided = false;
             if (P.margin0_rel < 1.0f) {           // tier 0: fp32
                 float qf[T];
-                prefix_scores_f32<T, DENSE>(qf, x, pa, mask, beta32);
+                if constexpr (R16) prefix_scores_f32<T, DENSE>(qf, xf, pa, mask, beta32);
+                else prefix_scores_f32<T, DENSE>(qf, x, pa, mask, beta32);
                 // fp32 image of the uniform: the top 27 bits (within 2^-24 relative + 2^-27 absolute of u)
                 const float u32 = (float)(ra >> 5) * 0x1p-27f;
                 decided = draw_fast_f32<G, T>(qf, u32, mask, gp_doc, P.margin0_rel, lig, lane, zn);
@@ -317,6 +373,12 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 int x_c[T];
 #pragma unroll
                 for (int s = 0; s < T; ++s) x_c[s] = x[s];
+                if constexpr (R16) {
+                    if (cur.c < 0) {
+#pragma unroll
+                        for (int s = 0; s < T; ++s) x_c[s] = (int)((s & 1) ? (uint32_t)x[s >> 1] >> 16 : (uint32_t)x[s >> 1] & 0xffffu);
+                    }
+                }
                 // (the callee reads the parameters from the kernel-argument segment: taking &P would force a scratch
                 // copy of all of P and put its pointers into VGPRs)
                 zn = cold_tiers<G, T, HAS_TAIL, DENSE>(s_ndk, x_c, s_nkc, tid, mask, uniform53(ra, rb), lig, lane,
@@ -346,7 +408,8 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
 #ifndef ABL_NOCOMMIT
             // the last site of the document is committed right away
             if (__builtin_expect(lig == 0 && n + 1 == len, 0))
-                commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)n * 4u), cur.v, cur.f, cur.zo, cur.zn, cur.c, KP);
+                commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)n * 4u), cur.v, cur.f, cur.zo, cur.zn,
+                                        R16 ? cur.c & 0x7fffffff : cur.c, KP);
 #endif
         };
         // (a short document LEAVES the loop after its last site: were the remaining sites merely skipped, the

@@ -175,6 +175,13 @@ int launch_sweep(const KParams &P, bool has_tail, bool fast, bool dense, int64_t
             return e == hipSuccess ? LLDA_OK : hip_fail(e);
         }
     }
+    if constexpr (G >= 32 && T == 16) {
+        if (P.n_kw16) {                                 // (llda_sweep checked: fast, dense, commit log)
+            hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true, true, false, true>), grid, block, 0, st, P);
+            const hipError_t e = hipGetLastError();
+            return e == hipSuccess ? LLDA_OK : hip_fail(e);
+        }
+    }
     if (!fast) {
         if (has_tail) hipLaunchKernelGGL((llda_sweep_exact_kernel<G, T, true>), grid, block, 0, st, P);
         else hipLaunchKernelGGL((llda_sweep_exact_kernel<G, T, false>), grid, block, 0, st, P);
@@ -586,6 +593,11 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? LLDA_OK : hip_fail(e);
     }
+    if (a->n_kw16) {
+        // 16-bit rows (bit 31 of csc_pos): the dense 16-slot kernel with the commit log, nothing else knows the flag
+        if (!(fast && dense && logged && L.T == 16 && L.G >= 32)) return LLDA_E_BAD_ARG;
+        P.n_kw16 = a->n_kw16;
+    }
     switch (L.G) {
     case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, fast, dense, blocks, st);
     case 16: return dispatch_sweep_T<16>(L.T, P, has_tail, fast, dense, blocks, st);
@@ -669,6 +681,30 @@ int llda_apply_rows(const int64_t *row_off, int32_t *rows, int64_t n_rows, int32
     if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
     hipLaunchKernelGGL(llda_apply_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, row_off, rows,
                        n_rows, L.KP, counts);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
+}
+
+int llda_rows16_ok(int32_t K)
+{
+    int rc;
+    const llda_layout *Lp = layout_of(K, &rc);
+    return !rc && !Lp->wide && Lp->T == 16 && Lp->G >= 32 && Lp->K == Lp->KP ? 1 : 0;
+}
+
+int llda_pack_rows16(const int32_t *n_kw, const uint8_t *row16, int64_t V, int32_t K, uint16_t *n_kw16, int32_t *status,
+                     void *stream)
+{
+    if (V < 0) return LLDA_E_BAD_ARG;
+    if (!llda_rows16_ok(K)) return LLDA_E_BAD_K;
+    if (V == 0) return LLDA_OK;
+    if (!n_kw || !row16 || !n_kw16) return LLDA_E_BAD_ARG;
+    int rc;
+    const llda_layout &L = *layout_of(K, &rc);
+    const int64_t blocks = (V * 2 * L.G + 255) / 256;
+    if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
+    hipLaunchKernelGGL(llda_pack_rows16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_kw, row16, n_kw16,
+                       V, L.G, status);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
 }

@@ -74,12 +74,20 @@ class GibbsSampler(object):
                all-reduced (asynchronously, on the collective's own stream) while range i+1 is still being sampled.
                Every range exchanges its own dense rows, so C ranges move C times the bytes -- see DESIGN.md section 7
                for when that pays.  Needs the commit-log exchange rows on every rank (else it is ignored).
+    rows16   : the sweep reads the n_kw rows of the words whose corpus-wide count fits 16 bits from a 16-bit image of
+               n_kw that is refreshed at the start of every sweep (``llda_pack_rows16``): half the bytes per row, for a
+               few more instructions per site.  Same results.  It pays when most sites read a row that no cache holds
+               (+30 % with uniform words over a 1 GB n_kw) and costs otherwise (-12 % on the Zipf corpus of BASELINE
+               configs[3], whose sweep is bound by instruction issue: DESIGN.md section 4.3).  None (default) = where the
+               kernel has it (dense mask, commit log, K = 512 or 1024), n_kw exceeds the 256 MiB Infinity Cache AND the
+               words whose rows fit that cache carry less than half of the sites; True = wherever the kernel has it;
+               False = off.
     """
 
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
                  stream_id=0, doc_base=0, device=None, group=None, sort_docs=True,
                  docs_per_group=0, sharded=True, sparse_labels=True, commit_log=None, exchange_always=False,
-                 overlap_ranges=1):
+                 overlap_ranges=1, rows16=None):
         _native.lib()                                       # fail loudly when the extension is missing
         _native.require_device()                            # ... or when no GPU is visible: there is no CPU fallback
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
@@ -183,9 +191,38 @@ class GibbsSampler(object):
         self.row_off = self.rows = self._rows_list = None
         if self.sharded and (_dist_active(self.group) or exchange_always):
             self._make_exchange_rows()
+        self.row16 = self.n_kw16 = None
+        if (rows16 is not False and self.S and self.dense_mask and self.commit_log is not None
+                and _native.rows16_ok(self.K) and self.alpha >= 1e-6 and self.beta >= 1e-6):
+            self._make_rows16(auto=rows16 is None)
 
+    ROWS16_CACHE_BYTES = 256 << 20   # rows16=None: the Infinity Cache; an n_kw below it is served from the caches anyway
     MAX_FREQ = 1 << 23   # v_mad_i32_i24 moves a site's count (include/llda_gibbs.h: freq)
     PAIR_LIMIT = 32767   # largest frequency mass of a word (all ranks) whose row is exchanged as int16 pairs
+
+    def _make_rows16(self, auto=False):
+        """16-bit rows (llda_sweep_args.n_kw16): an entry of n_kw can never exceed the total of its word's row -- the
+        sweep only moves a site's frequency between two topics of one word (LabeledLDA.py:109-111,123-125) and the
+        exchange sums such moves --, so the rows whose total is at most 65535 (all but the few hundred most frequent
+        words of a natural corpus) can be read from a 16-bit image.  The flag of a site's word rides in bit 31 of its
+        commit-log position, where the kernel sees it one site before it needs the row."""
+        total = self.n_kw.sum(dim=1, dtype=torch.int64)
+        if auto:
+            # cache-hostile corpora only: n_kw beyond the Infinity Cache, and the most frequent words whose rows would
+            # fill that cache carry less than half of the tokens
+            row_bytes = self.layout.KP * 4
+            if self.V * row_bytes <= self.ROWS16_CACHE_BYTES:
+                return
+            top = torch.topk(total, min(self.V, self.ROWS16_CACHE_BYTES // row_bytes)).values
+            if float(top.sum()) >= 0.5 * float(total.sum()):
+                return
+        fits = (total <= 65535) & (self.n_kw.min(dim=1).values >= 0)
+        if not bool(fits.any()):
+            return
+        self.row16 = fits.to(torch.uint8).contiguous()
+        self.n_kw16 = torch.zeros((self.V * self.layout.KP,), dtype=torch.int16, device=self.device)
+        flag = torch.where(fits[self.word.to(torch.int64)], -(1 << 31), 0).to(torch.int32)
+        self.csc_pos |= flag
 
     def _make_exchange_rows(self):
         """Exchange layout of the per-sweep count deltas when every rank folds a commit log: one row per word plus
@@ -371,6 +408,8 @@ class GibbsSampler(object):
         have_group = dist.is_available() and dist.is_initialized()
         exchange = self.sharded and (_dist_active(self.group) or self.exchange_always)
         n_ranges = len(self._ranges) - 1
+        if self.n_kw16 is not None:                           # this sweep's n_kw: nothing below changes it before the fold
+            _native.pack_rows16(self.n_kw, self.row16, self.K, self.n_kw16, self.status)
         # decided from values every rank agrees on (a rank with an empty shard logs nothing but must still issue
         # one collective per range)
         pipelined = exchange and self.rows is not None and n_ranges > 1
@@ -396,7 +435,7 @@ class GibbsSampler(object):
                               live_pos=self.live_pos,
                               live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
                               n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens,
-                              scratch=self._scratch)
+                              scratch=self._scratch, n_kw16=self.n_kw16)
             if pipelined:
                 # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
                 # collective's stream (ordered after the fold) while the next range is sampled on this one
@@ -464,6 +503,9 @@ class GibbsSampler(object):
         st = int(self.status[0].item())
         if st & 1:
             raise ValueError("a site had no topic with positive probability (pvals would be NaN)")
+        if st & 4:
+            raise RuntimeError("a count left 0 .. 65535 in a row of n_kw that is read as 16 bits: the counts handed to the "
+                               "sampler do not belong to its corpus")
 
     # ------------------------------------------------------------------ read-outs
     def loglik_sum(self):

@@ -93,7 +93,7 @@ def _digest(t):
     return hashlib.sha256(t.contiguous().cpu().numpy().tobytes()).hexdigest()
 
 
-def _slice_worker(rank, world, port, overlap, q):
+def _slice_worker(rank, world, port, overlap, rows16, q):
     from lda_thesis_amd.corpus import synthetic_corpus_blocks
     from lda_thesis_amd.sampler import GibbsSampler
     if world > 1:
@@ -106,8 +106,8 @@ def _slice_worker(rank, world, port, overlap, q):
     doc_off, word, freq, z = synthetic_corpus_blocks(lo, hi, SLICE_N, SLICE_V, SLICE_K, 1234, dev, zipf_s=1.0,
                                                      block=SLICE_BLOCK)
     s = GibbsSampler(doc_off, word, freq, z, SLICE_K, SLICE_V, 0.1, 0.01, labs=None, seed=42, doc_base=lo, device=dev,
-                     overlap_ranges=overlap)
-    facts = dict(rows=s.rows is not None, logged=s.commit_log is not None,
+                     overlap_ranges=overlap, rows16=rows16)
+    facts = dict(rows=s.rows is not None, logged=s.commit_log is not None, rows16=s.n_kw16 is not None,
                  pair_rows=int((s.row_off[:-1] < 0).sum()) if s.row_off is not None else -1,
                  collectives=len(s._rows_list) if s._rows_list is not None else 0)
     for _ in range(SLICE_SWEEPS):
@@ -134,23 +134,24 @@ def _setup_paths_only():
 
 @pytest.fixture(scope="module")
 def one_rank_slice():
-    (rank, counts, blocks, facts, tokens), = _spawn(1, _slice_worker, (1,))
+    (rank, counts, blocks, facts, tokens), = _spawn(1, _slice_worker, (1, False))
     assert facts["logged"] and not facts["rows"]        # one process: the log is folded straight into n_kw
     assert tokens == SLICE_DOCS * SLICE_N
     return counts, blocks
 
 
-@pytest.mark.parametrize("world,overlap", [(2, 1), (2, 2), (4, 1), (4, 2)])
-def test_configs3_slice_sharded_over_ranks_equals_the_one_rank_run(one_rank_slice, world, overlap):
+# (rows16: every rank reads the rare words' rows from the 16-bit image of its n_kw replica, llda_sweep_args.n_kw16)
+@pytest.mark.parametrize("world,overlap,rows16", [(2, 1, False), (2, 2, True), (4, 1, True), (4, 2, False)])
+def test_configs3_slice_sharded_over_ranks_equals_the_one_rank_run(one_rank_slice, world, overlap, rows16):
     counts1, blocks1 = one_rank_slice
-    res = _spawn(world, _slice_worker, (overlap,), timeout=900)
+    res = _spawn(world, _slice_worker, (overlap, rows16), timeout=900)
     for rank, counts, blocks, facts, tokens in res:
         assert counts == counts1, "rank %d: [n_kw | n_k] differs from the one-rank run" % rank
         assert tokens == SLICE_DOCS * SLICE_N
         # the path under test: every rank logs, the exchange travels as packed rows (int16 pairs for most words,
         # int32 for the hot ones), one collective per document range
         assert facts["rows"] and facts["logged"] and 0 < facts["pair_rows"] < SLICE_V
-        assert facts["collectives"] == overlap
+        assert facts["collectives"] == overlap and facts["rows16"] == rows16
     got = sorted(b for _, _, blocks, _, _ in res for b in blocks)
     assert got == sorted(blocks1), "z / n_dk of the shards differ from the one-rank run"
 

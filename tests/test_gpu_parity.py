@@ -314,6 +314,96 @@ def _run_vs_c(c_oracle, doc_off, word, freq, labs, z, K, V, alpha=0.1, beta=0.01
     return s
 
 
+def _rows16_corpus(K, seed):
+    """dense-mask corpus whose words straddle the 16-bit boundary: word 0 and word 3 far above 65535 tokens with all of
+    their sites in ONE topic at the start (entries of int32 rows above 2^16 and above 2^24), word 1 with exactly 65535
+    tokens in one topic (the largest 16-bit entry), word 2 with 65536 (the first total that must stay int32), the rest rare."""
+    rng = np.random.default_rng(seed)
+    D, V = 260, 90
+    lens = rng.integers(1, 70, size=D)
+    lens[:3] = (1, 2, 64)
+    doc_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    S = int(doc_off[-1])
+    p = 1.0 / np.arange(1, V + 1) ** 1.2
+    word = rng.choice(V, size=S, p=p / p.sum()).astype(np.int32)
+    word[:8] = (0, 1, 2, 3, 0, 1, 2, 3)
+    freq = rng.integers(1, 6, size=S).astype(np.int32)
+    z = rng.integers(0, K, size=S).astype(np.int64)
+    for w, total, topic in ((0, 20_000_000, 3), (1, 65535, K - 1), (2, 65536, 17), (3, 400_000, 8)):
+        idx = np.nonzero(word == w)[0]
+        freq[idx] = 1
+        freq[idx[0]] = 1 + (total - len(idx)) % (1 << 22)                # (frequencies stay below MAX_FREQ = 2^23)
+        rest = total - int(freq[idx].sum())
+        j = 1
+        while rest > 0:
+            add = min(rest, (1 << 22))
+            freq[idx[j % len(idx)]] += add
+            rest -= add
+            j += 1
+        assert int(freq[idx].sum()) == total and int(freq[idx].max()) < (1 << 23)
+        z[idx] = topic
+    return doc_off, word, freq, z, V
+
+
+@pytest.mark.parametrize("margin", [0, -1, 6])
+@pytest.mark.parametrize("K", [512, 1024])
+def test_16_bit_rows_equal_the_c_oracle(c_oracle, K, margin):
+    """llda_sweep_args.n_kw16: rows of n_kw read from their 16-bit image (llda_pack_rows16) next to int32 rows in the same
+    wavefront -- against the C oracle (LabeledLDA.py:106-125), three sweeps, ragged documents, every draw tier."""
+    from lda_thesis_amd.sampler import GibbsSampler
+    doc_off, word, freq, z, V = _rows16_corpus(K, K + margin)
+    labs = np.ones((len(doc_off) - 1, K), dtype=np.uint8)
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=7, commit_log=True, rows16=True, doc_base=11)
+    assert s.n_kw16 is not None
+    flagged = s.row16.cpu().numpy().astype(bool)
+    assert not flagged[0] and flagged[1] and not flagged[2] and not flagged[3] and flagged[4:].all()
+    assert int((s.csc_pos < 0).sum()) == int(flagged[word].sum()) > 0
+    assert int(s.n_kw.max()) > (1 << 24)
+    s.debug_margin = margin
+    cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
+    for i in range(3):
+        s.sweep()
+        cs.sweep(1, 7, i, doc_base=11, threads=4)
+        np.testing.assert_array_equal(s.z_topics(), cs.z)
+        np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+        np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+        np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
+    s.check_status()
+    # the image really is what the kernel read: the flagged rows of the LAST sweep's start, 16 bits per count
+    r = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=7, commit_log=True, rows16=False, doc_base=11)
+    assert r.n_kw16 is None and int((r.csc_pos < 0).sum()) == 0
+    for i in range(3):
+        r.sweep()
+    import torch
+    assert torch.equal(r.z, s.z) and torch.equal(r._counts, s._counts) and torch.equal(r.n_dk, s.n_dk)
+
+
+def test_16_bit_rows_flag_counts_that_do_not_belong_to_the_corpus():
+    """a count above 65535 in a row that is read as 16 bits (impossible for counts built from the corpus): llda_pack_rows16
+    sets status bit 2 and check_status raises"""
+    from lda_thesis_amd.sampler import GibbsSampler
+    doc_off, word, freq, z, V = _rows16_corpus(512, 1)
+    s = GibbsSampler(doc_off, word, freq, z, 512, V, 0.1, 0.01, labs=None, seed=7, commit_log=True, rows16=True)
+    s.sweep()
+    s.check_status()
+    s.n_kw[5, 100] = 70000
+    s.sweep()
+    with pytest.raises(RuntimeError, match="16 bits"):
+        s.check_status()
+
+
+def test_16_bit_rows_are_chosen_for_cache_hostile_corpora_only():
+    """rows16=None: on when n_kw exceeds the Infinity Cache and the words whose rows would fit it carry less than half of the
+    sites (uniform words over a large vocabulary); off for a Zipf corpus of the same size and for a small n_kw."""
+    from lda_thesis_amd.corpus import synthetic_corpus_blocks
+    from lda_thesis_amd.sampler import GibbsSampler
+    for zipf, V, want in ((0.0, 1_000_000, True), (1.0, 1_000_000, False), (0.0, 20_000, False)):
+        off, w, f, z = synthetic_corpus_blocks(0, 8000, 300, V, 512, 1234, "cuda", zipf_s=zipf, block=4000)
+        s = GibbsSampler(off, w, f, z, 512, V, 0.1, 0.01, labs=None, seed=1)
+        assert (s.n_kw16 is not None) == want, (zipf, V)
+        del s
+
+
 def test_edge_empty_shard_and_empty_documents(c_oracle):
     from lda_thesis_amd.sampler import GibbsSampler
     # a shard without documents: sweep is a no-op
