@@ -54,6 +54,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 N_SIMD = 1024                # 256 CUs x 4 SIMDs
 N_XCD = 8                    # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (1.16e9 per 63 ms launch = 8 x 2.3 GHz)
 MAX_CLOCK_HZ = 2.4e9         # MI355X_MICROARCH.md: max clock
+SALU_CYCLES_PER_INST = 2.5   # fitted: profiles/r03_issue_model.md
 VALU_CYCLES_PER_INST = 4     # SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.01 quad-cycles on this kernel (profiles/)
 
 WORKLOADS = {
@@ -527,7 +528,7 @@ PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
               ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
                       "GRBM_GUI_ACTIVE"]),
               ("l2", ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum"]),
-              ("ta", ["TA_BUSY_avr", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCC_READ_REQ_sum"]))
+              ("ta", ["TA_BUSY_avr", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCC_READ_REQ_sum", "SQ_INSTS_SALU", "SQ_INSTS_LDS"]))
 MALL_BYTES = 256 * 2 ** 20                                  # Infinity Cache (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0                                 # measured streaming ceiling of the guide
 
@@ -719,15 +720,29 @@ def roofline_json(kernel_ms, sites, docs, live_topics, pmc, source, stored_key=N
                 v["waves_per_simd_avg"] = pmc["SQ_WAVE_CYCLES"] * 4.0 / (cycles * N_SIMD)
         r["valu_issue"] = v
         cands["valu_issue"] = v["frac"]
+        if cycles and pmc.get("SQ_INSTS_SALU"):
+            # profiles/r03_issue_model.md: three variants of the K = 512 kernel (fewer bytes / more waves, each with a few
+            # more instructions) ran in 4 x VALU + 2.5 x SALU cycles per SIMD to within 2 % -- scalar instructions are not
+            # hidden behind vector ones there.  The 2.5 is FITTED on that kernel; for the others the figure is indicative.
+            ic = (VALU_CYCLES_PER_INST * insts + SALU_CYCLES_PER_INST * pmc["SQ_INSTS_SALU"]) / N_SIMD
+            r["issue_model"] = {"frac": ic / cycles, "cycles_per_simd": ic, "shader_cycles": cycles,
+                                "salu_insts_per_site": pmc["SQ_INSTS_SALU"] / sites,
+                                "model": "(%d x SQ_INSTS_VALU + %.1f x SQ_INSTS_SALU) / 1024 SIMDs over GRBM_GUI_ACTIVE / 8; the SALU "
+                                         "cost is fitted on three variants of the K = 512 kernel (profiles/r03_issue_model.md)" %
+                                         (VALU_CYCLES_PER_INST, SALU_CYCLES_PER_INST)}
+            cands["instruction_issue (VALU + SALU, fitted model)"] = ic / cycles
     if cands:
         best = max(cands, key=cands.get)
         r["binding_roof"] = best
         r["roof_fractions"] = cands
         r["headroom"] = 1.0 - cands[best]
-        r["binding_note"] = ("the larger of: fabric bytes / time / 8 TB/s (called 'hbm' only when the shared counts exceed the "
-                             "Infinity Cache) and VALU instructions x 4 cycles / time / (1024 SIMDs x 2.4 GHz); a kernel far "
-                             "below both is bound by the latency of its dependent chain at its occupancy "
-                             "(valu_issue.wave_cycles_waiting_frac)")
+        r["headroom"] = max(0.0, r["headroom"])
+        r["binding_note"] = ("the largest of: fabric bytes / time / 8 TB/s (called 'hbm' only when the shared counts exceed the "
+                             "Infinity Cache), VALU instructions x 4 cycles / time / (1024 SIMDs x 2.4 GHz), and the fitted "
+                             "instruction-issue model (VALU x 4 + SALU x 2.5 cycles per SIMD over the launch's shader cycles: "
+                             "profiles/r03_issue_model.md -- on the K = 512 kernel halving the fabric bytes or adding a fourth "
+                             "wave changed nothing, the time followed the instruction count); a kernel far below all three is "
+                             "bound by the latency of its dependent chain at its occupancy (valu_issue.wave_cycles_waiting_frac)")
     return r
 
 

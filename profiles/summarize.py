@@ -100,6 +100,10 @@ def main(tag, sub=None):
                 out.append("| VALU busy share of the profiled launch's cycles | %.3f (clock %.2f GHz) |" % (v["valu_busy_frac"], v.get("effective_clock_GHz", float("nan"))))
             if "wave_cycles_waiting_frac" in v:
                 out.append("| wave cycles waiting on an instruction; waves per SIMD | %.3f; %.2f |" % (v["wave_cycles_waiting_frac"], v.get("waves_per_simd_avg", float("nan"))))
+        im = r.get("issue_model")
+        if im:
+            out.append("| SALU instructions per site; issue model (4 x VALU + 2.5 x SALU cycles per SIMD / shader cycles) | %.1f; %.3f |" %
+                       (im["salu_insts_per_site"], im["frac"]))
         out.append("| binding roof (headroom) | %s (%.2f) |" % (r.get("binding_roof", "-"), r.get("headroom", float("nan"))))
         out.append("")
     block("synth2", line, line["config"]["sites_per_sweep"])
