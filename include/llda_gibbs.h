@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 15
+#define LLDA_ABI_VERSION 16
 #define LLDA_MAX_K 7688          /* every K up to here splits into <= 64 pairwise leaves                       */
 #define LLDA_MAX_KP 8192         /* longest padded row: 64 leaves x 128                                        */
 #define LLDA_MAX_LEAVES 8        /* "narrow" layouts: one lane group of <= 64 lanes x <= 16 slots per document  */
@@ -165,6 +165,11 @@ typedef struct llda_sweep_args {
                                     words only.  Taken by the dense 16-slot kernel with the commit log (llda_rows16_ok(K),
                                     dense_mask = 1, alpha, beta >= 1e-6); LLDA_E_BAD_ARG on any other path.  Results do
                                     not depend on it. */
+    const int32_t *site_row;     /* [dev] [S] with n_kw16 (ABI 16; LLDA_E_BAD_ARG when one comes without the other): where the
+                                    row of a site's word starts, in 16-byte units from n_kw --  word * KP / 4  for an int32 row,
+                                    ((char *)n_kw16 - (char *)n_kw) / 16 + word * KP / 8  for a 16-bit one (the two arrays within
+                                    32 GB of each other).  Static: which words are flagged never changes.  The kernel reads it
+                                    INSTEAD of word -- the choice between the two images costs it no instruction. */
 } llda_sweep_args;
 
 /* ---- host-only (no device needed) ---- */

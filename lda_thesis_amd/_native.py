@@ -16,7 +16,7 @@ MAX_KP = 8192
 MAX_LEAVES = 8          # narrow layouts
 MAX_WIDE_LEAVES = 64
 MAX_ROUNDS = 4
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -54,7 +54,7 @@ class LldaSweepArgs(ctypes.Structure):
                 ("stream_id", _c_u32), ("doc_base", _c_i64),
                 ("live_off", _c_p), ("live_pos", _c_p), ("scratch", _c_p), ("scratch_bytes", _c_i64),
                 ("live_max", _c_i32), ("max_doc_tokens", _c_i32), ("csc_pos", _c_p), ("commit_log", _c_p),
-                ("n_sites", _c_i64), ("site_rec", _c_p), ("n_kw16", _c_p)]
+                ("n_sites", _c_i64), ("site_rec", _c_p), ("n_kw16", _c_p), ("site_row", _c_p)]
 
 
 class LldaBatchArgs(ctypes.Structure):
@@ -190,10 +190,10 @@ def _launch(ref, fn, what, *args):
 def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
           status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
           dense_mask=False, debug_margin=0, live_off=None, live_pos=None, live_max=0, csc_pos=None, commit_log=None,
-          n_sites=None, site_rec=None, max_doc_tokens=0, scratch=None, n_kw16=None):
+          n_sites=None, site_rec=None, max_doc_tokens=0, scratch=None, n_kw16=None, site_row=None):
     """llda_sweep on the current torch stream.  All array arguments are torch CUDA tensors.  n_sites = the sites
     the D documents span (default: all of ``word``); scratch = a uint8 tensor of sweep_scratch_bytes(K, D) bytes (wide
-    layouts) or None; n_kw16 = the 16-bit image written by pack_rows16 (then csc_pos carries the row flags in bit 31) or None."""
+    layouts) or None; n_kw16 = the 16-bit image written by pack_rows16 (then csc_pos carries the row flags in bit 31 and site_row the row starts) or None."""
     a = LldaSweepArgs(_ptr(doc_off), _ptr(doc_order), _ptr(word), _ptr(freq), _ptr(z), _ptr(lab_mask),
                       _ptr(n_dk), _ptr(n_kw), _ptr(n_kw_delta), _ptr(n_k), _ptr(n_k_delta), _ptr(status),
                       int(D), int(V), int(K), int(docs_per_group), 1 if dense_mask else 0, int(debug_margin),
@@ -202,7 +202,7 @@ def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta
                       int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), _ptr(scratch),
                       0 if scratch is None else int(scratch.numel() * scratch.element_size()), int(live_max), int(max_doc_tokens),
                       _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites), _ptr(site_rec),
-                      _ptr(n_kw16))
+                      _ptr(n_kw16), _ptr(site_row))
     _launch(z, lib().llda_sweep, "llda_sweep", ctypes.byref(a))
 
 

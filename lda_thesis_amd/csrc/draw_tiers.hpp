@@ -37,11 +37,23 @@ __device__ __forceinline__ void prefix_scores_f32(float (&qw)[T], const XT (&x)[
         // two slots per instruction: (x + beta) * factor as packed fp32 (v_pk_add_f32, v_pk_mul_f32); a wave64
         // VALU instruction takes 4 cycles whether it produces one or two fp32 results per lane
         typedef float v2f __attribute__((ext_vector_type(2)));
-        const v2f xf = {(float)x[S], (float)x[S + 1]}, p2 = {pa[S], pa[S + 1]}, b2 = {beta, beta};
+        const v2f xf = {(float)x[S], (float)x[S + 1]}, b2 = {beta, beta};
+#ifdef ABL_NOFMA
+        const v2f p2 = {pa[S], pa[S + 1]};
         const v2f ws = (xf + b2) * p2;
         if constexpr (S == 0) qw[0] = ws.x;
         else qw[S] = qw[S - 1] + ws.x;
         qw[S + 1] = qw[S] + ws.y;
+#else
+        // the product and the running sum in ONE fused instruction per slot (an explicit fma: the translation unit is built
+        // with -ffp-contract=off): 8 v_pk_add + 16 v_fma instead of 8 + 8 v_pk_mul + 16 v_add.  One rounding where the
+        // unfused form has two, so the error bound of section 4.3 (one v per rounding) holds a fortiori; the sums stay
+        // non-decreasing (RN is monotone and the products are >= 0).
+        const v2f nb = xf + b2;
+        if constexpr (S == 0) qw[0] = nb.x * pa[0];
+        else qw[S] = __builtin_fmaf(nb.x, pa[S], qw[S - 1]);
+        qw[S + 1] = __builtin_fmaf(nb.y, pa[S + 1], qw[S]);
+#endif
         prefix_scores_f32<T, DENSE, S + 2>(qw, x, pa, mask, beta);
     } else if constexpr (S < T) {
         float ws = ((float)x[S] + beta) * pa[S];                 // num_b * fl32(a / den_b)
@@ -155,6 +167,62 @@ __device__ __forceinline__ uint64_t spread_any(uint64_t b)
 }
 
 // gp_all = __ballot(mask != 0) of the whole wavefront (uniform) for G >= 32, the group's own bits (per lane) below
+// Tier 0 for a dense mask and one or two documents per wavefront (the 16-slot K = 512 / 1024 kernels, bound by instruction
+// issue: every instruction below is one the site pays for).  Returns the wavefront's ballot of the lanes that are NOT sure
+// (uniform; 0 on the way all but one wavefront in a hundred take -- which half of it is unsure is the caller's business, behind
+// one scalar branch) and the position every lane's group drew in zn.  Every slot is allowed, so "first allowed slot above lo"
+// is the binary search's count itself, and the lane writes it down as the DEVICE POSITION it stands for right away:
+// pos_of<G,16>(lane, s) = (s >> 2) * 4G | lane << 2 | (s & 3), i.e. the search's four outcomes are four bits of the position
+// (a lane with q[15] <= lo has all four set and reads "slot 15").  The hit lane is the first lane with a slot above lo; were
+// rounding to leave none, the group's last lane answers with its last slot -- its bit is forced into the ballot -- which is what
+// the general path's my_miss / last-allowed-lane fall-back returns for a dense mask.
+template <int G>
+__device__ __forceinline__ uint64_t draw_fast_dense_f32(const float (&qw)[16], float u, float margin_rel, int lig, int lane, int &zn)
+{
+    static_assert(G == 32 || G == 64, "one or two documents per wavefront");
+    const float X = group_scan_f32<G>(qw[15], lig);
+    const float tot = bcast_last_f32<G>(X, lane);
+    const float prev = dpp_f32<DPP_WAVE_SHR1>(X);
+    const float tg = u * tot - (lig ? prev : 0.0f);
+    const float margin = tot * margin_rel;
+    const float lo = tg - margin, hi = tg + margin;
+    const bool c5 = qw[15] <= lo;
+    float ub = c5 ? __int_as_float(0x7f800000) : qw[15];           // smallest element known to be > lo (count_sorted_f32)
+    const bool c1 = qw[7] <= lo;
+    ub = c1 ? ub : qw[7];
+    const float m2 = c1 ? qw[11] : qw[3];
+    const float a1 = c1 ? qw[9] : qw[1], a5 = c1 ? qw[13] : qw[5];
+    const float e0 = c1 ? qw[8] : qw[0], e2 = c1 ? qw[10] : qw[2], e4 = c1 ? qw[12] : qw[4], e6 = c1 ? qw[14] : qw[6];
+    const bool c2 = m2 <= lo;
+    ub = c2 ? ub : m2;
+    const float m3 = c2 ? a5 : a1;
+    const float g0 = c2 ? e4 : e0, g2 = c2 ? e6 : e2;
+    const bool c3 = m3 <= lo;
+    ub = c3 ? ub : m3;
+    const float m4 = c3 ? g2 : g0;
+    const bool c4 = m4 <= lo;
+    ub = c4 ? ub : m4;
+    // the general path's guards on the total (tot > 0, margin < tot, tot finite) in one class test: tot - margin is a positive
+    // normal number exactly when all three hold (a difference down in the denormals counts as a failure; under FAST the total
+    // is above 1e-24).  0x2FF = every class but "positive normal".
+    // (v_cmp_class by hand: the builtin's result reaches the ballot through a select and a second compare.  margin_rel >= 1 --
+    // tier 0 switched off, llda_sweep_args.debug_margin -- fails the test too: the caller needs no test of its own.)
+    uint64_t bad_total;
+    asm("v_cmp_class_f32_e64 %0, %1, %2" : "=s"(bad_total) : "v"(tot - margin), "v"(0x2FF));
+    const uint64_t unsure = __ballot(!(ub > hi)) | bad_total;
+    const int p = (c1 ? 8 * G : 0) | (c2 ? 4 * G : 0) | (lig << 2) | (c3 ? 2 : 0) | (c4 ? 1 : 0);
+    const uint64_t above = __ballot(!c5);
+    if constexpr (G == 64) {
+        zn = __builtin_amdgcn_readlane(p, (int)__builtin_ctzll(above | (1ull << 63)));
+    } else {
+        const uint32_t f0 = (uint32_t)above | 0x80000000u, f1 = uniform_hi32(above) | 0x80000000u;
+        const int z0 = __builtin_amdgcn_readlane(p, (int)__builtin_ctz(f0));
+        const int z1 = __builtin_amdgcn_readlane(p, (int)__builtin_ctz(f1) + 32);
+        zn = (lane & 32) ? z1 : z0;
+    }
+    return unsure;
+}
+
 template <int G, int T>
 __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uint32_t mask, uint64_t gp,
                                               float margin_rel, int lig, int lane, int &zn)

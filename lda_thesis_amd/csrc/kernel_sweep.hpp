@@ -178,7 +178,8 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
     const float vbeta32 = (float)P.vbeta, alpha32 = (float)P.alpha, beta32 = (float)P.beta;
 
     const int64_t site_base = P.doc_off[0];                 // uniform: the bases below stay in SGPRs
-    const int32_t *word_b = P.word + site_base, *freq_b = P.freq + site_base;
+    // (16-bit rows: the row starts of llda_sweep_args.site_row stand in for the word ids)
+    const int32_t *word_b = (R16 ? P.site_row : P.word) + site_base, *freq_b = P.freq + site_base;
     const int32_t *csc_b = LOGGED ? P.csc_pos + site_base : nullptr;
     constexpr bool PACKED = REC;
     static_assert(!REC || (LOGGED && G <= 16), "site records: commit log, <= 16 lanes per document");
@@ -225,7 +226,16 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         // next site) rotate with the site index, and the site loop is unrolled by three: no register-to-register
         // moves for the pipeline (a rolled loop spends 17 v_mov per site on them; the compiler cannot unroll it
         // itself because the body contains convergent cross-lane operations).
-        struct SiteRegs { int v, f, zo, c, zn, lo, so; };    // (lo, so) = lane and slot of zo, decoded once per site
+        struct SiteRegs { int v, f, zo, c, zn, lo, so, rg, fs; };    // (lo, so) = lane and slot of zo, decoded once per site
+        // (rg, fs: 16-bit rows only -- the register of the row tuple that holds slot so of this site's row and the site's
+        // frequency shifted to its half of that register; per lane, for both documents of a wavefront at once)
+        auto packed_slot = [&](SiteRegs &R) {
+            if constexpr (R16) {
+                const int hm = R.c >> 31;                             // all ones for a 16-bit row: register so >> 1, odd slots up
+                R.rg = R.so >> (hm & 1);
+                R.fs = R.f << ((R.so << 4) & 16 & hm);                // (no borrow across the halves: the count includes f)
+            }
+        };
         // scalars of one site.  With 8 or 16 lanes per document a wavefront walks 8 / 4 documents, and every scalar
         // load touches that many cache lines: the kernel is then bound by the vector-memory address pipeline (TA
         // busy 74 % at K = 128), not by VALU issue.  PACKED: {word, freq, csc_pos} come as ONE 16-byte record per
@@ -244,9 +254,9 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         const uint32_t o0 = opaque_u32(sb + (uint32_t)n0 * 4u), o1 = opaque_u32(sb + (uint32_t)(n0 + 1 < len ? n0 + 1 : n0) * 4u);
         SiteRegs R0, R1, R2;
         R0.c = R1.c = 0;
-        load_scalars(R0, o0); R0.zn = 0; R0.lo = R0.so = 0;
-        load_scalars(R1, o1); R1.zn = 0; R1.lo = R1.so = 0;
-        R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = 0;
+        load_scalars(R0, o0); R0.zn = 0; R0.lo = R0.so = R0.rg = R0.fs = 0;
+        load_scalars(R1, o1); R1.zn = 0; R1.lo = R1.so = R1.rg = R1.fs = 0;
+        R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = R2.rg = R2.fs = 0;
         // INDEXED (one or two documents per wavefront, 16 slots): the row lives in one of two 16-register tuples whose
         // roles (row of this site / row of the next site, in flight) alternate, and the site's own count is removed
         // from it in place through a register index held in M0 -- 6 vector instructions per document instead of 34
@@ -259,8 +269,7 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
             if constexpr (R16) {
                 typedef int v4i __attribute__((ext_vector_type(4)));
                 const bool h = c < 0;
-                const LLDA_GLOBAL char *q = (h ? (const LLDA_GLOBAL char *)P.n_kw16 : (const LLDA_GLOBAL char *)P.n_kw) +
-                                            (int64_t)v * (h ? KP * 2 : KP * 4) + lig * 16;
+                const LLDA_GLOBAL char *q = (const LLDA_GLOBAL char *)P.n_kw + ((int64_t)v << 4) + lig * 16;   // v: site_row
                 const v4i a0 = *(const LLDA_GLOBAL v4i *)q, a1 = *(const LLDA_GLOBAL v4i *)(q + G * 16);
                 xl[0] = a0.x; xl[1] = a0.y; xl[2] = a0.z; xl[3] = a0.w;
                 xl[4] = a1.x; xl[5] = a1.y; xl[6] = a1.z; xl[7] = a1.w;
@@ -282,9 +291,11 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the previous site
             lane_slot_of<G, T>(R0.zo, R0.lo, R0.so);
+            packed_slot(R0);
             if (lig == R0.lo) count_update(s_ndk, s_nkc, s_pa, R0.so, tid, alpha32, vbeta32, -R0.f);
         }
 
+        const uint64_t lig0_w = __ballot(lig == 0);               // (uniform) first lanes of the wavefront's groups
         // one site: `cur` holds its scalars, `nxt` those of site n+1, `prv` those of site n-1 (committed here, then
         // reloaded with the scalars of site n+2)
         auto site = [&](const int n, SiteRegs &cur, SiteRegs &nxt, SiteRegs &prv, int (&xc)[T], int (&xnx)[INDEXED ? T : 1]) {
@@ -307,21 +318,21 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 v16i xv;
 #pragma unroll
                 for (int s = 0; s < T; ++s) xv[s] = xc[s];
+                const int own = (lig == cur.lo) ? cur.fs : 0;         // (packed_slot: the register and the shifted frequency)
 #pragma unroll
                 for (int g = 0; g < 64 / G; ++g) {
-                    int lo_g, so_g;                                   // scalar: zo, csc_pos are the same in every lane of a group
-                    lane_slot_of<G, T>(__builtin_amdgcn_readlane(zo, g * G), lo_g, so_g);
-                    const bool h_g = __builtin_amdgcn_readlane(cur.c, g * G) < 0;
-                    // a packed row: register so >> 1, upper half for odd slots (no borrow: the count includes f)
-                    const int reg = h_g ? so_g >> 1 : so_g, sh = h_g ? (so_g & 1) << 4 : 0;
-                    xv[reg & (T - 1)] -= (lane == g * G + lo_g) ? f << sh : 0;
+                    const int rg_g = __builtin_amdgcn_readlane(cur.rg, g * G);
+                    xv[rg_g & (T - 1)] -= (G == 64 || (lane / G) == g) ? own : 0;
                 }
 #pragma unroll
                 for (int s = 0; s < T; ++s) x[s] = xv[s];
-                if (cur.c < 0) {
+                // (two likely blocks, not if / else: the compiler moves BOTH arms of a divergent if / else out of line, three taken
+                // branches per site)
+                if (__builtin_expect_with_probability(cur.c < 0, 1, 0.6)) {
 #pragma unroll
                     for (int s = 0; s < T; ++s) xf[s] = (float)((s & 1) ? (uint32_t)x[s >> 1] >> 16 : (uint32_t)x[s >> 1] & 0xffffu);
-                } else {
+                }
+                if (__builtin_expect_with_probability(cur.c >= 0, 1, 0.6)) {
 #pragma unroll
                     for (int s = 0; s < T; ++s) xf[s] = (float)x[s];
                 }
@@ -330,11 +341,13 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 v16i xv;
 #pragma unroll
                 for (int s = 0; s < T; ++s) xv[s] = xc[s];
+                // (lane, slot) of zo were decoded per lane when the previous site took this one out of its topic; the slot is
+                // the same in every lane of a group: one v_readlane per document, no scalar decode
+                const int own = (lig == cur.lo) ? f : 0;
 #pragma unroll
                 for (int g = 0; g < 64 / G; ++g) {
-                    int lo_g, so_g;                                   // scalar: zo is the same in every lane of a group
-                    lane_slot_of<G, T>(__builtin_amdgcn_readlane(zo, g * G), lo_g, so_g);
-                    xv[so_g & (T - 1)] -= (lane == g * G + lo_g) ? f : 0;
+                    const int so_g = __builtin_amdgcn_readlane(cur.so, g * G);
+                    xv[so_g & (T - 1)] -= (G == 64 || (lane / G) == g) ? own : 0;
                 }
 #pragma unroll
                 for (int s = 0; s < T; ++s) x[s] = xv[s];
@@ -360,16 +373,9 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
             }
             // tiered draw
             int zn = -1;
-            bool decided = false;
-            if (P.margin0_rel < 1.0f) {           // tier 0: fp32
-                float qf[T];
-                if constexpr (R16) prefix_scores_f32<T, DENSE>(qf, xf, pa, mask, beta32);
-                else prefix_scores_f32<T, DENSE>(qf, x, pa, mask, beta32);
-                // fp32 image of the uniform: the top 27 bits (within 2^-24 relative + 2^-27 absolute of u)
-                const float u32 = (float)(ra >> 5) * 0x1p-27f;
-                decided = draw_fast_f32<G, T>(qf, u32, mask, gp_doc, P.margin0_rel, lig, lane, zn);
-            }
-            if (__builtin_expect(!decided, 0)) {
+            // the cold tiers for the lanes that enter; the "no topic with positive probability" outcome can only come from there
+            // (tier 0 always names a position), so its test lives behind the same rare branch
+            auto cold = [&]() {
                 int x_c[T];
 #pragma unroll
                 for (int s = 0; s < T; ++s) x_c[s] = x[s];
@@ -383,10 +389,32 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 // copy of all of P and put its pointers into VGPRs)
                 zn = cold_tiers<G, T, HAS_TAIL, DENSE>(s_ndk, x_c, s_nkc, tid, mask, uniform53(ra, rb), lig, lane,
                                                        (const KParams *)__builtin_amdgcn_kernarg_segment_ptr());
-            }
-            if (__builtin_expect(zn < 0, 0)) {
-                zn = zo;
-                if (lig == 0 && P.status) atomicOr(P.status, 1);    // no topic with positive probability
+                if (__builtin_expect(zn < 0, 0)) {
+                    zn = zo;
+                    if (lig == 0 && P.status) atomicOr(P.status, 1);    // no topic with positive probability
+                }
+            };
+            // fp32 image of the uniform: the top 27 bits (within 2^-24 relative + 2^-27 absolute of u)
+            const float u32 = (float)(ra >> 5) * 0x1p-27f;
+            if constexpr (DENSE && T == 16 && G >= 32) {
+                // tier 0: fp32 (a margin >= 1 switches it off by making every site unsure: no test here).  unsure = the
+                // wavefront's lanes tier 0 is not sure about (uniform)
+                float qf[T];
+                if constexpr (R16) prefix_scores_f32<T, DENSE>(qf, xf, pa, mask, beta32);
+                else prefix_scores_f32<T, DENSE>(qf, x, pa, mask, beta32);
+                const uint64_t unsure = draw_fast_dense_f32<G>(qf, u32, P.margin0_rel, lig, lane, zn);
+                if (__builtin_expect(unsure != 0, 0)) {                                  // one scalar branch per site
+                    if (__builtin_amdgcn_inverse_ballot_w64(spread_any<G>(unsure))) cold();   // the whole document group enters
+                }
+            } else {
+                bool decided = false;
+                if (P.margin0_rel < 1.0f) {           // tier 0: fp32
+                    float qf[T];
+                    if constexpr (R16) prefix_scores_f32<T, DENSE>(qf, xf, pa, mask, beta32);
+                    else prefix_scores_f32<T, DENSE>(qf, x, pa, mask, beta32);
+                    decided = draw_fast_f32<G, T>(qf, u32, mask, gp_doc, P.margin0_rel, lig, lane, zn);
+                }
+                if (__builtin_expect(!decided, 0)) cold();
             }
             cur.zn = zn;
 
@@ -398,16 +426,23 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 int ln, sn;
                 lane_slot_of<G, T>(zn, ln, sn);
                 lane_slot_of<G, T>(nxt.zo, nxt.lo, nxt.so);                  // (kept for the next site's removal from x)
+                packed_slot(nxt);
                 const int lo2 = nxt.lo, so2 = nxt.so;
                 const bool more = n + 1 < len;
                 const bool own_new = lig == ln, own_old = more && lig == lo2;
-                if (own_new || own_old)
+                const uint64_t both_w = __ballot(own_new) & __ballot(more) & __ballot(lig == lo2);   // (taken here: the compares' own masks)
+                if (__builtin_expect(own_new || own_old, 1))                      // (some lane of the wavefront always is)
                     count_update(s_ndk, s_nkc, s_pa, own_new ? sn : so2, tid, alpha32, vbeta32, own_new ? f : -nxt.f);
-                if (__builtin_expect(own_new && own_old, 0)) count_update(s_ndk, s_nkc, s_pa, so2, tid, alpha32, vbeta32, -nxt.f);
+                // (rare blocks behind ONE scalar branch on the ballot: entering and leaving a divergent region costs four
+                // scalar instructions whether or not a lane takes it, and the scalar unit's cycles are not hidden here)
+                if (__builtin_expect(both_w != 0, 0)) {
+                    if (own_new && own_old) count_update(s_ndk, s_nkc, s_pa, so2, tid, alpha32, vbeta32, -nxt.f);
+                }
             }
 #ifndef ABL_NOCOMMIT
             // the last site of the document is committed right away
-            if (__builtin_expect(lig == 0 && n + 1 == len, 0))
+            if (__builtin_expect((__ballot(n + 1 == len) & lig0_w) != 0, 0))
+              if (lig == 0 && n + 1 == len)
                 commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)n * 4u), cur.v, cur.f, cur.zo, cur.zn,
                                         R16 ? cur.c & 0x7fffffff : cur.c, KP);
 #endif

@@ -593,10 +593,13 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? LLDA_OK : hip_fail(e);
     }
+    if ((a->n_kw16 != nullptr) != (a->site_row != nullptr)) return LLDA_E_BAD_ARG;
     if (a->n_kw16) {
         // 16-bit rows (bit 31 of csc_pos): the dense 16-slot kernel with the commit log, nothing else knows the flag
         if (!(fast && dense && logged && L.T == 16 && L.G >= 32)) return LLDA_E_BAD_ARG;
+        if ((reinterpret_cast<uintptr_t>(a->n_kw16) | reinterpret_cast<uintptr_t>(a->n_kw)) & 15) return LLDA_E_BAD_ARG;
         P.n_kw16 = a->n_kw16;
+        P.site_row = a->site_row;
     }
     switch (L.G) {
     case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, fast, dense, blocks, st);

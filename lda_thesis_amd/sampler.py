@@ -191,7 +191,7 @@ class GibbsSampler(object):
         self.row_off = self.rows = self._rows_list = None
         if self.sharded and (_dist_active(self.group) or exchange_always):
             self._make_exchange_rows()
-        self.row16 = self.n_kw16 = None
+        self.row16 = self.n_kw16 = self.site_row = None
         if (rows16 is not False and self.S and self.dense_mask and self.commit_log is not None
                 and _native.rows16_ok(self.K) and self.alpha >= 1e-6 and self.beta >= 1e-6):
             self._make_rows16(auto=rows16 is None)
@@ -221,8 +221,19 @@ class GibbsSampler(object):
             return
         self.row16 = fits.to(torch.uint8).contiguous()
         self.n_kw16 = torch.zeros((self.V * self.layout.KP,), dtype=torch.int16, device=self.device)
-        flag = torch.where(fits[self.word.to(torch.int64)], -(1 << 31), 0).to(torch.int32)
-        self.csc_pos |= flag
+        flagged = fits[self.word.to(torch.int64)]
+        self.csc_pos |= torch.where(flagged, -(1 << 31), 0).to(torch.int32)
+        # llda_sweep_args.site_row: where the row of each site's word starts, in 16-byte units from n_kw (static)
+        KP = self.layout.KP
+        gap = self.n_kw16.data_ptr() - self.n_kw.data_ptr()
+        assert gap % 16 == 0 and KP % 8 == 0
+        w = self.word.to(torch.int64)
+        row = torch.where(flagged, gap // 16 + w * (KP // 8), w * (KP // 4))
+        if int(row.abs().max()) >= 1 << 31:                       # the two arrays more than 32 GB apart: int32 rows only
+            self.csc_pos &= 0x7fffffff
+            self.row16 = self.n_kw16 = None
+            return
+        self.site_row = row.to(torch.int32).contiguous()
 
     def _make_exchange_rows(self):
         """Exchange layout of the per-sweep count deltas when every rank folds a commit log: one row per word plus
@@ -435,7 +446,7 @@ class GibbsSampler(object):
                               live_pos=self.live_pos,
                               live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
                               n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens,
-                              scratch=self._scratch, n_kw16=self.n_kw16)
+                              scratch=self._scratch, n_kw16=self.n_kw16, site_row=self.site_row)
             if pipelined:
                 # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
                 # collective's stream (ordered after the fold) while the next range is sampled on this one
