@@ -103,6 +103,8 @@ def build_sampler(name, dev, rank, world, dist_on, docs_total=0, docs_per_group=
         Dt = docs_total
     info = dict(desc=desc, K=K, V=V, N=N, live_topics=float(K), docs_total=Dt)
     kw = {} if overlap is None else dict(overlap_ranges=overlap)
+    if rows16 is None and os.environ.get("LLDA_BENCH_ROWS16"):        # ablation: "on" / "off" for every sampler of the run
+        rows16 = os.environ["LLDA_BENCH_ROWS16"] == "on"
     if rows16 is not None:
         kw["rows16"] = rows16
     if name == "abstracts":

@@ -226,16 +226,7 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         // next site) rotate with the site index, and the site loop is unrolled by three: no register-to-register
         // moves for the pipeline (a rolled loop spends 17 v_mov per site on them; the compiler cannot unroll it
         // itself because the body contains convergent cross-lane operations).
-        struct SiteRegs { int v, f, zo, c, zn, lo, so, rg, fs; };    // (lo, so) = lane and slot of zo, decoded once per site
-        // (rg, fs: 16-bit rows only -- the register of the row tuple that holds slot so of this site's row and the site's
-        // frequency shifted to its half of that register; per lane, for both documents of a wavefront at once)
-        auto packed_slot = [&](SiteRegs &R) {
-            if constexpr (R16) {
-                const int hm = R.c >> 31;                             // all ones for a 16-bit row: register so >> 1, odd slots up
-                R.rg = R.so >> (hm & 1);
-                R.fs = R.f << ((R.so << 4) & 16 & hm);                // (no borrow across the halves: the count includes f)
-            }
-        };
+        struct SiteRegs { int v, f, zo, c, zn, lo, so; };    // (lo, so) = lane and slot of zo, decoded once per site
         // scalars of one site.  With 8 or 16 lanes per document a wavefront walks 8 / 4 documents, and every scalar
         // load touches that many cache lines: the kernel is then bound by the vector-memory address pipeline (TA
         // busy 74 % at K = 128), not by VALU issue.  PACKED: {word, freq, csc_pos} come as ONE 16-byte record per
@@ -254,9 +245,9 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         const uint32_t o0 = opaque_u32(sb + (uint32_t)n0 * 4u), o1 = opaque_u32(sb + (uint32_t)(n0 + 1 < len ? n0 + 1 : n0) * 4u);
         SiteRegs R0, R1, R2;
         R0.c = R1.c = 0;
-        load_scalars(R0, o0); R0.zn = 0; R0.lo = R0.so = R0.rg = R0.fs = 0;
-        load_scalars(R1, o1); R1.zn = 0; R1.lo = R1.so = R1.rg = R1.fs = 0;
-        R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = R2.rg = R2.fs = 0;
+        load_scalars(R0, o0); R0.zn = 0; R0.lo = R0.so = 0;
+        load_scalars(R1, o1); R1.zn = 0; R1.lo = R1.so = 0;
+        R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = 0;
         // INDEXED (one or two documents per wavefront, 16 slots): the row lives in one of two 16-register tuples whose
         // roles (row of this site / row of the next site, in flight) alternate, and the site's own count is removed
         // from it in place through a register index held in M0 -- 6 vector instructions per document instead of 34
@@ -291,7 +282,6 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the previous site
             lane_slot_of<G, T>(R0.zo, R0.lo, R0.so);
-            packed_slot(R0);
             if (lig == R0.lo) count_update(s_ndk, s_nkc, s_pa, R0.so, tid, alpha32, vbeta32, -R0.f);
         }
 
@@ -314,28 +304,36 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
             int x[T];
             [[maybe_unused]] float xf[R16 ? T : 1];                   // R16: the counts as fp32 (exact: 16-bit rows hold < 2^16)
             if constexpr (R16) {
-                typedef int v16i __attribute__((ext_vector_type(16)));
-                v16i xv;
+                // the row as it came (the cold tiers take the site's own count out of THEIR copy), converted, and the own count
+                // removed from the fp32 values through the slot index itself -- no register / half-word arithmetic for the packed
+                // rows.  fl32(x) - f IS fl32(x - f) while x < 2^24 (every 16-bit row, and every int32 row of a real corpus); an
+                // int32 count beyond that carries two more roundings (num within 5 v instead of 3 v, the compared difference
+                // within 107 v instead of 105 v of section 4.3 -- the margin is 128 v)
 #pragma unroll
-                for (int s = 0; s < T; ++s) xv[s] = xc[s];
-                const int own = (lig == cur.lo) ? cur.fs : 0;         // (packed_slot: the register and the shifted frequency)
-#pragma unroll
-                for (int g = 0; g < 64 / G; ++g) {
-                    const int rg_g = __builtin_amdgcn_readlane(cur.rg, g * G);
-                    xv[rg_g & (T - 1)] -= (G == 64 || (lane / G) == g) ? own : 0;
-                }
-#pragma unroll
-                for (int s = 0; s < T; ++s) x[s] = xv[s];
+                for (int s = 0; s < T; ++s) x[s] = xc[s];
+                const bool h = cur.c < 0;
                 // (two likely blocks, not if / else: the compiler moves BOTH arms of a divergent if / else out of line, three taken
                 // branches per site)
-                if (__builtin_expect_with_probability(cur.c < 0, 1, 0.6)) {
+                if (__builtin_expect_with_probability(h, 1, 0.6)) {
 #pragma unroll
                     for (int s = 0; s < T; ++s) xf[s] = (float)((s & 1) ? (uint32_t)x[s >> 1] >> 16 : (uint32_t)x[s >> 1] & 0xffffu);
                 }
-                if (__builtin_expect_with_probability(cur.c >= 0, 1, 0.6)) {
+                if (__builtin_expect_with_probability(!h, 1, 0.6)) {
 #pragma unroll
                     for (int s = 0; s < T; ++s) xf[s] = (float)x[s];
                 }
+                typedef float v16f __attribute__((ext_vector_type(16)));
+                v16f xv;
+#pragma unroll
+                for (int s = 0; s < T; ++s) xv[s] = xf[s];
+                const float own = (lig == cur.lo) ? (float)f : 0.0f;
+#pragma unroll
+                for (int g = 0; g < 64 / G; ++g) {
+                    const int so_g = __builtin_amdgcn_readlane(cur.so, g * G);
+                    xv[so_g & (T - 1)] -= (G == 64 || (lane / G) == g) ? own : 0.0f;
+                }
+#pragma unroll
+                for (int s = 0; s < T; ++s) xf[s] = xv[s];
             } else if constexpr (INDEXED) {
                 typedef int v16i __attribute__((ext_vector_type(16)));
                 v16i xv;
@@ -384,6 +382,7 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
 #pragma unroll
                         for (int s = 0; s < T; ++s) x_c[s] = (int)((s & 1) ? (uint32_t)x[s >> 1] >> 16 : (uint32_t)x[s >> 1] & 0xffffu);
                     }
+                    if (lig == cur.lo) x_c[cur.so] -= f;              // (x is the row as it came: see above)
                 }
                 // (the callee reads the parameters from the kernel-argument segment: taking &P would force a scratch
                 // copy of all of P and put its pointers into VGPRs)
@@ -426,7 +425,6 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 int ln, sn;
                 lane_slot_of<G, T>(zn, ln, sn);
                 lane_slot_of<G, T>(nxt.zo, nxt.lo, nxt.so);                  // (kept for the next site's removal from x)
-                packed_slot(nxt);
                 const int lo2 = nxt.lo, so2 = nxt.so;
                 const bool more = n + 1 < len;
                 const bool own_new = lig == ln, own_old = more && lig == lo2;

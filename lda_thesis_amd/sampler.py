@@ -76,12 +76,13 @@ class GibbsSampler(object):
                for when that pays.  Needs the commit-log exchange rows on every rank (else it is ignored).
     rows16   : the sweep reads the n_kw rows of the words whose corpus-wide count fits 16 bits from a 16-bit image of
                n_kw that is refreshed at the start of every sweep (``llda_pack_rows16``): half the bytes per row, for a
-               few more instructions per site.  Same results.  It pays when most sites read a row that no cache holds
-               (+30 % with uniform words over a 1 GB n_kw) and costs otherwise (-12 % on the Zipf corpus of BASELINE
-               configs[3], whose sweep is bound by instruction issue: DESIGN.md section 4.3).  None (default) = where the
-               kernel has it (dense mask, commit log, K = 512 or 1024), n_kw exceeds the 256 MiB Infinity Cache AND the
-               words whose rows fit that cache carry less than half of the sites; True = wherever the kernel has it;
-               False = off.
+               few more instructions per site.  Same results.  The int32 kernel of these layouts is bound by the fabric
+               (L2 line fills), the 16-bit one by instruction issue, and since round 3's trimming the latter is the faster
+               wherever the rows do not all sit in the L2s: + 10 % on BASELINE configs[3] (n_kw 205 MB), + 5 ... 8 % on Zipf
+               corpora with V = 300 000 / 1 000 000, + 50 % with uniform words over a 1 GB n_kw, + 13 ... 21 % at K = 1024;
+               - 6 % at K = 512 with a 41 MB n_kw.  None (default) = where the kernel has it (dense
+               mask, commit log, K = 512 or 1024) and n_kw is at least ROWS16_MIN_BYTES (64 MiB); True = wherever the
+               kernel has it; False = off.
     """
 
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
@@ -196,7 +197,7 @@ class GibbsSampler(object):
                 and _native.rows16_ok(self.K) and self.alpha >= 1e-6 and self.beta >= 1e-6):
             self._make_rows16(auto=rows16 is None)
 
-    ROWS16_CACHE_BYTES = 256 << 20   # rows16=None: the Infinity Cache; an n_kw below it is served from the caches anyway
+    ROWS16_MIN_BYTES = 64 << 20      # rows16=None: below this n_kw the L2s serve the int32 rows and the shorter kernel wins
     MAX_FREQ = 1 << 23   # v_mad_i32_i24 moves a site's count (include/llda_gibbs.h: freq)
     PAIR_LIMIT = 32767   # largest frequency mass of a word (all ranks) whose row is exchanged as int16 pairs
 
@@ -207,15 +208,8 @@ class GibbsSampler(object):
         words of a natural corpus) can be read from a 16-bit image.  The flag of a site's word rides in bit 31 of its
         commit-log position, where the kernel sees it one site before it needs the row."""
         total = self.n_kw.sum(dim=1, dtype=torch.int64)
-        if auto:
-            # cache-hostile corpora only: n_kw beyond the Infinity Cache, and the most frequent words whose rows would
-            # fill that cache carry less than half of the tokens
-            row_bytes = self.layout.KP * 4
-            if self.V * row_bytes <= self.ROWS16_CACHE_BYTES:
-                return
-            top = torch.topk(total, min(self.V, self.ROWS16_CACHE_BYTES // row_bytes)).values
-            if float(top.sum()) >= 0.5 * float(total.sum()):
-                return
+        if auto and self.V * self.layout.KP * 4 < self.ROWS16_MIN_BYTES:
+            return
         fits = (total <= 65535) & (self.n_kw.min(dim=1).values >= 0)
         if not bool(fits.any()):
             return

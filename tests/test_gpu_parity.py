@@ -392,15 +392,16 @@ def test_16_bit_rows_flag_counts_that_do_not_belong_to_the_corpus():
         s.check_status()
 
 
-def test_16_bit_rows_are_chosen_for_cache_hostile_corpora_only():
-    """rows16=None: on when n_kw exceeds the Infinity Cache and the words whose rows would fit it carry less than half of the
-    sites (uniform words over a large vocabulary); off for a Zipf corpus of the same size and for a small n_kw."""
+def test_16_bit_rows_are_chosen_by_the_size_of_n_kw():
+    """rows16=None: on when n_kw is at least GibbsSampler.ROWS16_MIN_BYTES (the L2s cannot hold the rows), whatever the word
+    distribution; off for a small n_kw, where the int32 kernel is the faster one."""
     from lda_thesis_amd.corpus import synthetic_corpus_blocks
     from lda_thesis_amd.sampler import GibbsSampler
-    for zipf, V, want in ((0.0, 1_000_000, True), (1.0, 1_000_000, False), (0.0, 20_000, False)):
+    for zipf, V, want in ((0.0, 1_000_000, True), (1.0, 1_000_000, True), (1.0, 100_000, True), (0.0, 20_000, False)):
         off, w, f, z = synthetic_corpus_blocks(0, 8000, 300, V, 512, 1234, "cuda", zipf_s=zipf, block=4000)
         s = GibbsSampler(off, w, f, z, 512, V, 0.1, 0.01, labs=None, seed=1)
         assert (s.n_kw16 is not None) == want, (zipf, V)
+        assert (s.site_row is not None) == want
         del s
 
 

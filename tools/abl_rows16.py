@@ -8,6 +8,8 @@ import bench
 bench.WORKLOADS["k1024"] = (125000, 300, 100000, 1024, 1.0, 15625, "K = 1024")
 bench.WORKLOADS["zipf_v300k"] = (125000, 300, 300000, 512, 1.0, 15625, "Zipf words, V = 300k: n_kw 614 MB")
 bench.WORKLOADS["zipf_v1m"] = (125000, 300, 1000000, 512, 1.0, 15625, "Zipf words, V = 1M: n_kw 2 GB")
+bench.WORKLOADS["zipf_v20k"] = (125000, 300, 20000, 512, 1.0, 15625, "Zipf words, V = 20k: n_kw 41 MB")
+bench.WORKLOADS["k1024_v20k"] = (62500, 300, 20000, 1024, 1.0, 15625, "K = 1024, Zipf words, V = 20k: n_kw 82 MB")
 bench.WORKLOADS["k1024_v500k"] = (125000, 300, 500000, 1024, 1.0, 15625, "K = 1024, Zipf words, V = 500k: n_kw 2 GB")
 dev = torch.device("cuda", 0)
 for name in (sys.argv[1:] or ["synth2", "synth2_hostile", "k1024"]):
