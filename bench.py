@@ -186,6 +186,17 @@ def checksum_verdict(name, docs_total, sweeps, got):
     return (got == want), "N = 1 digests after %d sweeps (%s): %r" % (sweeps, t.get("source", "stored"), want)
 
 
+def rows_description(sampler):
+    """how the sweep reads n_kw: int32 rows, or the 16-bit image (llda_sweep_args.n_kw16, refreshed inside every timed sweep)
+    for the words whose corpus-wide count fits 16 bits"""
+    if getattr(sampler, "n_kw16", None) is None:
+        return "int32"
+    flagged = sampler.row16[sampler.word.long()].float().mean().item() if sampler.S else 0.0
+    return ("16-bit image for the words whose corpus-wide count fits 16 bits (%.1f %% of the words, %.1f %% of this rank's sites; "
+            "llda_pack_rows16 runs inside every timed sweep), int32 rows for the others; same results (DESIGN.md section 4.1)" %
+            (100.0 * sampler.row16.float().mean().item(), 100.0 * flagged))
+
+
 def time_sweeps(sampler, steps, warmup, dist=None, dev=None):
     """warmup untimed sweeps, then exactly `steps` sweeps between barrier + synchronize; MAX over ranks.
     -> (seconds, mean sweep-kernel ms from HIP events on the launch stream, tier counters)"""
@@ -723,14 +734,15 @@ def roofline_json(kernel_ms, sites, docs, live_topics, pmc, source, stored_key=N
         r["valu_issue"] = v
         cands["valu_issue"] = v["frac"]
         if cycles and pmc.get("SQ_INSTS_SALU"):
-            # profiles/r03_issue_model.md: three variants of the K = 512 kernel (fewer bytes / more waves, each with a few
-            # more instructions) ran in 4 x VALU + 2.5 x SALU cycles per SIMD to within 2 % -- scalar instructions are not
-            # hidden behind vector ones there.  The 2.5 is FITTED on that kernel; for the others the figure is indicative.
+            # profiles/r03_issue_model.md: 4 x VALU + 2.5 x SALU cycles per SIMD reproduces the K = 512 kernel's rate when its rows
+            # sit in the caches (to 6 %) and the 16-bit-row kernel's (to 8 %).  The 2.5 is FITTED, and a kernel can sit at another
+            # roof with this figure near 1 -- the int32 K = 512 kernel did (section 4 of that note): read it next to the fabric
+            # fraction and valu_busy_frac, not instead of them.
             ic = (VALU_CYCLES_PER_INST * insts + SALU_CYCLES_PER_INST * pmc["SQ_INSTS_SALU"]) / N_SIMD
             r["issue_model"] = {"frac": ic / cycles, "cycles_per_simd": ic, "shader_cycles": cycles,
                                 "salu_insts_per_site": pmc["SQ_INSTS_SALU"] / sites,
                                 "model": "(%d x SQ_INSTS_VALU + %.1f x SQ_INSTS_SALU) / 1024 SIMDs over GRBM_GUI_ACTIVE / 8; the SALU "
-                                         "cost is fitted on three variants of the K = 512 kernel (profiles/r03_issue_model.md)" %
+                                         "cost is a fit (profiles/r03_issue_model.md, sections 3 - 5)" %
                                          (VALU_CYCLES_PER_INST, SALU_CYCLES_PER_INST)}
             cands["instruction_issue (VALU + SALU, fitted model)"] = ic / cycles
     if cands:
@@ -741,10 +753,13 @@ def roofline_json(kernel_ms, sites, docs, live_topics, pmc, source, stored_key=N
         r["headroom"] = max(0.0, r["headroom"])
         r["binding_note"] = ("the largest of: fabric bytes / time / 8 TB/s (called 'hbm' only when the shared counts exceed the "
                              "Infinity Cache), VALU instructions x 4 cycles / time / (1024 SIMDs x 2.4 GHz), and the fitted "
-                             "instruction-issue model (VALU x 4 + SALU x 2.5 cycles per SIMD over the launch's shader cycles: "
-                             "profiles/r03_issue_model.md -- on the K = 512 kernel halving the fabric bytes or adding a fourth "
-                             "wave changed nothing, the time followed the instruction count); a kernel far below all three is "
-                             "bound by the latency of its dependent chain at its occupancy (valu_issue.wave_cycles_waiting_frac)")
+                             "instruction-issue model (VALU x 4 + SALU x 2.5 cycles per SIMD over the launch's shader cycles).  "
+                             "profiles/r03_issue_model.md: with int32 rows the K = 512 kernel is fabric-bound (0.96 of 8 TB/s in L2 "
+                             "line fills; a fifth fewer issue cycles changed nothing), with the 16-bit rows this line runs on it "
+                             "moves half those bytes and is bound by instruction issue (a SIMD issues VALU in 0.81 of its cycles, "
+                             "the plateau the same stream reaches with every row in the caches is 0.82); a kernel far below all "
+                             "three is bound by the latency of its dependent chain at its occupancy "
+                             "(valu_issue.wave_cycles_waiting_frac)")
     return r
 
 
@@ -884,6 +899,7 @@ def main():
                        "sites_per_doc": N, "K": K, "V": V, "alpha": ALPHA, "beta": BETA,
                        "label_mask": "dense" if live == K else "sparse (%.2f live topics per doc)" % live,
                        "kernel": "sparse" if sampler.live_off is not None else "dense",
+                       "n_kw_rows": rows_description(sampler),
                        "sites_per_sweep": total_sites, "timed_seconds": dt,
                        "exchange": sampler.exchange_description() if world > 1 else "none (single GPU: the commit log is "
                                    "folded straight into n_kw)",
@@ -923,7 +939,7 @@ def main():
                 e = {"workload": i2["desc"], "value": v2, "unit": "Mtokens/s", "steps": st, "warmup": wu,
                      "ms_per_step": dt2 / st * 1e3, "timed_seconds": dt2, "docs": i2["docs_local"], "sites_per_sweep": s2.S,
                      "K": i2["K"], "V": i2["V"], "kernel": "sparse" if s2.live_off is not None else "dense",
-                     "kernel_ms": k2}
+                     "n_kw_rows": rows_description(s2), "kernel_ms": k2}
                 measured[wname] = dict(kernel_ms=k2, sites=s2.S, docs=i2["docs_local"], live=i2["live_topics"],
                                        shared=s2._counts.numel() * 4)
                 if wname == "abstracts":

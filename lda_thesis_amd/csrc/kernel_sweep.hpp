@@ -153,10 +153,13 @@ __device__ __forceinline__ void count_update(int (*s_ndk)[256], int (*s_nkc)[256
 // load paths met in a phi, the record's fields had to be COPIED into the registers of the other path, the copy needs the
 // value, and the compiler put s_waitcnt vmcnt(0) right behind the load -- i.e. behind the row prefetch issued just before.
 // R16: rows of n_kw whose counts fit 16 bits are read from their 16-bit image P.n_kw16 (llda_pack_rows16) -- half the
-// bytes through the fabric for exactly the rows that miss the L2 (the rare words); which sites do so is bit 31 of their
-// csc_pos, so the choice is known when the row is prefetched.  A 16-bit row arrives as two 16-byte chunks per lane
-// (slots 0..7, 8..15, two per register); the site's own count is removed from the packed register, and the
-// conversion to fp32 reads the halves directly (SDWA), so a 16-bit site costs no instruction more than a 32-bit one.
+// bytes through the fabric for exactly the rows that miss the L2 (the rare words).  Which sites do so is bit 31 of their
+// csc_pos and WHERE their row starts is llda_sweep_args.site_row (read instead of the word id), so the choice costs the
+// prefetch nothing.  A 16-bit row arrives as two 16-byte chunks per lane (slots 0..7, 8..15, two per register), the
+// conversion to fp32 reads the halves directly (SDWA), and the site's own count leaves the fp32 values through the slot
+// index.  What a 16-bit site costs over a 32-bit one: the second conversion arm when the two documents of a wavefront
+// differ (47 % of the sites of configs[3]) and the branch around the third and fourth chunk load.  This is the kernel the
+// K = 512 / 1024 lines of the bench run on (the int32 form is bound by the fabric, this one by issue).
 template <int G, int T, bool HAS_TAIL, bool DENSE, bool LOGGED, bool REC = false, bool R16 = false>
 __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : LLDA_WAVES) llda_sweep_kernel(const KParams P)
 {
