@@ -180,9 +180,25 @@ template <int G>
 __device__ __forceinline__ uint64_t draw_fast_dense_f32(const float (&qw)[16], float u, float margin_rel, int lig, int lane, int &zn)
 {
     static_assert(G == 32 || G == 64, "one or two documents per wavefront");
-    const float X = group_scan_f32<G>(qw[15], lig);
+    // inclusive scan over the lanes of the group: four row_shr steps inside the rows of 16, then the last lane of row 0 (2) into
+    // row 1 (3), and for 64 lanes the last lane of row 1 into rows 2 and 3.  The cross-row steps are ONE instruction each -- a DPP
+    // add whose row mask leaves the other rows alone (the compiler's form is v_mov 0 + v_mov_dpp + v_add: it does not fold a
+    // partial row mask into a floating-point add) -- written by hand together with the wait states a DPP source and a v_readlane
+    // of a freshly written register need (the hazard recogniser does not look inside inline assembly).
+    float X = qw[15];
+    X += dpp_f32<DPP_ROW_SHR + 1>(X);
+    X += dpp_f32<DPP_ROW_SHR + 2>(X);
+    X += dpp_f32<DPP_ROW_SHR + 4>(X);
+    X += dpp_f32<DPP_ROW_SHR + 8>(X);
+    if constexpr (G == 32) {
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1" : "+v"(X));
+    } else {
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" : "+v"(X));
+    }
     const float tot = bcast_last_f32<G>(X, lane);
-    const float prev = dpp_f32<DPP_WAVE_SHR1>(X);
+    // X of the lane below; 0.0 shifted into lane 0 (bound_ctrl: no register to preset)
+    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), DPP_WAVE_SHR1, 0xF, 0xF, true));
     const float tg = u * tot - (lig ? prev : 0.0f);
     const float margin = tot * margin_rel;
     const float lo = tg - margin, hi = tg + margin;

@@ -424,20 +424,41 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
             // scalars are in registers): the LDS state is final long before the next site's scores read it.
             // Both updates usually belong to different lanes and are done in ONE masked pass; a second pass runs
             // only for groups where the same lane owns both.
+            bool more;
             {
                 int ln, sn;
                 lane_slot_of<G, T>(zn, ln, sn);
                 lane_slot_of<G, T>(nxt.zo, nxt.lo, nxt.so);                  // (kept for the next site's removal from x)
                 const int lo2 = nxt.lo, so2 = nxt.so;
-                const bool more = n + 1 < len;
-                const bool own_new = lig == ln, own_old = more && lig == lo2;
-                const uint64_t both_w = __ballot(own_new) & __ballot(more) & __ballot(lig == lo2);   // (taken here: the compares' own masks)
-                if (__builtin_expect(own_new || own_old, 1))                      // (some lane of the wavefront always is)
-                    count_update(s_ndk, s_nkc, s_pa, own_new ? sn : so2, tid, alpha32, vbeta32, own_new ? f : -nxt.f);
-                // (rare blocks behind ONE scalar branch on the ballot: entering and leaving a divergent region costs four
-                // scalar instructions whether or not a lane takes it, and the scalar unit's cycles are not hidden here)
-                if (__builtin_expect(both_w != 0, 0)) {
-                    if (own_new && own_old) count_update(s_ndk, s_nkc, s_pa, so2, tid, alpha32, vbeta32, -nxt.f);
+                if constexpr (INDEXED) {
+                    // The three compares by hand, their lane masks as scalars: the compiler keeps such a mask as a per-lane bool
+                    // and, where a ballot of a COMBINATION is wanted, rebuilds it through v_cndmask + v_cmp_ne.  more = the
+                    // document has another site (also the site loop's exit test: returned).  (16-slot kernels with one or two
+                    // documents per wavefront only: the 16-lane K = 256 kernel ran 6 % SLOWER with this shorter sequence --
+                    // A/B on one box, same instruction counts elsewhere -- and keeps the compiler's.)
+                    uint64_t m_new, m_old_lane, m_more;
+                    asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m_new) : "v"(lig), "v"(ln));
+                    asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m_old_lane) : "v"(lig), "v"(lo2));
+                    asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m_more) : "v"(n + 1), "v"(len));
+                    const uint64_t m_old = m_old_lane & m_more, both_w = m_new & m_old;
+                    more = __builtin_amdgcn_inverse_ballot_w64(m_more);
+                    const bool own_new = __builtin_amdgcn_inverse_ballot_w64(m_new);
+                    if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_new | m_old), 1))   // (some lane of the wavefront always is)
+                        count_update(s_ndk, s_nkc, s_pa, own_new ? sn : so2, tid, alpha32, vbeta32, own_new ? f : -nxt.f);
+                    // (rare blocks behind ONE scalar branch on the ballot: entering and leaving a divergent region costs four
+                    // scalar instructions whether or not a lane takes it, and the scalar unit's cycles are not hidden here)
+                    if (__builtin_expect(both_w != 0, 0)) {
+                        if (__builtin_amdgcn_inverse_ballot_w64(both_w)) count_update(s_ndk, s_nkc, s_pa, so2, tid, alpha32, vbeta32, -nxt.f);
+                    }
+                } else {
+                    more = n + 1 < len;
+                    const bool own_new = lig == ln, own_old = more && lig == lo2;
+                    const uint64_t both_w = __ballot(own_new) & __ballot(more) & __ballot(lig == lo2);   // (taken here: the compares' own masks)
+                    if (__builtin_expect(own_new || own_old, 1))                      // (some lane of the wavefront always is)
+                        count_update(s_ndk, s_nkc, s_pa, own_new ? sn : so2, tid, alpha32, vbeta32, own_new ? f : -nxt.f);
+                    if (__builtin_expect(both_w != 0, 0)) {
+                        if (own_new && own_old) count_update(s_ndk, s_nkc, s_pa, so2, tid, alpha32, vbeta32, -nxt.f);
+                    }
                 }
             }
 #ifndef ABL_NOCOMMIT
@@ -447,24 +468,19 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)n * 4u), cur.v, cur.f, cur.zo, cur.zn,
                                         R16 ? cur.c & 0x7fffffff : cur.c, KP);
 #endif
+            return more;
         };
         // (a short document LEAVES the loop after its last site: were the remaining sites merely skipped, the
         // compiler would have to keep the unmodified row of the skipped sites alive for the next trip round the loop,
         // and the in-place update would need a copy of the tuple)
         if constexpr (INDEXED) {
             for (int n = n0;; n += 6) {                         // len > n0 here
-                site(n, R0, R1, R2, xn, xm);
-                if (n + 1 >= len) break;
-                site(n + 1, R1, R2, R0, xm, xn);
-                if (n + 2 >= len) break;
-                site(n + 2, R2, R0, R1, xn, xm);
-                if (n + 3 >= len) break;
-                site(n + 3, R0, R1, R2, xm, xn);
-                if (n + 4 >= len) break;
-                site(n + 4, R1, R2, R0, xn, xm);
-                if (n + 5 >= len) break;
-                site(n + 5, R2, R0, R1, xm, xn);
-                if (n + 6 >= len) break;
+                if (!site(n, R0, R1, R2, xn, xm)) break;                 // (site returns "the document has another site")
+                if (!site(n + 1, R1, R2, R0, xm, xn)) break;
+                if (!site(n + 2, R2, R0, R1, xn, xm)) break;
+                if (!site(n + 3, R0, R1, R2, xm, xn)) break;
+                if (!site(n + 4, R1, R2, R0, xn, xm)) break;
+                if (!site(n + 5, R2, R0, R1, xm, xn)) break;
             }
         } else {
             for (int n = n0;; n += 3) {
