@@ -127,6 +127,20 @@ def main(tag, sub=None):
     for extra in os.listdir(src):
         if extra.startswith(("bench_", "gather_", "abl_")) and extra != "bench_default.json" and not extra.endswith(".err"):
             shutil.copy(os.path.join(src, extra), os.path.join(prof, "%s_%s" % (tag, extra)))
+    # the int32 ablation of the timed line (tools/profile.sh: LLDA_BENCH_ROWS16=off)
+    i32 = os.path.join(src, "int32")
+    if os.path.exists(os.path.join(i32, "bench.json")):
+        shutil.copy(os.path.join(i32, "bench.json"), os.path.join(prof, "%s_int32_bench.json" % tag))
+        for tagp in ("fetch", "write", "sq", "l2", "ta"):
+            f = os.path.join(i32, "pmc", "pmc_%s.csv" % tagp)
+            if os.path.exists(f):
+                shutil.copy(f, os.path.join(prof, "%s_int32_pmc_%s.csv" % (tag, tagp)))
+        l32 = json.loads(open(os.path.join(i32, "bench.json")).read().strip().split("\n")[-1])
+        r = l32.get("roofline", {})
+        out += ["", "## the timed line with int32 rows (`LLDA_BENCH_ROWS16=off python bench.py --no-cpu --no-extras`)", "",
+                "* %.0f M sites/s, %.2f ms per sweep, kernel `%s` %.2f ms; fabric %.2f TB/s = %.2f of 8 TB/s, binding roof: %s" %
+                (l32["value"], l32["ms_per_step"], r.get("kernel", ""), r.get("kernel_ms", 0.0), r.get("achieved", 0.0) / 1e3,
+                 r.get("frac", 0.0), r.get("binding_roof", ""))]
     open(os.path.join(prof, "%s_summary.md" % tag), "w").write("\n".join(out) + "\n")
     print("\n".join(out))
 

@@ -46,4 +46,9 @@ python tools/bench_cascade.py --test-it 150 > $OUT/bench_cascade.json 2> /dev/nu
 python tools/bench_foldin.py --it 150 > $OUT/bench_foldin.json 2> /dev/null
 timeout 900 python bench.py --gpus 2 --dist-backend gloo --one-device --steps 5 --warmup 2 --no-extras > $OUT/bench_2rank_gloo_one_device.json 2> /dev/null
 timeout 600 python bench.py --make-checksums 64 > $OUT/checksums_synth2.json 2> /dev/null
+# the timed line with int32 rows (the 16-bit image off): the fabric-bound form of the kernel, with its counters
+mkdir -p $OUT/int32
+LLDA_BENCH_ROWS16=off timeout 900 python bench.py --no-cpu --no-extras --pmc-keep $OUT/int32/pmc > $OUT/int32/bench.json 2> /dev/null
+# int32 rows against 16-bit rows on this library, states compared (tools/abl_rows16.py)
+timeout 900 python tools/abl_rows16.py synth2 k1024 synth2_hostile zipf_v20k zipf_v300k 2>&1 | grep "|" > $OUT/abl_rows16.txt
 du -sh $OUT; ls $OUT $OUT/pmc
