@@ -103,7 +103,8 @@ typedef struct llda_sweep_args {
     int32_t        *status;      /* [dev] optional (may be NULL), int32[4]: word 0 bit 0 is set when a site had no
                                     topic with positive probability (the reference would raise);
                                     bit 1 (informational) when some site took the exact tier;
-                                    bit 2 when llda_pack_rows16 met a count outside 0 .. 65535 in a flagged row;
+                                    bit 2 when llda_pack_rows16 met a count outside 0 .. 65535 in a flagged row, or the
+                                    four-wave 16-bit-row kernel an entry of n_dk above 65535 (max_doc_tokens was not a bound);
                                     word 1 += sites the fp32 tier was unsure about, word 2 += sites that
                                     reached the exact tier (statistics)                           */
     int64_t  D;                  /* local documents                                            */
@@ -119,7 +120,8 @@ typedef struct llda_sweep_args {
                                     that keeps nothing of the row in registers, -4 on the register kernel with
                                     LDS copies of the counts whatever max_doc_tokens says, -5 on the fp64 register
                                     kernel without its fp32 tier, -6 the fp32 tier with fp64 factors in LDS even when
-                                    scratch is there, -7 with fp32 factors only whenever scratch is there                     */
+                                    scratch is there, -7 with fp32 factors only whenever scratch is there; -8 (with n_kw16)
+                                    production margins on the three-wave form of the 16-bit-row kernel                     */
     double   alpha, beta;        /* priors (LabeledLDA.py:55-56)                               */
     uint64_t seed;               /* RNG key                                                    */
     uint32_t sweep;              /* RNG counter word 3                                         */
@@ -138,9 +140,12 @@ typedef struct llda_sweep_args {
                                     fp64 factors in LDS (14 % slower there)                                                 */
     int64_t  scratch_bytes;      /* size of scratch                                                        */
     int32_t  live_max;           /* largest number of allowed topics of any document                  */
-    int32_t  max_doc_tokens;     /* (ABI 13) optional hint, 0 = unknown: an upper bound of the tokens (sum of freq) of any
-                                    document of the call.  Wide layouts only: below 32 768 the kernel keeps the document's
-                                    count CHANGES as int16 in LDS instead of copies of the counts (more wavefronts per CU) */
+    int32_t  max_doc_tokens;     /* (ABI 13) optional hint, 0 = unknown: an upper bound of every entry of n_dk of the call --
+                                    the tokens (sum of freq, plus any phantom counts) of its largest document.  Wide layouts:
+                                    below 32 768 the kernel keeps the document's count CHANGES as int16 in LDS instead of copies
+                                    of the counts (more wavefronts per CU).  With n_kw16: below 65 536 the kernel packs n_dk with
+                                    its sweep-start value into one LDS word and runs FOUR waves per SIMD instead of three
+                                    (debug_margin -8: three regardless); an entry above the bound sets status bit 2         */
     /* optional commit log (both non-NULL): instead of two int32 atomics on n_kw_delta per changed site the
      * kernels store ONE word (old position | new position << 16) at the site's place in WORD-major order;
      * llda_commit_log then folds the log into the counts word by word without global atomics.  (No-return

@@ -298,10 +298,22 @@ __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uin
 //           correctly rounded and q1 faithful, q2 = RN(q1 + (w - S q1) y) is the correctly rounded
 //           quotient; llda_selftest_div checks it against the hardware division), keyed draw.
 // Returns the chosen device position or -1.
-template <int G, int T, bool HAS_TAIL, bool DENSE>
+// W4: s_ndk holds n_dk | sweep-start n_dk << 16 and s_nkc is really the workgroup's copy of the sweep-start n_k, indexed by
+// device position (kernel_sweep.hpp, count_update_w4)
+template <int G, int T, bool HAS_TAIL, bool DENSE, bool W4 = false>
 __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, const int (*s_nkc)[256], int tid,
                                        uint32_t mask, double u, int lig, int lane, const KParams *P)
 {
+    // the document's n_dk and the n_k it sees at slot s
+    auto nd_of = [&](int s) { return W4 ? s_ndk[s][tid] & 0xffff : s_ndk[s][tid]; };
+    auto nk_of = [&](int s) {
+        if constexpr (W4) {
+            const int w = s_ndk[s][tid];
+            return ((const int *)s_nkc)[pos_of<G, T>(lig, s)] + (w & 0xffff) - (int)((uint32_t)w >> 16);
+        } else {
+            return s_nkc[s][tid];
+        }
+    };
     // Tier 1 is unrolled and lives in registers (the kernel is LDS-limited to 3 waves per SIMD, which leaves 168
     // VGPRs: scratch round trips here stalled the whole wave); the exact tier, ~1e-9 per site, stays rolled over
     // a scratch array.
@@ -317,11 +329,11 @@ __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, co
 #pragma unroll
         for (int s = 0; s < T; ++s) {
             // 1/den to within 2^-50: hardware estimate + two Newton steps (tier 1 only needs a few 2^-53)
-            const double den = (double)s_nkc[s][tid] + vbeta;
+            const double den = (double)nk_of(s) + vbeta;
             double y = __builtin_amdgcn_rcp(den);
             y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
             y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
-            const double ws = ((double)s_ndk[s][tid] + alpha) * (((double)x[s] + beta) * y);
+            const double ws = ((double)nd_of(s) + alpha) * (((double)x[s] + beta) * y);
             run = run + (((lmask >> s) & 1u) ? ws : 0.0);
             w[s] = run;
         }
@@ -354,7 +366,7 @@ __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, co
 #pragma unroll 1
     for (int s = 0; s < T; ++s) {
         // prob = lab * a * (num_b / den_b)   (LabeledLDA.py:113-116)
-        const double ws = ((double)s_ndk[s][tid] + alpha) * (((double)x[s] + beta) / ((double)s_nkc[s][tid] + vbeta));
+        const double ws = ((double)nd_of(s) + alpha) * (((double)x[s] + beta) / ((double)nk_of(s) + vbeta));
         const double v = ((lmask >> s) & 1u) ? ws : 0.0;
         w[s] = v;
         if (HAS_TAIL && s == P->tail_row && leaf == P->last_leaf) tv = v;

@@ -146,6 +146,17 @@ __device__ __forceinline__ void count_update(int (*s_ndk)[256], int (*s_nkc)[256
     s_pa[slot][tid] = tier0_factor(nd, nk, alpha32, vbeta32);
 }
 
+// W4 form (four waves per SIMD): n_dk and its sweep-start value share one LDS word (n_dk | start << 16; both below 2^16, checked
+// when the document is staged), the n_k the document sees is the workgroup's copy of the sweep-start n_k plus the difference
+__device__ __forceinline__ void count_update_w4(int (*s_ndk)[256], const int *s_nk0, float (*s_pa)[256], int slot, int pos,
+                                                int tid, float alpha32, float vbeta32, int df)
+{
+    const int w = s_ndk[slot][tid] + df;                              // (0 <= n_dk + df < 2^16: no carry into the upper half)
+    s_ndk[slot][tid] = w;
+    const int nd = w & 0xffff, nk = s_nk0[pos] + nd - (int)((uint32_t)w >> 16);
+    s_pa[slot][tid] = tier0_factor(nd, nk, alpha32, vbeta32);
+}
+
 // LOGGED: the commit goes to the word-major commit log (csc_pos / commit_log non-NULL) -- a compile-time fact, so the
 // instantiation carries neither the atomics path nor the pointer tests (the kernel is VALU-issue bound and short of
 // SGPRs: every uniform test in the site loop costs).
@@ -160,19 +171,28 @@ __device__ __forceinline__ void count_update(int (*s_ndk)[256], int (*s_nkc)[256
 // index.  What a 16-bit site costs over a 32-bit one: the second conversion arm when the two documents of a wavefront
 // differ (47 % of the sites of configs[3]) and the branch around the third and fourth chunk load.  This is the kernel the
 // K = 512 / 1024 lines of the bench run on (the int32 form is bound by the fabric, this one by issue).
-template <int G, int T, bool HAS_TAIL, bool DENSE, bool LOGGED, bool REC = false, bool R16 = false>
-__global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : LLDA_WAVES) llda_sweep_kernel(const KParams P)
+// W4: the 16-bit-row kernel at FOUR waves per SIMD (it is bound by instruction issue with a SIMD idle in a fifth of its cycles at
+// three: DESIGN.md section 4.1) -- 36 / 40 KB of LDS per workgroup (count_update_w4) and at most 128 VGPRs: ONE row tuple (the row
+// dies with its conversion; the 0.6 % of the sites that go on to the cold tiers fetch theirs again).  Documents of at most 65 535
+// tokens (llda_sweep_args.max_doc_tokens).
+template <int G, int T, bool HAS_TAIL, bool DENSE, bool LOGGED, bool REC = false, bool R16 = false, bool W4 = false>
+__global__ void __launch_bounds__(256, W4 ? 4 : (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : LLDA_WAVES) llda_sweep_kernel(const KParams P)
 {
     static_assert(!R16 || (G >= 32 && T == 16 && DENSE && LOGGED && !REC), "16-bit rows: the dense 16-slot kernel with the commit log");
+    static_assert(!W4 || R16, "four waves: the 16-bit-row kernel");
     constexpr int KP = G * T;
     constexpr int GPB = 256 / G;              // lane groups (documents in flight) per workgroup
     __shared__ int s_nk[KP];                  // workgroup accumulator of the n_k changes
-    __shared__ int s_ndk[T][256];             // n_dk row of the document
-    __shared__ int s_nkc[T][256];             // n_k as the document sees it
+    __shared__ int s_ndk[T][256];             // n_dk row of the document (W4: | sweep-start n_dk << 16)
+    __shared__ int s_nkc[W4 ? 1 : T][256];    // n_k as the document sees it (W4: derived, see s_nk0)
+    __shared__ int s_nk0[W4 ? KP : 1];        // W4: the sweep-start n_k, one copy per workgroup
     __shared__ float s_pa[T][256];            // tier-0 factor fl32((n_dk + alpha) / (n_k + V*beta))
 
     const int tid = threadIdx.x;
     for (int i = tid; i < KP; i += 256) s_nk[i] = 0;
+    if constexpr (W4) {
+        for (int i = tid; i < KP; i += 256) s_nk0[i] = P.n_k[i];
+    }
     __syncthreads();
 
     const int lane = tid & 63;
@@ -202,11 +222,20 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
             int r[T], k[T];
             load_lane_row<G, T>(ndk_row, lig, r);
             load_lane_row<G, T>(P.n_k, lig, k);
+            [[maybe_unused]] int big = 0;
 #pragma unroll
             for (int s = 0; s < T; ++s) {
-                s_ndk[s][tid] = r[s];
-                s_nkc[s][tid] = k[s];                              // sweep-start n_k
+                if constexpr (W4) {
+                    s_ndk[s][tid] = r[s] | (r[s] << 16);
+                    big |= r[s];
+                } else {
+                    s_ndk[s][tid] = r[s];
+                    s_nkc[s][tid] = k[s];                          // sweep-start n_k
+                }
                 s_pa[s][tid] = tier0_factor(r[s], k[s], alpha32, vbeta32);
+            }
+            if constexpr (W4) {                                    // a count that does not fit the packed word: the caller's
+                if (((uint32_t)big >> 16) && P.status) atomicOr(P.status, 4);   // max_doc_tokens was not a bound (status bit 2)
             }
         }
         // (DENSE: every slot of every lane is an allowed topic -- a constant, not a register)
@@ -257,7 +286,8 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         // for the 16 compare-free selects of onehot_add_to.  The site loop is then unrolled by six (two tuples x
         // three scalar sets).
         constexpr bool INDEXED = G >= 32 && T == 16;
-        int xn[T], xm[INDEXED ? T : 1];
+        constexpr int XM = INDEXED && !W4 ? T : 1;      // the second row tuple (W4: none)
+        int xn[T], xm[XM];
         // the row of word v into xl; c = the site's csc_pos (bit 31: 16-bit row, slots 8j .. 8j+7 of all lanes contiguous)
         auto load_word_row = [&](int (&xl)[T], const int v, const int c) {
             if constexpr (R16) {
@@ -285,13 +315,16 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         {   // site 0 leaves its topic (LabeledLDA.py:109-111); later sites do so at the end of the previous site
             lane_slot_of<G, T>(R0.zo, R0.lo, R0.so);
-            if (lig == R0.lo) count_update(s_ndk, s_nkc, s_pa, R0.so, tid, alpha32, vbeta32, -R0.f);
+            if (lig == R0.lo) {
+                if constexpr (W4) count_update_w4(s_ndk, s_nk0, s_pa, R0.so, R0.zo, tid, alpha32, vbeta32, -R0.f);
+                else count_update(s_ndk, s_nkc, s_pa, R0.so, tid, alpha32, vbeta32, -R0.f);
+            }
         }
 
         const uint64_t lig0_w = __ballot(lig == 0);               // (uniform) first lanes of the wavefront's groups
         // one site: `cur` holds its scalars, `nxt` those of site n+1, `prv` those of site n-1 (committed here, then
         // reloaded with the scalars of site n+2)
-        auto site = [&](const int n, SiteRegs &cur, SiteRegs &nxt, SiteRegs &prv, int (&xc)[T], int (&xnx)[INDEXED ? T : 1]) {
+        auto site = [&](const int n, SiteRegs &cur, SiteRegs &nxt, SiteRegs &prv, int (&xc)[T], int (&xnx)[XM]) {
             const int f = cur.f, zo = cur.zo;
             // the cached tier-0 factors of the lane, fetched from LDS first thing: nothing below depends on them until
             // the scores, and the kernel is bound by the latency of one wavefront's instruction stream (39 % of the
@@ -356,7 +389,7 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                 // written to a second array so that the next row can be loaded into xn right away
                 onehot_add_to<T>(x, xc, (lig == cur.lo) ? (1u << cur.so) : 0u, f);   // m = -1 at the slot: += (-1) * f
             }
-            int (&xl)[T] = *(int (*)[T])(INDEXED ? (void *)&xnx : (void *)&xc);     // where the next row goes
+            int (&xl)[T] = *(int (*)[T])(INDEXED && !W4 ? (void *)&xnx : (void *)&xc);     // where the next row goes (W4: one tuple)
 #ifndef ABL_NOCOMMIT
             if (lig == 0 && n > n0)
                 commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn,
@@ -378,19 +411,22 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
             // (tier 0 always names a position), so its test lives behind the same rare branch
             auto cold = [&]() {
                 int x_c[T];
+                if constexpr (W4) load_word_row(x_c, cur.v, cur.c);     // (the row's registers went to the next site's prefetch)
+                else {
 #pragma unroll
-                for (int s = 0; s < T; ++s) x_c[s] = x[s];
+                    for (int s = 0; s < T; ++s) x_c[s] = x[s];
+                }
                 if constexpr (R16) {
                     if (cur.c < 0) {
 #pragma unroll
-                        for (int s = 0; s < T; ++s) x_c[s] = (int)((s & 1) ? (uint32_t)x[s >> 1] >> 16 : (uint32_t)x[s >> 1] & 0xffffu);
+                        for (int s = T - 1; s >= 0; --s) x_c[s] = (int)((s & 1) ? (uint32_t)x_c[s >> 1] >> 16 : (uint32_t)x_c[s >> 1] & 0xffffu);
                     }
                     if (lig == cur.lo) x_c[cur.so] -= f;              // (x is the row as it came: see above)
                 }
                 // (the callee reads the parameters from the kernel-argument segment: taking &P would force a scratch
                 // copy of all of P and put its pointers into VGPRs)
-                zn = cold_tiers<G, T, HAS_TAIL, DENSE>(s_ndk, x_c, s_nkc, tid, mask, uniform53(ra, rb), lig, lane,
-                                                       (const KParams *)__builtin_amdgcn_kernarg_segment_ptr());
+                zn = cold_tiers<G, T, HAS_TAIL, DENSE, W4>(s_ndk, x_c, W4 ? (const int (*)[256])s_nk0 : s_nkc, tid, mask, uniform53(ra, rb),
+                                                           lig, lane, (const KParams *)__builtin_amdgcn_kernarg_segment_ptr());
                 if (__builtin_expect(zn < 0, 0)) {
                     zn = zo;
                     if (lig == 0 && P.status) atomicOr(P.status, 1);    // no topic with positive probability
@@ -443,12 +479,18 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
                     const uint64_t m_old = m_old_lane & m_more, both_w = m_new & m_old;
                     more = __builtin_amdgcn_inverse_ballot_w64(m_more);
                     const bool own_new = __builtin_amdgcn_inverse_ballot_w64(m_new);
-                    if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_new | m_old), 1))   // (some lane of the wavefront always is)
-                        count_update(s_ndk, s_nkc, s_pa, own_new ? sn : so2, tid, alpha32, vbeta32, own_new ? f : -nxt.f);
+                    if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_new | m_old), 1)) { // (some lane of the wavefront always is)
+                        if constexpr (W4) count_update_w4(s_ndk, s_nk0, s_pa, own_new ? sn : so2, own_new ? zn : nxt.zo, tid, alpha32,
+                                                          vbeta32, own_new ? f : -nxt.f);
+                        else count_update(s_ndk, s_nkc, s_pa, own_new ? sn : so2, tid, alpha32, vbeta32, own_new ? f : -nxt.f);
+                    }
                     // (rare blocks behind ONE scalar branch on the ballot: entering and leaving a divergent region costs four
                     // scalar instructions whether or not a lane takes it, and the scalar unit's cycles are not hidden here)
                     if (__builtin_expect(both_w != 0, 0)) {
-                        if (__builtin_amdgcn_inverse_ballot_w64(both_w)) count_update(s_ndk, s_nkc, s_pa, so2, tid, alpha32, vbeta32, -nxt.f);
+                        if (__builtin_amdgcn_inverse_ballot_w64(both_w)) {
+                            if constexpr (W4) count_update_w4(s_ndk, s_nk0, s_pa, so2, nxt.zo, tid, alpha32, vbeta32, -nxt.f);
+                            else count_update(s_ndk, s_nkc, s_pa, so2, tid, alpha32, vbeta32, -nxt.f);
+                        }
                     }
                 } else {
                     more = n + 1 < len;
@@ -473,7 +515,13 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         // (a short document LEAVES the loop after its last site: were the remaining sites merely skipped, the
         // compiler would have to keep the unmodified row of the skipped sites alive for the next trip round the loop,
         // and the in-place update would need a copy of the tuple)
-        if constexpr (INDEXED) {
+        if constexpr (W4) {
+            for (int n = n0;; n += 3) {                         // one row tuple: unrolled by the three scalar sets only
+                if (!site(n, R0, R1, R2, xn, xm)) break;
+                if (!site(n + 1, R1, R2, R0, xn, xm)) break;
+                if (!site(n + 2, R2, R0, R1, xn, xm)) break;
+            }
+        } else if constexpr (INDEXED) {
             for (int n = n0;; n += 6) {                         // len > n0 here
                 if (!site(n, R0, R1, R2, xn, xm)) break;                 // (site returns "the document has another site")
                 if (!site(n + 1, R1, R2, R0, xm, xn)) break;
@@ -498,7 +546,7 @@ __global__ void __launch_bounds__(256, (T <= 12 && G >= 16) ? LLDA_WAVES + 1 : L
         load_lane_row<G, T>(ndk_row, lig, old);
 #pragma unroll
         for (int s = 0; s < T; ++s) {
-            cur[s] = s_ndk[s][tid];
+            cur[s] = W4 ? s_ndk[s][tid] & 0xffff : s_ndk[s][tid];
             const int dl = cur[s] - old[s];
             if (dl) atomicAdd(&s_nk[pos_of<G, T>(lig, s)], dl);
         }

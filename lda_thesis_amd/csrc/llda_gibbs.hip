@@ -33,6 +33,9 @@
 //   kernel_wide.hpp     the general path for K with more than 8 pairwise leaves (one wavefront per document)
 //   this file           host side: layout (llda_layout_init), dispatch, C entry points
 #include <hip/hip_runtime.h>
+#ifndef ABL_EXTRA_LDS_BYTES
+#define ABL_EXTRA_LDS_BYTES 0      // occupancy ablation: dynamic LDS nobody uses (tools: -DABL_EXTRA_LDS_BYTES=20000 -> 2 workgroups per CU)
+#endif
 #include <stdint.h>
 #include <math.h>
 #include <string.h>
@@ -177,7 +180,8 @@ int launch_sweep(const KParams &P, bool has_tail, bool fast, bool dense, int64_t
     }
     if constexpr (G >= 32 && T == 16) {
         if (P.n_kw16) {                                 // (llda_sweep checked: fast, dense, commit log)
-            hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true, true, false, true>), grid, block, 0, st, P);
+            if (P.w4) hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true, true, false, true, true>), grid, block, 0, st, P);
+            else hipLaunchKernelGGL((llda_sweep_kernel<G, T, false, true, true, false, true>), grid, block, ABL_EXTRA_LDS_BYTES, st, P);
             const hipError_t e = hipGetLastError();
             return e == hipSuccess ? LLDA_OK : hip_fail(e);
         }
@@ -457,8 +461,8 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     const bool dense = fast && a->dense_mask != 0 && L.K == L.KP;
     // debug_margin: 0 = production margins; n > 0 = 2^-n (wider: more fallbacks); -1 = always exact tier;
     // -2 = no fp32 tier
-    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 || a->debug_margin == -3 || a->debug_margin == -4 || a->debug_margin == -5 || a->debug_margin == -6 || a->debug_margin == -7 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
-    P.margin0_rel = a->debug_margin == 0 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
+    P.margin_rel = a->debug_margin == 0 || a->debug_margin == -2 || a->debug_margin == -3 || a->debug_margin == -4 || a->debug_margin == -5 || a->debug_margin == -6 || a->debug_margin == -7 || a->debug_margin == -8 ? 0x1p-40 : (a->debug_margin > 0 ? ldexp(1.0, -a->debug_margin) : 2.0);
+    P.margin0_rel = a->debug_margin == 0 || a->debug_margin == -8 ? (float)LLDA_MARGIN0 : (a->debug_margin > 0 && a->debug_margin < 16 ? ldexpf(1.0f, -a->debug_margin) : 2.0f);
     hipStream_t st = (hipStream_t)stream;
 
     if (L.wide && fast && a->dense_mask == 0 && a->live_off && a->live_pos && a->live_max >= 1 &&
@@ -600,6 +604,8 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         if ((reinterpret_cast<uintptr_t>(a->n_kw16) | reinterpret_cast<uintptr_t>(a->n_kw)) & 15) return LLDA_E_BAD_ARG;
         P.n_kw16 = a->n_kw16;
         P.site_row = a->site_row;
+        // four waves per SIMD: n_dk and its sweep-start value share an LDS word (debug_margin -8: the three-wave form regardless)
+        P.w4 = a->max_doc_tokens > 0 && a->max_doc_tokens < 65536 && a->debug_margin != -8;
     }
     switch (L.G) {
     case 8: return dispatch_sweep_T<8>(L.T, P, has_tail, fast, dense, blocks, st);

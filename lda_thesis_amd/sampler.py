@@ -228,6 +228,10 @@ class GibbsSampler(object):
             self.row16 = self.n_kw16 = None
             return
         self.site_row = row.to(torch.int32).contiguous()
+        # llda_sweep_args.max_doc_tokens: below 2^16 the 16-bit-row kernel packs n_dk with its sweep-start value and runs four
+        # waves per SIMD.  The row sums of n_dk bound every entry and never change (a site moves its count between two topics).
+        if not self.max_doc_tokens and self.D:
+            self.max_doc_tokens = int(min(int(self.n_dk.sum(dim=1, dtype=torch.int64).max().item()), 2 ** 31 - 1))
 
     def _make_exchange_rows(self):
         """Exchange layout of the per-sweep count deltas when every rank folds a commit log: one row per word plus
@@ -509,8 +513,8 @@ class GibbsSampler(object):
         if st & 1:
             raise ValueError("a site had no topic with positive probability (pvals would be NaN)")
         if st & 4:
-            raise RuntimeError("a count left 0 .. 65535 in a row of n_kw that is read as 16 bits: the counts handed to the "
-                               "sampler do not belong to its corpus")
+            raise RuntimeError("a count left 0 .. 65535 where it is kept in 16 bits (a flagged row of n_kw, or an entry of n_dk "
+                               "under the four-wave kernel): the counts handed to the sampler do not belong to its corpus")
 
     # ------------------------------------------------------------------ read-outs
     def loglik_sum(self):

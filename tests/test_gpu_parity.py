@@ -378,6 +378,91 @@ def test_16_bit_rows_equal_the_c_oracle(c_oracle, K, margin):
     assert torch.equal(r.z, s.z) and torch.equal(r._counts, s._counts) and torch.equal(r.n_dk, s.n_dk)
 
 
+def _rows16_corpus_short_docs(K, seed):
+    """dense-mask corpus for the FOUR-wave form of the 16-bit-row kernel: every document below 2^16 tokens (n_dk and its
+    sweep-start value share an LDS word there), words 0 and 3 above 65535 tokens in total (int32 rows, entries above 2^16 with
+    all of word 0 in one topic at the start), word 1 just below, the rest rare; ragged documents from one site to 70."""
+    rng = np.random.default_rng(seed)
+    D, V = 900, 120
+    lens = rng.integers(1, 71, size=D)
+    lens[:3] = (1, 2, 70)
+    doc_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    S = int(doc_off[-1])
+    p = 1.0 / np.arange(1, V + 1) ** 1.1
+    word = rng.choice(V, size=S, p=p / p.sum()).astype(np.int32)
+    word[:8] = (0, 1, 2, 3, 0, 1, 2, 3)
+    freq = rng.integers(1, 6, size=S).astype(np.int32)
+    hot = (word == 0) | (word == 3)
+    freq[hot] = rng.integers(200, 900, size=int(hot.sum())).astype(np.int32)
+    z = rng.integers(0, K, size=S).astype(np.int64)
+    z[word == 0] = 3
+    i1 = np.nonzero(word == 1)[0]
+    freq[i1] = 1
+    freq[i1[0]] += 65535 - int(freq[i1].sum())                            # word 1: exactly 65535 tokens, in one document ...
+    z[i1] = K - 1
+    doc_of = np.searchsorted(doc_off, np.arange(S), side="right") - 1
+    tokens = np.bincount(doc_of, weights=freq, minlength=D)
+    assert tokens.max() < 65536 + 65535                                   # ... whose other sites are trimmed below
+    for d in np.nonzero(tokens >= 65536)[0]:
+        sl = slice(doc_off[d], doc_off[d + 1])
+        other = np.nonzero(word[sl] != 1)[0] + doc_off[d]
+        freq[other] = 1
+    tokens = np.bincount(doc_of, weights=freq, minlength=D)
+    if tokens.max() >= 65536:                                             # word 1's big site itself: give it a document of its own size
+        freq[i1[0]] = 60000
+        freq[i1[1 % len(i1)]] += 5535 if len(i1) > 1 else 0
+    tokens = np.bincount(doc_of, weights=freq, minlength=D)
+    assert tokens.max() < 65536
+    assert int(freq[word == 0].sum()) > 65535 and int(freq[word == 3].sum()) > 65535
+    return doc_off, word, freq, z, V
+
+
+@pytest.mark.parametrize("margin", [0, -1, 6])
+@pytest.mark.parametrize("K", [512, 1024])
+def test_16_bit_rows_four_waves_equal_the_c_oracle(c_oracle, K, margin):
+    """the four-wave form of the 16-bit-row kernel (documents below 2^16 tokens: llda_sweep_args.max_doc_tokens) against the C
+    oracle (LabeledLDA.py:106-125), every draw tier -- and against the three-wave form (debug_margin -8) at production margins"""
+    import torch
+    from lda_thesis_amd.sampler import GibbsSampler
+    doc_off, word, freq, z, V = _rows16_corpus_short_docs(K, 3 * K + margin)
+    labs = np.ones((len(doc_off) - 1, K), dtype=np.uint8)
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=9, commit_log=True, rows16=True, doc_base=5)
+    assert s.n_kw16 is not None and 0 < s.max_doc_tokens < 65536
+    flagged = s.row16.cpu().numpy().astype(bool)
+    assert not flagged[0] and not flagged[3] and flagged[1] and flagged[4:].all()
+    assert int(s.n_kw.max()) > (1 << 16)
+    s.debug_margin = margin
+    cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
+    for i in range(3):
+        s.sweep()
+        cs.sweep(1, 9, i, doc_base=5, threads=4)
+        np.testing.assert_array_equal(s.z_topics(), cs.z)
+        np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+        np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+        np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
+    s.check_status()
+    if margin == 0:
+        r = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=9, commit_log=True, rows16=True, doc_base=5)
+        r.debug_margin = -8                                              # the three-wave form, production margins
+        for i in range(3):
+            r.sweep()
+        assert torch.equal(r.z, s.z) and torch.equal(r._counts, s._counts) and torch.equal(r.n_dk, s.n_dk)
+        assert torch.equal(r.status[1:3], s.status[1:3])                 # the same sites left tier 0 / reached the exact tier
+
+
+def test_16_bit_rows_four_waves_flag_a_wrong_token_bound():
+    """a max_doc_tokens that is not a bound (a count of n_dk above 65535 under the four-wave form): status bit 2, check_status raises"""
+    from lda_thesis_amd.sampler import GibbsSampler
+    doc_off, word, freq, z, V = _rows16_corpus_short_docs(512, 1)
+    s = GibbsSampler(doc_off, word, freq, z, 512, V, 0.1, 0.01, labs=None, seed=7, commit_log=True, rows16=True)
+    s.sweep()
+    s.check_status()
+    s.n_dk[2, 7] += 70000
+    s.sweep()
+    with pytest.raises(RuntimeError, match="16 bits"):
+        s.check_status()
+
+
 def test_16_bit_rows_flag_counts_that_do_not_belong_to_the_corpus():
     """a count above 65535 in a row that is read as 16 bits (impossible for counts built from the corpus): llda_pack_rows16
     sets status bit 2 and check_status raises"""
