@@ -732,34 +732,34 @@ def roofline_json(kernel_ms, sites, docs, live_topics, pmc, source, stored_key=N
             if cycles:
                 v["waves_per_simd_avg"] = pmc["SQ_WAVE_CYCLES"] * 4.0 / (cycles * N_SIMD)
         r["valu_issue"] = v
-        cands["valu_issue"] = v["frac"]
+        # the issue-side roof: the MEASURED share of cycles a SIMD issues VALU where the counter is there (never above 1), else the
+        # instruction count at the nominal clock
+        cands["valu_issue"] = min(1.0, v.get("valu_busy_frac", v["frac"]))
         if cycles and pmc.get("SQ_INSTS_SALU"):
-            # profiles/r03_issue_model.md: 4 x VALU + 2.5 x SALU cycles per SIMD reproduces the K = 512 kernel's rate when its rows
-            # sit in the caches (to 6 %) and the 16-bit-row kernel's (to 8 %).  The 2.5 is FITTED, and a kernel can sit at another
-            # roof with this figure near 1 -- the int32 K = 512 kernel did (section 4 of that note): read it next to the fabric
-            # fraction and valu_busy_frac, not instead of them.
+            # profiles/r03_issue_model.md: 4 x VALU + 2.5 x SALU cycles per SIMD was FITTED on the K = 512 kernels at three waves
+            # per SIMD (it reproduced their rate to 2 - 8 %, and still sat near 1 on a kernel that was bound by the fabric).  At
+            # four waves the scalar instructions of one wave hide behind the vector ones of the others and the figure exceeds 1:
+            # informational only, not one of the roofs below.
             ic = (VALU_CYCLES_PER_INST * insts + SALU_CYCLES_PER_INST * pmc["SQ_INSTS_SALU"]) / N_SIMD
             r["issue_model"] = {"frac": ic / cycles, "cycles_per_simd": ic, "shader_cycles": cycles,
                                 "salu_insts_per_site": pmc["SQ_INSTS_SALU"] / sites,
-                                "model": "(%d x SQ_INSTS_VALU + %.1f x SQ_INSTS_SALU) / 1024 SIMDs over GRBM_GUI_ACTIVE / 8; the SALU "
-                                         "cost is a fit (profiles/r03_issue_model.md, sections 3 - 5)" %
-                                         (VALU_CYCLES_PER_INST, SALU_CYCLES_PER_INST)}
-            cands["instruction_issue (VALU + SALU, fitted model)"] = ic / cycles
+                                "model": "(%d x SQ_INSTS_VALU + %.1f x SQ_INSTS_SALU) / 1024 SIMDs over GRBM_GUI_ACTIVE / 8; a fit at three "
+                                         "waves per SIMD (profiles/r03_issue_model.md), above 1 where more waves overlap the scalar "
+                                         "instructions: not a roof" % (VALU_CYCLES_PER_INST, SALU_CYCLES_PER_INST)}
     if cands:
         best = max(cands, key=cands.get)
         r["binding_roof"] = best
         r["roof_fractions"] = cands
         r["headroom"] = 1.0 - cands[best]
         r["headroom"] = max(0.0, r["headroom"])
-        r["binding_note"] = ("the largest of: fabric bytes / time / 8 TB/s (called 'hbm' only when the shared counts exceed the "
-                             "Infinity Cache), VALU instructions x 4 cycles / time / (1024 SIMDs x 2.4 GHz), and the fitted "
-                             "instruction-issue model (VALU x 4 + SALU x 2.5 cycles per SIMD over the launch's shader cycles).  "
+        r["binding_note"] = ("the larger of: fabric bytes / time / 8 TB/s (called 'hbm' only when the shared counts exceed the "
+                             "Infinity Cache) and the share of its cycles in which a SIMD issues VALU (valu_issue.valu_busy_frac; "
+                             "SQ_INSTS_VALU x 4 cycles / time / (1024 SIMDs x 2.4 GHz) where that counter is missing).  "
                              "profiles/r03_issue_model.md: with int32 rows the K = 512 kernel is fabric-bound (0.96 of 8 TB/s in L2 "
-                             "line fills; a fifth fewer issue cycles changed nothing), with the 16-bit rows this line runs on it "
-                             "moves half those bytes and is bound by instruction issue (a SIMD issues VALU in 0.81 of its cycles, "
-                             "the plateau the same stream reaches with every row in the caches is 0.82); a kernel far below all "
-                             "three is bound by the latency of its dependent chain at its occupancy "
-                             "(valu_issue.wave_cycles_waiting_frac)")
+                             "line fills; a fifth fewer issue cycles changed nothing); with the 16-bit rows it moves half those "
+                             "bytes and is bound by instruction issue -- VALU-busy 0.81 at three waves per SIMD, 0.90 at the four "
+                             "it runs at when documents hold fewer than 2^16 tokens; a kernel far below both is bound by the "
+                             "latency of its dependent chain at its occupancy (valu_issue.wave_cycles_waiting_frac)")
     return r
 
 
