@@ -80,8 +80,11 @@ class GibbsSampler(object):
                (L2 line fills), the 16-bit one by instruction issue, and since round 3's trimming the latter is the faster
                wherever the rows do not all sit in the L2s: + 10 % on BASELINE configs[3] (n_kw 205 MB), + 5 ... 8 % on Zipf
                corpora with V = 300 000 / 1 000 000, + 50 % with uniform words over a 1 GB n_kw, + 13 ... 21 % at K = 1024;
-               - 6 % at K = 512 with a 41 MB n_kw.  None (default) = where the kernel has it (dense
-               mask, commit log, K = 512 or 1024) and n_kw is at least ROWS16_MIN_BYTES (64 MiB); True = wherever the
+               - 6 % at K = 512 with a 41 MB n_kw, all at three waves per SIMD.  Where every document holds fewer than 2^16 tokens
+               the kernel packs n_dk with its sweep-start value and runs FOUR waves per SIMD: another + 7 ... 10 %, and ahead of
+               the int32 kernel at every size measured.  None (default) = where the kernel has it (dense
+               mask, commit log, K = 512 or 1024) and either every document is below 2^16 tokens or n_kw is at least
+               ROWS16_MIN_BYTES (64 MiB); True = wherever the
                kernel has it; False = off.
     """
 
@@ -197,7 +200,8 @@ class GibbsSampler(object):
                 and _native.rows16_ok(self.K) and self.alpha >= 1e-6 and self.beta >= 1e-6):
             self._make_rows16(auto=rows16 is None)
 
-    ROWS16_MIN_BYTES = 64 << 20      # rows16=None: below this n_kw the L2s serve the int32 rows and the shorter kernel wins
+    ROWS16_MIN_BYTES = 64 << 20      # rows16=None, documents of 2^16 tokens or more (three waves per SIMD): below this n_kw
+                                     # the L2s serve the int32 rows and the shorter kernel wins
     MAX_FREQ = 1 << 23   # v_mad_i32_i24 moves a site's count (include/llda_gibbs.h: freq)
     PAIR_LIMIT = 32767   # largest frequency mass of a word (all ranks) whose row is exchanged as int16 pairs
 
@@ -208,7 +212,10 @@ class GibbsSampler(object):
         words of a natural corpus) can be read from a 16-bit image.  The flag of a site's word rides in bit 31 of its
         commit-log position, where the kernel sees it one site before it needs the row."""
         total = self.n_kw.sum(dim=1, dtype=torch.int64)
-        if auto and self.V * self.layout.KP * 4 < self.ROWS16_MIN_BYTES:
+        # (the row sums of n_dk bound every entry and never change: a site moves its count between two topics)
+        tokens_max = int(min(int(self.n_dk.sum(dim=1, dtype=torch.int64).max().item()), 2 ** 31 - 1)) if self.D else 0
+        four_waves = 0 < tokens_max < 65536
+        if auto and not four_waves and self.V * self.layout.KP * 4 < self.ROWS16_MIN_BYTES:
             return
         fits = (total <= 65535) & (self.n_kw.min(dim=1).values >= 0)
         if not bool(fits.any()):
@@ -229,9 +236,9 @@ class GibbsSampler(object):
             return
         self.site_row = row.to(torch.int32).contiguous()
         # llda_sweep_args.max_doc_tokens: below 2^16 the 16-bit-row kernel packs n_dk with its sweep-start value and runs four
-        # waves per SIMD.  The row sums of n_dk bound every entry and never change (a site moves its count between two topics).
-        if not self.max_doc_tokens and self.D:
-            self.max_doc_tokens = int(min(int(self.n_dk.sum(dim=1, dtype=torch.int64).max().item()), 2 ** 31 - 1))
+        # waves per SIMD
+        if not self.max_doc_tokens:
+            self.max_doc_tokens = tokens_max
 
     def _make_exchange_rows(self):
         """Exchange layout of the per-sweep count deltas when every rank folds a commit log: one row per word plus
