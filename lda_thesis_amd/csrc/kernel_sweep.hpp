@@ -234,8 +234,16 @@ __global__ void __launch_bounds__(256, W4 ? 4 : (T <= 12 && G >= 16) ? LLDA_WAVE
                 }
                 s_pa[s][tid] = tier0_factor(r[s], k[s], alpha32, vbeta32);
             }
-            if constexpr (W4) {                                    // a count that does not fit the packed word: the caller's
-                if (((uint32_t)big >> 16) && P.status) atomicOr(P.status, 4);   // max_doc_tokens was not a bound (status bit 2)
+            if constexpr (W4) {
+                // the packed word holds the counts of a document of at most 65 535 tokens: a start value beyond 16 bits, or a
+                // document whose counts add up to more (one topic could collect them all before the sweep is over), means the
+                // caller's max_doc_tokens was not a bound -- status bit 2, once per document, outside the site loop
+                int tokens = 0;
+#pragma unroll
+                for (int s = 0; s < T; ++s) tokens += (int)((uint32_t)r[s] & 0xffffu);
+#pragma unroll
+                for (int m = 1; m < G; m <<= 1) tokens += __shfl_xor(tokens, m, G);
+                if ((((uint32_t)big >> 16) || tokens > 65535) && P.status) atomicOr(P.status, 4);
             }
         }
         // (DENSE: every slot of every lane is an allowed topic -- a constant, not a register)

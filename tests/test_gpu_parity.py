@@ -461,6 +461,12 @@ def test_16_bit_rows_four_waves_flag_a_wrong_token_bound():
     s.sweep()
     with pytest.raises(RuntimeError, match="16 bits"):
         s.check_status()
+    # ... and counts that each fit but add up to more than the packed word may ever have to hold
+    s = GibbsSampler(doc_off, word, freq, z, 512, V, 0.1, 0.01, labs=None, seed=7, commit_log=True, rows16=True)
+    s.n_dk[2, :3] += 30000
+    s.sweep()
+    with pytest.raises(RuntimeError, match="16 bits"):
+        s.check_status()
 
 
 def test_16_bit_rows_flag_counts_that_do_not_belong_to_the_corpus():
