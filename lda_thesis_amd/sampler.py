@@ -143,7 +143,8 @@ class GibbsSampler(object):
         self.z = self._topic_pos[as_dev(z, torch.int64)].to(torch.int32)
 
         self.lab_mask = self._make_masks(labs)
-        self.dense_mask = labs is None
+        # every topic allowed in every document (no labs, or label sets that are all complete): the kernels skip the mask
+        self.dense_mask = labs is None or (self.D > 0 and bool((self.lab_mask == self._make_masks(None)[:1]).all()))
         # sparse label sets (Labeled LDA proper): positions of the allowed topics per document, ascending;
         # the library then runs one lane per ALLOWED topic (llda_sweep_sparse_kernel)
         self.live_off = self.live_pos = None

@@ -36,6 +36,10 @@ TINY = [
     ("k512",     24, 150,  511, 200,      (10, 60),  0.1, 0.01, 2),    # 4 full leaves
     ("k777",     16, 120,  776, 300,      (10, 50),  0.1, 0.01, 2),    # unbalanced tree
     ("k1024",    12, 100, 1023, 400,      (10, 40),  0.1, 0.01, 2),    # the largest narrow K: 8 full leaves, 64 lanes x 16 slots
+    # every label in every document (ALL_LABELS below): a dense mask with K == KP -- the dense 16-slot kernels with the commit log,
+    # i.e. the 16-bit rows at four waves per SIMD the bench's headline runs on, against the reference itself
+    ("k512dense",  30, 150,  511, 511,    (10, 60),  0.1, 0.01, 2),
+    ("k1024dense", 12, 100, 1023, 1023,   (10, 40),  0.1, 0.01, 2),
     # wide layouts (more than 8 pairwise leaves: 64-lane tiers of one wavefront)
     ("k1031",    10, 100, 1030, 400,      (10, 40),  0.1, 0.01, 2),    # 9 leaves -> 2 tiers x 16 slots, tail 7
     ("k1100",    10, 100, 1099,  30,      (10, 40),  0.1, 0.01, 2),    # 16 leaves, 12 slots per lane, tail 4, sparse labels
@@ -44,13 +48,21 @@ TINY = [
 ]
 
 
+ALL_LABELS = ("k512dense", "k1024dense")      # fixtures whose documents carry the whole label set
+
+
+def all_labels(name, docs, labs, labelset):
+    """labs of fixture `name`: every label in every document for the ALL_LABELS fixtures, else as drawn"""
+    return [list(labelset) for _ in docs] if name in ALL_LABELS else labs
+
+
 def tiny_corpus(name):
     """-> (docs, labs, labelset, alpha, beta, sweeps, numpy_seed) of fixture tiny_<name>."""
     for (nm, D, V, nl, ml, (lo, hi), alpha, beta, sweeps) in TINY:
         if nm == name:
             rng = np.random.default_rng(sum(map(ord, name)))
             docs, labs, labelset = synth_corpus(rng, D, V, nl, ml, lo, hi)
-            return docs, labs, labelset, alpha, beta, sweeps, 1000 + len(name)
+            return docs, all_labels(name, docs, labs, labelset), labelset, alpha, beta, sweeps, 1000 + len(name)
     raise KeyError(name)
 
 

@@ -29,7 +29,7 @@ sys.path.insert(0, HERE)
 import llda_oracle as orc          # noqa: E402
 import refshim                     # noqa: E402
 from lda_thesis_amd.text import Dictionary  # noqa: E402
-from fixture_corpora import TINY, synth_corpus  # noqa: E402
+from fixture_corpora import TINY, all_labels, synth_corpus  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 REF_L, REF_C = refshim.import_reference()
@@ -136,6 +136,7 @@ def gen_tiny(only=None):
             continue
         rng = np.random.default_rng(sum(map(ord, name)))
         docs, labs, labelset = synth_corpus(rng, D, V, nl, ml, lo, hi)
+        labs = all_labels(name, docs, labs, labelset)
         dicti = Dictionary(docs)
         np.random.seed(1000 + len(name))
         m0 = REF_L.LabeledLDA(docs, labs, list(labelset), dicti, alpha, beta)

@@ -35,6 +35,23 @@ def test_sweeps_match_reference_o3(name, margin):
     s.check_status()
 
 
+@pytest.mark.parametrize("name", ["tiny_k512dense", "tiny_k1024dense"])
+def test_headline_kernels_match_reference_o3(name):
+    """every label in every document (a dense mask, K == KP) with the commit log: the kernels of the bench's timed line -- 16-bit rows
+    at four waves per SIMD (rows16 True / None), at three (debug_margin -8), int32 rows -- against the reference's own O3 sweeps"""
+    g = load_golden(name)
+    for rows16, margin, four in ((None, 0, True), (True, 0, True), (True, -8, False), (True, 6, True), (True, -1, True), (False, 0, False)):
+        s = make_sampler(g, commit_log=True, rows16=rows16)
+        assert s.dense_mask and s.commit_log is not None and (s.n_kw16 is not None) == (rows16 is not False)
+        if rows16 is not False:
+            assert 0 < s.max_doc_tokens < 65536 and bool(s.row16.all())
+        s.debug_margin = margin
+        for i in range(int(g["sweeps"])):
+            s.sweep()
+            assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics(), name)
+        s.check_status()
+
+
 @pytest.mark.parametrize("name", [n for n in TINY if int(n.split("k")[-1].rstrip("dense")) > 1024])
 def test_wide_layout_kernels_agree_with_reference(c_oracle, name):
     """wide layouts (more than 8 pairwise leaves): the LDS-only tiered kernel (debug_margin -3; production runs the one that
