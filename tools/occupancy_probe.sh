@@ -1,10 +1,11 @@
 #!/bin/bash
-# How much does the 16-bit-row sweep kernel depend on its wave count?  Builds the library with dummy dynamic LDS on the THREE-wave
-# form's launch (-DABL_EXTRA_LDS_BYTES=20000: two workgroups per CU instead of three) in the build container:
-#   bash tools/occupancy_probe.sh build
-# and times it against the in-tree library on the GPU box (debug: the four-wave form is the production one; the probe library is
-# compared on workloads whose documents hold 2^16 tokens or more, or with LLDA_BENCH... see tools/ab_lib.py):
-#   gpurun -- 'bash tools/occupancy_probe.sh run synth2 k1024'
+# How much does the THREE-wave 16-bit-row sweep kernel depend on its wave count?  (Measured before the four-wave form existed: 67.0 ms
+# at two waves per SIMD against 50.9 at three on configs[3] -- the measurement that made the case for the fourth wave)
+# Builds the library with dummy dynamic LDS on that kernel's launch (-DABL_EXTRA_LDS_BYTES=20000: two workgroups per CU) in the build
+# container:            bash tools/occupancy_probe.sh build
+# and times it against the in-tree library on the GPU box:    gpurun -- 'bash tools/occupancy_probe.sh run <workload> ...'
+# The dummy LDS only reaches the three-wave form, which runs where a document holds 2^16 tokens or more (else the production library
+# runs the four-wave form and the pair compares two waves with four).
 set -e
 cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
