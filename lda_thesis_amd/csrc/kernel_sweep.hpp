@@ -127,7 +127,8 @@ __global__ void __launch_bounds__(256) llda_sweep_exact_kernel(const KParams P)
 // loop: + 10 % at 16 lanes per document (K = 192), + 17 % at 32 and 64 (K = 384, 768); the 8-lane layouts, bound by the
 // vector-memory address pipeline, lose 6 % with a fourth wave and stay at 3 (tools/abl_vocab.py).  With 16 slots per lane
 // a fourth wave needs both LDS packing and ~40 fewer VGPRs: a packed-LDS build at 128 VGPRs spilled six values per site,
-// and every scratch reload waits for vmcnt(0), i.e. for the row prefetch -- 98 ms instead of 58 at K = 512.
+// and every scratch reload waits for vmcnt(0), i.e. for the row prefetch -- 98 ms instead of 58 at K = 512.  The 16-bit-row kernel
+// does run at four (template parameter W4 below: one row tuple, packed LDS, no spill in the site loop).
 
 // tier-0 factor of one topic: fl32(a * y) with a = fl32(n_dk + alpha), y = v_rcp_f32(fl32(n_k + V*beta)).
 // n_dk and n_k of a topic always change together, so the product is cached as ONE float per slot.
