@@ -199,13 +199,16 @@ def rows_description(sampler):
 
 def time_sweeps(sampler, steps, warmup, dist=None, dev=None, events=True):
     """warmup untimed sweeps, then exactly `steps` sweeps between barrier + synchronize; MAX over ranks.
-    -> (seconds, mean sweep-kernel ms from HIP events on the launch stream, tier counters).
-    events=False (sweeps of well under a millisecond: the two event records per sweep are GPU commands of their own and cost 6.5 us
-    of a 67 us abstracts sweep, tools/cpu_overhead_probe.py): the timed sweeps run without them and the kernel time comes from up to
-    200 further sweeps, outside the timed region."""
+    -> (seconds, mean sweep-kernel ms from HIP events on the launch stream).
+    events=False (single process only; sweeps of well under a millisecond: the two event records per sweep are GPU commands of their
+    own and cost 6.5 us of a 67 us abstracts sweep, tools/cpu_overhead_probe.py): the timed sweeps run without them and the kernel
+    time comes from up to 200 FURTHER sweeps outside the timed region -- the sampler has then run warmup + steps + min(steps, 200)
+    sweeps (sampler.sweeps_done says so; whatever is computed from its state afterwards is a state that many sweeps old)."""
     for _ in range(warmup):
         sampler.sweep()
     if not events:
+        if dist is not None:
+            raise ValueError("time_sweeps(events=False) is a single-process measurement")
         sampler.kernel_events = None
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -244,6 +247,62 @@ def time_sweeps(sampler, steps, warmup, dist=None, dev=None, events=True):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
+def host_cpu():
+    """(model name, logical cores, physical cores) of this host from /proc/cpuinfo."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model == "unknown":
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid))
+                pid = cid = None
+        if pid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, logical, (len(phys) or logical)
+
+
+STRONG_CPU_DOCS = 100000     # documents of the strong (OpenMP C) baseline leg at its largest thread count
+
+
+def cpu_strong_leg(sampler, info, labs_rows=None):
+    """the strong CPU baseline: oracle/llda_oracle.c (snapshot sweeps, OpenMP over documents) on up to STRONG_CPU_DOCS documents of
+    the SAME workload with min(physical cores, 64) threads and with half / a quarter of them (on proportionally fewer documents,
+    so that every leg runs about as long) -> {"best": {...}, "legs": [...]}."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    _, logical, phys = host_cpu()
+    cap = max(1, min(phys, 64))
+    n_top = min(info["docs_local"], STRONG_CPU_DOCS)
+    doc_off = sampler.doc_off[:n_top + 1].cpu().numpy()
+    S = int(doc_off[-1])
+    word, freq = sampler.word[:S].cpu().numpy(), sampler.freq[:S].cpu().numpy()
+    z = sampler._pos_topic[sampler.z[:S].to(torch.int64)].cpu().numpy()
+    n_k_v, n_zk = sampler.n_k_v(), sampler.n_zk()
+    n_d_k = sampler.n_dk[:n_top][:, sampler._topic_pos].cpu().numpy().astype(np.int64)
+    legs = []
+    for threads in sorted({cap, max(1, cap // 2), max(1, cap // 4)}, reverse=True):
+        n = max(1, n_top * threads // cap)
+        s1 = int(doc_off[n])
+        t0 = time.perf_counter()
+        c_oracle.sweep_docs(np.arange(n) + sampler.doc_base, doc_off[:n + 1], word[:s1], freq[:s1], z[:s1],
+                            None if labs_rows is None else labs_rows[:n], n_d_k[:n], n_k_v, n_zk, sampler.V, sampler.alpha,
+                            sampler.beta, sampler.seed, 0, threads=threads)
+        dt = time.perf_counter() - t0
+        legs.append({"threads": threads, "docs": n, "sites": s1, "seconds": dt, "value": s1 / dt / 1e6})
+    return {"best": max(legs, key=lambda l: l["value"]), "legs": legs, "physical_cores": phys, "logical_cores": logical}
+
+
 def cpu_baseline(sampler, doc_off, word, freq, n_docs_py, n_docs_c, labs=None):
     """Reference CPU path restated (oracle/) on a bounded sample of the SAME workload, timed on this
     host.  'port' = numpy per-site loop issuing the op sequence of LabeledLDA.py:108-125 on one core
@@ -306,7 +365,18 @@ def cpu_baseline_json(sampler, info, name, value):
         nmax = int(h_off[n_py])
         h_word, h_freq = info["word"][:nmax].cpu().numpy(), info["freq"][:nmax].cpu().numpy()
     base, cores = cpu_baseline(sampler, h_off, h_word, h_freq, n_py, n_c, labs_h)
+    strong = None
+    if name != "abstracts":                            # (abstracts: the whole corpus already ran on all cores above)
+        lab_rows = None
+        if name in ("synth2_sparse", "synth2_sparse_hier"):
+            n_top = min(Dg, STRONG_CPU_DOCS)
+            lab_rows = np.zeros((n_top, K), dtype=np.uint8)
+            lh = info["lab"][:n_top].cpu().numpy()
+            lab_rows[np.repeat(np.arange(n_top), 8), lh.reshape(-1)] = 1
+        strong = cpu_strong_leg(sampler, info, lab_rows)
+    model, logical, phys = host_cpu()
     return {
+        "cpu_model": model, "physical_cores": phys, "c_port_strong": strong,
         "value": base["numpy"]["value"], "unit": "Mtokens/s", "cores": 1, "kind": "port",
         "sample": "first %d docs (%d sites) of the same workload, 1 sweep, numpy per-site loop "
                   "restating LabeledLDA.py:108-125 (oracle/llda_oracle.py sweep_sequential), %.1f s"
@@ -335,7 +405,7 @@ def cascade_extra():
     docs, labs, labelset = cascade_corpus_from_csr(g["doc_off"], g["word"], g["freq"], g["lab_off"], g["lab_idx"], names)
     dicti = Dictionary(docs)
     walls = []
-    for _ in range(4):
+    for _ in range(7):                                         # one cold call + six warm ones
         np.random.seed(0)
         model = CascadeLDA(docs, labs, list(labelset), dicti, alpha=ALPHA, beta=BETA, seed=1)
         torch.cuda.synchronize()
@@ -349,7 +419,8 @@ def cascade_extra():
     sites = int(sum(int(lens[p["docs"]].sum()) for p in plans))
     return {"workload": "CascadeLDA on abstracts_data.csv (fixture), go_down_tree(it=4, s=2): ensemble of per-node L-LDA "
                         "sub-problems, all trained together on this GPU (BASELINE configs[4])",
-            "value": min(walls[1:]), "unit": "s", "higher_is_better": False, "cold_first_call_s": walls[0],
+            "value": min(walls[1:]), "median_s": float(np.median(walls[1:])), "max_s": max(walls[1:]),
+            "unit": "s", "higher_is_better": False, "cold_first_call_s": walls[0],
             "warm_calls_s": walls[1:], "sub_problems": len(plans), "sites_per_ensemble_sweep": sites,
             "Msites_per_s": sites * 4 / min(walls[1:]) / 1e6,
             "reference_cpu_s": 66.8, "reference_cpu_note": "the reference's go_down_tree(4, 2) on one core of the survey "
@@ -782,6 +853,120 @@ def roofline_json(kernel_ms, sites, docs, live_topics, pmc, source, stored_key=N
     return r
 
 
+# ------------------------------------------------------------------------------------------------ the printed line
+LINE_LIMIT = 8000            # bytes: the driver keeps an 8 KB tail of stdout and parses the LAST line of it
+
+
+def _num(x, digits=6):
+    """numbers for the printed line: floats rounded to `digits` significant digits, everything else as is"""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, x))
+    return x
+
+
+def compact_roofline(r):
+    """numbers only: what the judge recomputes.  achieved / frac / traffic as in roofline_json (fabric bytes from the PMC passes over
+    the kernel's mean time, against 8 TB/s); algorithmic_* = SURVEY 8(d) bytes of one launch and their rate."""
+    if not r:
+        return None
+    v, l2 = r.get("valu_issue") or {}, r.get("l2") or {}
+    out = {"bound": r.get("bound"), "kernel": r.get("kernel"), "kernel_ms": r.get("kernel_ms"), "achieved": r.get("achieved"),
+           "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"), "traffic": r.get("traffic"),
+           "traffic_kind": r.get("traffic_kind"), "algorithmic_bytes": r.get("algorithmic_bytes_per_launch"),
+           "algorithmic_GBps": r.get("algorithmic_GBps"), "traffic_over_algorithmic": r.get("traffic_over_algorithmic"),
+           "valu_busy_frac": v.get("valu_busy_frac"), "valu_insts_per_site": v.get("valu_insts_per_site"),
+           "waves_per_simd": v.get("waves_per_simd_avg"), "wave_cycles_waiting_frac": v.get("wave_cycles_waiting_frac"),
+           "l2_hit_rate": l2.get("hit_rate"), "fabric_read_requests_per_site": l2.get("fabric_read_requests_per_site"),
+           "ta_busy_frac": r.get("ta_busy_frac"), "binding_roof": (r.get("binding_roof") or "").split(" ")[0] or None}
+    return {k: _num(x, 5) for k, x in out.items()}
+
+
+def compact_cpu(c):
+    if not c:
+        return None
+    out = {k: _num(c.get(k), 5) for k in ("value", "unit", "cores", "kind", "cpu_model", "host_cores", "physical_cores")
+           if c.get(k) is not None}
+    out["sample"] = str(c.get("sample", ""))[:200]
+    if c.get("c_port_1thread_Mtokens_s") is not None:
+        out["c_port_1thread"] = _num(c["c_port_1thread_Mtokens_s"], 5)
+    if c.get("c_port_allcores_Mtokens_s") is not None:
+        out["c_port_allcores_small_sample"] = _num(c["c_port_allcores_Mtokens_s"], 5)
+    st = c.get("c_port_strong")
+    if st:
+        b = st["best"]
+        out["c_port_strong"] = {"value": _num(b["value"], 5), "threads": b["threads"], "docs": b["docs"],
+                                "seconds": _num(b["seconds"], 4),
+                                "legs": [[l["threads"], _num(l["value"], 4)] for l in st["legs"]]}
+    for k in ("train_s", "test_s"):
+        if c.get(k) is not None:
+            out[k] = _num(c[k], 5)
+    return out
+
+
+def compact_extra(e):
+    """{value, unit, ms_per_step, frac, binding_roof} (+ the CPU figures where the workload has them) of one extra workload"""
+    out = {"value": _num(e.get("value")), "unit": e.get("unit")}
+    for k in ("ms_per_step", "kernel_ms", "steps", "speedup_vs_cpu_port", "cold_first_call_s", "median_s", "max_s"):
+        if e.get(k) is not None:
+            out[k] = _num(e[k], 5)
+    r = e.get("roofline")
+    if r:
+        c = compact_roofline(r)
+        out.update({k: c[k] for k in ("frac", "binding_roof", "traffic_over_algorithmic", "valu_busy_frac", "l2_hit_rate",
+                                      "fabric_read_requests_per_site")})
+    if e.get("cpu_baseline"):
+        cb = e["cpu_baseline"]
+        out["cpu"] = {"value": _num(cb.get("value"), 5), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                      "scaled_from_sample": "scaled" in str(cb.get("sample", ""))}
+        if cb.get("c_port_strong"):
+            out["cpu"]["c_port_strong"] = _num(cb["c_port_strong"]["best"]["value"], 5)
+    if e.get("stages_s"):
+        out["stages_s"] = {k: _num(x, 4) for k, x in e["stages_s"].items()}
+    return out
+
+
+def compact_line(detail, detail_path=None):
+    """The ONE line the driver parses, from the full record `detail` (which goes to --detail-out): numbers only, no prose, at most
+    LINE_LIMIT bytes -- if it ever grew beyond that the extras are dropped before the line is allowed to become unparseable."""
+    cfg = detail.get("config", {})
+    line = {k: _num(detail.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                              "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: _num(cfg.get(k)) for k in ("workload", "docs_total", "docs_per_gpu", "sites_per_doc", "K", "V", "alpha",
+                                                     "beta", "label_mask", "kernel", "n_kw_rows_short", "sites_per_sweep",
+                                                     "timed_seconds", "state_checksum_n_k", "state_checksum_n_kw",
+                                                     "sweeps_behind_checksum", "build_info", "abi", "library")
+                      if cfg.get(k) is not None}
+    line["config"]["workload"] = str(cfg.get("workload", ""))[:160]
+    if detail_path:
+        line["config"]["detail"] = detail_path
+    line["roofline"] = compact_roofline(detail.get("roofline"))
+    line["cpu_baseline"] = compact_cpu(detail.get("cpu_baseline"))
+    if detail.get("speedup_vs_cpu_port") is not None:
+        line["speedup_vs_cpu_port"] = _num(detail["speedup_vs_cpu_port"], 5)
+    if detail.get("draw_tiers"):
+        line["draw_tiers"] = detail["draw_tiers"]
+    for k in ("checksum_matches_n1",):
+        if k in detail:
+            line[k] = detail[k]
+    if detail.get("exchange_ms"):
+        line["exchange_ms"] = {k: _num(x, 5) for k, x in detail["exchange_ms"].items() if not isinstance(x, (dict, list, str))}
+    if detail.get("overlap_probe"):
+        pr = detail["overlap_probe"]
+        line["overlap_probe"] = {k: _num(pr.get(k), 5) for k in ("overlap_ranges", "steps", "ms_per_step", "checksum_matches_n1")}
+        if isinstance(pr.get("exchange_ms"), dict):
+            line["overlap_probe"]["exposed_ms_per_sweep"] = _num(pr["exchange_ms"].get("exposed_ms_per_sweep"), 5)
+    if detail.get("extra"):
+        line["extra"] = {k: compact_extra(e) for k, e in detail["extra"].items()}
+    if len(json.dumps(line)) > LINE_LIMIT and "extra" in line:
+        line["extra"] = {k: {"value": e.get("value"), "unit": e.get("unit")} for k, e in line["extra"].items()}
+    if len(json.dumps(line)) > LINE_LIMIT:
+        line.pop("extra", None)
+        line["config"] = {"workload": line["config"]["workload"], "build_info": line["config"].get("build_info")}
+    return line
+
+
 # ------------------------------------------------------------------------------------------------ main
 def self_launch(args):
     """--gpus N > 1 without torch.distributed.run around us: start N ranks of this script."""
@@ -806,6 +991,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
     ap.add_argument("--pmc-keep", default="", help="directory to keep the raw counter CSVs of the in-run passes in")
     ap.add_argument("--pmc-inner", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--detail-out", default=os.path.join("gpurun_out", "bench_detail.json"),
+                    help="file that receives the full record (notes, models, every counter); the printed line holds numbers only")
     ap.add_argument("--make-checksums", type=int, default=0,
                     help="N = 1: run this many sweeps, print the digests after each (the content of one entry of "
                          "profiles/state_checksums.json) and exit")
@@ -829,6 +1016,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    from lda_thesis_amd import _native
+    build_bits, build_names = _native.build_info()
+    if build_bits:
+        raise SystemExit("bench.py: %s was built with %s (llda_build_info() = %#x): not the production library, no line is printed"
+                         % (_native.LIB_PATH, ", ".join(build_names), build_bits))
     if args.pmc_inner:
         pmc_inner(dev, args.pmc_inner.split(","))
         return
@@ -919,6 +1111,8 @@ def main():
                        "label_mask": "dense" if live == K else "sparse (%.2f live topics per doc)" % live,
                        "kernel": "sparse" if sampler.live_off is not None else "dense",
                        "n_kw_rows": rows_description(sampler),
+                       "n_kw_rows_short": "int32" if getattr(sampler, "n_kw16", None) is None else "16-bit image + int32 hot rows",
+                       "build_info": build_bits, "abi": _native.ABI_VERSION, "library": os.path.relpath(_native.LIB_PATH, ROOT),
                        "sites_per_sweep": total_sites, "timed_seconds": dt,
                        "exchange": sampler.exchange_description() if world > 1 else "none (single GPU: the commit log is "
                                    "folded straight into n_kw)",
@@ -1007,7 +1201,17 @@ def main():
                                                        source, stored_key=wname, shared_bytes=m["shared"])
         if extra:
             line["extra"] = extra
-        print(json.dumps(line))
+        detail_path = None
+        if args.detail_out:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(args.detail_out)), exist_ok=True)
+                with open(args.detail_out, "w") as fh:
+                    json.dump(line, fh, indent=1)
+                detail_path = args.detail_out
+            except OSError as e:                                  # the line must survive a read-only tree
+                print("bench.py: could not write %s: %r" % (args.detail_out, e), file=sys.stderr)
+        sys.stdout.flush()
+        print(json.dumps(compact_line(line, detail_path)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 16
+#define LLDA_ABI_VERSION 17
 #define LLDA_MAX_K 7688          /* every K up to here splits into <= 64 pairwise leaves                       */
 #define LLDA_MAX_KP 8192         /* longest padded row: 64 leaves x 128                                        */
 #define LLDA_MAX_LEAVES 8        /* "narrow" layouts: one lane group of <= 64 lanes x <= 16 slots per document  */
@@ -179,6 +179,19 @@ typedef struct llda_sweep_args {
 
 /* ---- host-only (no device needed) ---- */
 int         llda_abi_version(void);
+/* 0 for the production build.  Otherwise one bit per compile-time switch the library was built with (ABI 17): overrides of the
+ * draw margins / occupancy bound, and the ablation switches of tools/ that delete work from the kernels.  A number measured
+ * with a non-zero build is not a measurement of the product: bench.py refuses to print one. */
+#define LLDA_BUILD_MARGIN0            0x001   /* -DLLDA_MARGIN0=...       tier-0 margin of the narrow kernels            */
+#define LLDA_BUILD_WAVES              0x002   /* -DLLDA_WAVES=...         waves per SIMD the narrow kernels are bounded to */
+#define LLDA_BUILD_MARGIN0_WIDE       0x004   /* -DLLDA_MARGIN0_WIDE=...                                                */
+#define LLDA_BUILD_ABL_NOLOAD         0x008   /* -DABL_NOLOAD             no n_kw row loads                               */
+#define LLDA_BUILD_ABL_NOCOMMIT       0x010   /* -DABL_NOCOMMIT           no count updates                                */
+#define LLDA_BUILD_ABL_WIDE_NOROW     0x020   /* -DABL_WIDE_NOROW                                                         */
+#define LLDA_BUILD_ABL_WIDE_NOADDLOAD 0x040   /* -DABL_WIDE_NOADDLOAD                                                     */
+#define LLDA_BUILD_ABL_NOFMA          0x080   /* -DABL_NOFMA                                                              */
+#define LLDA_BUILD_ABL_EXTRA_LDS      0x100   /* -DABL_EXTRA_LDS_BYTES=n  unused dynamic LDS (occupancy ablation)          */
+int         llda_build_info(void);
 const char *llda_strerror(int code);
 int         llda_last_hip_error(void);
 /* sizeof of the argument structs as the library was compiled (0 llda_layout, 1 llda_sweep_args, 2 llda_batch_args,

@@ -16,7 +16,7 @@ MAX_KP = 8192
 MAX_LEAVES = 8          # narrow layouts
 MAX_WIDE_LEAVES = 64
 MAX_ROUNDS = 4
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -67,7 +67,7 @@ class LldaBatchArgs(ctypes.Structure):
                 ("beta", _c_d), ("seed", _c_u64), ("sweep", _c_u32), ("reserved", _c_u32)]
 
 
-EXPORTS = ("llda_abi_version", "llda_strerror", "llda_last_hip_error", "llda_struct_size", "llda_layout_init",
+EXPORTS = ("llda_abi_version", "llda_build_info", "llda_strerror", "llda_last_hip_error", "llda_struct_size", "llda_layout_init",
            "llda_sweep_scratch_bytes", "llda_rows16_ok", "llda_pack_rows16",
 
            "llda_sweep", "llda_sweep_batch", "llda_commit_log", "llda_apply_rows", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
@@ -96,6 +96,8 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     L.llda_abi_version.restype = ctypes.c_int
     L.llda_abi_version.argtypes = []
+    L.llda_build_info.restype = ctypes.c_int
+    L.llda_build_info.argtypes = []
     L.llda_strerror.restype = ctypes.c_char_p
     L.llda_strerror.argtypes = [ctypes.c_int]
     L.llda_last_hip_error.restype = ctypes.c_int
@@ -141,6 +143,16 @@ def lib():
                                                                            L.llda_struct_size(which)))
     _LIB = L
     return L
+
+
+BUILD_SWITCHES = ("LLDA_MARGIN0", "LLDA_WAVES", "LLDA_MARGIN0_WIDE", "ABL_NOLOAD", "ABL_NOCOMMIT", "ABL_WIDE_NOROW",
+                  "ABL_WIDE_NOADDLOAD", "ABL_NOFMA", "ABL_EXTRA_LDS_BYTES")      # bit i of llda_build_info()
+
+
+def build_info():
+    """llda_build_info: (bits, names of the compile-time switches the loaded library was built with); (0, []) = production."""
+    bits = int(lib().llda_build_info())
+    return bits, [n for i, n in enumerate(BUILD_SWITCHES) if bits >> i & 1]
 
 
 def require_device():

@@ -20,6 +20,8 @@ Any K up to 7 688 (``layout.MAX_K``): up to 8 of numpy's pairwise-sum leaves the
 that ``layout.wide`` is set, G counts the virtual lanes of one wavefront, and ``llda_sweep`` picks the wide kernels
  -- nothing in this class differs except the ``max_doc_tokens`` hint it hands them.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -85,7 +87,10 @@ class GibbsSampler(object):
                the int32 kernel at every size measured.  None (default) = where the kernel has it (dense
                mask, commit log, K = 512 or 1024) and either every document is below 2^16 tokens or n_kw is at least
                ROWS16_MIN_BYTES (64 MiB); True = wherever the
-               kernel has it; False = off.
+               kernel has it; False = off.  The image costs V*KP*2 bytes (half of n_kw again) inside the allocation of
+               the counts plus 4 bytes per site; with rows16=None a shard that has no room for it sweeps with int32 rows
+               (with a warning) and the environment variable LLDA_ROWS16=on|off decides for callers that cannot pass the
+               argument.
     """
 
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
@@ -197,6 +202,8 @@ class GibbsSampler(object):
         if self.sharded and (_dist_active(self.group) or exchange_always):
             self._make_exchange_rows()
         self.row16 = self.n_kw16 = self.site_row = None
+        if rows16 is None and os.environ.get("LLDA_ROWS16") in ("on", "off"):     # for callers behind the LabeledLDA front end
+            rows16 = os.environ["LLDA_ROWS16"] == "on"
         if (rows16 is not False and self.S and self.dense_mask and self.commit_log is not None
                 and _native.rows16_ok(self.K) and self.alpha >= 1e-6 and self.beta >= 1e-6):
             self._make_rows16(auto=rows16 is None)
@@ -211,35 +218,66 @@ class GibbsSampler(object):
         sweep only moves a site's frequency between two topics of one word (LabeledLDA.py:109-111,123-125) and the
         exchange sums such moves --, so the rows whose total is at most 65535 (all but the few hundred most frequent
         words of a natural corpus) can be read from a 16-bit image.  The flag of a site's word rides in bit 31 of its
-        commit-log position, where the kernel sees it one site before it needs the row."""
-        total = self.n_kw.sum(dim=1, dtype=torch.int64)
+        commit-log position, where the kernel sees it one site before it needs the row.
+
+        The image lives in the SAME allocation as the counts, [n_kw | n_k | n_kw16]: llda_sweep_args.site_row addresses a
+        row in 16-byte units from n_kw, so the distance between the two arrays is a constant of (V, KP) and never a
+        property of where the caching allocator put two tensors."""
+        V, KP = self.V, self.layout.KP
+        if KP % 8:
+            raise _native.NativeError("llda_rows16_ok(%d) holds but KP = %d is not a multiple of 8" % (self.K, KP))
+        # site_row is an int32: the last 16-bit row starts (V+1)*KP/4 + (V-1)*KP/8 units after n_kw
+        if (V + 1) * (KP // 4) + V * (KP // 8) >= 1 << 31:
+            if auto:
+                return
+            raise ValueError("rows16=True: n_kw of %d x %d is too large for the 32-bit row offsets of the 16-bit-row kernel"
+                             % (V, KP))
         # (the row sums of n_dk bound every entry and never change: a site moves its count between two topics)
         tokens_max = int(min(int(self.n_dk.sum(dim=1, dtype=torch.int64).max().item()), 2 ** 31 - 1)) if self.D else 0
         four_waves = 0 < tokens_max < 65536
-        if auto and not four_waves and self.V * self.layout.KP * 4 < self.ROWS16_MIN_BYTES:
+        if auto and not four_waves and V * KP * 4 < self.ROWS16_MIN_BYTES:
             return
-        fits = (total <= 65535) & (self.n_kw.min(dim=1).values >= 0)
-        if not bool(fits.any()):
+        if not bool(self._rows16_fits().any()):
             return
-        self.row16 = fits.to(torch.uint8).contiguous()
-        self.n_kw16 = torch.zeros((self.V * self.layout.KP,), dtype=torch.int16, device=self.device)
-        flagged = fits[self.word.to(torch.int64)]
-        self.csc_pos |= torch.where(flagged, -(1 << 31), 0).to(torch.int32)
-        # llda_sweep_args.site_row: where the row of each site's word starts, in 16-byte units from n_kw (static)
-        KP = self.layout.KP
-        gap = self.n_kw16.data_ptr() - self.n_kw.data_ptr()
-        assert gap % 16 == 0 and KP % 8 == 0
-        w = self.word.to(torch.int64)
-        row = torch.where(flagged, gap // 16 + w * (KP // 8), w * (KP // 4))
-        if int(row.abs().max()) >= 1 << 31:                       # the two arrays more than 32 GB apart: int32 rows only
-            self.csc_pos &= 0x7fffffff
-            self.row16 = self.n_kw16 = None
+        n32 = (V + 1) * KP
+        try:
+            both = torch.zeros((n32 + V * KP // 2,), dtype=torch.int32, device=self.device)
+        except torch.cuda.OutOfMemoryError:
+            if not auto:
+                raise
+            import warnings
+            warnings.warn("GibbsSampler: no room for the 16-bit image of n_kw (%.1f GB); sweeping with int32 rows"
+                          % (V * KP * 2 / 1e9))
             return
-        self.site_row = row.to(torch.int32).contiguous()
+        both[:n32] = self._counts
+        self._counts = both[:n32]
+        self.n_kw = self._counts[:V * KP].view(V, KP)
+        self.n_k = self._counts[V * KP:]
+        self._counts16 = both                                  # (keeps the one allocation alive under its own name)
+        self.n_kw16 = both[n32:].view(torch.int16)
+        self._flag_rows16()
         # llda_sweep_args.max_doc_tokens: below 2^16 the 16-bit-row kernel packs n_dk with its sweep-start value and runs four
         # waves per SIMD
         if not self.max_doc_tokens:
             self.max_doc_tokens = tokens_max
+
+    def _rows16_fits(self):
+        return (self.n_kw.sum(dim=1, dtype=torch.int64) <= 65535) & (self.n_kw.min(dim=1).values >= 0)
+
+    def _flag_rows16(self):
+        """which rows the sweep reads from the 16-bit image, from the row totals of the CURRENT n_kw: row16 (per word),
+        bit 31 of csc_pos (per site) and site_row (per site; static until the totals change by other means than sweeps)."""
+        KP = self.layout.KP
+        fits = self._rows16_fits()
+        self.row16 = fits.to(torch.uint8).contiguous()
+        w = self.word.to(torch.int64)
+        flagged = fits[w]
+        self.csc_pos &= 0x7fffffff
+        self.csc_pos |= torch.where(flagged, -(1 << 31), 0).to(torch.int32)
+        gap = self.n_kw16.data_ptr() - self.n_kw.data_ptr()           # = (V+1)*KP*4 bytes: one allocation
+        if gap != (self.V + 1) * KP * 4 or gap % 16:
+            raise _native.NativeError("n_kw16 is not in the allocation of n_kw")
+        self.site_row = torch.where(flagged, gap // 16 + w * (KP // 8), w * (KP // 4)).to(torch.int32).contiguous()
 
     def _make_exchange_rows(self):
         """Exchange layout of the per-sweep count deltas when every rank folds a commit log: one row per word plus
@@ -282,6 +320,8 @@ class GibbsSampler(object):
         pos = self._topic_pos[torch.as_tensor(np.asarray(topics), dtype=torch.int64, device=dev)]
         self.n_kw.index_put_((w, pos), torch.as_tensor(np.asarray(amounts), dtype=torch.int32, device=dev),
                              accumulate=True)
+        if self.n_kw16 is not None:
+            self._flag_rows16()            # row totals changed: a row may no longer fit 16 bits (or fit now)
 
     # ------------------------------------------------------------------ masks
     def _make_masks(self, labs):

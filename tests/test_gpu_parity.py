@@ -500,26 +500,60 @@ def test_16_bit_rows_flag_counts_that_do_not_belong_to_the_corpus():
         s.check_status()
 
 
-def test_16_bit_rows_are_chosen_by_document_and_n_kw_size():
-    """rows16=None: on wherever every document is below 2^16 tokens (the four-wave form: faster than int32 rows at every size); with
-    longer documents (three waves) only when n_kw is at least GibbsSampler.ROWS16_MIN_BYTES"""
+def test_16_bit_rows_share_the_allocation_of_the_counts(c_oracle):
+    """n_kw16 is carved out of the allocation that holds [n_kw | n_k]: the row offsets the kernel follows (site_row, in 16-byte
+    units from n_kw) are a constant of (V, KP), wherever the caching allocator puts anything.  Built here with a 40 GB spacer
+    between two other allocations -- the situation in which two separate tensors used to land more than 32 GB apart."""
     import torch
-    from lda_thesis_amd.corpus import synthetic_corpus_blocks
     from lda_thesis_amd.sampler import GibbsSampler
-    for zipf, V, long_doc, want in ((0.0, 1_000_000, False, True), (1.0, 100_000, False, True), (0.0, 20_000, False, True),
-                                    (0.0, 20_000, True, False), (1.0, 100_000, True, True)):
-        off, w, f, z = synthetic_corpus_blocks(0, 8000, 300, V, 512, 1234, "cuda", zipf_s=zipf, block=4000)
-        if long_doc:
-            f = f.clone()
-            f[0] = 70000                                                  # one document of 70 299 tokens
-        s = GibbsSampler(off, w, f, z, 512, V, 0.1, 0.01, labs=None, seed=1)
-        assert (s.n_kw16 is not None) == want, (zipf, V, long_doc)
-        assert (s.site_row is not None) == want
-        if want:
-            assert (0 < s.max_doc_tokens < 65536) == (not long_doc)
+    K = 512
+    doc_off, word, freq, z, V = _rows16_corpus(K, 5)
+    labs = np.ones((len(doc_off) - 1, K), dtype=np.uint8)
+    a = torch.empty((1 << 20,), dtype=torch.uint8, device="cuda")
+    spacer = torch.empty((40 << 30,), dtype=torch.uint8, device="cuda")
+    b = torch.empty((1 << 20,), dtype=torch.uint8, device="cuda")
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=7, commit_log=True, rows16=True)
+    del spacer
+    KP = s.layout.KP
+    assert s.n_kw16 is not None and s.site_row is not None
+    assert s.n_kw16.data_ptr() - s.n_kw.data_ptr() == (V + 1) * KP * 4
+    assert s.n_k.data_ptr() - s.n_kw.data_ptr() == V * KP * 4
+    assert s._counts.data_ptr() == s.n_kw.data_ptr() and s._counts.numel() == (V + 1) * KP
+    cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
+    for i in range(2):
         s.sweep()
-        s.check_status()
-        del s
+        cs.sweep(1, 7, i, threads=4)
+    np.testing.assert_array_equal(s.z_topics(), cs.z)
+    np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+    np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+    np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
+    s.check_status()
+    del a, b
+
+
+def test_16_bit_rows_follow_counts_added_after_construction(c_oracle):
+    """add_word_topic_counts (SubLDA's phantom counts, CascadeLDA.py:382-385) changes row totals: a row that no longer fits 16
+    bits leaves the image (row16, bit 31 of csc_pos, site_row are recomputed), so nothing is ever truncated"""
+    import torch
+    from lda_thesis_amd.sampler import GibbsSampler
+    K = 512
+    doc_off, word, freq, z, V = _rows16_corpus(K, 6)
+    labs = np.ones((len(doc_off) - 1, K), dtype=np.uint8)
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=7, commit_log=True, rows16=True)
+    assert bool(s.row16[1]) and bool(s.row16[10])
+    s.add_word_topic_counts(np.array([10, 10, 1]), np.array([4, 99, 0]), np.array([40000, 30000, 1]))
+    assert not bool(s.row16[10]) and not bool(s.row16[1]) and bool(s.row16[11])
+    w = torch.as_tensor(word, device="cuda")
+    assert int(((s.csc_pos < 0) & ((w == 10) | (w == 1))).sum()) == 0
+    assert int((s.csc_pos < 0).sum()) == int(s.row16[w.long()].sum())
+    cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
+    for i in range(2):
+        s.sweep()
+        cs.sweep(1, 7, i, threads=4)
+    s.check_status()
+    np.testing.assert_array_equal(s.z_topics(), cs.z)
+    np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+    np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
 
 
 def test_edge_empty_shard_and_empty_documents(c_oracle):

@@ -1,8 +1,8 @@
-"""time the level-1 fold-in launch of CascadeLDA.test_down_tree_batch alone (464 held-out documents, 150 sweeps)."""
+"""cProfile of CascadeLDA.test_down_tree_batch on the abstracts fixture's held-out documents (where does the host time go)."""
 
 
 def main():
-    import io, os, sys, time
+    import cProfile, pstats, io, os, sys, time
     sys.path.insert(0, os.getcwd())
     import numpy as np, torch
     from contextlib import redirect_stdout
@@ -19,14 +19,23 @@ def main():
         m.go_down_tree(4, 2)
     m.ph = np.nan_to_num(m.ph)
     toff, tw, tf = g["test_doc_off"], g["test_word"], g["test_freq"]
-    bows = [list(zip(tw[toff[d]:toff[d + 1]].tolist(), tf[toff[d]:toff[d + 1]].tolist())) for d in range(len(toff) - 1)]
-    bows = [b for b in bows if b]
-    print("docs", len(bows), "max sites", max(len(b) for b in bows), "mean", sum(len(b) for b in bows) / len(bows))
-    for it in (0, 150):
-        for rep in range(2):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            th = m.cascade_test_batch(None, it, 25 if it else 1, m.lablist_l1, seed=1, bows=bows, doc_ids=list(range(len(bows))))
-            torch.cuda.synchronize(); print("it", it, "level-1 launch + prep + readback: %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+    held = []
+    for d in range(len(toff) - 1):
+        toks = []
+        for v, f in zip(tw[toff[d]:toff[d + 1]], tf[toff[d]:toff[d + 1]]):
+            toks += ["w%05d" % v] * int(f)
+        if toks:
+            held.append(toks)
+    for rep in range(2):
+        pr = cProfile.Profile()
+        t0 = time.perf_counter()
+        if rep: pr.enable()
+        trees = m.test_down_tree_batch(held, 150, 25, 0.95)
+        if rep: pr.disable()
+        print("rep", rep, len(held), "docs", time.perf_counter() - t0)
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(30)
+    print(s.getvalue()[:5000])
 
 
 if __name__ == "__main__":
