@@ -189,12 +189,21 @@ def checksum_verdict(name, docs_total, sweeps, got):
 def rows_description(sampler):
     """how the sweep reads n_kw: int32 rows, or the 16-bit image (llda_sweep_args.n_kw16, refreshed inside every timed sweep)
     for the words whose corpus-wide count fits 16 bits"""
+    if getattr(sampler, "n_kw_img", None) is not None:
+        return ("saturating %d-bit image of n_kw (llda_pack_image runs inside every timed sweep); an entry that shows the saturation "
+                "value is re-read from the int32 counts; same results" % (8 * sampler.n_kw_img.element_size()))
     if getattr(sampler, "n_kw16", None) is None:
         return "int32"
     flagged = sampler.row16[sampler.word.long()].float().mean().item() if sampler.S else 0.0
     return ("16-bit image for the words whose corpus-wide count fits 16 bits (%.1f %% of the words, %.1f %% of this rank's sites; "
             "llda_pack_rows16 runs inside every timed sweep), int32 rows for the others; same results (DESIGN.md section 4.1)" %
             (100.0 * sampler.row16.float().mean().item(), 100.0 * flagged))
+
+
+def rows_short(sampler):
+    if getattr(sampler, "n_kw_img", None) is not None:
+        return "%d-bit saturating image + int32 escapes" % (8 * sampler.n_kw_img.element_size())
+    return "int32" if getattr(sampler, "n_kw16", None) is None else "16-bit image + int32 hot rows"
 
 
 def time_sweeps(sampler, steps, warmup, dist=None, dev=None, events=True):
@@ -908,7 +917,7 @@ def compact_cpu(c):
 def compact_extra(e):
     """{value, unit, ms_per_step, frac, binding_roof} (+ the CPU figures where the workload has them) of one extra workload"""
     out = {"value": _num(e.get("value")), "unit": e.get("unit")}
-    for k in ("ms_per_step", "kernel_ms", "steps", "speedup_vs_cpu_port", "cold_first_call_s", "median_s", "max_s"):
+    for k in ("ms_per_step", "kernel_ms", "steps", "speedup_vs_cpu_port", "cold_first_call_s", "median_s", "max_s", "n_kw_rows_short"):
         if e.get(k) is not None:
             out[k] = _num(e[k], 5)
     r = e.get("roofline")
@@ -1111,7 +1120,7 @@ def main():
                        "label_mask": "dense" if live == K else "sparse (%.2f live topics per doc)" % live,
                        "kernel": "sparse" if sampler.live_off is not None else "dense",
                        "n_kw_rows": rows_description(sampler),
-                       "n_kw_rows_short": "int32" if getattr(sampler, "n_kw16", None) is None else "16-bit image + int32 hot rows",
+                       "n_kw_rows_short": rows_short(sampler),
                        "build_info": build_bits, "abi": _native.ABI_VERSION, "library": os.path.relpath(_native.LIB_PATH, ROOT),
                        "sites_per_sweep": total_sites, "timed_seconds": dt,
                        "exchange": sampler.exchange_description() if world > 1 else "none (single GPU: the commit log is "
@@ -1152,7 +1161,7 @@ def main():
                 e = {"workload": i2["desc"], "value": v2, "unit": "Mtokens/s", "steps": st, "warmup": wu,
                      "ms_per_step": dt2 / st * 1e3, "timed_seconds": dt2, "docs": i2["docs_local"], "sites_per_sweep": s2.S,
                      "K": i2["K"], "V": i2["V"], "kernel": "sparse" if s2.live_off is not None else "dense",
-                     "n_kw_rows": rows_description(s2), "kernel_ms": k2}
+                     "n_kw_rows": rows_description(s2), "n_kw_rows_short": rows_short(s2), "kernel_ms": k2}
                 measured[wname] = dict(kernel_ms=k2, sites=s2.S, docs=i2["docs_local"], live=i2["live_topics"],
                                        shared=s2._counts.numel() * 4)
                 if wname == "abstracts":

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 17
+#define LLDA_ABI_VERSION 18
 #define LLDA_MAX_K 7688          /* every K up to here splits into <= 64 pairwise leaves                       */
 #define LLDA_MAX_KP 8192         /* longest padded row: 64 leaves x 128                                        */
 #define LLDA_MAX_LEAVES 8        /* "narrow" layouts: one lane group of <= 64 lanes x <= 16 slots per document  */
@@ -172,9 +172,18 @@ typedef struct llda_sweep_args {
                                     not depend on it. */
     const int32_t *site_row;     /* [dev] [S] with n_kw16 (ABI 16; LLDA_E_BAD_ARG when one comes without the other): where the
                                     row of a site's word starts, in 16-byte units from n_kw --  word * KP / 4  for an int32 row,
-                                    ((char *)n_kw16 - (char *)n_kw) / 16 + word * KP / 8  for a 16-bit one (the two arrays within
-                                    32 GB of each other).  Static: which words are flagged never changes.  The kernel reads it
+                                    ((char *)n_kw16 - (char *)n_kw) / 16 + word * KP / 8  for a 16-bit one (int32 offsets: the caller
+                                    carves both arrays out of ONE allocation, so the distance is a constant of V and KP).  Static: which words are flagged never changes.  The kernel reads it
                                     INSTEAD of word -- the choice between the two images costs it no instruction. */
+    const void    *n_kw_img;     /* [dev] [V*KP] optional (ABI 18), sparse label sets only (live_off / live_pos; LLDA_E_BAD_ARG on
+                                    any other path): the narrow image of THIS sweep's n_kw written by llda_pack_image -- one
+                                    byte (img_bits 8) or one 16-bit word (img_bits 16) per count, SATURATING at 255 / 65535.
+                                    The sparse-label kernel gathers its counts from the image (a row spans a quarter / half
+                                    as many cache lines; that kernel is bound by L2 line fills) and re-reads an entry that
+                                    shows the saturation value from n_kw itself, so any count is legal and the results do not
+                                    depend on the image.  Needs alpha, beta >= 1e-6 like the sparse-label kernel itself. */
+    int32_t  img_bits;           /* 0 (no image), 8 or 16                                                    */
+    int32_t  reserved_img;       /* 0                                                                         */
 } llda_sweep_args;
 
 /* ---- host-only (no device needed) ---- */
@@ -288,6 +297,12 @@ int llda_apply_rows(const int64_t *row_off, int32_t *rows, int64_t n_rows, int32
  * of status word 0. */
 int llda_pack_rows16(const int32_t *n_kw, const uint8_t *row16, int64_t V, int32_t K, uint16_t *n_kw16, int32_t *status,
                      void *stream);
+
+/* The saturating narrow image of n counts for llda_sweep_args.n_kw_img (ABI 18): img[i] = min(n_kw[i], 255) as uint8_t
+ * (bits 8) or min(n_kw[i], 65535) as uint16_t (bits 16); a negative count saturates as well.  n = V*KP, a multiple of 4;
+ * n_kw and img 16-byte / 4-byte aligned.  Call it once per sweep, after the counts of the previous sweep were folded in and
+ * before the first llda_sweep. */
+int llda_pack_image(const int32_t *n_kw, int64_t n, int32_t bits, void *img, void *stream);
 
 /* Count initialisation from assignments: LabeledLDA.py:89-92.  n_dk, n_kw, n_k must be zeroed by the
  * caller; z holds device positions.  (The SubLDA phantom-column quirk, CascadeLDA.py:382-385, is a

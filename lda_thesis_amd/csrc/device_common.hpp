@@ -43,6 +43,8 @@ struct KParams {
     const int32_t *site_rec;   // optional [S][4]: {word, freq, csc_pos, 0} per site (kernels with <= 16 lanes per document)
     const uint16_t *n_kw16;    // optional 16-bit image of n_kw (llda_pack_rows16); sites with bit 31 of csc_pos set read it
     const int32_t *site_row;   // with n_kw16: start of the row of each site's word, 16-byte units from n_kw (read instead of word)
+    const void *img;           // sparse-label kernels: optional narrow image of n_kw (llda_pack_image: one byte / 16-bit word per count,
+                               // saturating); an entry that reads 255 / 65535 is re-read from n_kw
     int w4;                    // with n_kw16: documents hold < 2^16 tokens -- the four-wave form of the kernel may run
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];   // 4 bits per leaf: partner leaf
 };

@@ -32,6 +32,28 @@ __global__ void __launch_bounds__(256) llda_pack_rows16_kernel(const int32_t *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// llda_pack_image: the saturating narrow image of n_kw the sparse-label kernels gather from (llda_sweep_args.n_kw_img).  One
+// thread per four counts: a 16-byte load, a 4- or 8-byte store.
+// ---------------------------------------------------------------------------------------------
+template <int BITS>
+__global__ void __launch_bounds__(256) llda_pack_image_kernel(const int4 *__restrict__ n_kw, void *__restrict__ out, int64_t n4)
+{
+    constexpr uint32_t SAT = BITS == 8 ? 255u : 65535u;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n4; t += (int64_t)gridDim.x * 256) {
+        const int4 a = n_kw[t];
+        const uint32_t x = min((uint32_t)a.x, SAT), y = min((uint32_t)a.y, SAT), z = min((uint32_t)a.z, SAT), w = min((uint32_t)a.w, SAT);
+        if constexpr (BITS == 8) {
+            static_cast<uint32_t *>(out)[t] = x | (y << 8) | (z << 16) | (w << 24);
+        } else {
+            uint2 o;
+            o.x = x | (y << 16);
+            o.y = z | (w << 16);
+            static_cast<uint2 *>(out)[t] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fold of the commit log into word-major counts (llda_commit_log, include/llda_gibbs.h): one wavefront per
 // item (a run of log entries of one word), a histogram of the word's row per wavefront in LDS.  The histogram
 // is flushed either by walking the item's entries again (short items: each touched entry is claimed with an LDS

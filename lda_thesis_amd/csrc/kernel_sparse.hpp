@@ -180,7 +180,17 @@ __device__ void sparse_wide_init();
 // n_k changes go straight to global atomics instead of a workgroup accumulator of KP ints)
 template <class PT> struct sparse_is_wide { static constexpr bool value = false; };
 
-template <int GS, class PT = KParams>
+// IMG = 8 / 16: the gathers read a NARROW IMAGE of n_kw (P.img: one byte / one 16-bit word per count, saturating; written by
+// llda_pack_image at the start of the sweep) -- a row spans a quarter / half as many 128-byte lines, so the eight-odd gathers of a
+// site fall into fewer distinct lines and four / two times as many rows stay in the L2s: the kernel is bound by the L2's line
+// fills (profiles/r03k_summary.md: 4.2 fills per site, 8.8 x the algorithmic bytes).  An entry that reads as the saturation value
+// (255 / 65535) ESCAPES to the int32 count in n_kw itself; the escape loads are issued by every lane (a lane whose entry did not
+// saturate re-reads n_kw[0], one line the L1 keeps), so the number of loads in flight is the same on every path and the three-deep
+// software pipeline below stays exact: at the top of batch b the narrow gathers of b+1 and the escapes of b are in flight.
+template <int IMG> struct img_elem { typedef uint8_t T; static constexpr int SAT = 255; };
+template <> struct img_elem<16> { typedef uint16_t T; static constexpr int SAT = 65535; };
+
+template <int GS, class PT = KParams, int IMG = 0>
 __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const PT P)
 {
     constexpr int GPB = 256 / GS;
@@ -260,41 +270,115 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const PT P)
                 xg[6] = col[(int64_t)w6 * KP]; xg[7] = col[(int64_t)w7 * KP];
             }
         };
-        BatchScalars Sc, Sn;
-        load_scalars(0, Sc);
-        load_scalars(8, Sn);
-        int xg[8];
-        gather(0, Sc.v, xg);
-        for (int n0 = 0; n0 < max_len; n0 += 8) {
-            const int nb = max(0, min(8, len - n0));
-            int xg_next[8];
-            gather(n0 + 8, Sn.v, xg_next);
-            BatchScalars Sf;
-            load_scalars(n0 + 16, Sf);
-            const int sv = Sc.v, sf = Sc.f, sz = Sc.z, sc = Sc.c;
-            int su_lo, su_hi;
-            {   // keyed uniform of site n0+jj: Philox block (site >> 1), words (0,1) / (2,3) by parity
-                const int n = n0 + jj;
-                uint32_t c0 = (uint32_t)(n >> 1), c1 = gdoc, c2 = P.stream_id, c3 = P.sweep;
-                philox4x32_10(c0, c1, c2, c3, P.key0, P.key1);
-                const uint32_t ra = (n & 1) ? c2 : c0, rb = (n & 1) ? c3 : c1;
-                const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
-                su_lo = __double2loint(u); su_hi = __double2hiint(u);
-            }
+        if constexpr (IMG == 0) {
+            BatchScalars Sc, Sn;
+            load_scalars(0, Sc);
+            load_scalars(8, Sn);
+            int xg[8];
+            gather(0, Sc.v, xg);
+            for (int n0 = 0; n0 < max_len; n0 += 8) {
+                const int nb = max(0, min(8, len - n0));
+                int xg_next[8];
+                gather(n0 + 8, Sn.v, xg_next);
+                BatchScalars Sf;
+                load_scalars(n0 + 16, Sf);
+                const int sv = Sc.v, sf = Sc.f, sz = Sc.z, sc = Sc.c;
+                int su_lo, su_hi;
+                {   // keyed uniform of site n0+jj: Philox block (site >> 1), words (0,1) / (2,3) by parity
+                    const int n = n0 + jj;
+                    uint32_t c0 = (uint32_t)(n >> 1), c1 = gdoc, c2 = P.stream_id, c3 = P.sweep;
+                    philox4x32_10(c0, c1, c2, c3, P.key0, P.key1);
+                    const uint32_t ra = (n & 1) ? c2 : c0, rb = (n & 1) ? c3 : c1;
+                    const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+                    su_lo = __double2loint(u); su_hi = __double2hiint(u);
+                }
 
-            int my_zn = sz;
-            int done = 0;                     // sites of this batch
-#define LLDA_SPARSE_SITE(J)                                                                                    \
-            sparse_site<GS, J>(P, -1, -1, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
-                               gbase, gmask);
-            LLDA_SPARSE_SITE(0) LLDA_SPARSE_SITE(1) LLDA_SPARSE_SITE(2) LLDA_SPARSE_SITE(3)
-            LLDA_SPARSE_SITE(4) LLDA_SPARSE_SITE(5) LLDA_SPARSE_SITE(6) LLDA_SPARSE_SITE(7)
-#undef LLDA_SPARSE_SITE
-            // commit the sites of the batch: lane j handles site n0+j
-            if (lig < 8 && lig < done) commit_site(*kernarg_fresh<PT>(), s0 + n0 + lig, sv, sf, sz, my_zn, sc, KP);
-            Sc = Sn; Sn = Sf;
+                int my_zn = sz;
+                int done = 0;                     // sites of this batch
+    #define LLDA_SPARSE_SITE(J)                                                                                    \
+                sparse_site<GS, J>(P, -1, -1, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
+                                   gbase, gmask);
+                LLDA_SPARSE_SITE(0) LLDA_SPARSE_SITE(1) LLDA_SPARSE_SITE(2) LLDA_SPARSE_SITE(3)
+                LLDA_SPARSE_SITE(4) LLDA_SPARSE_SITE(5) LLDA_SPARSE_SITE(6) LLDA_SPARSE_SITE(7)
+    #undef LLDA_SPARSE_SITE
+                // commit the sites of the batch: lane j handles site n0+j
+                if (lig < 8 && lig < done) commit_site(*kernarg_fresh<PT>(), s0 + n0 + lig, sv, sf, sz, my_zn, sc, KP);
+                Sc = Sn; Sn = Sf;
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) xg[j] = xg_next[j];
+            }
+        } else {
+            typedef typename img_elem<IMG>::T IT;
+            constexpr int SAT = img_elem<IMG>::SAT;
+            auto narrow = [&](const int n0b, const int sv, int (&xn)[8]) {
+                const int nbb = max(0, min(8, len - n0b));
+                const int w0 = bcast_lane<GS, 0>(sv, lig), w1 = bcast_lane<GS, 1>(sv, lig), w2 = bcast_lane<GS, 2>(sv, lig),
+                          w3 = bcast_lane<GS, 3>(sv, lig), w4 = bcast_lane<GS, 4>(sv, lig), w5 = bcast_lane<GS, 5>(sv, lig),
+                          w6 = bcast_lane<GS, 6>(sv, lig), w7 = bcast_lane<GS, 7>(sv, lig);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xg[j] = xg_next[j];
+                for (int j = 0; j < 8; ++j) xn[j] = 0;
+                if (live && nbb > 0) {
+                    const LLDA_GLOBAL IT *col = (const LLDA_GLOBAL IT *)P.img + pos;
+                    xn[0] = col[(int64_t)w0 * KP]; xn[1] = col[(int64_t)w1 * KP]; xn[2] = col[(int64_t)w2 * KP];
+                    xn[3] = col[(int64_t)w3 * KP]; xn[4] = col[(int64_t)w4 * KP]; xn[5] = col[(int64_t)w5 * KP];
+                    xn[6] = col[(int64_t)w6 * KP]; xn[7] = col[(int64_t)w7 * KP];
+                }
+            };
+            // (lanes without a document or past its allowed topics hold 0 in xn: never saturated, they read n_kw[0])
+            auto escape = [&](const int sv, const int (&xn)[8], int (&xe)[8]) {
+                const int w0 = bcast_lane<GS, 0>(sv, lig), w1 = bcast_lane<GS, 1>(sv, lig), w2 = bcast_lane<GS, 2>(sv, lig),
+                          w3 = bcast_lane<GS, 3>(sv, lig), w4 = bcast_lane<GS, 4>(sv, lig), w5 = bcast_lane<GS, 5>(sv, lig),
+                          w6 = bcast_lane<GS, 6>(sv, lig), w7 = bcast_lane<GS, 7>(sv, lig);
+                const LLDA_GLOBAL int32_t *cnt = (const LLDA_GLOBAL int32_t *)P.n_kw;
+#define LLDA_ESC(J, W) xe[J] = cnt[xn[J] == SAT ? (int64_t)(W) * KP + pos : (int64_t)0];
+                LLDA_ESC(0, w0) LLDA_ESC(1, w1) LLDA_ESC(2, w2) LLDA_ESC(3, w3)
+                LLDA_ESC(4, w4) LLDA_ESC(5, w5) LLDA_ESC(6, w6) LLDA_ESC(7, w7)
+#undef LLDA_ESC
+            };
+            BatchScalars S0, S1, S2;
+            load_scalars(0, S0);
+            load_scalars(8, S1);
+            load_scalars(16, S2);
+            int xn0[8], xe0[8], xn1[8];
+            narrow(0, S0.v, xn0);
+            narrow(8, S1.v, xn1);
+            escape(S0.v, xn0, xe0);
+            for (int n0 = 0; n0 < max_len; n0 += 8) {
+                const int nb = max(0, min(8, len - n0));
+                int xg[8];                                     // the counts of batch n0: image entry, or its escape
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xg[j] = (xn0[j] == SAT) ? xe0[j] : xn0[j];
+                int xn2[8];
+                narrow(n0 + 16, S2.v, xn2);
+                BatchScalars S3;
+                load_scalars(n0 + 24, S3);
+                int xe1[8];
+                escape(S1.v, xn1, xe1);
+                const int sv = S0.v, sf = S0.f, sz = S0.z, sc = S0.c;
+                int su_lo, su_hi;
+                {   // keyed uniform of site n0+jj: Philox block (site >> 1), words (0,1) / (2,3) by parity
+                    const int n = n0 + jj;
+                    uint32_t c0 = (uint32_t)(n >> 1), c1 = gdoc, c2 = P.stream_id, c3 = P.sweep;
+                    philox4x32_10(c0, c1, c2, c3, P.key0, P.key1);
+                    const uint32_t ra = (n & 1) ? c2 : c0, rb = (n & 1) ? c3 : c1;
+                    const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+                    su_lo = __double2loint(u); su_hi = __double2hiint(u);
+                }
+
+                int my_zn = sz;
+                int done = 0;                     // sites of this batch
+    #define LLDA_SPARSE_SITE(J)                                                                                    \
+                sparse_site<GS, J>(P, -1, -1, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
+                                   gbase, gmask);
+                LLDA_SPARSE_SITE(0) LLDA_SPARSE_SITE(1) LLDA_SPARSE_SITE(2) LLDA_SPARSE_SITE(3)
+                LLDA_SPARSE_SITE(4) LLDA_SPARSE_SITE(5) LLDA_SPARSE_SITE(6) LLDA_SPARSE_SITE(7)
+    #undef LLDA_SPARSE_SITE
+                // commit the sites of the batch: lane j handles site n0+j
+                if (lig < 8 && lig < done) commit_site(*kernarg_fresh<PT>(), s0 + n0 + lig, sv, sf, sz, my_zn, sc, KP);
+                S0 = S1; S1 = S2; S2 = S3;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { xn0[j] = xn1[j]; xe0[j] = xe1[j]; xn1[j] = xn2[j]; }
+            }
         }
         if (live) {
             *ndk_p = ndk;

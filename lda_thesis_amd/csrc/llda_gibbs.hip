@@ -476,6 +476,17 @@ int64_t llda_sweep_scratch_bytes(int32_t K, int64_t D)
     return (int64_t)wide_blocks(D) * Lp->KP * 8;          // one row of doubles per workgroup of the wide sweep
 }
 
+// llda_sweep_args.n_kw_img / img_bits -> KParams.img of a sparse-label launch
+static int take_image(const llda_sweep_args *a, KParams &P)
+{
+    P.img = nullptr;
+    if (!a->n_kw_img && !a->img_bits) return LLDA_OK;
+    if (!a->n_kw_img || (a->img_bits != 8 && a->img_bits != 16)) return LLDA_E_BAD_ARG;
+    if (reinterpret_cast<uintptr_t>(a->n_kw_img) & 3) return LLDA_E_BAD_ARG;
+    P.img = a->n_kw_img;
+    return LLDA_OK;
+}
+
 int llda_sweep(const llda_sweep_args *a, void *stream)
 {
     if (!a || a->D < 0 || a->V < 1) return LLDA_E_BAD_ARG;
@@ -537,18 +548,26 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         const size_t lds = (size_t)L.KP * 8 + 16;
         const dim3 grid((unsigned)blocks), block(256);
         int rl;
+        const int rimg = take_image(a, W);
+        if (rimg) return rimg;
+#define LLDA_SPARSE_WIDE_I(GS_, IMG_)                                                                       \
+        rl = allow_lds(llda_sweep_sparse_kernel<GS_, WSParams, IMG_>, lds);                                 \
+        if (rl) return rl;                                                                                  \
+        hipLaunchKernelGGL((llda_sweep_sparse_kernel<GS_, WSParams, IMG_>), grid, block, lds, st, W);
 #define LLDA_SPARSE_WIDE(GS_)                                                                       \
     case GS_:                                                                                       \
-        rl = allow_lds(llda_sweep_sparse_kernel<GS_, WSParams>, lds);                               \
-        if (rl) return rl;                                                                          \
-        hipLaunchKernelGGL((llda_sweep_sparse_kernel<GS_, WSParams>), grid, block, lds, st, W);     \
+        if (a->img_bits == 8) { LLDA_SPARSE_WIDE_I(GS_, 8) }                                        \
+        else if (a->img_bits == 16) { LLDA_SPARSE_WIDE_I(GS_, 16) }                                 \
+        else { LLDA_SPARSE_WIDE_I(GS_, 0) }                                                         \
         break;
         switch (GS) { LLDA_SPARSE_WIDE(8) LLDA_SPARSE_WIDE(16) LLDA_SPARSE_WIDE(32) LLDA_SPARSE_WIDE(64) }
 #undef LLDA_SPARSE_WIDE
+#undef LLDA_SPARSE_WIDE_I
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? LLDA_OK : hip_fail(e);
     }
     if (L.wide) {                                           // more than 8 pairwise leaves: the general path
+        if (a->n_kw_img || a->img_bits) return LLDA_E_BAD_ARG;   // the narrow image belongs to the sparse-label kernels
         WParams W;
         memset(&W, 0, sizeof W);
         W.k = P;
@@ -641,15 +660,20 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         P.live_off = a->live_off; P.live_pos = a->live_pos;
         if (a->debug_margin < 0) P.margin_rel = 2.0;       // test hook: every site goes through the exact pipeline
         const dim3 grid((unsigned)blocks), block(256);
-        switch (G) {
-        case 8: hipLaunchKernelGGL(llda_sweep_sparse_kernel<8>, grid, block, 0, st, P); break;
-        case 16: hipLaunchKernelGGL(llda_sweep_sparse_kernel<16>, grid, block, 0, st, P); break;
-        case 32: hipLaunchKernelGGL(llda_sweep_sparse_kernel<32>, grid, block, 0, st, P); break;
-        default: hipLaunchKernelGGL(llda_sweep_sparse_kernel<64>, grid, block, 0, st, P); break;
-        }
+        const int rimg = take_image(a, P);
+        if (rimg) return rimg;
+#define LLDA_SPARSE(GS_)                                                                                              \
+    case GS_:                                                                                                         \
+        if (a->img_bits == 8) hipLaunchKernelGGL((llda_sweep_sparse_kernel<GS_, KParams, 8>), grid, block, 0, st, P);       \
+        else if (a->img_bits == 16) hipLaunchKernelGGL((llda_sweep_sparse_kernel<GS_, KParams, 16>), grid, block, 0, st, P); \
+        else hipLaunchKernelGGL((llda_sweep_sparse_kernel<GS_, KParams, 0>), grid, block, 0, st, P);                       \
+        break;
+        switch (G) { LLDA_SPARSE(8) LLDA_SPARSE(16) LLDA_SPARSE(32) LLDA_SPARSE(64) }
+#undef LLDA_SPARSE
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? LLDA_OK : hip_fail(e);
     }
+    if (a->n_kw_img || a->img_bits) return LLDA_E_BAD_ARG;         // the narrow image belongs to the sparse-label kernels
     if ((a->n_kw16 != nullptr) != (a->site_row != nullptr)) return LLDA_E_BAD_ARG;
     if (a->n_kw16) {
         // 16-bit rows (bit 31 of csc_pos): the dense 16-slot kernel with the commit log, nothing else knows the flag
@@ -767,6 +791,24 @@ int llda_pack_rows16(const int32_t *n_kw, const uint8_t *row16, int64_t V, int32
     if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
     hipLaunchKernelGGL(llda_pack_rows16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_kw, row16, n_kw16,
                        V, L.G, status);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
+}
+
+int llda_pack_image(const int32_t *n_kw, int64_t n, int32_t bits, void *img, void *stream)
+{
+    if (n < 0 || (n & 3) || (bits != 8 && bits != 16)) return LLDA_E_BAD_ARG;
+    if (n == 0) return LLDA_OK;
+    if (!n_kw || !img) return LLDA_E_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(n_kw) & 15) || (reinterpret_cast<uintptr_t>(img) & (bits == 8 ? 3 : 7))) return LLDA_E_BAD_ARG;
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (bits == 8)
+        hipLaunchKernelGGL(llda_pack_image_kernel<8>, grid, block, 0, (hipStream_t)stream, reinterpret_cast<const int4 *>(n_kw), img, n4);
+    else
+        hipLaunchKernelGGL(llda_pack_image_kernel<16>, grid, block, 0, (hipStream_t)stream, reinterpret_cast<const int4 *>(n_kw), img, n4);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
 }

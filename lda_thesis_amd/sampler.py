@@ -91,12 +91,19 @@ class GibbsSampler(object):
                the counts plus 4 bytes per site; with rows16=None a shard that has no room for it sweeps with int32 rows
                (with a warning) and the environment variable LLDA_ROWS16=on|off decides for callers that cannot pass the
                argument.
+    image    : sparse label sets (the sparse-label kernel): the kernel gathers its counts from a SATURATING narrow image of n_kw
+               (8 or 16 bits per count, refreshed by ``llda_pack_image`` at the start of every sweep) and re-reads an entry that
+               shows 255 / 65535 from n_kw itself: a row spans a quarter / half as many cache lines, and the kernel is bound by
+               the L2's line fills.  Same results.  None (default) = 8, 16 or no image by the size of the problem (n_kw of at
+               least IMAGE_MIN_BYTES and IMAGE_MIN_SITES sites) and the share of gathers that would escape; 0 = off; 8 / 16 = that
+               image wherever the sparse-label kernel runs.  Costs V*KP (8) or 2*V*KP (16) bytes; LLDA_IMAGE=0|8|16 in the
+               environment decides for callers that cannot pass the argument.
     """
 
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
                  stream_id=0, doc_base=0, device=None, group=None, sort_docs=True,
                  docs_per_group=0, sharded=True, sparse_labels=True, commit_log=None, exchange_always=False,
-                 overlap_ranges=1, rows16=None):
+                 overlap_ranges=1, rows16=None, image=None):
         _native.lib()                                       # fail loudly when the extension is missing
         _native.require_device()                            # ... or when no GPU is visible: there is no CPU fallback
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
@@ -207,6 +214,52 @@ class GibbsSampler(object):
         if (rows16 is not False and self.S and self.dense_mask and self.commit_log is not None
                 and _native.rows16_ok(self.K) and self.alpha >= 1e-6 and self.beta >= 1e-6):
             self._make_rows16(auto=rows16 is None)
+        self.n_kw_img = None
+        if image is None and os.environ.get("LLDA_IMAGE") in ("0", "8", "16"):   # for callers behind the LabeledLDA front end
+            image = int(os.environ["LLDA_IMAGE"])
+        if image not in (None, 0, 8, 16):
+            raise ValueError("image must be None (automatic), 0 (off), 8 or 16")
+        if (image != 0 and self.S and self.live_off is not None and self.alpha >= 1e-6 and self.beta >= 1e-6
+                and self.V * self.beta < 2.0 ** 40):
+            self._make_image(image)
+
+    IMAGE_MIN_BYTES = 32 << 20       # image=None: below this n_kw (the eight L2s hold it) or below IMAGE_MIN_SITES sites the per-sweep
+    IMAGE_MIN_SITES = 1 << 20        # llda_pack_image pass costs more than the line fills it saves
+    IMAGE_MAX_ESCAPES = 0.25         # image=None: the narrowest image whose sampled escape rate stays below this
+
+    def _image_escape_rates(self, sample=1 << 18):
+        """share of the gathers of a sweep (site x allowed topic of its document) whose count would saturate an 8-bit / a 16-bit
+        image, over an evenly strided sample of the local sites and the CURRENT counts -> (rate8, rate16)"""
+        dev = self.device
+        step = max(1, self.S // sample)
+        sites = torch.arange(0, self.S, step, device=dev)
+        docs = torch.bucketize(sites, self.doc_off[1:], right=True)
+        lo, n = self.live_off[docs], (self.live_off[docs + 1] - self.live_off[docs])
+        j = torch.arange(self.live_max, device=dev)
+        ok = j[None, :] < n[:, None]
+        pos = self.live_pos[torch.where(ok, lo[:, None] + j[None, :], lo[:, None]).clamp_(max=max(self.live_pos.numel() - 1, 0))].to(torch.int64)
+        x = self.n_kw[self.word[sites].to(torch.int64)[:, None], pos]
+        total = max(int(ok.sum().item()), 1)
+        return (int(((x >= 255) & ok).sum().item()) / total, int(((x >= 65535) & ok).sum().item()) / total)
+
+    def _make_image(self, bits=None):
+        """the saturating narrow image of n_kw for the sparse-label kernels (llda_sweep_args.n_kw_img): uint8 / int16 [V, KP],
+        refreshed by llda_pack_image at the start of every sweep.  bits=None picks 8, 16 or no image from the size of the problem
+        and the sampled escape rates; the choice only ever changes how fast a sweep runs."""
+        n = self.V * self.layout.KP
+        if bits is None:
+            if n * 4 < self.IMAGE_MIN_BYTES or self.S < self.IMAGE_MIN_SITES:
+                return
+            r8, r16 = self._image_escape_rates()
+            bits = 8 if r8 <= self.IMAGE_MAX_ESCAPES else 16 if r16 <= self.IMAGE_MAX_ESCAPES else 0
+            if not bits:
+                return
+        try:
+            self.n_kw_img = torch.zeros((n,), dtype=torch.uint8 if bits == 8 else torch.int16, device=self.device)
+        except torch.cuda.OutOfMemoryError:
+            import warnings
+            warnings.warn("GibbsSampler: no room for the %d-bit image of n_kw (%.1f GB); gathering from n_kw itself" % (bits, n * bits / 8e9))
+            self.n_kw_img = None
 
     ROWS16_MIN_BYTES = 64 << 20      # rows16=None, documents of 2^16 tokens or more (three waves per SIMD): below this n_kw
                                      # the L2s serve the int32 rows and the shorter kernel wins
@@ -467,6 +520,8 @@ class GibbsSampler(object):
         n_ranges = len(self._ranges) - 1
         if self.n_kw16 is not None:                           # this sweep's n_kw: nothing below changes it before the fold
             _native.pack_rows16(self.n_kw, self.row16, self.K, self.n_kw16, self.status)
+        if self.n_kw_img is not None:
+            _native.pack_image(self.n_kw, self.n_kw_img)
         # decided from values every rank agrees on (a rank with an empty shard logs nothing but must still issue
         # one collective per range)
         pipelined = exchange and self.rows is not None and n_ranges > 1
@@ -492,7 +547,7 @@ class GibbsSampler(object):
                               live_pos=self.live_pos,
                               live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
                               n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens,
-                              scratch=self._scratch, n_kw16=self.n_kw16, site_row=self.site_row)
+                              scratch=self._scratch, n_kw16=self.n_kw16, site_row=self.site_row, n_kw_img=self.n_kw_img)
             if pipelined:
                 # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
                 # collective's stream (ordered after the fold) while the next range is sampled on this one

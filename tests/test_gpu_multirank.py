@@ -156,6 +156,70 @@ def test_configs3_slice_sharded_over_ranks_equals_the_one_rank_run(one_rank_slic
     assert got == sorted(blocks1), "z / n_dk of the shards differ from the one-rank run"
 
 
+# ---- the same slice with SPARSE label sets (root + 7 labels per document): the sparse-label kernel, with and without its narrow image
+SPARSE_DOCS = 100000
+
+
+def _sparse_slice_worker(rank, world, port, image, q):
+    from lda_thesis_amd.corpus import synthetic_corpus_blocks
+    from lda_thesis_amd.sampler import GibbsSampler
+    if world > 1:
+        dev = _setup(rank, world, port, True)
+    else:
+        _setup_paths_only()
+        torch.cuda.set_device(0)
+        dev = "cuda:0"
+    lo, hi = SPARSE_DOCS // world * rank, SPARSE_DOCS // world * (rank + 1)
+    doc_off, word, freq, _ = synthetic_corpus_blocks(lo, hi, SLICE_N, SLICE_V, SLICE_K, 1234, dev, zipf_s=1.0, block=SLICE_BLOCK)
+    labs, zs = [], []
+    for b in range(lo // SLICE_BLOCK, hi // SLICE_BLOCK):            # label sets and start topics seeded per block of documents
+        rng = np.random.default_rng(1000 + b)
+        lab = np.sort(rng.integers(1, SLICE_K - 8, size=(SLICE_BLOCK, 7)), axis=1) + np.arange(7)
+        lab = np.concatenate([np.zeros((SLICE_BLOCK, 1), dtype=lab.dtype), lab], axis=1)
+        pick = rng.integers(0, 8, size=(SLICE_BLOCK, SLICE_N))
+        labs.append(lab)
+        zs.append(np.take_along_axis(lab, pick, axis=1).reshape(-1))
+    lab, z = np.concatenate(labs), np.concatenate(zs)
+    lab_off = np.arange(0, 8 * (hi - lo) + 1, 8, dtype=np.int64)
+    s = GibbsSampler(doc_off, word, freq, z, SLICE_K, SLICE_V, 0.1, 0.01, labs=(lab_off, lab.reshape(-1)), seed=42, doc_base=lo,
+                     device=dev, image=image)
+    facts = dict(sparse=s.live_off is not None, image=0 if s.n_kw_img is None else 8 * s.n_kw_img.element_size(),
+                 rows=s.rows is not None, logged=s.commit_log is not None)
+    for _ in range(SLICE_SWEEPS):
+        s.sweep()
+    s.check_status()
+    torch.cuda.synchronize()
+    nb = SLICE_BLOCK * SLICE_N
+    blocks = [(lo // SLICE_BLOCK + b, _digest(s.z[b * nb:(b + 1) * nb]),
+               _digest(s.n_dk[b * SLICE_BLOCK:(b + 1) * SLICE_BLOCK])) for b in range((hi - lo) // SLICE_BLOCK)]
+    q.put((rank, _digest(s._counts), blocks, facts, int(s.n_k.sum(dtype=torch.int64))))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def one_rank_sparse_slice():
+    (rank, counts, blocks, facts, tokens), = _spawn(1, _sparse_slice_worker, (0,))
+    assert facts["sparse"] and facts["image"] == 0 and tokens == SPARSE_DOCS * SLICE_N
+    return counts, blocks
+
+
+@pytest.mark.parametrize("world,image", [(1, 8), (1, 16), (1, None), (2, 8), (2, 16), (4, None)])
+def test_sparse_label_slice_with_the_narrow_image_equals_the_plain_one_rank_run(one_rank_sparse_slice, world, image):
+    """llda_sweep_args.n_kw_img on a 100 000-document slice of the sparse variant of configs[3]: every rank packs the image of ITS
+    replica of n_kw after the exchange; states equal the one-process run without an image, bit for bit"""
+    counts1, blocks1 = one_rank_sparse_slice
+    res = _spawn(world, _sparse_slice_worker, (image,), timeout=900)
+    for rank, counts, blocks, facts, tokens in res:
+        assert counts == counts1, "rank %d: [n_kw | n_k] differs from the one-rank run without an image" % rank
+        assert tokens == SPARSE_DOCS * SLICE_N and facts["sparse"] and facts["logged"]
+        assert facts["image"] == (image if image is not None else facts["image"]) and facts["image"] in (8, 16)
+        assert facts["rows"] == (world > 1)
+    got = sorted(b for _, _, blocks, _, _ in res for b in blocks)
+    assert got == sorted(blocks1), "z / n_dk of the shards differ from the one-rank run"
+
+
 # ------------------------------------------------------------------------------------------------ (iii) drop-in classes
 def _llda(rank, world, port, q):
     _llda_worker(rank, world, port, q, hip=True)

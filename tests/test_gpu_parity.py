@@ -617,15 +617,18 @@ def test_edge_tiny_priors_take_the_exact_kernel(c_oracle):
 
 
 # ---- sparse-label kernel (one lane per allowed topic) -------------------------------------------------
+@pytest.mark.parametrize("image", [0, 8, 16])
 @pytest.mark.parametrize("margin", [0, 6, -1])
 @pytest.mark.parametrize("name", ["tiny_k40", "tiny_k392", "tiny_k200", "sublda", "tiny_k1100"])
-def test_sparse_kernel_matches_reference_o3(name, margin):
+def test_sparse_kernel_matches_reference_o3(name, margin, image):
     """fixtures whose documents allow few topics run through llda_sweep_sparse_kernel; margin 6 sends many sites
-    through the in-kernel exact tier (exact_site_wave), -1 every site."""
+    through the in-kernel exact tier (exact_site_wave), -1 every site; image 8 / 16: the gathers read the saturating narrow
+    image of n_kw (llda_pack_image) and escape to n_kw where it shows 255 / 65535."""
     g = load_golden(name)
-    s = make_sampler(g)
+    s = make_sampler(g, image=image)
     if s.live_off is None:
         pytest.skip("label sets too dense for the sparse kernel")
+    assert (s.n_kw_img is not None) == bool(image)
     s.debug_margin = margin
     for i in range(int(g["sweeps"])):
         s.sweep()
@@ -637,6 +640,17 @@ def test_sparse_kernel_matches_reference_o3(name, margin):
 @pytest.mark.parametrize("K", [9, 40, 100, 129, 190, 257, 392, 640, 777, 900, 968, 1024,
                                1031, 1500, 2100, 3000, 7688])      # the last five: wide layouts (wide exact tier, LDS lock)
 def test_sparse_kernel_exact_tier_on_every_layout_shape(c_oracle, K, margin):
+    _sparse_exact_tier_case(c_oracle, K, margin, 0)
+
+
+@pytest.mark.parametrize("image", [8, 16])
+@pytest.mark.parametrize("K", [9, 129, 392, 777, 1024, 1031, 3000])
+def test_sparse_kernel_exact_tier_with_the_narrow_image(c_oracle, K, image):
+    """the same with the gathers going through the 8- / 16-bit image: the exact tier sees the escaped counts too"""
+    _sparse_exact_tier_case(c_oracle, K, 6, image)
+
+
+def _sparse_exact_tier_case(c_oracle, K, margin, image):
     """exact_site_wave (the reference's fp64 pipeline run by a whole wavefront in the dense layout, with G, T, tail and
     the leaf-combine schedule as run-time values): every site (margin -1) or a mixture with decided sites inside one
     wavefront (margin 2^-6) of sparse-label documents, for one / two / four / seven (unbalanced tree) / eight leaves,
@@ -652,8 +666,9 @@ def test_sparse_kernel_exact_tier_on_every_layout_shape(c_oracle, K, margin):
         n = int(rng.integers(0, min(20, K // 4 - 1) + 1))
         labs[d, rng.choice(K - 1, size=n, replace=False) + 1] = 1
     z = np.concatenate([rng.choice(np.nonzero(labs[d])[0], size=doc_off[d + 1] - doc_off[d]) for d in range(D)])
-    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=77, doc_base=3)
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=77, doc_base=3, image=image)
     assert s.live_off is not None                      # the sparse kernel runs
+    assert (s.n_kw_img is not None) == bool(image)
     s.debug_margin = margin
     cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
     for i in range(3):
@@ -665,6 +680,84 @@ def test_sparse_kernel_exact_tier_on_every_layout_shape(c_oracle, K, margin):
         np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
     s.check_status()
     assert int(s.status[2]) > 0                        # sites really went through the exact tier
+
+
+def _image_corpus(K, seed, D=700, V=150):
+    """sparse label sets (root + up to 7 labels) over a corpus whose counts straddle BOTH saturation values of the narrow image:
+    word 0 with 20 million tokens (entries far above 65535), word 1 with a few hundred thousand (entries around 65535: some
+    above, some below), word 2 around 255, word 3 exactly 255 tokens in one topic and word 4 exactly 65535, the rest rare; ragged
+    documents from one site to 70, so batches of 8 sites end everywhere."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, 71, size=D)
+    lens[:3] = (1, 2, 70)
+    doc_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    S = int(doc_off[-1])
+    word = np.concatenate([np.sort(rng.choice(V, size=n, replace=False, p=None)) for n in lens]).astype(np.int32)
+    hot = rng.random(S) < 0.5                                          # half of the documents' first words are the hot ones
+    first = np.zeros(S, dtype=bool)
+    first[doc_off[:-1]] = True
+    word[first & hot] = rng.integers(0, 5, size=int((first & hot).sum()))
+    for d in range(D):                                                 # keep word ids unique and ascending inside a document
+        sl = slice(doc_off[d], doc_off[d + 1])
+        w = np.unique(word[sl])
+        while len(w) < lens[d]:
+            w = np.unique(np.concatenate([w, rng.integers(5, V, size=lens[d] - len(w))]))
+        word[sl] = w
+    freq = rng.integers(1, 4, size=S).astype(np.int32)
+    labs = np.zeros((D, K), dtype=np.uint8)
+    labs[:, 0] = 1
+    for d in range(D):
+        labs[d, rng.choice(K - 1, size=int(rng.integers(0, 8)), replace=False) + 1] = 1
+    doc_of = np.searchsorted(doc_off, np.arange(S), side="right") - 1
+    z = np.array([rng.choice(np.nonzero(labs[d])[0]) for d in doc_of], dtype=np.int64)
+    for w, total in ((0, 20_000_000), (1, 400_000), (2, 2_000), (3, 255), (4, 65535)):
+        idx = np.nonzero(word == w)[0]
+        assert len(idx) >= 4, (w, len(idx))
+        freq[idx] = 1
+        rest = total - len(idx)
+        j = 0
+        while rest > 0:
+            add = min(rest, (1 << 22))
+            freq[idx[j % len(idx)]] += add
+            rest -= add
+            j += 1
+        assert int(freq[idx].sum()) == total and int(freq[idx].max()) < (1 << 23)
+        if w in (3, 4):
+            z[idx] = 0                                                 # the whole word in the root topic: one entry == SAT
+    return doc_off, word, freq, z, labs, V
+
+
+@pytest.mark.parametrize("image", [8, 16])
+@pytest.mark.parametrize("K", [64, 392, 512, 1500])
+def test_narrow_image_escapes_equal_the_c_oracle(c_oracle, K, image):
+    """llda_sweep_args.n_kw_img: counts below, at and above the saturation value of the image next to each other in one wavefront
+    -- 255 / 65535 exactly, 20 million -- against the C oracle (LabeledLDA.py:106-125), three sweeps, production margins and the
+    exact tier; and bit for bit the sampler that gathers from n_kw itself."""
+    import torch
+    from lda_thesis_amd.sampler import GibbsSampler
+    doc_off, word, freq, z, labs, V = _image_corpus(K, 5 * K + image)
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=21, doc_base=9, image=image)
+    r = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=21, doc_base=9, image=0)
+    assert s.live_off is not None and s.n_kw_img is not None and r.n_kw_img is None
+    sat = 255 if image == 8 else 65535
+    assert int((s.n_kw == sat).sum()) >= 1 and int((s.n_kw > sat).sum()) >= 1 and int(s.n_kw.max()) > (1 << 22)
+    cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
+    for i in range(3):
+        s.debug_margin = r.debug_margin = (0, 6, -1)[i]
+        s.sweep()
+        r.sweep()
+        cs.sweep(1, 21, i, doc_base=9, threads=4)
+        np.testing.assert_array_equal(s.z_topics(), cs.z)
+        np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+        np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+        np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
+        assert torch.equal(r.z, s.z) and torch.equal(r._counts, s._counts) and torch.equal(r.n_dk, s.n_dk)
+    s.check_status()
+    # the image the NEXT sweep would read is the saturated copy of the counts
+    import lda_thesis_amd._native as nat
+    nat.pack_image(s.n_kw, s.n_kw_img)
+    img = s.n_kw_img.to(torch.int32) & (0xff if image == 8 else 0xffff)
+    assert torch.equal(img, s.n_kw.reshape(-1).clamp(max=sat))
 
 
 def test_sparse_and_dense_kernels_agree_on_a_large_sparse_workload(c_oracle):
