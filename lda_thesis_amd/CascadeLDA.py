@@ -492,14 +492,14 @@ class CascadeLDA(object):
         dict(parent, labset (children, 'root' NOT yet inserted), K, docs (member document ids, ascending),
         allowed ((D_p, A_max) local topic ids of every member, ascending, -1 padded; topic 0 = the sub-problem's
         'root'), n_allowed)."""
-        members, kids = {}, {}
-        for d, lab in enumerate(self.rawlabs):
-            for x in set(lab):
-                members.setdefault(x, []).append(d)                 # `parent in lab` (sub_corpus)
-        for level, lists in ((1, self.l2), (2, self.l3)):
-            for d, lab in enumerate(lists):
-                for x in lab:
-                    kids.setdefault(x[:level], []).append((d, x))
+        # self.labs[d, labelmap[x]] is 1 exactly when x is among the raw labels of document d (set_label), so `parent in lab`
+        # (sub_corpus, CascadeLDA.py:115) and "the children of parent the document carries" are column reads of that matrix
+        L = np.asarray(self.labs) != 0
+        col = self.labelmap
+        by_prefix = {}
+        for x in self.lablist:
+            if len(x) in (2, 3):
+                by_prefix.setdefault(x[:-1], []).append(x)
         order = ["root"]
         for l in [x for x in self.lablist_l1 if x != "root"]:
             order.append(l)
@@ -509,20 +509,17 @@ class CascadeLDA(object):
             if parent == "root":
                 docs = np.arange(self.D, dtype=np.int64)
                 labset = [x for x in self.lablist_l1 if x != "root"]
-                pairs = [(d, x) for d, lab in enumerate(self.l1) for x in lab]
+                sub = L[:, [col[x] for x in labset]]
             else:
-                docs = np.asarray(members.get(parent, []), dtype=np.int64)
-                inside = set(members.get(parent, []))
-                pairs = [(d, x) for d, x in kids.get(parent, []) if d in inside]
-                labset = sorted(set(x for _, x in pairs))
-            local = {x: i + 1 for i, x in enumerate(labset)}
+                docs = np.flatnonzero(L[:, col[parent]]).astype(np.int64)
+                names = sorted(set(by_prefix.get(parent, [])))
+                sub = L[docs][:, [col[x] for x in names]] if names else np.zeros((len(docs), 0), dtype=bool)
+                present = sub.any(axis=0)
+                labset = [x for x, here in zip(names, present) if here]      # sorted(set(...)) of the labels that occur
+                sub = sub[:, present]
             K = 1 + len(labset)
-            flags = np.zeros((len(docs), K), dtype=bool)
-            flags[:, 0] = True
-            if pairs:
-                pd = np.searchsorted(docs, np.fromiter((d for d, _ in pairs), dtype=np.int64, count=len(pairs)))
-                pk = np.fromiter((local[x] for _, x in pairs), dtype=np.int64, count=len(pairs))
-                flags[pd, pk] = True
+            flags = np.ones((len(docs), K), dtype=bool)
+            flags[:, 1:] = sub
             n_allowed = flags.sum(axis=1)
             a_max = int(n_allowed.max()) if len(docs) else 1
             # ascending local topic ids, -1 padded: argsort of ~flags is stable, allowed topics come first
@@ -576,35 +573,41 @@ class CascadeLDA(object):
 
     def _go_down_tree_batched(self, it, s, world, rank, keep_state):
         import torch
-        from .ensemble import Ensemble, draw_initial_topics
+        from .ensemble import Ensemble
         plans = self.plan_subproblems()
         doc_off, word, freq = csr_from_doc_tups(self.doc_tups)
         lens = np.diff(doc_off)
+        from .ensemble import MAX_BATCH_K, MAX_BATCH_ALLOWED, draw_initial_topics_device
+        # decided from ALL plans, so that every rank takes the same path (the caller restores numpy's stream)
+        if any(pl["K"] > MAX_BATCH_K or (len(pl["docs"]) and int(pl["n_allowed"].max()) > MAX_BATCH_ALLOWED) for pl in plans):
+            return None, False
         # initial assignments of EVERY sub-problem, in visiting order, from numpy's global stream -- exactly the
         # uniforms the reference's per-document np.random.choice calls consume (CascadeLDA.py:373-381)
-        sites = [int(lens[pl["docs"]].sum()) for pl in plans]
+        n_docs = np.array([len(pl["docs"]) for pl in plans], dtype=np.int64)
+        inst_len = lens[np.concatenate([pl["docs"] for pl in plans])]
+        site_end = np.concatenate(([0], np.cumsum(inst_len)))[np.cumsum(n_docs)]
+        sites = np.diff(np.concatenate(([0], site_end))).tolist()
         a_max = max(pl["allowed"].shape[1] for pl in plans)
-        allowed_all = np.full((sum(len(pl["docs"]) for pl in plans), a_max), -1, dtype=np.int64)
+        allowed_all = np.full((int(n_docs.sum()), a_max), -1, dtype=np.int64)
         row = 0
         for pl in plans:
             allowed_all[row:row + len(pl["docs"]), :pl["allowed"].shape[1]] = pl["allowed"]
             row += len(pl["docs"])
         n_allowed_all = np.concatenate([pl["n_allowed"] for pl in plans])
-        inst_len = np.concatenate([lens[pl["docs"]] for pl in plans])
         u = np.random.random_sample(int(inst_len.sum()))            # (= the plans' draws one after the other)
-        z_all = draw_initial_topics(allowed_all, n_allowed_all, np.repeat(np.arange(len(inst_len)), inst_len), u)
-        z_local = np.split(z_all, np.cumsum(sites)[:-1])
         owner = lpt_assign(sites, world)
         mine = [i for i in range(len(plans)) if owner[i] == rank]
-        from .ensemble import MAX_BATCH_K, MAX_BATCH_ALLOWED
-        # decided from ALL plans, so that every rank takes the same path
-        if any(pl["K"] > MAX_BATCH_K or (len(pl["docs"]) and int(pl["n_allowed"].max()) > MAX_BATCH_ALLOWED) for pl in plans):
-            return owner, False
         if not mine:                                   # more ranks than sub-problems: nothing to train here
             self._owned_rows = np.zeros(0, dtype=np.int64)
             self._ensemble = None
             return owner, True
-        ens = Ensemble([plans[i] for i in mine], [z_local[i] for i in mine], doc_off, word, freq,
+
+        def z_start(dev):                              # on the ensemble's device: the searchsorted of 1.3 M uniforms
+            z_all = draw_initial_topics_device(allowed_all, n_allowed_all, inst_len, u, dev)
+            if len(mine) < len(plans):                 # this rank's sub-problems only
+                z_all = torch.cat([z_all[int(site_end[i]) - sites[i]:int(site_end[i])] for i in mine])
+            return z_all
+        ens = Ensemble([plans[i] for i in mine], z_start, doc_off, word, freq,
                        self.V, self.alpha, self.beta, self.seed, device=self._device, streams=mine)
         ens.debug_margin = self._batch_debug_margin
         for i in mine:

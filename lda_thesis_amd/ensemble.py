@@ -59,12 +59,37 @@ def draw_initial_topics(allowed, n_allowed, inst_of_site, uniforms):
     return allowed[inst_of_site, k]
 
 
+def draw_initial_topics_device(allowed, n_allowed, inst_len, uniforms, device):
+    """draw_initial_topics on the device: ``allowed`` (I, A_max) / ``n_allowed`` (I,) / ``inst_len`` (I,) host arrays, the
+    uniforms of numpy's stream (host, one per site) -> local topic of every site as an int64 device tensor.
+    numpy's ``searchsorted(cdf, u, 'right')`` is k = #{j : cdf[j] <= u}; the cdf of A equal weights is within a few ulps of
+    (j + 1) / A, so floor(u * A) is at most one off and two exact comparisons against the SAME table settle it."""
+    a_max = int(n_allowed.max())
+    tab = torch.from_numpy(choice_cdf_table(a_max)).to(device).reshape(-1)
+    al = torch.from_numpy(np.ascontiguousarray(allowed)).to(device)
+    na = torch.from_numpy(np.ascontiguousarray(n_allowed)).to(device)
+    inst = torch.repeat_interleave(torch.arange(al.shape[0], device=device), torch.from_numpy(np.ascontiguousarray(inst_len)).to(device))
+    u = torch.from_numpy(uniforms).to(device)
+    A = na[inst]
+    row = (A - 1) * a_max
+    k = torch.minimum((u * A.to(torch.float64)).to(torch.int64), A - 1)
+    for _ in range(3):
+        too_low = tab[row + k] <= u                                   # cdf[k] <= u: the answer is beyond k
+        too_high = (k > 0) & (tab[row + torch.clamp(k - 1, min=0)] > u)
+        k = k + too_low.to(torch.int64) - too_high.to(torch.int64)
+    ok = (tab[row + k] > u) & ((k == 0) | (tab[row + torch.clamp(k - 1, min=0)] <= u))
+    if not bool(ok.all()):
+        raise AssertionError("draw_initial_topics_device: a draw did not settle")
+    return al[inst, k]
+
+
 class Ensemble(object):
     """Device state of a set of sub-problems (``plans``: see CascadeLDA.plan_subproblems) and the sweep driver."""
 
     def __init__(self, plans, z_local, doc_off, word, freq, V, alpha, beta, seed, device=None, streams=None):
         """streams[i] = RNG stream of plans[i] (default i).  plans[i]: dict(K, docs (member document ids), allowed (D_p, A_max) local topics ascending, padded
-        with -1, n_allowed (D_p,)); z_local[i]: initial local topic of every site of plan i (instance order)."""
+        with -1, n_allowed (D_p,)); z_local[i]: initial local topic of every site of plan i (instance order) -- or ONE int64 device
+        tensor holding those of all plans, in that order, or a function of the device that returns it."""
         _native.lib()
         _native.require_device()
         self.device = dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
@@ -110,8 +135,12 @@ class Ensemble(object):
         for i, pl in enumerate(plans):
             pos_tab[i, :pl["K"]] = layouts[pl["K"]].topic_pos
             rank_tab[i, :pl["K"]] = layouts[pl["K"]].lm_topic_pos
-        z_loc = np.concatenate(z_local) if P else np.zeros(0, np.int64)
-        z_pos = pos_tab[inst_prob[inst_of_site], z_loc]
+        if callable(z_local):
+            z_local = z_local(dev)
+        z_on_device = isinstance(z_local, torch.Tensor)
+        if not z_on_device:
+            z_loc = np.concatenate(z_local) if P else np.zeros(0, np.int64)
+            z_pos = pos_tab[inst_prob[inst_of_site], z_loc]
         # allowed positions of every instance, in draw order
         allowed = np.full((self.I, a_max), -1, dtype=np.int64)
         row = 0
@@ -136,8 +165,12 @@ class Ensemble(object):
             return torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dtype)
 
         self.inst_off, self.word, self.freq = up(inst_off, torch.int64), up(w_s, torch.int32), up(f_s, torch.int32)
-        self.z = up(z_pos, torch.int32)
         self.inst_prob, self.inst_doc = up(inst_prob, torch.int32), up(inst_doc, torch.int32)
+        i_s = up(inst_of_site, torch.int64)
+        if z_on_device:
+            self.z = up(pos_tab, torch.int64)[self.inst_prob.to(torch.int64)[i_s], z_local.to(dev)].to(torch.int32)
+        else:
+            self.z = up(z_pos, torch.int32)
         self.live_off, self.live_pos = up(live_off, torch.int64), up(live_pos, torch.int32)
         self.ndk_off = up(ndk_off[:-1], torch.int64)
         self.kw_off, self.nk_off, self.kp = up(kw_off, torch.int64), up(nk_off, torch.int64), up(kp, torch.int32)
@@ -159,7 +192,6 @@ class Ensemble(object):
         self.delta = torch.zeros((self.total,), dtype=torch.int32, device=dev)
         self.n_dk = torch.zeros((max(self.ndk_total, 1),), dtype=torch.int32, device=dev)
         if self.S:
-            i_s = up(inst_of_site, torch.int64)
             p_s = self.inst_prob.to(torch.int64)[i_s]
             kp_s = self.kp.to(torch.int64)[p_s]
             z64, w64, f64 = self.z.to(torch.int64), self.word.to(torch.int64), self.freq.to(torch.int64)

@@ -95,7 +95,7 @@ class OracleBackend(object):
     def sweep(self, *, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
               status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
               dense_mask=False, debug_margin=0, live_off=None, live_pos=None, live_max=0, csc_pos=None, commit_log=None, n_sites=None, site_rec=None,
-              max_doc_tokens=0, scratch=None, n_kw16=None, site_row=None):
+              max_doc_tokens=0, scratch=None, n_kw16=None, site_row=None, n_kw_img=None):
         import torch
         lay = self._lay(K)
         tp = lay.topic_pos.astype(np.int64)
