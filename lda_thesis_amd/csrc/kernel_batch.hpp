@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) llda_sweep_batch_kernel(const BParams P)
         int my_zn = sz;
         int done = 0;
 #define LLDA_BATCH_SITE(J)                                                                                     \
-        sparse_site<GS, J>(P, layK, KP, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
+        sparse_site<GS, J, false>(P, layK, KP, nb, sf, sz, su_lo, su_hi, 0, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
                            gbase, gmask);
         LLDA_BATCH_SITE(0) LLDA_BATCH_SITE(1) LLDA_BATCH_SITE(2) LLDA_BATCH_SITE(3)
         LLDA_BATCH_SITE(4) LLDA_BATCH_SITE(5) LLDA_BATCH_SITE(6) LLDA_BATCH_SITE(7)

@@ -114,28 +114,47 @@ __device__ __noinline__ int exact_call(const KParams *K, int, int, double wx, in
                            K->rounds_pk, lane);
 }
 
+// sum over the GS lanes of a group in every lane, fp32 (any association order)
+template <int GS>
+__device__ __forceinline__ float allsum_any_f32(float x, int lane)
+{
+    x += dpp_f32<DPP_XOR1>(x);
+    x += dpp_f32<DPP_XOR2>(x);
+    x += dpp_f32<DPP_HALF_MIRROR>(x);
+    if constexpr (GS >= 16) x += dpp_f32<DPP_ROW_ROR + 8>(x);
+    if constexpr (GS >= 32) x += __shfl_xor(x, 16, GS);
+    if constexpr (GS == 64) x += __shfl_xor(x, 32, GS);
+    return x;
+}
+
 // One site of the sparse kernel (J = index inside the current batch of 8 sites), branch free on the decided path:
 // every lane of the wavefront executes every instruction and the per-group condition "is site J part of this batch?"
 // is data -- divergent branches here cost more in exec-mask bookkeeping (SGPR spills) than the arithmetic they skip.
-// The reciprocal y of n_k + V*beta is recomputed ONCE per site, after the removal (it then also covers the previous
+//
+// T0 (round 4): the decision is first taken in fp32 -- tier 0 of DESIGN.md section 4.3 restricted to the live topics.  With
+// v = 2^-24 and the total normalised to 1: a = fl(ndk + alpha32), num = fl(x + beta32), den = fl(nk + vbeta32) carry <= 3v each
+// (conversion of a count >= 2^24, the rounded prior, the sum), y = v_rcp_f32(den) (1 ulp) is within 5v of 1/den, w = fl(a * fl(num * y))
+// within 13v; the inclusive scan over <= 64 lanes adds <= 6v, so every Q and the total are within 19v; t = fl(uf * tot) with uf the
+// uniform rounded to fp32 within 20.5v; the compared difference fl(Q - t) within 19v + 20.5v + 1v < 41v of its real value, the exact
+// pipeline within 2^-44.  A site is SURE when every live lane of its group has |Q - t| > margin0 * tot with margin0 = 2^-17 = 128v
+// (KParams.margin0_rel, the dense kernels' margin): all signs are then those of the exact pipeline and the same topic is selected.
+// `tot - margin` being a positive normal number is the guard tot > 0, margin < tot, tot finite in one class test.  When ANY site of the
+// wavefront is unsure (about 10^-4 per site at production margins; a scalar branch on a ballot) the whole wavefront takes the fp64
+// decision below for this site -- which gives the sure groups the same answer and sends what IT cannot decide to the exact pipeline.
+//
+// The fp64 decision: the reciprocal y of n_k + V*beta is recomputed ONCE per site, after the removal (it then also covers the previous
 // site's add-back).  A site the margin cannot decide (~1e-11 per site; the only branch, wave-uniform) is resolved on
 // the spot by exact_site_wave(): the reference's fp64 pipeline in the dense layout of the problem (`lay`), run by
 // the whole wavefront for that document -- the topic is the exact pipeline's either way.
 // (layK, layKP: topics and row length of the caller's problem in the batched kernel -- per lane group; the sparse
 // kernel of one problem passes -1 and the layout is read from the kernel arguments in the rare branch that needs it)
 template <int GS, int J, class PT>
-__device__ __forceinline__ void sparse_site(const PT &P, int layK, int layKP, int nb, int sf, int sz, int su_lo,
-                                            int su_hi, const int (&xg)[8], bool live, int pos, int A, int &ndk, int &nk,
-                                            int &my_zn, int &done, int lig, int lane, int gbase, uint64_t gmask)
+__device__ __forceinline__ int sparse_decide_f64(const PT &P, int layK, int layKP, int active, int zo, int su_lo, int su_hi, int x,
+                                                 bool live, int pos, int A, int ndk, int nk, int lig, int lane, int gbase, uint64_t gmask)
 {
-    // (the per-group flags are 0 / -1 integers in VGPRs: as `bool`s they would each occupy an SGPR pair)
-    const int f = bcast_lane<GS, J>(sf, lig), zo = bcast_lane<GS, J>(sz, lig);
     const double u = __hiloint2double(bcast_lane<GS, J>(su_hi, lig), bcast_lane<GS, J>(su_lo, lig));
-    const int active = (J < nb) ? -1 : 0;
-    const int rm = f & active & ((pos == zo) ? -1 : 0);                             // LabeledLDA.py:109-111
-    ndk -= rm; nk -= rm;
     const double y = rcp_newton((double)nk + P.vbeta);
-    const double w = live ? ((double)ndk + P.alpha) * (((double)(xg[J] - rm) + P.beta) * y) : 0.0;
+    const double w = live ? ((double)ndk + P.alpha) * (((double)x + P.beta) * y) : 0.0;
     const double Q = scan_any_f64<GS>(w, lig);
     const double tot = allsum_any_f64<GS>(w, lane);
     const double t = u * tot, margin = tot * P.margin_rel;
@@ -148,7 +167,7 @@ __device__ __forceinline__ void sparse_site(const PT &P, int layK, int layKP, in
     if (__builtin_expect(todo != 0, 0)) {
         // exact tier: one undecided document of the wavefront at a time (all 64 lanes take part)
         if (lane == 0 && P.status) { atomicOr(P.status, 2); }
-        const double wx = live ? ((double)ndk + P.alpha) * (((double)(xg[J] - rm) + P.beta) / ((double)nk + P.vbeta)) : 0.0;
+        const double wx = live ? ((double)ndk + P.alpha) * (((double)x + P.beta) / ((double)nk + P.vbeta)) : 0.0;
         while (todo) {
             const int first = (int)__ffsll((unsigned long long)todo) - 1;
             const int base = first & ~(GS - 1);
@@ -163,6 +182,46 @@ __device__ __forceinline__ void sparse_site(const PT &P, int layK, int layKP, in
                 if (lig == 0 && P.status) atomicAdd(P.status + 2, 1);               // statistics: exact-tier sites
             }
         }
+    }
+    return zn;
+}
+
+template <int GS, int J, bool T0, class PT>
+__device__ __forceinline__ void sparse_site(const PT &P, int layK, int layKP, int nb, int sf, int sz, int su_lo,
+                                            int su_hi, int su_f, const int (&xg)[8], bool live, int pos, int A, int &ndk, int &nk,
+                                            int &my_zn, int &done, int lig, int lane, int gbase, uint64_t gmask)
+{
+    // (the per-group flags are 0 / -1 integers in VGPRs: as `bool`s they would each occupy an SGPR pair)
+    const int f = bcast_lane<GS, J>(sf, lig), zo = bcast_lane<GS, J>(sz, lig);
+    const int active = (J < nb) ? -1 : 0;
+    const int rm = f & active & ((pos == zo) ? -1 : 0);                             // LabeledLDA.py:109-111
+    ndk -= rm; nk -= rm;
+    const int x = xg[J] - rm;
+    int zn;
+    if constexpr (T0) {
+        const float uf = __int_as_float(bcast_lane<GS, J>(su_f, lig));
+        const float yf = __builtin_amdgcn_rcpf((float)nk + P.vbeta32);
+        const float wf = live ? ((float)ndk + P.alpha32) * (((float)x + P.beta32) * yf) : 0.0f;
+        const float Qf = group_scan_f32<GS>(wf, lig);
+        const float totf = allsum_any_f32<GS>(wf, lane);
+        const float tf = uf * totf, mf = totf * P.margin0_rel;
+        // sure: every live lane is outside the band, and tot - margin is a positive normal number (tot > 0, margin < tot, finite)
+        const bool unsure0 = (active != 0) & ((live & !(fabsf(Qf - tf) > mf)) | !__builtin_amdgcn_classf(totf - mf, 0x100));
+        const uint64_t cold = __ballot(unsure0);
+        if (__builtin_expect(cold == 0, 1)) {
+            const uint64_t gf = (__ballot(live && Qf > tf) >> gbase) & gmask;
+            const int sel = gf ? (int)__ffsll((unsigned long long)gf) - 1 : A - 1;
+            zn = allor_i32<GS>((lig == sel) ? pos : 0, lane);
+        } else {
+            if (lane == 0 && P.status) {                                            // statistics: sites the fp32 tier left undecided
+                int n = 0;
+                for (int g = 0; g < 64; g += GS) n += ((cold >> g) & gmask) ? 1 : 0;
+                atomicAdd(P.status + 1, n);
+            }
+            zn = sparse_decide_f64<GS, J>(P, layK, layKP, active, zo, su_lo, su_hi, x, live, pos, A, ndk, nk, lig, lane, gbase, gmask);
+        }
+    } else {
+        zn = sparse_decide_f64<GS, J>(P, layK, layKP, active, zo, su_lo, su_hi, x, live, pos, A, ndk, nk, lig, lane, gbase, gmask);
     }
     // add the site back (LabeledLDA.py:121-125)
     const int back = active & f & ((pos == zn) ? -1 : 0);
@@ -283,20 +342,20 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const PT P)
                 BatchScalars Sf;
                 load_scalars(n0 + 16, Sf);
                 const int sv = Sc.v, sf = Sc.f, sz = Sc.z, sc = Sc.c;
-                int su_lo, su_hi;
+                int su_lo, su_hi, su_f;
                 {   // keyed uniform of site n0+jj: Philox block (site >> 1), words (0,1) / (2,3) by parity
                     const int n = n0 + jj;
                     uint32_t c0 = (uint32_t)(n >> 1), c1 = gdoc, c2 = P.stream_id, c3 = P.sweep;
                     philox4x32_10(c0, c1, c2, c3, P.key0, P.key1);
                     const uint32_t ra = (n & 1) ? c2 : c0, rb = (n & 1) ? c3 : c1;
                     const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
-                    su_lo = __double2loint(u); su_hi = __double2hiint(u);
+                    su_lo = __double2loint(u); su_hi = __double2hiint(u); su_f = __float_as_int((float)u);
                 }
 
                 int my_zn = sz;
                 int done = 0;                     // sites of this batch
     #define LLDA_SPARSE_SITE(J)                                                                                    \
-                sparse_site<GS, J>(P, -1, -1, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
+                sparse_site<GS, J, true>(P, -1, -1, nb, sf, sz, su_lo, su_hi, su_f, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
                                    gbase, gmask);
                 LLDA_SPARSE_SITE(0) LLDA_SPARSE_SITE(1) LLDA_SPARSE_SITE(2) LLDA_SPARSE_SITE(3)
                 LLDA_SPARSE_SITE(4) LLDA_SPARSE_SITE(5) LLDA_SPARSE_SITE(6) LLDA_SPARSE_SITE(7)
@@ -355,20 +414,20 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const PT P)
                 int xe1[8];
                 escape(S1.v, xn1, xe1);
                 const int sv = S0.v, sf = S0.f, sz = S0.z, sc = S0.c;
-                int su_lo, su_hi;
+                int su_lo, su_hi, su_f;
                 {   // keyed uniform of site n0+jj: Philox block (site >> 1), words (0,1) / (2,3) by parity
                     const int n = n0 + jj;
                     uint32_t c0 = (uint32_t)(n >> 1), c1 = gdoc, c2 = P.stream_id, c3 = P.sweep;
                     philox4x32_10(c0, c1, c2, c3, P.key0, P.key1);
                     const uint32_t ra = (n & 1) ? c2 : c0, rb = (n & 1) ? c3 : c1;
                     const double u = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
-                    su_lo = __double2loint(u); su_hi = __double2hiint(u);
+                    su_lo = __double2loint(u); su_hi = __double2hiint(u); su_f = __float_as_int((float)u);
                 }
 
                 int my_zn = sz;
                 int done = 0;                     // sites of this batch
     #define LLDA_SPARSE_SITE(J)                                                                                    \
-                sparse_site<GS, J>(P, -1, -1, nb, sf, sz, su_lo, su_hi, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
+                sparse_site<GS, J, true>(P, -1, -1, nb, sf, sz, su_lo, su_hi, su_f, xg, live, pos, A, ndk, nk, my_zn, done, lig, lane, \
                                    gbase, gmask);
                 LLDA_SPARSE_SITE(0) LLDA_SPARSE_SITE(1) LLDA_SPARSE_SITE(2) LLDA_SPARSE_SITE(3)
                 LLDA_SPARSE_SITE(4) LLDA_SPARSE_SITE(5) LLDA_SPARSE_SITE(6) LLDA_SPARSE_SITE(7)

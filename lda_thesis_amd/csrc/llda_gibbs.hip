@@ -512,6 +512,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     P.D = a->D; P.doc_base = a->doc_base;
     P.alpha = a->alpha; P.beta = a->beta;
     P.vbeta = (double)a->V * a->beta;                       // V * beta evaluated first (LabeledLDA.py:115)
+    P.alpha32 = (float)a->alpha; P.beta32 = (float)a->beta; P.vbeta32 = (float)P.vbeta;
     P.key0 = (uint32_t)a->seed; P.key1 = (uint32_t)(a->seed >> 32);
     P.sweep = a->sweep; P.stream_id = a->stream_id;
     fill_schedule(L, P.last_leaf, P.tail, P.tail_row, P.n_rounds, P.xor_tree, P.rounds_pk);

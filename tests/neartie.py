@@ -33,7 +33,7 @@ def _gap(cum, t):
 
 
 def make_neartie_state(K, D, dense, seed, rng, max_sites=4, safe=2.0 ** -14, tuned=2.0 ** -24, alpha=0.1, beta=0.01,
-                       stream=0, doc_base=0):
+                       stream=0, doc_base=0, label_count=None):
     """-> dict(doc_off, word, freq, z, labs, n_d_k, n_k_v, n_zk, V, n_tuned, tuned_gap_max, safe_gap_min)."""
     lay = orc.layout(K)
     lens = rng.integers(1, max_sites + 1, size=D)
@@ -45,7 +45,13 @@ def make_neartie_state(K, D, dense, seed, rng, max_sites=4, safe=2.0 ** -14, tun
     freq = rng.integers(1, 4, size=S).astype(np.int32)
     n_zk = np.floor(np.exp(rng.uniform(np.log(1e3), np.log(1e6), size=K))).astype(np.int64)
     labs = np.ones((D, K), dtype=np.uint8)
-    if not dense:
+    if not dense and label_count is not None:                # sparse label sets: root + up to label_count labels per document
+        labs = np.zeros((D, K), dtype=np.uint8)
+        labs[:, 0] = 1
+        for d in range(D):
+            n = int(rng.integers(max(1, label_count - 2), label_count + 1))
+            labs[d, rng.choice(K - 1, size=min(n, K - 1), replace=False) + 1] = 1
+    elif not dense:
         labs = (rng.random((D, K)) < 0.4).astype(np.uint8)
         labs[:, 0] = 1
     z = np.zeros(S, dtype=np.int64)

@@ -871,3 +871,39 @@ def test_adversarial_near_ties_for_the_fp32_tier(c_oracle, K, dense):
     for m in (-6, -7):
         if m in runs:
             assert int(runs[m][4][1]) == st["n_tuned"]
+
+
+@pytest.mark.parametrize("K,labels,image", [(40, 7, 0), (392, 7, 0), (512, 7, 8), (512, 20, 16), (777, 40, 0), (1031, 7, 0), (2048, 7, 8)])
+def test_adversarial_near_ties_for_the_sparse_fp32_tier(c_oracle, K, labels, image):
+    """the same for the sparse-label kernel's tier 0 (kernel_sparse.hpp: fp32 scores of the allowed topics, margin 2^-17, bound
+    41 * 2^-24): the last site of every document within 2^-24 of a prefix-sum boundary, all others at least 2^-14.5 away.  Tier 0
+    must hand exactly the tuned sites to the fp64 decision, and the sweep must leave what the exact pipeline and the C oracle leave
+    (/root/reference/LabeledLDA.py:113-119) -- with and without the narrow image (8, 16 and 64 lanes per document; wide layouts)."""
+    import neartie
+    from lda_thesis_amd.sampler import GibbsSampler
+    st = neartie.make_neartie_state(K, 1200 if K <= 1024 else 400, False, seed=4242, rng=np.random.default_rng(K + labels), doc_base=7,
+                                    label_count=labels)
+    assert st["tuned_gap_max"] < 2.0 ** -23 and st["safe_gap_min"] > 2.0 ** -14.5
+    counts = dict(n_d_k=st["n_d_k"], n_k_v=st["n_k_v"], n_zk=st["n_zk"])
+    runs = {}
+    for margin in (0, -1):
+        s = GibbsSampler(st["doc_off"], st["word"], st["freq"], st["z"], K, st["V"], st["alpha"], st["beta"],
+                         labs=st["labs"], counts=counts, seed=4242, doc_base=7, image=image)
+        assert s.live_off is not None and (s.n_kw_img is not None) == bool(image)
+        s.debug_margin = margin
+        s.sweep()
+        s.check_status()
+        runs[margin] = (s.z_topics(), s.n_d_k(), s.n_k_v(), s.n_zk(), s.status.cpu().numpy())
+    cs = c_oracle.CState(st["doc_off"], st["word"], st["freq"], st["z"], st["labs"], st["n_d_k"], st["n_k_v"],
+                         st["n_zk"], st["V"], st["alpha"], st["beta"])
+    cs.sweep(1, 4242, 0, doc_base=7, threads=4)
+    for margin in (0, -1):
+        z, ndk, nkv, nzk, _ = runs[margin]
+        np.testing.assert_array_equal(z, cs.z)
+        np.testing.assert_array_equal(ndk, cs.n_d_k)
+        np.testing.assert_array_equal(nkv, cs.n_k_v)
+        np.testing.assert_array_equal(nzk, cs.n_zk)
+    # production run: the fp32 tier gave up on every tuned site and on no other; the fp64 decision behind it settled (nearly) all of
+    # them -- a tuned threshold may sit within 2^-40 of its boundary, which is the exact pipeline's to decide
+    assert int(runs[0][4][1]) == st["n_tuned"] and int(runs[0][4][2]) <= st["n_tuned"] // 100
+    assert int(runs[-1][4][2]) == int(st["doc_off"][-1])          # debug_margin -1: every site through the exact pipeline
