@@ -143,3 +143,29 @@ def test_integration_md_stub_struct_definitions_match_the_library():
 def _native_abi():
     from lda_thesis_amd import _native
     return _native.ABI_VERSION
+
+
+def test_build_info_reports_every_ablation_switch(tmp_path):
+    """llda_build_info(): 0 for the production library (the one in the tree: bench.py prints no line otherwise); every compile-time
+    switch of tools/ (-DABL_*, -DLLDA_MARGIN0 / _WAVES overrides) sets its LLDA_BUILD_* bit -- checked on csrc/build_info.hpp, which
+    is all of llda_build_info(), with the host compiler."""
+    import subprocess
+    from lda_thesis_amd import _native
+    assert _native.build_info() == (0, [])
+    src = tmp_path / "bi.cpp"
+    src.write_text('#include "build_info.hpp"\n#include "llda_gibbs.h"\n#include <stdio.h>\n'
+                   'int main() { printf("%d\\n", (int)(LLDA_BUILD_INFO_BITS)); return 0; }\n')
+    inc = ["-I", os.path.join(ROOT, "lda_thesis_amd", "csrc"), "-I", os.path.join(ROOT, "include")]
+
+    def bits(*defs):
+        exe = str(tmp_path / "bi")
+        subprocess.check_call(["g++", "-o", exe, str(src)] + inc + list(defs))
+        return int(subprocess.check_output([exe]).decode())
+    assert bits() == 0
+    want = {"-DLLDA_MARGIN0=0x1p-16f": 0x001, "-DLLDA_WAVES=2": 0x002, "-DLLDA_MARGIN0_WIDE=0.1f": 0x004, "-DABL_NOLOAD": 0x008,
+            "-DABL_NOCOMMIT": 0x010, "-DABL_WIDE_NOROW": 0x020, "-DABL_WIDE_NOADDLOAD": 0x040, "-DABL_NOFMA": 0x080,
+            "-DABL_EXTRA_LDS_BYTES=20000": 0x100}
+    for d, b in want.items():
+        assert bits(d) == b, d
+    assert bits(*want) == 0x1ff
+    assert [n for i, n in enumerate(_native.BUILD_SWITCHES)] == [d[2:].split("=")[0] for d in want]
