@@ -8,6 +8,11 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
     import bench
+    docs = 0
+    if "--docs" in sys.argv:                       # e.g. --docs 1000000: the sparse variant of configs[3] at its full size
+        i = sys.argv.index("--docs")
+        docs = int(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
     names = sys.argv[1:] or ["synth2_sparse", "synth_wide_sparse", "synth2_sparse_hier"]
     dev = torch.device("cuda", 0)
     for name in names:
@@ -16,12 +21,12 @@ def main():
                 os.environ.pop("LLDA_IMAGE", None)
             else:
                 os.environ["LLDA_IMAGE"] = image
-            s, info = bench.build_sampler(name, dev, 0, 1, False)
+            s, info = bench.build_sampler(name, dev, 0, 1, False, docs_total=docs)
             r8, r16 = s._image_escape_rates()
-            dt, kms = bench.time_sweeps(s, 50, 5)
+            dt, kms = bench.time_sweeps(s, 50 if not docs else 20, 5)
             bits = 0 if s.n_kw_img is None else 8 * s.n_kw_img.element_size()
             print("%-20s image %-4s -> %2d bits  kernel %.4f ms  %.0f M sites/s (wall %.0f)  escapes8 %.3f escapes16 %.4f  digests %s" %
-                  (name, image, bits, kms, s.S / kms / 1e3, s.S * 50 / dt / 1e6, r8, r16, bench.state_checksums(s)), flush=True)
+                  (name, image, bits, kms, s.S / kms / 1e3, s.S * (50 if not docs else 20) / dt / 1e6, r8, r16, bench.state_checksums(s)), flush=True)
             del s, info
             torch.cuda.empty_cache()
 
