@@ -162,3 +162,54 @@ def test_full_size_production_margins_vs_no_fp32_tier(name):
     st = a.status.cpu().numpy()
     assert 0 < int(st[1]) < a.S // 20                      # the fp32 tier was unsure about some sites, but few
     assert int(b.status[1]) == 2 * b.S                     # ... and b sent every site to the fp64 tiers
+
+
+def sparse_corpus(docs):
+    """the sparse variant of configs[3] (root + 7 random labels per document, as bench.py's synth2_sparse builds it)"""
+    from lda_thesis_amd.corpus import synthetic_corpus_blocks
+    N, V, K = 300, 100_000, 512
+    doc_off, word, freq, _ = synthetic_corpus_blocks(0, docs, N, V, K, 1234, "cuda")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99)
+    lab = torch.sort(torch.randint(1, K - 8, (docs, 7), device="cuda", generator=gen), dim=1).values + torch.arange(7, device="cuda")
+    lab = torch.cat([torch.zeros((docs, 1), dtype=lab.dtype, device="cuda"), lab], dim=1)
+    pick = torch.randint(0, 8, (docs * N,), device="cuda", generator=gen)
+    z = lab.repeat_interleave(N, dim=0)[torch.arange(docs * N, device="cuda"), pick]
+    return doc_off, word, freq, z, lab, K, V
+
+
+@pytest.mark.parametrize("docs,n_docs,bits", [(125_000, 2000, 8), (1_000_000, 1500, 8)])
+def test_full_size_sparse_labels_sampled_documents_vs_c_oracle(c_oracle, docs, n_docs, bits):
+    """the sparse-label kernel at full size with the image GibbsSampler picks by itself (8 bits: 7 % of the gathers escape to the
+    int32 counts at 125 000 documents, 35 % at 1 000 000), fp32 tier 0 first: sampled documents against the C oracle
+    (LabeledLDA.py:106-125 restated), two sweeps, a fresh sample each."""
+    from lda_thesis_amd.sampler import GibbsSampler
+    doc_off, word, freq, z, lab, K, V = sparse_corpus(docs)
+    lab_off = np.arange(0, 8 * docs + 1, 8, dtype=np.int64)
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=(lab_off, lab.reshape(-1).cpu().numpy()), seed=42)
+    del z
+    assert s.live_off is not None and s.commit_log is not None and s.n_kw_img is not None
+    assert 8 * s.n_kw_img.element_size() == bits
+    r8, r16 = s._image_escape_rates()
+    assert 0.02 < r8 < s.IMAGE_MAX_ESCAPES and r16 < r8
+    rng = np.random.default_rng(7)
+    for _ in range(2):
+        sel, sel_t, loc_off, idx = sample_documents(s, n_docs, rng)
+        n_k_v, n_zk = s.n_k_v(), s.n_zk()
+        word_h, freq_h = s.word[idx].cpu().numpy(), s.freq[idx].cpu().numpy()
+        z0 = s._pos_topic[s.z[idx].to(torch.int64)].cpu().numpy()
+        ndk0 = s.n_dk[sel_t][:, s._topic_pos].cpu().numpy().astype(np.int64)
+        labs_sel = np.zeros((n_docs, K), dtype=np.uint8)
+        labs_sel[np.repeat(np.arange(n_docs), 8), lab[sel_t].cpu().numpy().reshape(-1)] = 1
+        sweep = s.sweeps_done
+        s.sweep()
+        z_want, ndk_want = c_oracle.sweep_docs(sel, loc_off, word_h, freq_h, z0, labs_sel, ndk0, n_k_v, n_zk, V, 0.1, 0.01, 42, sweep,
+                                               threads=min(32, os.cpu_count() or 1))
+        z_got = s._pos_topic[s.z[idx].to(torch.int64)].cpu().numpy()
+        np.testing.assert_array_equal(z_got, z_want)
+        np.testing.assert_array_equal(s.n_dk[sel_t][:, s._topic_pos].cpu().numpy().astype(np.int64), ndk_want)
+        assert int((z_got != z0).sum()) > z0.size // 2
+    s.check_status()
+    check_conservation(s)
+    st = s.status.cpu().numpy()
+    assert 0 < int(st[1]) < s.S // 100                     # the fp32 tier handed a few sites to the fp64 decision
