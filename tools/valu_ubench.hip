@@ -11,8 +11,8 @@ template <int KIND>
 __global__ void __launch_bounds__(256) bench(long long *out, int iters, double seed)
 {
     // 8 independent chains so dependent-issue latency does not dominate
-    double d[8]; int i[8];
-    for (int k = 0; k < 8; ++k) { d[k] = seed + k + threadIdx.x; i[k] = (int)seed + k + threadIdx.x; }
+    double d[8]; int i[8]; float f[8];
+    for (int k = 0; k < 8; ++k) { d[k] = seed + k + threadIdx.x; i[k] = (int)seed + k + threadIdx.x; f[k] = (float)seed * 1e-3f + k; }
     long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
         if (KIND == 0) { REP16(asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1" : "+v"(i[0]), "+v"(i[1]), "+v"(i[2]), "+v"(i[3]), "+v"(i[4]) : );) }
@@ -38,10 +38,20 @@ __global__ void __launch_bounds__(256) bench(long long *out, int iters, double s
         if (KIND == 20) { REP16(asm volatile("ds_bpermute_b32 %0, %4, %0\n ds_bpermute_b32 %1, %4, %1\n ds_bpermute_b32 %2, %4, %2\n ds_bpermute_b32 %3, %4, %3\n s_waitcnt lgkmcnt(0)" : "+v"(i[0]), "+v"(i[1]), "+v"(i[2]), "+v"(i[3]) : "v"(i[4]));) }
         if (KIND == 21) { REP16(asm volatile("v_mov_b32 %0, %4\n v_mov_b32 %1, %4\n v_mov_b32 %2, %4\n v_mov_b32 %3, %4" : "+v"(i[0]), "+v"(i[1]), "+v"(i[2]), "+v"(i[3]) : "v"(i[4]));) }
         if (KIND == 22) { REP16(asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_hi_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_hi_u32 %3, %3, %4" : "+v"(i[0]), "+v"(i[1]), "+v"(i[2]), "+v"(i[3]) : "v"(i[4]));) }
+        // fp32 instructions of the dense tier 0 (round 4): is a packed fp32 instruction one issue slot or two?
+        if (KIND == 23) { REP16(asm volatile("v_fma_f32 %0, %0, %4, %0\n v_fma_f32 %1, %1, %4, %1\n v_fma_f32 %2, %2, %4, %2\n v_fma_f32 %3, %3, %4, %3" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "v"(f[4]));) }
+        if (KIND == 24) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %0\n v_pk_fma_f32 %1, %1, %4, %1\n v_pk_fma_f32 %2, %2, %4, %2\n v_pk_fma_f32 %3, %3, %4, %3" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "v"(d[4]));) }
+        if (KIND == 25) { REP16(asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "v"(d[4]));) }
+        if (KIND == 26) { REP16(asm volatile("v_cvt_f32_u32_sdwa %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %2, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %3, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]) : "v"(i[0]), "v"(i[1]));) }
+        if (KIND == 27) { REP16(asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1" : "+v"(f[0]) : );) }
+        if (KIND == 28) { REP16(asm volatile("v_cmp_le_f32_e64 s[10:11], %0, %4\n v_cndmask_b32_e64 %0, %0, %4, s[10:11]\n v_cmp_le_f32_e64 s[12:13], %1, %4\n v_cndmask_b32_e64 %1, %1, %4, s[12:13]" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "v"(f[4]) : "s10", "s11", "s12", "s13");) }
+        if (KIND == 29) { REP16(asm volatile("v_cvt_f32_i32 %0, %4\n v_cvt_f32_i32 %1, %5\n v_cvt_f32_i32 %2, %6\n v_cvt_f32_i32 %3, %7" : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]) : "v"(i[0]), "v"(i[1]), "v"(i[2]), "v"(i[3]));) }
+        if (KIND == 30) { REP16(asm volatile("v_fma_f32 %0, %0, %1, %0\n v_fma_f32 %0, %0, %1, %0\n v_fma_f32 %0, %0, %1, %0\n v_fma_f32 %0, %0, %1, %0" : "+v"(f[0]) : "v"(f[4]));) }
+        if (KIND == 31) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %1, %0\n v_pk_fma_f32 %0, %0, %1, %0\n v_pk_fma_f32 %0, %0, %1, %0\n v_pk_fma_f32 %0, %0, %1, %0" : "+v"(d[0]) : "v"(d[4]));) }
     }
     long long t1 = clock64();
     double acc = 0; int ia = 0;
-    for (int k = 0; k < 8; ++k) { acc += d[k]; ia += i[k]; }
+    for (int k = 0; k < 8; ++k) { acc += d[k] + f[k]; ia += i[k]; }
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
     if (acc == 1.2345 && ia == 77) out[1] = 1;
 }
@@ -99,5 +109,14 @@ int main()
     run<21>("v_mov_b32", dout);
     run<22>("mul_lo/hi_u32", dout);
     run<20>("ds_bpermute x4+wait", dout);
+    run<23>("v_fma_f32", dout);
+    run<24>("v_pk_fma_f32", dout);
+    run<25>("v_pk_add_f32", dout);
+    run<26>("v_cvt_f32_u32_sdwa", dout);
+    run<29>("v_cvt_f32_i32", dout);
+    run<28>("cmp_le_f32+cndmask", dout);
+    run<27>("add_f32_dpp+nop x4 (dependent)", dout);
+    run<30>("v_fma_f32 dependent", dout);
+    run<31>("v_pk_fma_f32 dependent", dout);
     return 0;
 }
