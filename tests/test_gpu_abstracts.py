@@ -16,12 +16,12 @@ from conftest import GOLDEN, load_golden
 pytestmark = pytest.mark.gpu
 
 
-def make(g):
+def make(g, **kw):
     from lda_thesis_amd.sampler import GibbsSampler
     return GibbsSampler(g["doc_off"], g["word"].astype(np.int32), g["freq"].astype(np.int32),
                         g["z_init"].astype(np.int64), int(g["K"]), int(g["V"]), float(g["alpha"]),
                         float(g["beta"]), labs=(g["lab_off"], g["lab_idx"].astype(np.int64)), counts=None,
-                        seed=int(g["seed"]))
+                        seed=int(g["seed"]), **kw)
 
 
 def digest(s):
@@ -42,12 +42,19 @@ def test_abstracts_first_sweeps_bit_exact():
     s.check_status()
 
 
+# image: the sampler's own choice for this corpus (no image: 24 MB of counts, 200 000 sites), and the saturating 8- / 16-bit image of
+# the sparse-label kernel forced on -- a real corpus whose hot words' counts escape the 8-bit image (llda_sweep_args.n_kw_img)
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "abstracts_d3_s200.npz")),
                     reason="200-sweep reference digests not generated yet")
-def test_abstracts_200_sweeps_bit_exact():
+@pytest.mark.parametrize("image", [None, 8, 16])
+def test_abstracts_200_sweeps_bit_exact(image):
     g = load_golden("abstracts_d3")
     h = load_golden("abstracts_d3_s200")
-    s = make(g)
+    s = make(g, image=image)
+    assert s.live_off is not None and (s.n_kw_img is not None) == bool(image)
+    if image == 8:
+        r8, _ = s._image_escape_rates()
+        assert r8 > 0.0                                     # some gathers of this corpus do escape to the int32 counts
     for i in range(1, 201):
         s.sweep()
         if i in (50, 100, 200):
