@@ -114,6 +114,7 @@ class GibbsSampler(object):
         self.sharded = bool(sharded)
         self.docs_per_group = int(docs_per_group)
         self.sweeps_done = 0
+        self._parts_cache = {}
         self.debug_margin = 0          # test hook of the two-tier draw (include/llda_gibbs.h)
         self.kernel_events = None      # set to [] to record a (start, end) HIP event pair per sweep kernel
         self.exchange_always = bool(exchange_always)   # take the exchange path even with a single rank (tests)
@@ -458,6 +459,34 @@ class GibbsSampler(object):
                 lo = hi
         return calls or [(0, 0, None)]                       # (a rank without documents)
 
+    def _lane_parts(self, lo, hi, order):
+        """the launches of one llda_sweep call: [(doc_order, documents, live_max)].  Dense masks, or sparse label sets of at most 8
+        topics per document: one launch.  Otherwise the sparse-label kernel gives every document as many lanes as the LARGEST
+        label set of its launch needs (8, 16, 32 or 64: 8 ... 1 documents per wavefront), so the documents are split by the lanes
+        THEY need -- a corpus in which a few documents carry twenty labels and the rest a handful no longer runs all of them one to
+        a half-wavefront.  Which launch a document is in changes nothing (snapshot semantics); ``order`` is kept inside a class."""
+        if self.live_off is None or self.live_max <= 8 or hi <= lo:
+            return [(order, hi - lo, self.live_max)]
+        key = (lo, hi, None if order is None else order.data_ptr())
+        hit = self._parts_cache.get(key)
+        if hit is not None:
+            return hit
+        idx = order.to(torch.int64) if order is not None else torch.arange(hi - lo, device=self.device)
+        n = (self.live_off[lo + 1:hi + 1] - self.live_off[lo:hi])[idx]
+        parts = []
+        for lanes, low in ((8, 0), (16, 8), (32, 16), (64, 32)):
+            sel = idx[(n > low) & (n <= lanes)]
+            if sel.numel():
+                parts.append((sel.to(torch.int32).contiguous(), int(sel.numel()), lanes))
+        sel = idx[n == 0]                                    # (documents that allow nothing: with the first class, as before)
+        if sel.numel():
+            if parts and parts[0][2] == 8:
+                parts[0] = (torch.cat([parts[0][0], sel.to(torch.int32)]).contiguous(), parts[0][1] + int(sel.numel()), 8)
+            else:
+                parts.insert(0, (sel.to(torch.int32).contiguous(), int(sel.numel()), 8))
+        self._parts_cache = {key: parts}                      # (one entry: the order only changes when a caller replaces it)
+        return parts
+
     def _make_commit_log(self):
         """word-major (CSC) view of the sites -- range by range when the exchange is pipelined over document ranges
         -- : position of every site, frequencies in that order, and the work items of llda_commit_log (runs of at
@@ -537,19 +566,21 @@ class GibbsSampler(object):
                 call += 1
                 s0 = 0 if len(self._calls) == 1 else int(self._off_host[lo])
                 s1 = self.S if len(self._calls) == 1 else int(self._off_host[hi])
-                _native.sweep(doc_off=self.doc_off[lo:hi + 1], doc_order=order, word=self.word, freq=self.freq,
-                              z=self.z, lab_mask=self.lab_mask[lo:hi], n_dk=self.n_dk[lo:hi], n_kw=self.n_kw,
-                              n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=nk_delta,
-                              status=self.status, D=hi - lo, V=self.V, K=self.K, alpha=self.alpha,
-                              beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
-                              stream_id=self.stream_id, doc_base=self.doc_base + lo,
-                              docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
-                              debug_margin=self.debug_margin,
-                              live_off=None if self.live_off is None else self.live_off[lo:hi + 1],
-                              live_pos=self.live_pos,
-                              live_max=self.live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
-                              n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens,
-                              scratch=self._scratch, n_kw16=self.n_kw16, site_row=self.site_row, n_kw_img=self.n_kw_img)
+                # (sparse label sets: one launch per class of lanes a document needs -- see _lane_parts)
+                for part, n_docs, live_max in self._lane_parts(lo, hi, order):
+                    _native.sweep(doc_off=self.doc_off[lo:hi + 1], doc_order=part, word=self.word, freq=self.freq,
+                                  z=self.z, lab_mask=self.lab_mask[lo:hi], n_dk=self.n_dk[lo:hi], n_kw=self.n_kw,
+                                  n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=nk_delta,
+                                  status=self.status, D=n_docs, V=self.V, K=self.K, alpha=self.alpha,
+                                  beta=self.beta, seed=self.seed, sweep=self.sweeps_done,
+                                  stream_id=self.stream_id, doc_base=self.doc_base + lo,
+                                  docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
+                                  debug_margin=self.debug_margin,
+                                  live_off=None if self.live_off is None else self.live_off[lo:hi + 1],
+                                  live_pos=self.live_pos,
+                                  live_max=live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
+                                  n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens,
+                                  scratch=self._scratch, n_kw16=self.n_kw16, site_row=self.site_row, n_kw_img=self.n_kw_img)
             if pipelined:
                 # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
                 # collective's stream (ordered after the fold) while the next range is sampled on this one

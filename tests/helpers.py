@@ -97,6 +97,30 @@ class OracleBackend(object):
               dense_mask=False, debug_margin=0, live_off=None, live_pos=None, live_max=0, csc_pos=None, commit_log=None, n_sites=None, site_rec=None,
               max_doc_tokens=0, scratch=None, n_kw16=None, site_row=None, n_kw_img=None):
         import torch
+        if doc_order is not None and int(D) < int(doc_off.shape[0]) - 1:
+            # a launch over a SUBSET of the call's documents (GibbsSampler._lane_parts): the same through views of those documents
+            sel = doc_order.numpy().astype(np.int64)[:int(D)]
+            off = doc_off.numpy()
+            lens = off[sel + 1] - off[sel]
+            sub_off = np.concatenate(([0], np.cumsum(lens)))
+            sites = np.concatenate([np.arange(off[d], off[d + 1]) for d in sel]) if len(sel) else np.zeros(0, np.int64)
+            st, sd = torch.from_numpy(sites), torch.from_numpy(sel)
+            z_sub, ndk_sub = z[st].clone(), n_dk[sd].clone()
+            log_sub = None if commit_log is None else torch.zeros((len(sites),), dtype=commit_log.dtype)
+            pos_sub = None if commit_log is None else torch.arange(len(sites), dtype=torch.int32)
+            for d_i, d in enumerate(sel):                      # (RNG keys are per document: one document at a time keeps doc_base right)
+                a, b = int(sub_off[d_i]), int(sub_off[d_i + 1])
+                zz, nn = z_sub[a:b].clone(), ndk_sub[d_i:d_i + 1].clone()
+                self.sweep(doc_off=torch.from_numpy(np.array([0, b - a])), doc_order=None, word=word[st[a:b]], freq=freq[st[a:b]], z=zz,
+                           lab_mask=lab_mask[sd[d_i:d_i + 1]], n_dk=nn, n_kw=n_kw, n_kw_delta=n_kw_delta, n_k=n_k, n_k_delta=n_k_delta,
+                           status=status, D=1, V=V, K=K, alpha=alpha, beta=beta, seed=seed, sweep=sweep, stream_id=stream_id,
+                           doc_base=doc_base + int(d), csc_pos=None if commit_log is None else pos_sub[a:b] - a,
+                           commit_log=None if commit_log is None else log_sub[a:b])
+                z_sub[a:b], ndk_sub[d_i:d_i + 1] = zz, nn
+            z[st], n_dk[sd] = z_sub, ndk_sub
+            if commit_log is not None:
+                commit_log[csc_pos[st].to(torch.int64) & 0x7fffffff] = log_sub
+            return
         lay = self._lay(K)
         tp = lay.topic_pos.astype(np.int64)
         labs = lay.labs_from_masks(lab_mask.numpy())

@@ -907,3 +907,40 @@ def test_adversarial_near_ties_for_the_sparse_fp32_tier(c_oracle, K, labels, ima
     # them -- a tuned threshold may sit within 2^-40 of its boundary, which is the exact pipeline's to decide
     assert int(runs[0][4][1]) == st["n_tuned"] and int(runs[0][4][2]) <= st["n_tuned"] // 100
     assert int(runs[-1][4][2]) == int(st["doc_off"][-1])          # debug_margin -1: every site through the exact pipeline
+
+
+@pytest.mark.parametrize("K,image", [(392, 0), (512, 8), (2048, 8)])
+def test_sparse_documents_are_split_by_the_lanes_they_need(c_oracle, K, image):
+    """GibbsSampler._lane_parts: a corpus in which most documents allow a handful of topics and a few allow up to 64 runs as one launch of
+    the sparse-label kernel per class of lanes (8 / 16 / 32 / 64 per document) instead of giving every document 64 lanes; the state is
+    the C oracle's (LabeledLDA.py:106-125) and bit for bit that of the single launch."""
+    import torch
+    from lda_thesis_amd.sampler import GibbsSampler
+    rng = np.random.default_rng(K)
+    D, V = 600, 500
+    doc_off, word, freq, _, _ = synth(rng, D, V, K, 0, 50, True)
+    labs = np.zeros((D, K), dtype=np.uint8)
+    labs[:, 0] = 1
+    n_lab = rng.choice([3, 7, 12, 15, 25, 31, 40, 63], size=D, p=[0.4, 0.3, 0.08, 0.07, 0.05, 0.04, 0.03, 0.03])
+    for d in range(D):
+        labs[d, rng.choice(K - 1, size=n_lab[d], replace=False) + 1] = 1
+    z = np.concatenate([rng.choice(np.nonzero(labs[d])[0], size=doc_off[d + 1] - doc_off[d]) for d in range(D)])
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=5, doc_base=2, image=image)
+    one = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=5, doc_base=2, image=image)
+    one._lane_parts = lambda lo, hi, order: [(order, hi - lo, one.live_max)]          # every document with 64 lanes, as before
+    assert s.live_off is not None and s.live_max == 64
+    parts = s._lane_parts(0, s.D, s.doc_order)
+    assert [p[2] for p in parts] == [8, 16, 32, 64] and sum(p[1] for p in parts) == D
+    assert sorted(torch.cat([p[0] for p in parts]).cpu().tolist()) == list(range(D))
+    cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
+    for i in range(3):
+        s.debug_margin = one.debug_margin = (0, 6, 0)[i]
+        s.sweep()
+        one.sweep()
+        cs.sweep(1, 5, i, doc_base=2, threads=4)
+        np.testing.assert_array_equal(s.z_topics(), cs.z)
+        np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+        np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+        np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
+        assert torch.equal(one.z, s.z) and torch.equal(one._counts, s._counts) and torch.equal(one.n_dk, s.n_dk)
+    s.check_status()
