@@ -160,7 +160,7 @@ class GibbsSampler(object):
         self.dense_mask = labs is None or (self.D > 0 and bool((self.lab_mask == self._make_masks(None)[:1]).all()))
         # sparse label sets (Labeled LDA proper): positions of the allowed topics per document, ascending;
         # the library then runs one lane per ALLOWED topic (llda_sweep_sparse_kernel)
-        self.live_off = self.live_pos = None
+        self.live_off = self.live_pos = self._heavy = None
         self.live_max = 0
         if sparse_labels and labs is not None and self.D > 0:
             self._make_live()
@@ -405,25 +405,37 @@ class GibbsSampler(object):
         return m
 
     def _make_live(self):
+        """per document the device positions of its allowed topics (draw order) for the sparse-label kernel.  A document that allows
+        more than 64 topics or more than a quarter of K is HEAVY: it keeps an empty list and is swept by the dense kernel with its
+        label mask (its own launch, _lane_parts); when more than half of the documents are heavy the whole shard takes the dense
+        kernel, as if sparse_labels were off."""
         lay, dev = self.layout, self.device
         shifts = torch.arange(lay.T, device=dev, dtype=torch.int32)
         lm_pos = torch.from_numpy(lay.lm_pos.astype(np.int64)).to(dev)
-        counts, pos = [], []
+        counts, pos, heavy = [], [], []
         step = max(1, (1 << 26) // lay.KP)                 # documents per chunk: the (chunk, KP) 0/1 matrix stays small
         for d0 in range(0, self.D, step):
             bits = (self.lab_mask[d0:d0 + step].to(torch.int32) & 0xFFFF)          # (chunk, G) lane masks
             allowed = ((bits.unsqueeze(-1) >> shifts) & 1).reshape(bits.shape[0], lay.KP)   # (lane, slot) order = draw order
             c = allowed.sum(dim=1)
-            if int(c.max().item()) > 64 or int(c.max().item()) * 4 > self.K:
-                return                                                         # dense kernel is the better fit
+            h = (c > 64) | (c * 4 > self.K)
+            allowed = allowed * (~h).to(allowed.dtype)[:, None]
             _, lm = torch.nonzero(allowed, as_tuple=True)                      # row-major => draw order ascending
-            counts.append(c)
+            counts.append(torch.where(h, torch.zeros_like(c), c))
+            heavy.append(h)
             pos.append(lm_pos[lm])                                             # ... as memory positions
+        heavy = torch.cat(heavy)
+        n_heavy = int(heavy.sum().item())
+        if n_heavy * 2 > self.D:
+            return                                                             # dense kernel is the better fit
         counts = torch.cat(counts)
         self.live_off = torch.zeros((self.D + 1,), dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=self.live_off[1:])
         self.live_pos = torch.cat(pos).to(torch.int32).contiguous()
+        if self.live_pos.numel() == 0:                                         # (a pointer the library can test)
+            self.live_pos = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.live_max = int(counts.max().item())
+        self._heavy = heavy if n_heavy else None
 
     def _make_ranges(self):
         """document bounds of the overlap ranges (contiguous, balanced by site count); one range = no overlap."""
@@ -460,12 +472,13 @@ class GibbsSampler(object):
         return calls or [(0, 0, None)]                       # (a rank without documents)
 
     def _lane_parts(self, lo, hi, order):
-        """the launches of one llda_sweep call: [(doc_order, documents, live_max)].  Dense masks, or sparse label sets of at most 8
-        topics per document: one launch.  Otherwise the sparse-label kernel gives every document as many lanes as the LARGEST
-        label set of its launch needs (8, 16, 32 or 64: 8 ... 1 documents per wavefront), so the documents are split by the lanes
-        THEY need -- a corpus in which a few documents carry twenty labels and the rest a handful no longer runs all of them one to
-        a half-wavefront.  Which launch a document is in changes nothing (snapshot semantics); ``order`` is kept inside a class."""
-        if self.live_off is None or self.live_max <= 8 or hi <= lo:
+        """the launches of one llda_sweep call: [(doc_order, documents, live_max)]; live_max 0 = the dense kernel with the label masks.
+        Dense masks, or sparse label sets of at most 8 topics per document: one launch.  Otherwise the sparse-label kernel gives every
+        document as many lanes as the LARGEST label set of its launch needs (8, 16, 32 or 64: 8 ... 1 documents per wavefront), so the
+        documents are split by the lanes THEY need -- a corpus in which a few documents carry twenty labels and the rest a handful no
+        longer runs all of them one to a half-wavefront -- and the HEAVY documents (_make_live) go to the dense kernel.  Which launch a
+        document is in changes nothing (snapshot semantics); ``order`` is kept inside a class."""
+        if self.live_off is None or (self.live_max <= 8 and self._heavy is None) or hi <= lo:
             return [(order, hi - lo, self.live_max)]
         key = (lo, hi, None if order is None else order.data_ptr())
         hit = self._parts_cache.get(key)
@@ -473,17 +486,15 @@ class GibbsSampler(object):
             return hit
         idx = order.to(torch.int64) if order is not None else torch.arange(hi - lo, device=self.device)
         n = (self.live_off[lo + 1:hi + 1] - self.live_off[lo:hi])[idx]
+        heavy = self._heavy[lo:hi][idx] if self._heavy is not None else torch.zeros_like(n, dtype=torch.bool)
         parts = []
-        for lanes, low in ((8, 0), (16, 8), (32, 16), (64, 32)):
-            sel = idx[(n > low) & (n <= lanes)]
+        for lanes, low in ((8, -1), (16, 8), (32, 16), (64, 32)):             # (a document that allows nothing: first class, as before)
+            sel = idx[(n > low) & (n <= lanes) & ~heavy]
             if sel.numel():
                 parts.append((sel.to(torch.int32).contiguous(), int(sel.numel()), lanes))
-        sel = idx[n == 0]                                    # (documents that allow nothing: with the first class, as before)
+        sel = idx[heavy]
         if sel.numel():
-            if parts and parts[0][2] == 8:
-                parts[0] = (torch.cat([parts[0][0], sel.to(torch.int32)]).contiguous(), parts[0][1] + int(sel.numel()), 8)
-            else:
-                parts.insert(0, (sel.to(torch.int32).contiguous(), int(sel.numel()), 8))
+            parts.append((sel.to(torch.int32).contiguous(), int(sel.numel()), 0))
         self._parts_cache = {key: parts}                      # (one entry: the order only changes when a caller replaces it)
         return parts
 
@@ -568,6 +579,7 @@ class GibbsSampler(object):
                 s1 = self.S if len(self._calls) == 1 else int(self._off_host[hi])
                 # (sparse label sets: one launch per class of lanes a document needs -- see _lane_parts)
                 for part, n_docs, live_max in self._lane_parts(lo, hi, order):
+                    sparse = self.live_off is not None and live_max > 0
                     _native.sweep(doc_off=self.doc_off[lo:hi + 1], doc_order=part, word=self.word, freq=self.freq,
                                   z=self.z, lab_mask=self.lab_mask[lo:hi], n_dk=self.n_dk[lo:hi], n_kw=self.n_kw,
                                   n_kw_delta=self.n_kw_delta, n_k=self.n_k, n_k_delta=nk_delta,
@@ -576,11 +588,12 @@ class GibbsSampler(object):
                                   stream_id=self.stream_id, doc_base=self.doc_base + lo,
                                   docs_per_group=self.docs_per_group, dense_mask=self.dense_mask,
                                   debug_margin=self.debug_margin,
-                                  live_off=None if self.live_off is None else self.live_off[lo:hi + 1],
-                                  live_pos=self.live_pos,
+                                  live_off=self.live_off[lo:hi + 1] if sparse else None,
+                                  live_pos=self.live_pos if sparse else None,
                                   live_max=live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
                                   n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens,
-                                  scratch=self._scratch, n_kw16=self.n_kw16, site_row=self.site_row, n_kw_img=self.n_kw_img)
+                                  scratch=self._scratch, n_kw16=self.n_kw16, site_row=self.site_row,
+                                  n_kw_img=self.n_kw_img if sparse else None)
             if pipelined:
                 # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
                 # collective's stream (ordered after the fold) while the next range is sampled on this one

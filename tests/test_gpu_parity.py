@@ -909,29 +909,38 @@ def test_adversarial_near_ties_for_the_sparse_fp32_tier(c_oracle, K, labels, ima
     assert int(runs[-1][4][2]) == int(st["doc_off"][-1])          # debug_margin -1: every site through the exact pipeline
 
 
-@pytest.mark.parametrize("K,image", [(392, 0), (512, 8), (2048, 8)])
-def test_sparse_documents_are_split_by_the_lanes_they_need(c_oracle, K, image):
+@pytest.mark.parametrize("K,image,heavy", [(392, 0, False), (512, 8, False), (2048, 8, False), (392, 0, True), (512, 8, True), (100, 0, True),
+                                           (1100, 16, True)])
+def test_sparse_documents_are_split_by_the_lanes_they_need(c_oracle, K, image, heavy):
     """GibbsSampler._lane_parts: a corpus in which most documents allow a handful of topics and a few allow up to 64 runs as one launch of
-    the sparse-label kernel per class of lanes (8 / 16 / 32 / 64 per document) instead of giving every document 64 lanes; the state is
-    the C oracle's (LabeledLDA.py:106-125) and bit for bit that of the single launch."""
+    the sparse-label kernel per class of lanes (8 / 16 / 32 / 64 per document) instead of giving every document 64 lanes; `heavy`: a few
+    documents allow more than 64 topics / more than a quarter of K -- they alone take the dense kernel with their label masks (before,
+    one such document sent the whole corpus there).  The state is the C oracle's (LabeledLDA.py:106-125) and bit for bit that of the
+    dense kernel on everything."""
     import torch
     from lda_thesis_amd.sampler import GibbsSampler
-    rng = np.random.default_rng(K)
+    rng = np.random.default_rng(K + heavy)
     D, V = 600, 500
     doc_off, word, freq, _, _ = synth(rng, D, V, K, 0, 50, True)
     labs = np.zeros((D, K), dtype=np.uint8)
     labs[:, 0] = 1
-    n_lab = rng.choice([3, 7, 12, 15, 25, 31, 40, 63], size=D, p=[0.4, 0.3, 0.08, 0.07, 0.05, 0.04, 0.03, 0.03])
+    top = min(63, K // 4 - 1)
+    sizes = [3, 7, min(12, top), min(15, top), min(25, top), min(31, top), min(40, top), top]
+    n_lab = rng.choice(sizes, size=D, p=[0.4, 0.3, 0.08, 0.07, 0.05, 0.04, 0.03, 0.03])
+    if heavy:
+        n_lab[rng.choice(D, size=25, replace=False)] = rng.choice([K // 4 + 1, min(K - 1, 70), K - 1], size=25)
     for d in range(D):
         labs[d, rng.choice(K - 1, size=n_lab[d], replace=False) + 1] = 1
     z = np.concatenate([rng.choice(np.nonzero(labs[d])[0], size=doc_off[d + 1] - doc_off[d]) for d in range(D)])
     s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=5, doc_base=2, image=image)
-    one = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=5, doc_base=2, image=image)
-    one._lane_parts = lambda lo, hi, order: [(order, hi - lo, one.live_max)]          # every document with 64 lanes, as before
-    assert s.live_off is not None and s.live_max == 64
+    one = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=5, doc_base=2, sparse_labels=False)
+    assert s.live_off is not None and one.live_off is None
     parts = s._lane_parts(0, s.D, s.doc_order)
-    assert [p[2] for p in parts] == [8, 16, 32, 64] and sum(p[1] for p in parts) == D
+    classes = [p[2] for p in parts]
+    assert classes == sorted(set(classes) - {0}) + ([0] if heavy else []) and len(classes) >= 3 and sum(p[1] for p in parts) == D
     assert sorted(torch.cat([p[0] for p in parts]).cpu().tolist()) == list(range(D))
+    if heavy:
+        assert parts[-1][1] == 25 and (s._heavy.cpu().numpy() == ((n_lab + 1 > 64) | ((n_lab + 1) * 4 > K))).all()
     cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
     for i in range(3):
         s.debug_margin = one.debug_margin = (0, 6, 0)[i]
