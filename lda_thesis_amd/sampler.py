@@ -495,7 +495,9 @@ class GibbsSampler(object):
         sel = idx[heavy]
         if sel.numel():
             parts.append((sel.to(torch.int32).contiguous(), int(sel.numel()), 0))
-        self._parts_cache = {key: parts}                      # (one entry: the order only changes when a caller replaces it)
+        if len(self._parts_cache) >= 64:                      # (grows only when a caller keeps replacing doc_order)
+            self._parts_cache.clear()
+        self._parts_cache[key] = parts
         return parts
 
     def _make_commit_log(self):
