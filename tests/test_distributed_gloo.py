@@ -109,9 +109,9 @@ def test_two_rank_sharded_sweeps_match_single_process_golden(name, counts_mode, 
     procs = [ctx.Process(target=_worker, args=(r, 2, port, name, counts_mode, overlap, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=600) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert sum(n for _, _, n in res) == int(load_golden(name)["D"])
@@ -127,9 +127,9 @@ def test_rank_with_an_empty_shard_issues_the_same_collectives(overlap):
     procs = [ctx.Process(target=_worker, args=(r, 3, port, "tiny_k40", "built", overlap, q, True)) for r in range(3)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=600) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert sorted(n for _, _, n in res)[0] == 0
@@ -202,9 +202,9 @@ def test_cascade_subproblems_spread_over_two_ranks(batched):
     procs = [ctx.Process(target=_cascade_worker, args=(r, 2, port, batched, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=600) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == [0, 1]                      # both ranks own some sub-problems
@@ -223,9 +223,9 @@ def test_cascade_rank_without_subproblems(batched):
     procs = [ctx.Process(target=_cascade_idle, args=(r, 2, port, batched, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=600) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == [0]
@@ -274,8 +274,8 @@ def test_dropin_labeledlda_shards_documents_over_ranks():
     procs = [ctx.Process(target=_llda_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=600) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
