@@ -988,6 +988,15 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+_T0 = time.time()
+
+
+def trace(msg):
+    """LLDA_BENCH_TRACE=1: time-stamped progress on stderr (every rank)"""
+    if os.environ.get("LLDA_BENCH_TRACE"):
+        print("[bench %6.1f s rank %s] %s" % (time.time() - _T0, os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1042,12 +1051,17 @@ def main():
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
+    trace("process group ready" if dist is not None else "single process")
+    if os.environ.get("LLDA_BENCH_TRACE"):                # where every rank stands if the run is still going after a minute
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("LLDA_BENCH_TRACE_DUMP_S", "60")), repeat=False, file=sys.stderr)
     name = args.workload
     sampler, info = build_sampler(name, dev, rank, world, dist is not None, docs_total=args.docs,
                                   docs_per_group=args.docs_per_group, force_exchange=args.force_exchange,
                                   overlap=None if args.overlap < 0 else args.overlap)
     sites_local = sampler.S
     torch.cuda.synchronize()
+    trace("sampler built: %d local sites" % sites_local)
     if args.make_checksums:
         if world != 1:
             raise SystemExit("--make-checksums is a single-GPU run")
@@ -1062,6 +1076,7 @@ def main():
         print(json.dumps({"%s:%d" % (name, info["docs_total"]): out}))
         return
     dt, kavg = time_sweeps(sampler, args.steps, args.warmup, dist, dev)
+    trace("timed sweeps done: %.3f s" % dt)
     tier = sampler.status.cpu().numpy().astype(np.int64)
     total_sites = sites_local
     sums = state_checksums(sampler)
@@ -1100,6 +1115,7 @@ def main():
         probe["state_checksum_n_k_after_probe"] = psums["n_k"]
         probe["checksum_matches_n1"], _ = checksum_verdict(name, info["docs_total"], sampler.sweeps_done, psums)
 
+    trace("probes done")
     if rank == 0:
         K, V, N = info["K"], info["V"], info["N"]
         live = info["live_topics"]
@@ -1221,9 +1237,12 @@ def main():
                 print("bench.py: could not write %s: %r" % (args.detail_out, e), file=sys.stderr)
         sys.stdout.flush()
         print(json.dumps(compact_line(line, detail_path)), flush=True)
+    trace("line printed / waiting at the final barrier")
     if dist is not None:
         dist.barrier()
+        trace("final barrier passed")
         dist.destroy_process_group()
+    trace("done")
 
 
 if __name__ == "__main__":
