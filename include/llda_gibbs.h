@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 18
+#define LLDA_ABI_VERSION 19
 #define LLDA_MAX_K 7688          /* every K up to here splits into <= 64 pairwise leaves                       */
 #define LLDA_MAX_KP 8192         /* longest padded row: 64 leaves x 128                                        */
 #define LLDA_MAX_LEAVES 8        /* "narrow" layouts: one lane group of <= 64 lanes x <= 16 slots per document  */
@@ -184,6 +184,14 @@ typedef struct llda_sweep_args {
                                     depend on the image.  Needs alpha, beta >= 1e-6 like the sparse-label kernel itself. */
     int32_t  img_bits;           /* 0 (no image), 8 or 16                                                    */
     int32_t  reserved_img;       /* 0                                                                         */
+    const uint8_t *row16;        /* [dev] [V] optional (ABI 19), with n_kw16 and WITHOUT site_row: the per-word flags llda_pack_rows16_all
+                                    wrote for THIS sweep's n_kw (1 = every count of the row fits 16 bits; n_kw16 then holds EVERY
+                                    row).  K = 512 (32 lanes x 16 slots) with dense_mask = 1, the commit log, alpha, beta >= 1e-6 and
+                                    0 < max_doc_tokens < 65 536 (LLDA_E_BAD_ARG otherwise): the kernel that walks FOUR documents per
+                                    wavefront, 16 lanes x 32 slots each (kernel_quad.hpp) -- the per-iteration work of scan, search,
+                                    pick and count update is shared by four sites instead of two.  A site whose row is not flagged
+                                    reads the int32 row (no prefetch: meant to be rare).  Bit 31 of csc_pos is ignored.  Results do
+                                    not depend on it. */
 } llda_sweep_args;
 
 /* ---- host-only (no device needed) ---- */
@@ -297,6 +305,12 @@ int llda_apply_rows(const int64_t *row_off, int32_t *rows, int64_t n_rows, int32
  * of status word 0. */
 int llda_pack_rows16(const int32_t *n_kw, const uint8_t *row16, int64_t V, int32_t K, uint16_t *n_kw16, int32_t *status,
                      void *stream);
+
+/* The 16-bit image of EVERY row of n_kw plus, per word, whether all counts of its row fit 16 bits in this sweep's n_kw
+ * (row16[v] = 1; ABI 19) -- for llda_sweep_args.row16.  K = 512 only (LLDA_E_BAD_K otherwise); n_kw and n_kw16 16-byte aligned.
+ * Call it once per sweep, after the counts of the previous sweep were folded in and before the first llda_sweep.  The image of an
+ * unflagged row holds the low halves of its counts and is never read. */
+int llda_pack_rows16_all(const int32_t *n_kw, int64_t V, int32_t K, uint16_t *n_kw16, uint8_t *row16, void *stream);
 
 /* The saturating narrow image of n counts for llda_sweep_args.n_kw_img (ABI 18): img[i] = min(n_kw[i], 255) as uint8_t
  * (bits 8) or min(n_kw[i], 65535) as uint16_t (bits 16); a negative count saturates as well.  n = V*KP, a multiple of 4;

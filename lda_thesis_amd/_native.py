@@ -16,7 +16,7 @@ MAX_KP = 8192
 MAX_LEAVES = 8          # narrow layouts
 MAX_WIDE_LEAVES = 64
 MAX_ROUNDS = 4
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -55,7 +55,7 @@ class LldaSweepArgs(ctypes.Structure):
                 ("live_off", _c_p), ("live_pos", _c_p), ("scratch", _c_p), ("scratch_bytes", _c_i64),
                 ("live_max", _c_i32), ("max_doc_tokens", _c_i32), ("csc_pos", _c_p), ("commit_log", _c_p),
                 ("n_sites", _c_i64), ("site_rec", _c_p), ("n_kw16", _c_p), ("site_row", _c_p),
-                ("n_kw_img", _c_p), ("img_bits", _c_i32), ("reserved_img", _c_i32)]
+                ("n_kw_img", _c_p), ("img_bits", _c_i32), ("reserved_img", _c_i32), ("row16", _c_p)]
 
 
 class LldaBatchArgs(ctypes.Structure):
@@ -69,7 +69,7 @@ class LldaBatchArgs(ctypes.Structure):
 
 
 EXPORTS = ("llda_abi_version", "llda_build_info", "llda_strerror", "llda_last_hip_error", "llda_struct_size", "llda_layout_init",
-           "llda_sweep_scratch_bytes", "llda_rows16_ok", "llda_pack_rows16", "llda_pack_image",
+           "llda_sweep_scratch_bytes", "llda_rows16_ok", "llda_pack_rows16", "llda_pack_rows16_all", "llda_pack_image",
 
            "llda_sweep", "llda_sweep_batch", "llda_commit_log", "llda_apply_rows", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
            "llda_readout_phi", "llda_readout_theta", "llda_selftest_div")
@@ -113,6 +113,8 @@ def lib():
     L.llda_rows16_ok.argtypes = [_c_i32]
     L.llda_pack_rows16.restype = ctypes.c_int
     L.llda_pack_rows16.argtypes = [_c_p, _c_p, _c_i64, _c_i32, _c_p, _c_p, _c_p]
+    L.llda_pack_rows16_all.restype = ctypes.c_int
+    L.llda_pack_rows16_all.argtypes = [_c_p, _c_i64, _c_i32, _c_p, _c_p, _c_p]
     L.llda_pack_image.restype = ctypes.c_int
     L.llda_pack_image.argtypes = [_c_p, _c_i64, _c_i32, _c_p, _c_p]
     L.llda_sweep_batch.restype = ctypes.c_int
@@ -205,11 +207,12 @@ def _launch(ref, fn, what, *args):
 def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
           status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
           dense_mask=False, debug_margin=0, live_off=None, live_pos=None, live_max=0, csc_pos=None, commit_log=None,
-          n_sites=None, site_rec=None, max_doc_tokens=0, scratch=None, n_kw16=None, site_row=None, n_kw_img=None):
+          n_sites=None, site_rec=None, max_doc_tokens=0, scratch=None, n_kw16=None, site_row=None, n_kw_img=None, row16=None):
     """llda_sweep on the current torch stream.  All array arguments are torch CUDA tensors.  n_sites = the sites
     the D documents span (default: all of ``word``); scratch = a uint8 tensor of sweep_scratch_bytes(K, D) bytes (wide
     layouts) or None; n_kw16 = the 16-bit image written by pack_rows16 (then csc_pos carries the row flags in bit 31 and site_row the row starts) or None;
-    n_kw_img = the saturating uint8 / int16 image written by pack_image (sparse label sets) or None."""
+    n_kw_img = the saturating uint8 / int16 image written by pack_image (sparse label sets) or None; row16 = the per-word flags
+    written by pack_rows16_all (with n_kw16, without site_row: the four-documents-per-wavefront kernel of K = 512) or None."""
     img_bits = 0 if n_kw_img is None else 8 * n_kw_img.element_size()
     a = LldaSweepArgs(_ptr(doc_off), _ptr(doc_order), _ptr(word), _ptr(freq), _ptr(z), _ptr(lab_mask),
                       _ptr(n_dk), _ptr(n_kw), _ptr(n_kw_delta), _ptr(n_k), _ptr(n_k_delta), _ptr(status),
@@ -219,7 +222,7 @@ def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta
                       int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), _ptr(scratch),
                       0 if scratch is None else int(scratch.numel() * scratch.element_size()), int(live_max), int(max_doc_tokens),
                       _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites), _ptr(site_rec),
-                      _ptr(n_kw16), _ptr(site_row), _ptr(n_kw_img), img_bits, 0)
+                      _ptr(n_kw16), _ptr(site_row), _ptr(n_kw_img), img_bits, 0, _ptr(row16))
     _launch(z, lib().llda_sweep, "llda_sweep", ctypes.byref(a))
 
 
@@ -237,6 +240,12 @@ def pack_rows16(n_kw, row16, K, n_kw16, status):
     """llda_pack_rows16 on the current torch stream: the 16-bit image of the rows of n_kw flagged in row16 (uint8 [V])."""
     _launch(n_kw, lib().llda_pack_rows16, "llda_pack_rows16", _ptr(n_kw), _ptr(row16), int(row16.numel()), int(K),
             _ptr(n_kw16), _ptr(status))
+
+
+def pack_rows16_all(n_kw, K, n_kw16, row16):
+    """llda_pack_rows16_all on the current torch stream: the 16-bit image of EVERY row of n_kw and, in row16 (uint8 [V]), whether
+    all counts of the row fit 16 bits."""
+    _launch(n_kw, lib().llda_pack_rows16_all, "llda_pack_rows16_all", _ptr(n_kw), int(row16.numel()), int(K), _ptr(n_kw16), _ptr(row16))
 
 
 def pack_image(n_kw, img):

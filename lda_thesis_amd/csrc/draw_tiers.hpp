@@ -298,22 +298,13 @@ __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uin
 //           correctly rounded and q1 faithful, q2 = RN(q1 + (w - S q1) y) is the correctly rounded
 //           quotient; llda_selftest_div checks it against the hardware division), keyed draw.
 // Returns the chosen device position or -1.
-// W4: s_ndk holds n_dk | sweep-start n_dk << 16 and s_nkc is really the workgroup's copy of the sweep-start n_k, indexed by
-// device position (kernel_sweep.hpp, count_update_w4)
-template <int G, int T, bool HAS_TAIL, bool DENSE, bool W4 = false>
-__device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, const int (*s_nkc)[256], int tid,
-                                       uint32_t mask, double u, int lig, int lane, const KParams *P)
+// ACC: where the document's counts live -- nd(s) = its n_dk at slot s of this lane, nk(s) = the n_k it sees there,
+// stats() = this lane group reports the tier statistics (one group per site)
+template <int G, int T, bool HAS_TAIL, bool DENSE, class ACC>
+__device__ __noinline__ int cold_tiers_acc(const ACC dc, const int *x, uint32_t mask, double u, int lig, int lane, const KParams *P)
 {
-    // the document's n_dk and the n_k it sees at slot s
-    auto nd_of = [&](int s) { return W4 ? s_ndk[s][tid] & 0xffff : s_ndk[s][tid]; };
-    auto nk_of = [&](int s) {
-        if constexpr (W4) {
-            const int w = s_ndk[s][tid];
-            return ((const int *)s_nkc)[pos_of<G, T>(lig, s)] + (w & 0xffff) - (int)((uint32_t)w >> 16);
-        } else {
-            return s_nkc[s][tid];
-        }
-    };
+    auto nd_of = [&](int s) { return dc.nd(s); };
+    auto nk_of = [&](int s) { return dc.nk(s); };
     // Tier 1 is unrolled and lives in registers (the kernel is LDS-limited to 3 waves per SIMD, which leaves 168
     // VGPRs: scratch round trips here stalled the whole wave); the exact tier, ~1e-9 per site, stays rolled over
     // a scratch array.
@@ -322,7 +313,7 @@ __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, co
     const double alpha = P->alpha, beta = P->beta, vbeta = P->vbeta;
     const uint32_t lmask = DENSE ? 0xFFFFu : mask;
     double w[T];
-    if (lig == 0 && P->status) atomicAdd(P->status + 1, 1);      // statistics: sites tier 0 was unsure about
+    if (lig == 0 && dc.stats() && P->status) atomicAdd(P->status + 1, 1);      // statistics: sites tier 0 was unsure about
     // ---- tier 1: unnormalised fp64 prefix sums, margin 2^-40 of the total ----
     {
         double run = 0.0;
@@ -360,7 +351,7 @@ __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, co
         }
     }
     // ---- exact tier: the reference's fp64 pipeline, bit for bit ----
-    if (lig == 0 && P->status) { atomicOr(P->status, 2); atomicAdd(P->status + 2, 1); }   // the exact tier ran
+    if (lig == 0 && dc.stats() && P->status) { atomicOr(P->status, 2); atomicAdd(P->status + 2, 1); }   // the exact tier ran
     const int leaf = lig >> 3;
     double acc = 0.0, tv = 0.0;
 #pragma unroll 1
@@ -396,6 +387,34 @@ __device__ __noinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, co
     const int sl = hit ? (int)__ffsll((unsigned long long)gf) - 1 : 63 - (int)__clzll((unsigned long long)gp);
     const int my = hit ? (int)__ffs((int)(fm | 0x10000u)) - 1 : 31 - (int)__clz((int)(mask | 1u));
     return pos_of<G, T>(sl, __shfl(my, sl, G));
+}
+
+// the counts of the LDS-staged kernels (kernel_sweep.hpp): [slot][thread] arrays.
+// W4: s_ndk holds n_dk | sweep-start n_dk << 16 and s_nkc is really the workgroup's copy of the sweep-start n_k, indexed by
+// device position (kernel_sweep.hpp, count_update_w4)
+template <int G, int T, bool W4>
+struct LdsCounts {
+    const int (*s_ndk)[256];
+    const int (*s_nkc)[256];
+    int tid, lig;
+    __device__ __forceinline__ int nd(int s) const { return W4 ? s_ndk[s][tid] & 0xffff : s_ndk[s][tid]; }
+    __device__ __forceinline__ int nk(int s) const
+    {
+        if constexpr (W4) {
+            const int w = s_ndk[s][tid];
+            return ((const int *)s_nkc)[pos_of<G, T>(lig, s)] + (w & 0xffff) - (int)((uint32_t)w >> 16);
+        } else {
+            return s_nkc[s][tid];
+        }
+    }
+    __device__ __forceinline__ bool stats() const { return true; }
+};
+template <int G, int T, bool HAS_TAIL, bool DENSE, bool W4 = false>
+__device__ __forceinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, const int (*s_nkc)[256], int tid,
+                                          uint32_t mask, double u, int lig, int lane, const KParams *P)
+{
+    const LdsCounts<G, T, W4> acc{s_ndk, s_nkc, tid, lig};
+    return cold_tiers_acc<G, T, HAS_TAIL, DENSE>(acc, x, mask, u, lig, lane, P);
 }
 
 // store the new assignment of a site and move its count in n_kw_delta (int32 atomics, no return value)

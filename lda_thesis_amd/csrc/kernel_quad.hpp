@@ -1,0 +1,424 @@
+// kernel_quad.hpp -- llda_sweep_quad_kernel: the K = 512 dense kernel with FOUR documents per wavefront
+// Part of the single translation unit llda_gibbs.hip (included in order; see the contents list there).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Why.  llda_sweep_kernel<32,16,..,R16,W4> (kernel_sweep.hpp) is bound by instruction issue: 84 vector instructions per site of
+// which 20 are the arithmetic of the 512 scores (profiles/r05_site_loop_budget.md); the other ~130 per wavefront iteration -- lane scan,
+// threshold, search, pick, count update, addresses, commit -- are paid once per iteration whatever the number of documents in the
+// wavefront.  Here a document is walked by 16 lanes x 32 slots, four documents per wavefront: the fixed part is shared by four sites.
+// LDS holds the same 4 KB per document, so a CU holds the same 32 documents -- in 8 wavefronts (two per SIMD, 256 VGPRs) instead of 16.
+//
+// Geometry.  The layout of K = 512 is 32 lanes x 16 slots (llda_layout: G = 32, T = 16).  Quad lane lq plays the standard lanes
+// 2 lq and 2 lq + 1 one after the other, so the draw order (standard lane, slot) is unchanged:
+//     device position     pos   = i << 7 | lq << 3 | e << 2 | c        i = slot >> 2, e = standard lane & 1, c = slot & 3
+//     register / LDS slot rho   = 8 i + 2 c + e: the pair (2a, 2a + 1), a = 4 i + c, holds element a of chain A (the slots of
+//                         standard lane 2 lq) and of chain B (those of lane 2 lq + 1): one packed fma advances both chains
+// Rows come from the 16-bit image of n_kw (llda_pack_rows16_all: EVERY row, with a per-row flag "all counts fit" decided per sweep);
+// a site whose row does not fit reads the int32 row without prefetch.  Documents of at most 65 535 tokens (n_dk packed with its
+// sweep-start value, as the W4 form).
+//
+// Tier 0 with two chains of 16 per lane: every prefix within (12 + 16) v of the lane's share, the lane total one more,
+// four scan steps: X and the total within 33 v, the target fl(u~ tot~ - X~[g-1]) (one fma) within 69.2 v, its bounds 70.2 v; chain A is
+// compared directly (98.2 v), chain B against the bounds minus chain A's total (99.2 v) -- inside the 105 v of the 2-document kernel,
+// margin 128 v.  Int32 rows with counts >= 2^24: + 2 v.
+// ---------------------------------------------------------------------------------------------
+constexpr int QT = 32;        // slots per quad lane
+constexpr int QNT = 128;      // threads per workgroup: two wavefronts, eight documents
+
+// slot number of a device position: rho = 8 i + 2 c + e
+__device__ __forceinline__ int quad_rho(int pos) { return ((pos >> 4) & 0x18) | ((pos & 3) << 1) | ((pos >> 2) & 1); }
+constexpr int quad_rho_of(int i, int e, int c) { return 8 * i + 2 * c + e; }
+
+// the counts of one document for the cold tiers, which play it in the STANDARD layout (32 lanes x 16 slots)
+struct QuadCounts {
+    const int (*s_ndk)[QNT];
+    const int *s_nk0;
+    int t;         // thread of the workgroup that holds this standard lane's slots
+    int e;         // standard lane & 1
+    int g;         // standard lane
+    bool st;
+    __device__ __forceinline__ int word(int s) const { return s_ndk[8 * (s >> 2) + 2 * (s & 3) + e][t]; }
+    __device__ __forceinline__ int nd(int s) const { return word(s) & 0xffff; }
+    __device__ __forceinline__ int nk(int s) const
+    {
+        const int w = word(s);
+        return s_nk0[pos_of<32, 16>(g, s)] + (w & 0xffff) - (int)((uint32_t)w >> 16);
+    }
+    __device__ __forceinline__ bool stats() const { return st; }
+};
+
+// One undecided site: both halves of the wavefront play the document in the standard layout (the upper half silently), the row
+// comes from n_kw itself.  tbase = thread of the document's quad lane 0; w, f, zo = word, frequency and old position of the site.
+__device__ __noinline__ int quad_cold(const int (*s_ndk)[QNT], const int *s_nk0, int tbase, int w, int f, int zo, uint32_t ra,
+                                      uint32_t rb, int lane, const KParams *P)
+{
+    const int g = lane & 31;
+    int x[16];
+    gload_lane_row<32, 16>(P->n_kw, (int64_t)w * 512, g, x);
+    int lo, so;
+    lane_slot_of<32, 16>(zo, lo, so);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) x[s] -= (g == lo && s == so) ? f : 0;       // the site's own count (LabeledLDA.py:109-111)
+    const QuadCounts dc{s_ndk, s_nk0, tbase + (g >> 1), g & 1, g, lane < 32};
+    return cold_tiers_acc<32, 16, false, true>(dc, x, 0xFFFFu, uniform53(ra, rb), g, lane, P);
+}
+
+typedef float q_v2f __attribute__((ext_vector_type(2)));
+typedef float q_v32f __attribute__((ext_vector_type(32)));
+
+// Tier 0 for four documents at once.  xv = the row minus the site's own count (fp32, exact), pa = the cached factors, both in slot
+// order rho: the pair (2a, 2a+1) holds element a of chain A and of chain B, so ONE packed instruction advances both chains.
+// Returns the wavefront's ballot of the lanes that are not sure; zn = the position every lane's document drew.
+__device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa)[16], float u, float margin_rel, float beta,
+                                              int lq, int bp_last, int &zn)
+{
+    const q_v2f b2 = {beta, beta};
+    q_v2f Q[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const q_v2f x2 = {xv[2 * a], xv[2 * a + 1]};
+        const q_v2f nb = x2 + b2;
+        if (a == 0) Q[0] = nb * pa[0];
+        else Q[a] = __builtin_elementwise_fma(nb, pa[a], Q[a - 1]);
+    }
+    // inclusive scan over the 16 lanes of the document = one DPP row
+    float X = Q[15].x + Q[15].y;
+    X += dpp_f32<DPP_ROW_SHR + 1>(X);
+    X += dpp_f32<DPP_ROW_SHR + 2>(X);
+    X += dpp_f32<DPP_ROW_SHR + 4>(X);
+    X += dpp_f32<DPP_ROW_SHR + 8>(X);
+    const float tot = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_last, __float_as_int(X)));     // the row's last lane
+    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), DPP_ROW_SHR + 1, 0xF, 0xF, true));
+    const float tg = __builtin_fmaf(u, tot, -prev);
+    const float margin = tot * margin_rel;
+    const float lo0 = tg - margin, hi0 = tg + margin;
+    // chain A or chain B?
+    const bool c0 = Q[15].x <= lo0;
+    const float dA = c0 ? Q[15].x : 0.0f;
+    const float lo = lo0 - dA, hi = hi0 - dA;
+    float q[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) q[a] = c0 ? Q[a].y : Q[a].x;
+    // branch-free binary search (draw_tiers.hpp, count_sorted_f32) that keeps the smallest element found above lo
+    const bool c5 = q[15] <= lo;
+    float ub = c5 ? __int_as_float(0x7f800000) : q[15];
+    const bool c1 = q[7] <= lo;
+    ub = c1 ? ub : q[7];
+    const float m2 = c1 ? q[11] : q[3];
+    const float a1 = c1 ? q[9] : q[1], a5 = c1 ? q[13] : q[5];
+    const float e0 = c1 ? q[8] : q[0], e2 = c1 ? q[10] : q[2], e4 = c1 ? q[12] : q[4], e6 = c1 ? q[14] : q[6];
+    const bool c2 = m2 <= lo;
+    ub = c2 ? ub : m2;
+    const float m3 = c2 ? a5 : a1;
+    const float g0 = c2 ? e4 : e0, g2 = c2 ? e6 : e2;
+    const bool c3 = m3 <= lo;
+    ub = c3 ? ub : m3;
+    const float m4 = c3 ? g2 : g0;
+    const bool c4 = m4 <= lo;
+    ub = c4 ? ub : m4;
+    // guards on the total in one class test (draw_fast_dense_f32): tot - margin is a positive normal number
+    uint64_t bad_total;
+    asm("v_cmp_class_f32_e64 %0, %1, %2" : "=s"(bad_total) : "v"(tot - margin), "v"(0x2FF));
+    const uint64_t unsure = __ballot(!(ub > hi)) | bad_total;
+    // the position this lane would name, keyed by its lane; the document's first lane with a slot above lo wins (none: 511, the
+    // last slot of the last lane).  Row-wide minimum: four DPP steps, one instruction each (the compiler's form is three)
+    const uint32_t p = (c1 ? 256u : 0u) | (c2 ? 128u : 0u) | (c3 ? 2u : 0u) | (c4 ? 1u : 0u) | (c0 ? 4u : 0u) | ((uint32_t)lq << 3);
+    uint32_t key = c5 ? 0xFFFFu : (((uint32_t)lq << 9) | p);
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(key));
+    zn = (int)(key & 511u);
+    return unsure;
+}
+
+struct QuadSite { int v, f, zo, c, zn, lo, so; };     // (lo, so) = quad lane and slot rho of zo
+
+__global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P)
+{
+    constexpr int KP = 512;
+    __shared__ int s_nk[KP];                   // workgroup accumulator of the n_k changes
+    __shared__ int s_nk0[KP];                  // the sweep-start n_k
+    __shared__ int s_ndk[QT][QNT];             // n_dk | sweep-start n_dk << 16, [rho][thread]
+    __shared__ float s_pa[QT][QNT];            // tier-0 factor fl32((n_dk + alpha) / (n_k + V*beta))
+    __shared__ float s_u[QNT / 16][32];        // the fp32 uniforms of the next 32 sites of every document
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KP; i += QNT) {
+        s_nk[i] = 0;
+        s_nk0[i] = P.n_k[i];
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, lq = tid & 15, row = lane >> 4, grp = tid >> 4;
+    const float vbeta32 = (float)P.vbeta, alpha32 = (float)P.alpha, beta32 = (float)P.beta;
+    const int bp_last = (lane | 15) << 2;
+    const uint64_t lq0_w = 0x0001000100010001ull;            // quad lane 0 of the four documents
+
+    const int64_t site_base = P.doc_off[0];
+    const int32_t *word_b = P.word + site_base, *freq_b = P.freq + site_base, *csc_b = P.csc_pos + site_base;
+    int32_t *z_b = P.z + site_base;
+
+    typedef int v4i __attribute__((ext_vector_type(4)));
+
+    auto update = [&](int sg, int pos, int df) {
+        const int w = s_ndk[sg][tid] + df;                           // (0 <= n_dk + df < 2^16: no carry into the upper half)
+        s_ndk[sg][tid] = w;
+        const int nd = w & 0xffff, nk = s_nk0[pos] + nd - (int)((uint32_t)w >> 16);
+        s_pa[sg][tid] = tier0_factor(nd, nk, alpha32, vbeta32);
+    };
+
+    for (int it = 0; it < P.dpg; ++it) {
+        const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * (QNT / 16) + grp;
+        // a lane group without a document walks a copy of the last one with no sites: every lane of the wavefront stays in the site
+        // loop (the cold tiers need all of them) and nothing it computes is stored
+        const bool valid = idx < P.D;
+        const int64_t ic = valid ? idx : P.D - 1;
+        const int64_t d = P.doc_order ? (int64_t)P.doc_order[ic] : ic;
+        int64_t s0 = P.doc_off[d];
+        int len = valid ? (int)(P.doc_off[d + 1] - s0) : 0;
+        if (len <= 0) {
+            len = 0;
+            s0 = site_base;
+        }
+        const int maxlen = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
+                               max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
+        if (maxlen == 0) continue;                                   // (uniform)
+
+        int32_t *ndk_row = P.n_dk + d * KP;
+        {
+            int big = 0, tokens = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v4i a = ((const v4i *)ndk_row)[i * 32 + 2 * lq], b = ((const v4i *)ndk_row)[i * 32 + 2 * lq + 1];
+                const int r[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int rho = quad_rho_of(i, j >> 2, j & 3);
+                    const int k = s_nk0[i * 128 + lq * 8 + j];
+                    s_ndk[rho][tid] = r[j] | (r[j] << 16);
+                    s_pa[rho][tid] = tier0_factor(r[j], k, alpha32, vbeta32);
+                    big |= r[j];
+                    tokens += (int)((uint32_t)r[j] & 0xffffu);
+                }
+            }
+            // the packed word holds the counts of a document of at most 65 535 tokens (kernel_sweep.hpp, W4): status bit 2 otherwise
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) tokens += __shfl_xor(tokens, m, 16);
+            if (valid && (((uint32_t)big >> 16) || tokens > 65535) && P.status) atomicOr(P.status, 4);
+        }
+        const uint32_t gdoc = (uint32_t)(d + P.doc_base);
+        const uint32_t sb = (uint32_t)(s0 - site_base) * 4u;
+        const int last = len > 0 ? len - 1 : 0;
+        auto off_of = [&](int n) { return opaque_u32(sb + (uint32_t)min(n, last) * 4u); };
+        auto load_scalars = [&](QuadSite &R, const uint32_t o) {
+            R.v = gload_i32(word_b, o); R.f = gload_i32(freq_b, o); R.c = gload_i32(csc_b, o); R.zo = gload_i32(z_b, o);
+        };
+        auto decode_old = [&](QuadSite &R) {
+            R.lo = (R.zo >> 3) & 15;
+            R.so = quad_rho(R.zo);
+        };
+        // the 16-bit row of word v: chunks (e, j) = slots 8j .. 8j+7 of standard lane 2 lq + e, and the row's flag
+        // (32-bit byte offsets from the image: llda_sweep checked V * 1024 < 2^32)
+        int xp[16], fl;
+        auto load_row16 = [&](const int v) {
+            const LLDA_GLOBAL char *q = (const LLDA_GLOBAL char *)P.n_kw16 + (((uint32_t)v << 10) + (uint32_t)lq * 32u);
+            const v4i a = *(const LLDA_GLOBAL v4i *)q, b = *(const LLDA_GLOBAL v4i *)(q + 512);
+            const v4i c = *(const LLDA_GLOBAL v4i *)(q + 16), e = *(const LLDA_GLOBAL v4i *)(q + 528);
+            xp[0] = a.x; xp[1] = a.y; xp[2] = a.z; xp[3] = a.w;
+            xp[4] = b.x; xp[5] = b.y; xp[6] = b.z; xp[7] = b.w;
+            xp[8] = c.x; xp[9] = c.y; xp[10] = c.z; xp[11] = c.w;
+            xp[12] = e.x; xp[13] = e.y; xp[14] = e.z; xp[15] = e.w;
+            fl = *(const LLDA_GLOBAL uint8_t *)((const LLDA_GLOBAL char *)P.row16 + (uint32_t)v);
+        };
+
+        QuadSite R0, R1, R2;
+        load_scalars(R0, off_of(0)); R0.zn = 0;
+        load_scalars(R1, off_of(1)); R1.zn = 0; R1.lo = R1.so = 0;
+        R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = 0;
+        load_row16(R0.v);
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        decode_old(R0);
+        if (len > 0 && lq == R0.lo) update(R0.so, R0.zo, -R0.f);      // site 0 leaves its topic (LabeledLDA.py:109-111)
+
+        auto site = [&](const int n, QuadSite &cur, QuadSite &nxt, QuadSite &prv) {
+            const bool act = n < len, more = n + 1 < len;
+            const int f = cur.f, zo = cur.zo;
+            q_v2f pa[16];
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                pa[a].x = s_pa[2 * a][tid];
+                pa[a].y = s_pa[2 * a + 1][tid];
+            }
+            // the random bits of 32 sites at a time (one Philox block per lane serves two sites); their fp32 images -- the top 27
+            // bits, within 2^-24 relative + 2^-27 absolute of u -- go through LDS, the bits themselves are only needed by the cold tiers
+            if ((n & 31) == 0) {
+                r0 = (uint32_t)(n >> 1) + (uint32_t)lq; r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
+                philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
+                s_u[grp][2 * lq] = (float)(r0 >> 5) * 0x1p-27f;
+                s_u[grp][2 * lq + 1] = (float)(r2 >> 5) * 0x1p-27f;
+            }
+            const float u32 = s_u[grp][n & 31];
+            __builtin_amdgcn_sched_barrier(0);
+            // the row as fp32 (exact: 16-bit counts; an int32 count beyond 2^24 rounds, section 4.3)
+            q_v32f xv;
+            const uint64_t wide_w = __ballot(fl == 0);
+            if (__builtin_expect(wide_w == 0, 1)) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int e = k >> 3, j = (k >> 2) & 1, m = k & 3;
+                    const int i = 2 * j + (m >> 1), c = 2 * (m & 1);
+                    xv[quad_rho_of(i, e, c)] = (float)((uint32_t)xp[k] & 0xffffu);
+                    xv[quad_rho_of(i, e, c + 1)] = (float)((uint32_t)xp[k] >> 16);
+                }
+            } else {
+                // some document's word has a count beyond 16 bits: its lanes read the int32 row now (no prefetch)
+                int xi[QT];
+#pragma unroll
+                for (int s = 0; s < QT; ++s) xi[s] = 0;
+                if (fl == 0) {
+                    const LLDA_GLOBAL v4i *q = (const LLDA_GLOBAL v4i *)((const LLDA_GLOBAL int32_t *)P.n_kw + ((uint64_t)(uint32_t)cur.v << 9));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const v4i a = q[i * 32 + 2 * lq], b = q[i * 32 + 2 * lq + 1];
+                        xi[quad_rho_of(i, 0, 0)] = a.x; xi[quad_rho_of(i, 0, 1)] = a.y; xi[quad_rho_of(i, 0, 2)] = a.z; xi[quad_rho_of(i, 0, 3)] = a.w;
+                        xi[quad_rho_of(i, 1, 0)] = b.x; xi[quad_rho_of(i, 1, 1)] = b.y; xi[quad_rho_of(i, 1, 2)] = b.z; xi[quad_rho_of(i, 1, 3)] = b.w;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int e = k >> 3, j = (k >> 2) & 1, m = k & 3;
+                    const int i = 2 * j + (m >> 1), c = 2 * (m & 1);
+                    const int ra_ = quad_rho_of(i, e, c), rb_ = quad_rho_of(i, e, c + 1);
+                    xv[ra_] = fl == 0 ? (float)xi[ra_] : (float)((uint32_t)xp[k] & 0xffffu);
+                    xv[rb_] = fl == 0 ? (float)xi[rb_] : (float)((uint32_t)xp[k] >> 16);
+                }
+            }
+            // the site's own count leaves the fp32 row through the slot index (uniform in a document): per document ONE indexed
+            // read-modify-write under the document's exec mask
+            {
+                const float own = (act && lq == cur.lo) ? (float)f : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int so_r = __builtin_amdgcn_readlane(cur.so, r * 16);
+                    const uint64_t em = 0xFFFFull << (16 * r);
+                    asm volatile("s_mov_b64 exec, %2\n\ts_set_gpr_idx_on %1, gpr_idx(SRC0,DST)\n\tv_sub_f32_e32 v64, v64, %3\n\t"
+                                 "s_set_gpr_idx_off\n\ts_mov_b64 exec, -1"
+                                 : "+{v[64:95]}"(xv) : "s"(so_r), "s"(em), "v"(own));
+                }
+            }
+            // commit of site n-1 (deferred: its stores leave under this site's arithmetic)
+            if (lq == 0 && n > 0 && act)
+                commit_site_off<true>(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn, prv.c & 0x7fffffff, KP);
+            load_row16(nxt.v);                                         // row of site n+1 (clamped)
+            load_scalars(prv, off_of(n + 2));                          // scalars of site n+2 (clamped)
+
+            int zn;
+            uint64_t unsure = quad_draw(xv, pa, u32, P.margin0_rel, beta32, lq, bp_last, zn) & __ballot(act);
+            if (__builtin_expect(unsure != 0, 0)) {
+                // the cold tiers, one undecided document at a time, the whole wavefront playing it in the standard layout
+                uint32_t rows = (((uint32_t)unsure & 0xffffu) ? 1u : 0u) | (((uint32_t)unsure >> 16) ? 2u : 0u) |
+                                (((uint32_t)(unsure >> 32) & 0xffffu) ? 4u : 0u) | ((uint32_t)(unsure >> 48) ? 8u : 0u);
+                rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows);
+                const int holder = (n >> 1) & 15;
+                const uint32_t ra_l = (n & 1) ? r2 : r0, rb_l = (n & 1) ? r3 : r1;
+                while (rows) {
+                    const int r = __builtin_ctz(rows);
+                    rows &= rows - 1;
+                    const int src = r * 16;
+                    const int zo_r = __builtin_amdgcn_readlane(zo, src);
+                    int zc = quad_cold(s_ndk, s_nk0, (tid & 64) + src, __builtin_amdgcn_readlane(cur.v, src),
+                                       __builtin_amdgcn_readlane(f, src), zo_r,
+                                       (uint32_t)__builtin_amdgcn_readlane((int)ra_l, src + holder),
+                                       (uint32_t)__builtin_amdgcn_readlane((int)rb_l, src + holder), lane,
+                                       (const KParams *)__builtin_amdgcn_kernarg_segment_ptr());
+                    if (__builtin_expect(zc < 0, 0)) {
+                        zc = zo_r;
+                        if (lane == 0 && P.status) atomicOr(P.status, 1);   // no topic with positive probability
+                    }
+                    zn = (row == r) ? zc : zn;
+                }
+            }
+            cur.zn = zn;
+
+            // add the site back (LabeledLDA.py:121-125) and take the NEXT site out of its topic, in one masked pass; a second pass
+            // for the documents where one lane owns both
+            {
+                const int ln = (zn >> 3) & 15, sn = quad_rho(zn);
+                decode_old(nxt);
+                const bool own_new = act && lq == ln, own_old = more && lq == nxt.lo;
+                if (own_new || own_old) update(own_new ? sn : nxt.so, own_new ? zn : nxt.zo, own_new ? f : -nxt.f);
+                if (__builtin_expect(__ballot(own_new && own_old) != 0, 0)) {
+                    if (own_new && own_old) update(nxt.so, nxt.zo, -nxt.f);
+                }
+            }
+            // the last site of a document is committed right away
+            if (__builtin_expect((__ballot(act && !more) & lq0_w) != 0, 0))
+                if (lq == 0 && act && !more)
+                    commit_site_off<true>(P, z_b, opaque_u32(sb + (uint32_t)n * 4u), cur.v, cur.f, cur.zo, cur.zn, cur.c & 0x7fffffff, KP);
+        };
+        for (int n = 0;; n += 3) {                                  // (uniform trip count: the longest document of the wavefront)
+            site(n, R0, R1, R2);
+            if (n + 1 >= maxlen) break;
+            site(n + 1, R1, R2, R0);
+            if (n + 2 >= maxlen) break;
+            site(n + 2, R2, R0, R1);
+            if (n + 3 >= maxlen) break;
+        }
+
+        // document done: fold its n_dk change into the workgroup's n_k accumulator, store the row
+        if (valid && len > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int w = s_ndk[quad_rho_of(i, j >> 2, j & 3)][tid];
+                    o[j] = w & 0xffff;
+                    const int dl = o[j] - (int)((uint32_t)w >> 16);
+                    if (dl) atomicAdd(&s_nk[i * 128 + lq * 8 + j], dl);
+                }
+                v4i a = {o[0], o[1], o[2], o[3]}, b = {o[4], o[5], o[6], o[7]};
+                ((v4i *)ndk_row)[i * 32 + 2 * lq] = a;
+                ((v4i *)ndk_row)[i * 32 + 2 * lq + 1] = b;
+            }
+        }
+    }
+
+    __syncthreads();
+    for (int i = tid; i < KP; i += QNT) {
+        const int dl = s_nk[i];
+        if (dl) atomicAdd(P.n_k_delta + i, dl);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// llda_pack_rows16_all: the 16-bit image of EVERY row of n_kw (32-lane layouts: one wavefront per row, the packing of
+// llda_pack_rows16) and, per row, whether all of its counts fit 16 bits THIS sweep (row16[v] = 1) -- a row that does not is read
+// from n_kw itself by the sweep.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) llda_pack_rows16_all_kernel(const int32_t *__restrict__ n_kw, uint16_t *__restrict__ out,
+                                                                   uint8_t *__restrict__ row16, int64_t V)
+{
+    constexpr int G = 32;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t w = t >> 6;                                        // (a wavefront never straddles two rows)
+    if (w >= V) return;
+    const int c = (int)(t & 63), j = c >> 5, g = c & 31;
+    const int4 *src = reinterpret_cast<const int4 *>(n_kw + w * (int64_t)(G * 16));
+    const int4 a = src[(2 * j) * G + g], b = src[(2 * j + 1) * G + g];
+    const int m = a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w;
+    const bool wide = __ballot((unsigned)m > 0xffffu) != 0;          // (a negative count is "wide" too)
+    uint4 o;
+    o.x = ((uint32_t)a.x & 0xffffu) | ((uint32_t)a.y << 16);
+    o.y = ((uint32_t)a.z & 0xffffu) | ((uint32_t)a.w << 16);
+    o.z = ((uint32_t)b.x & 0xffffu) | ((uint32_t)b.y << 16);
+    o.w = ((uint32_t)b.z & 0xffffu) | ((uint32_t)b.w << 16);
+    reinterpret_cast<uint4 *>(out + w * (int64_t)(G * 16))[j * G + g] = o;
+    if (c == 0) row16[w] = wide ? 0 : 1;
+}
+
+}  // namespace

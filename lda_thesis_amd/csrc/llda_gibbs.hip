@@ -24,6 +24,7 @@
 //                                                 document): the sparse kernels' answer to a site they cannot decide
 //   kernel_sweep.hpp    llda_sweep_exact_kernel   general kernel, every site through the exact pipeline
 //                       llda_sweep_kernel         tiered kernel, per-document state in LDS (the hot kernel)
+//   kernel_quad.hpp     llda_sweep_quad_kernel    K = 512 dense, 16-bit image: FOUR documents per wavefront (the bench's timed kernel)
 //   kernel_sparse.hpp   llda_sweep_sparse_kernel  one lane per ALLOWED topic for sparse label sets
 //   kernel_batch.hpp    llda_sweep_batch_kernel   one sweep over many independent small problems (CascadeLDA's
 //                                                 ensemble) in one launch, sparse-kernel arithmetic
@@ -52,6 +53,7 @@
 #include "draw_tiers.hpp"
 #include "exact_generic.hpp"
 #include "kernel_sweep.hpp"
+#include "kernel_quad.hpp"
 #include "kernel_sparse.hpp"
 #include "kernel_batch.hpp"
 #include "kernel_readout.hpp"
@@ -625,6 +627,24 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         return e == hipSuccess ? LLDA_OK : hip_fail(e);
     }
     if (a->n_kw_img || a->img_bits) return LLDA_E_BAD_ARG;         // the narrow image belongs to the sparse-label kernels
+    if (a->row16) {
+        // four documents per wavefront (kernel_quad.hpp): K = 512 dense with the commit log, every row in the 16-bit image, flags per
+        // word from llda_pack_rows16_all, documents below 2^16 tokens
+        if (!a->n_kw16 || a->site_row) return LLDA_E_BAD_ARG;
+        if (!(fast && dense && logged && L.T == 16 && L.G == 32)) return LLDA_E_BAD_ARG;
+        if (!(a->max_doc_tokens > 0 && a->max_doc_tokens < 65536)) return LLDA_E_BAD_ARG;
+        if ((reinterpret_cast<uintptr_t>(a->n_kw16) | reinterpret_cast<uintptr_t>(a->n_kw)) & 15) return LLDA_E_BAD_ARG;
+        if (a->V >= (1LL << 22)) return LLDA_E_BAD_ARG;                  // (the image is addressed with 32-bit byte offsets)
+        if (a->n_sites < 1) return LLDA_OK;                              // (documents without sites: nothing to sample)
+        P.n_kw16 = a->n_kw16;
+        P.row16 = a->row16;
+        const int64_t per_q = (int64_t)(QNT / 16) * dpg;
+        const int64_t qblocks = (a->D + per_q - 1) / per_q;
+        if (qblocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
+        hipLaunchKernelGGL(llda_sweep_quad_kernel, dim3((unsigned)qblocks), dim3(QNT), 0, st, P);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? LLDA_OK : hip_fail(e);
+    }
     if ((a->n_kw16 != nullptr) != (a->site_row != nullptr)) return LLDA_E_BAD_ARG;
     if (a->n_kw16) {
         // 16-bit rows (bit 31 of csc_pos): the dense 16-slot kernel with the commit log, nothing else knows the flag
@@ -742,6 +762,23 @@ int llda_pack_rows16(const int32_t *n_kw, const uint8_t *row16, int64_t V, int32
     if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
     hipLaunchKernelGGL(llda_pack_rows16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_kw, row16, n_kw16,
                        V, L.G, status);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
+}
+
+int llda_pack_rows16_all(const int32_t *n_kw, int64_t V, int32_t K, uint16_t *n_kw16, uint8_t *row16, void *stream)
+{
+    if (V < 0) return LLDA_E_BAD_ARG;
+    int rc;
+    const llda_layout *Lp = layout_of(K, &rc);
+    if (rc) return rc;
+    if (!llda_rows16_ok(K) || Lp->G != 32) return LLDA_E_BAD_K;
+    if (V == 0) return LLDA_OK;
+    if (!n_kw || !row16 || !n_kw16) return LLDA_E_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(n_kw16) | reinterpret_cast<uintptr_t>(n_kw)) & 15) return LLDA_E_BAD_ARG;
+    const int64_t blocks = (V * 64 + 255) / 256;
+    if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
+    hipLaunchKernelGGL(llda_pack_rows16_all_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_kw, n_kw16, row16, V);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
 }

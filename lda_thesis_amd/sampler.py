@@ -91,6 +91,11 @@ class GibbsSampler(object):
                the counts plus 4 bytes per site; with rows16=None a shard that has no room for it sweeps with int32 rows
                (with a warning) and the environment variable LLDA_ROWS16=on|off decides for callers that cannot pass the
                argument.
+    quad     : K = 512 with the 16-bit rows and every document below 2^16 tokens: the kernel that walks FOUR documents per wavefront
+               (16 lanes x 32 slots each; csrc/kernel_quad.hpp) on an image of EVERY row -- which rows fit 16 bits is decided per
+               sweep by ``llda_pack_rows16_all`` from the counts themselves; a row that does not is read as int32.  Same results.
+               None (default) = wherever it applies; False = the two-documents-per-wavefront kernel; LLDA_QUAD=on|off in the
+               environment decides for callers that cannot pass the argument.
     image    : sparse label sets (the sparse-label kernel): the kernel gathers its counts from a SATURATING narrow image of n_kw
                (8 or 16 bits per count, refreshed by ``llda_pack_image`` at the start of every sweep) and re-reads an entry that
                shows 255 / 65535 from n_kw itself: a row spans a quarter / half as many cache lines, and the kernel is bound by
@@ -103,7 +108,7 @@ class GibbsSampler(object):
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
                  stream_id=0, doc_base=0, device=None, group=None, sort_docs=True,
                  docs_per_group=0, sharded=True, sparse_labels=True, commit_log=None, exchange_always=False,
-                 overlap_ranges=1, rows16=None, image=None):
+                 overlap_ranges=1, rows16=None, image=None, quad=None):
         _native.lib()                                       # fail loudly when the extension is missing
         _native.require_device()                            # ... or when no GPU is visible: there is no CPU fallback
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
@@ -210,8 +215,15 @@ class GibbsSampler(object):
         if self.sharded and (_dist_active(self.group) or exchange_always):
             self._make_exchange_rows()
         self.row16 = self.n_kw16 = self.site_row = None
+        self.quad = False
+        for var, allowed in (("LLDA_ROWS16", ("on", "off")), ("LLDA_QUAD", ("on", "off")), ("LLDA_IMAGE", ("0", "8", "16"))):
+            if os.environ.get(var) is not None and os.environ[var] not in allowed:
+                raise ValueError("%s=%r: expected one of %s" % (var, os.environ[var], ", ".join(allowed)))
         if rows16 is None and os.environ.get("LLDA_ROWS16") in ("on", "off"):     # for callers behind the LabeledLDA front end
             rows16 = os.environ["LLDA_ROWS16"] == "on"
+        if quad is None and os.environ.get("LLDA_QUAD") in ("on", "off"):
+            quad = os.environ["LLDA_QUAD"] == "on"
+        self._quad_wanted = quad
         if (rows16 is not False and self.S and self.dense_mask and self.commit_log is not None
                 and _native.rows16_ok(self.K) and self.alpha >= 1e-6 and self.beta >= 1e-6):
             self._make_rows16(auto=rows16 is None)
@@ -293,7 +305,10 @@ class GibbsSampler(object):
         four_waves = 0 < tokens_max < 65536
         if auto and not four_waves and V * KP * 4 < self.ROWS16_MIN_BYTES:
             return
-        if not bool(self._rows16_fits().any()):
+        quad = bool(self._quad_wanted is not False and four_waves and self.layout.G == 32 and self.layout.T == 16 and V < (1 << 22))
+        if self._quad_wanted and not quad:
+            raise ValueError("quad=True: needs K = 512, documents of fewer than 65 536 tokens and a vocabulary below 2^22 words")
+        if not quad and not bool(self._rows16_fits().any()):
             return
         n32 = (V + 1) * KP
         try:
@@ -311,6 +326,13 @@ class GibbsSampler(object):
         self.n_k = self._counts[V * KP:]
         self._counts16 = both                                  # (keeps the one allocation alive under its own name)
         self.n_kw16 = both[n32:].view(torch.int16)
+        # four documents per wavefront (llda_sweep_args.row16): K = 512, documents below 2^16 tokens; the flags are the library's,
+        # rewritten every sweep
+        self.quad = quad
+        if self.quad:
+            self.row16 = torch.zeros((V,), dtype=torch.uint8, device=self.device)
+            self.max_doc_tokens = tokens_max
+            return
         self._flag_rows16()
         # llda_sweep_args.max_doc_tokens: below 2^16 the 16-bit-row kernel packs n_dk with its sweep-start value and runs four
         # waves per SIMD
@@ -376,7 +398,7 @@ class GibbsSampler(object):
         pos = self._topic_pos[torch.as_tensor(np.asarray(topics), dtype=torch.int64, device=dev)]
         self.n_kw.index_put_((w, pos), torch.as_tensor(np.asarray(amounts), dtype=torch.int32, device=dev),
                              accumulate=True)
-        if self.n_kw16 is not None:
+        if self.n_kw16 is not None and not self.quad:
             self._flag_rows16()            # row totals changed: a row may no longer fit 16 bits (or fit now)
 
     # ------------------------------------------------------------------ masks
@@ -562,7 +584,9 @@ class GibbsSampler(object):
         have_group = dist.is_available() and dist.is_initialized()
         exchange = self.sharded and (_dist_active(self.group) or self.exchange_always)
         n_ranges = len(self._ranges) - 1
-        if self.n_kw16 is not None:                           # this sweep's n_kw: nothing below changes it before the fold
+        if self.quad:                                         # this sweep's n_kw: nothing below changes it before the fold
+            _native.pack_rows16_all(self.n_kw, self.K, self.n_kw16, self.row16)
+        elif self.n_kw16 is not None:
             _native.pack_rows16(self.n_kw, self.row16, self.K, self.n_kw16, self.status)
         if self.n_kw_img is not None:
             _native.pack_image(self.n_kw, self.n_kw_img)
@@ -595,7 +619,7 @@ class GibbsSampler(object):
                                   live_max=live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
                                   n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens,
                                   scratch=self._scratch, n_kw16=self.n_kw16, site_row=self.site_row,
-                                  n_kw_img=self.n_kw_img if sparse else None)
+                                  n_kw_img=self.n_kw_img if sparse else None, row16=self.row16 if self.quad else None)
             if pipelined:
                 # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
                 # collective's stream (ordered after the fold) while the next range is sampled on this one

@@ -37,19 +37,28 @@ def test_sweeps_match_reference_o3(name, margin):
 
 @pytest.mark.parametrize("name", ["tiny_k512dense", "tiny_k1024dense"])
 def test_headline_kernels_match_reference_o3(name):
-    """every label in every document (a dense mask, K == KP) with the commit log: the kernels of the bench's timed line -- 16-bit rows
-    at four waves per SIMD (rows16 True / None), at three (debug_margin -8), int32 rows -- against the reference's own O3 sweeps"""
+    """every label in every document (a dense mask, K == KP) with the commit log: the kernels of the bench's timed line -- at K = 512 four
+    documents per wavefront on the image of every row (quad None / True: production margins, margins 2^-6 that mix the tiers inside a
+    wavefront, no fp32 tier, everything through the exact tier), the two-document 16-bit-row kernel at four waves per SIMD (quad False)
+    and at three (debug_margin -8), int32 rows -- against the reference's own O3 sweeps"""
     g = load_golden(name)
-    for rows16, margin, four in ((None, 0, True), (True, 0, True), (True, -8, False), (True, 6, True), (True, -1, True), (False, 0, False)):
-        s = make_sampler(g, commit_log=True, rows16=rows16)
+    k512 = int(g["K"]) == 512
+    for rows16, margin, quad in ((None, 0, None), (True, 0, True if k512 else None), (True, 6, None), (True, -2, None), (True, -1, None),
+                                 (True, 0, False), (True, -8, False), (True, 6, False), (True, -1, False), (False, 0, None)):
+        s = make_sampler(g, commit_log=True, rows16=rows16, quad=quad)
         assert s.dense_mask and s.commit_log is not None and (s.n_kw16 is not None) == (rows16 is not False)
+        assert s.quad == (k512 and rows16 is not False and quad is not False)
         if rows16 is not False:
-            assert 0 < s.max_doc_tokens < 65536 and bool(s.row16.all())
+            assert 0 < s.max_doc_tokens < 65536
+            if not s.quad:
+                assert bool(s.row16.all())
         s.debug_margin = margin
         for i in range(int(g["sweeps"])):
             s.sweep()
             assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics(), name)
         s.check_status()
+        if s.quad:
+            assert bool(s.row16.all()) and s.site_row is None           # (the library's flags: every row of the fixture fits)
 
 
 @pytest.mark.parametrize("name", [n for n in TINY if int(n.split("k")[-1].rstrip("dense")) > 1024])
