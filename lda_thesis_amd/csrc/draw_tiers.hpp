@@ -299,7 +299,7 @@ __device__ __forceinline__ bool draw_fast_f32(const float (&qw)[T], float u, uin
 //           quotient; llda_selftest_div checks it against the hardware division), keyed draw.
 // Returns the chosen device position or -1.
 // ACC: where the document's counts live -- nd(s) = its n_dk at slot s of this lane, nk(s) = the n_k it sees there,
-// stats() = this lane group reports the tier statistics (one group per site)
+// count_unsure() / stats() = this lane group reports "tier 0 was unsure" / "the exact tier ran" (one group per site)
 template <int G, int T, bool HAS_TAIL, bool DENSE, class ACC>
 __device__ __noinline__ int cold_tiers_acc(const ACC dc, const int *x, uint32_t mask, double u, int lig, int lane, const KParams *P)
 {
@@ -313,7 +313,7 @@ __device__ __noinline__ int cold_tiers_acc(const ACC dc, const int *x, uint32_t 
     const double alpha = P->alpha, beta = P->beta, vbeta = P->vbeta;
     const uint32_t lmask = DENSE ? 0xFFFFu : mask;
     double w[T];
-    if (lig == 0 && dc.stats() && P->status) atomicAdd(P->status + 1, 1);      // statistics: sites tier 0 was unsure about
+    if (lig == 0 && dc.count_unsure() && P->status) atomicAdd(P->status + 1, 1);      // statistics: sites tier 0 was unsure about
     // ---- tier 1: unnormalised fp64 prefix sums, margin 2^-40 of the total ----
     {
         double run = 0.0;
@@ -408,6 +408,7 @@ struct LdsCounts {
         }
     }
     __device__ __forceinline__ bool stats() const { return true; }
+    __device__ __forceinline__ bool count_unsure() const { return true; }
 };
 template <int G, int T, bool HAS_TAIL, bool DENSE, bool W4 = false>
 __device__ __forceinline__ int cold_tiers(const int (*s_ndk)[256], const int *x, const int (*s_nkc)[256], int tid,

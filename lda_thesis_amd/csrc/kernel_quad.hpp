@@ -48,6 +48,7 @@ struct QuadCounts {
         return s_nk0[pos_of<32, 16>(g, s)] + (w & 0xffff) - (int)((uint32_t)w >> 16);
     }
     __device__ __forceinline__ bool stats() const { return st; }
+    __device__ __forceinline__ bool count_unsure() const { return false; }     // (the kernel counted the site before its own tier 1)
 };
 
 // One undecided site: both halves of the wavefront play the document in the standard layout (the upper half silently), the row
@@ -135,7 +136,67 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
     return unsure;
 }
 
+// Tier 1 in the quad layout, for the wavefront iterations in which tier 0 is unsure about some document: the decision from
+// unnormalised fp64 prefix sums with the margin 2^-40 of the total (draw_tiers.hpp, cold_tiers_acc: the same test on a different
+// association order -- the bound there, 254 u < 2^-44, grows by the 16 more additions of a 32-slot chain).  All four documents at once;
+// xv = the row minus the site's own count, exact in fp32.  Returns the ballot of the lanes that are STILL not sure; zn as quad_draw.
+__device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_ndk)[QNT], const int *s_nk0, int tid, int lq, double u,
+                                               double alpha, double beta, double vbeta, double margin_rel, int &zn)
+{
+    double W[QT];
+    double run = 0.0;
+#pragma unroll
+    for (int k = 0; k < QT; ++k) {                       // k = position in the draw order of the lane: chain A, then chain B
+        const int e = k >> 4, a = k & 15, i = a >> 2, c = a & 3;
+        const int rho = quad_rho_of(i, e, c);
+        const int w = s_ndk[rho][tid];
+        const int nd = w & 0xffff, nk = s_nk0[(i << 7) | (lq << 3) | (e << 2) | c] + nd - (int)((uint32_t)w >> 16);
+        const double den = (double)nk + vbeta;
+        double y = __builtin_amdgcn_rcp(den);
+        y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+        y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+        run = run + ((double)nd + alpha) * (((double)xv[rho] + beta) * y);
+        W[k] = run;
+    }
+    const double X = group_scan<16>(run, lq);
+    const double tot = bcast_last<16>(X, tid & 63);
+    const double prev = dpp_f64<DPP_ROW_SHR + 1>(X);                   // (0.0 into the first lane of the row)
+    const double tg = u * tot - prev;
+    const double margin = tot * margin_rel;
+    const double lo = tg - margin, hi = tg + margin;
+    int cnt_lo = 0, cnt_hi = 0;
+#pragma unroll
+    for (int k = 0; k < QT; ++k) {
+        cnt_lo += (W[k] <= lo) ? 1 : 0;
+        cnt_hi += (W[k] <= hi) ? 1 : 0;
+    }
+    const uint64_t unsure = __ballot((cnt_lo != cnt_hi) || !(tot > 0.0) || !(margin < tot));
+    // position of chain index cnt_lo: e = k >> 4, i = (k >> 2) & 3, c = k & 3
+    const uint32_t k = (uint32_t)cnt_lo;
+    const uint32_t p = (((k >> 2) & 3u) << 7) | ((uint32_t)lq << 3) | (((k >> 4) & 1u) << 2) | (k & 3u);
+    uint32_t key = cnt_lo >= QT ? 0xFFFFu : (((uint32_t)lq << 9) | p);
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(key));
+    zn = (int)(key & 511u);
+    return unsure;
+}
+
 struct QuadSite { int v, f, zo, c, zn, lo, so; };     // (lo, so) = quad lane and slot rho of zo
+
+// -DQUAD_PROFILE (tools/quad_phase_profile.py; never in a production build: llda_build_info reports it): wavefront 0 of workgroup 0
+// stamps the shader clock at the phase boundaries of every site and adds the differences up in status[8 + phase]
+#ifdef QUAD_PROFILE
+#define QP_DECL uint32_t qp_t = 0, qp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define QP_START() do { __builtin_amdgcn_sched_barrier(0); qp_t = (uint32_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define QP_MARK(k) do { __builtin_amdgcn_sched_barrier(0); const uint32_t qp_n = (uint32_t)__builtin_amdgcn_s_memtime(); \
+                        qp_acc[k] += qp_n - qp_t; qp_t = qp_n; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define QP_DECL
+#define QP_START()
+#define QP_MARK(k)
+#endif
 
 __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P)
 {
@@ -163,6 +224,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
     int32_t *z_b = P.z + site_base;
 
     typedef int v4i __attribute__((ext_vector_type(4)));
+    QP_DECL;
 
     auto update = [&](int sg, int pos, int df) {
         const int w = s_ndk[sg][tid] + df;                           // (0 <= n_dk + df < 2^16: no carry into the upper half)
@@ -225,6 +287,12 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
         // (32-bit byte offsets from the image: llda_sweep checked V * 1024 < 2^32)
         int xp[16], fl;
         auto load_row16 = [&](const int v) {
+#ifdef ABL_NOLOAD
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xp[k] = ((v + k) & 7) * 0x10001;      // ablation: no n_kw traffic
+            fl = 1;
+            return;
+#endif
             const LLDA_GLOBAL char *q = (const LLDA_GLOBAL char *)P.n_kw16 + (((uint32_t)v << 10) + (uint32_t)lq * 32u);
             const v4i a = *(const LLDA_GLOBAL v4i *)q, b = *(const LLDA_GLOBAL v4i *)(q + 512);
             const v4i c = *(const LLDA_GLOBAL v4i *)(q + 16), e = *(const LLDA_GLOBAL v4i *)(q + 528);
@@ -247,6 +315,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
         auto site = [&](const int n, QuadSite &cur, QuadSite &nxt, QuadSite &prv) {
             const bool act = n < len, more = n + 1 < len;
             const int f = cur.f, zo = cur.zo;
+            QP_START();
             q_v2f pa[16];
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
@@ -305,35 +374,53 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 for (int r = 0; r < 4; ++r) {
                     const int so_r = __builtin_amdgcn_readlane(cur.so, r * 16);
                     const uint64_t em = 0xFFFFull << (16 * r);
-                    asm volatile("s_mov_b64 exec, %2\n\ts_set_gpr_idx_on %1, gpr_idx(SRC0,DST)\n\tv_sub_f32_e32 v64, v64, %3\n\t"
-                                 "s_set_gpr_idx_off\n\ts_mov_b64 exec, -1"
+                    // (s_nop 3 behind s_set_gpr_idx_on: without it the v_sub used a STALE index every few thousand sites -- measured, tools/quad_debug.py:
+                    // the stray write cleared a live register of a later workgroup; the compiler's own sequences put no VALU write of the index
+                    // SGPR this close in front, and the hazard tables list nothing for it)
+                    asm volatile("s_mov_b64 exec, %2\n\ts_set_gpr_idx_on %1, gpr_idx(SRC0,DST)\n\ts_nop 3\n\tv_sub_f32_e32 v64, v64, %3\n\t"
+                                 "s_nop 0\n\ts_set_gpr_idx_off\n\ts_mov_b64 exec, -1"
                                  : "+{v[64:95]}"(xv) : "s"(so_r), "s"(em), "v"(own));
                 }
             }
             // commit of site n-1 (deferred: its stores leave under this site's arithmetic)
+#ifndef ABL_NOCOMMIT
             if (lq == 0 && n > 0 && act)
                 commit_site_off<true>(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn, prv.c & 0x7fffffff, KP);
+#endif
             load_row16(nxt.v);                                         // row of site n+1 (clamped)
             load_scalars(prv, off_of(n + 2));                          // scalars of site n+2 (clamped)
+            QP_MARK(0);                                                // pa, row, conversion, own count, commit, loads issued
 
             int zn;
             uint64_t unsure = quad_draw(xv, pa, u32, P.margin0_rel, beta32, lq, bp_last, zn) & __ballot(act);
+            QP_MARK(1);                                                // chains, scan, search, pick
             if (__builtin_expect(unsure != 0, 0)) {
-                // the cold tiers, one undecided document at a time, the whole wavefront playing it in the standard layout
-                uint32_t rows = (((uint32_t)unsure & 0xffffu) ? 1u : 0u) | (((uint32_t)unsure >> 16) ? 2u : 0u) |
-                                (((uint32_t)(unsure >> 32) & 0xffffu) ? 4u : 0u) | ((uint32_t)(unsure >> 48) ? 8u : 0u);
-                rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows);
+                // tier 1 (fp64, margin 2^-40) right here, in this layout, for all four documents; what IT cannot decide (~1e-9 of the
+                // sites) goes to the exact tier out of line, one document at a time, the whole wavefront playing it in the standard layout
                 const int holder = (n >> 1) & 15;
                 const uint32_t ra_l = (n & 1) ? r2 : r0, rb_l = (n & 1) ? r3 : r1;
-                while (rows) {
+                const int bp_h = ((lane & 48) | holder) << 2;
+                const uint32_t ra = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_h, (int)ra_l), rb = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_h, (int)rb_l);
+                const uint64_t t0_w = unsure;                          // documents tier 0 was unsure about
+                if (lq == 0 && ((t0_w >> (lane & 48)) & 0xFFFFull) && P.status) atomicAdd(P.status + 1, 1);   // statistics
+                int z1;
+                const uint64_t still = (P.margin_rel < 1.0 ? quad_tier1(xv, s_ndk, s_nk0, tid, lq, uniform53(ra, rb), P.alpha, P.beta, P.vbeta,
+                                                                       P.margin_rel, z1) : ~0ull) & __ballot(act);
+                const bool mine0 = ((t0_w >> (lane & 48)) & 0xFFFFull) != 0;
+                zn = mine0 ? z1 : zn;
+                uint32_t rows = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    rows |= (((t0_w >> (16 * r)) & 0xFFFFull) && ((still >> (16 * r)) & 0xFFFFull)) ? (1u << r) : 0u;
+                rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows);
+                while (__builtin_expect(rows != 0, 0)) {
                     const int r = __builtin_ctz(rows);
                     rows &= rows - 1;
                     const int src = r * 16;
                     const int zo_r = __builtin_amdgcn_readlane(zo, src);
                     int zc = quad_cold(s_ndk, s_nk0, (tid & 64) + src, __builtin_amdgcn_readlane(cur.v, src),
-                                       __builtin_amdgcn_readlane(f, src), zo_r,
-                                       (uint32_t)__builtin_amdgcn_readlane((int)ra_l, src + holder),
-                                       (uint32_t)__builtin_amdgcn_readlane((int)rb_l, src + holder), lane,
+                                       __builtin_amdgcn_readlane(f, src), zo_r, (uint32_t)__builtin_amdgcn_readlane((int)ra, src),
+                                       (uint32_t)__builtin_amdgcn_readlane((int)rb, src), lane,
                                        (const KParams *)__builtin_amdgcn_kernarg_segment_ptr());
                     if (__builtin_expect(zc < 0, 0)) {
                         zc = zo_r;
@@ -343,6 +430,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 }
             }
             cur.zn = zn;
+            QP_MARK(2);                                                // (cold tiers)
 
             // add the site back (LabeledLDA.py:121-125) and take the NEXT site out of its topic, in one masked pass; a second pass
             // for the documents where one lane owns both
@@ -355,10 +443,13 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                     if (own_new && own_old) update(nxt.so, nxt.zo, -nxt.f);
                 }
             }
+            QP_MARK(3);                                                // count update
             // the last site of a document is committed right away
+#ifndef ABL_NOCOMMIT
             if (__builtin_expect((__ballot(act && !more) & lq0_w) != 0, 0))
                 if (lq == 0 && act && !more)
                     commit_site_off<true>(P, z_b, opaque_u32(sb + (uint32_t)n * 4u), cur.v, cur.f, cur.zo, cur.zn, cur.c & 0x7fffffff, KP);
+#endif
         };
         for (int n = 0;; n += 3) {                                  // (uniform trip count: the longest document of the wavefront)
             site(n, R0, R1, R2);
@@ -369,6 +460,13 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             if (n + 3 >= maxlen) break;
         }
 
+#ifdef QUAD_PROFILE
+        if (blockIdx.x == 0 && tid == 0 && P.status) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) atomicAdd(P.status + 8 + k, (int)qp_acc[k]);
+            atomicAdd(P.status + 16, maxlen);
+        }
+#endif
         // document done: fold its n_dk change into the workgroup's n_k accumulator, store the row
         if (valid && len > 0) {
 #pragma unroll
