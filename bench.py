@@ -194,6 +194,11 @@ def rows_description(sampler):
                 "value is re-read from the int32 counts; same results" % (8 * sampler.n_kw_img.element_size()))
     if getattr(sampler, "n_kw16", None) is None:
         return "int32"
+    if getattr(sampler, "quad", False):
+        fits = float(sampler.row16.float().mean().item())
+        return ("16-bit image of EVERY row (llda_pack_rows16_all runs inside every timed sweep and flags the rows whose counts all fit: "
+                "%.2f %% of the words this sweep; the others are read as int32), four documents per wavefront; same results "
+                "(DESIGN.md section 4.1)" % (100.0 * fits))
     flagged = sampler.row16[sampler.word.long()].float().mean().item() if sampler.S else 0.0
     return ("16-bit image for the words whose corpus-wide count fits 16 bits (%.1f %% of the words, %.1f %% of this rank's sites; "
             "llda_pack_rows16 runs inside every timed sweep), int32 rows for the others; same results (DESIGN.md section 4.1)" %
@@ -203,6 +208,8 @@ def rows_description(sampler):
 def rows_short(sampler):
     if getattr(sampler, "n_kw_img", None) is not None:
         return "%d-bit saturating image + int32 escapes" % (8 * sampler.n_kw_img.element_size())
+    if getattr(sampler, "quad", False):
+        return "16-bit image of every row, four documents per wavefront"
     return "int32" if getattr(sampler, "n_kw16", None) is None else "16-bit image + int32 hot rows"
 
 

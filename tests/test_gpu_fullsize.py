@@ -139,6 +139,8 @@ def test_full_size_sampled_documents_vs_c_oracle(c_oracle, name, n_docs):
     s = make(doc_off, word, freq, z, K, V)
     del z
     assert s.commit_log is not None and s.debug_margin == 0     # production path: tiers + word-major commit log
+    if K == 512:
+        assert s.n_kw16 is not None and s.quad                   # ... on the kernel bench.py times
     rng = np.random.default_rng(2024)
     for _ in range(2):
         sweep_and_check_sample(s, c_oracle, n_docs, rng)
@@ -146,13 +148,17 @@ def test_full_size_sampled_documents_vs_c_oracle(c_oracle, name, n_docs):
     check_conservation(s)
 
 
-@pytest.mark.parametrize("name", ["synth1", "synth2_shard"])
+@pytest.mark.parametrize("name", ["synth1", "synth2_shard", "synth2_1M"])
 def test_full_size_production_margins_vs_no_fp32_tier(name):
     """every site of the full-size sweep: the production tiers (fp32 decision first) pick the topic the fp64 tiers
-    pick with the fp32 tier switched off (debug_margin = -2), two sweeps."""
+    pick with the fp32 tier switched off (debug_margin = -2), two sweeps.  synth2_1M is the workload bench.py times, on the
+    instantiation it times (K = 512: four documents per wavefront on the 16-bit image, 3 * 10^8 sites)."""
     doc_off, word, freq, z, K, V = corpus(name)
     a = make(doc_off, word, freq, z, K, V)
     b = make(doc_off, word, freq, z, K, V)
+    del z
+    if K == 512:
+        assert a.n_kw16 is not None and a.quad and b.quad
     b.debug_margin = -2
     for _ in range(2):
         a.sweep()
@@ -213,3 +219,34 @@ def test_full_size_sparse_labels_sampled_documents_vs_c_oracle(c_oracle, docs, n
     check_conservation(s)
     st = s.status.cpu().numpy()
     assert 0 < int(st[1]) < s.S // 100                     # the fp32 tier handed a few sites to the fp64 decision
+
+
+@pytest.mark.parametrize("docs", [31_250])
+def test_quad_kernel_equals_the_two_document_kernel_in_every_tier_mode(docs):
+    """K = 512: four documents per wavefront (csrc/kernel_quad.hpp) against the two-document 16-bit-row kernel on a slice of configs[3]
+    large enough for every CU to run several workgroups at once -- the full integer state after each of two sweeps, with production
+    margins, without the fp32 tier, with margins 2^-6 and with every site through the exact tier (9.4 million sites each).
+    (A stale register index in the quad kernel's own-count removal showed only beyond the first workgroup of a CU and only once enough
+    registers were live for the stray write to land in one: tools/quad_debug.py.)"""
+    from lda_thesis_amd.corpus import synthetic_corpus_blocks
+    doc_off, word, freq, z = synthetic_corpus_blocks(0, docs, 300, 100_000, 512, 1234, "cuda", block=15625)
+    ref = None
+    for quad, margin in ((False, 0), (True, 0), (True, -2), (True, 6), (True, -1)):
+        s = make(doc_off, word, freq, z, 512, 100_000, quad=quad)
+        assert s.quad == quad and s.n_kw16 is not None
+        s.debug_margin = margin
+        states = []
+        for _ in range(2):
+            s.sweep()
+            states.append((s.z.clone(), s.n_dk.clone(), s._counts.clone()))
+        s.check_status()
+        st = s.status.cpu().numpy()
+        if margin == -1:
+            assert int(st[2]) == 2 * s.S                                  # every site reached the exact tier
+        if margin == 0:
+            assert 0 < int(st[1]) < s.S // 20 and int(st[2]) < 10
+        if ref is None:
+            ref = states
+        for (a, b) in zip(ref, states):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), (quad, margin)
+        del s

@@ -443,24 +443,31 @@ def _rows16_corpus_short_docs(K, seed):
     return doc_off, word, freq, z, V
 
 
-@pytest.mark.parametrize("margin", [0, -1, 6])
-@pytest.mark.parametrize("K", [512, 1024])
-def test_16_bit_rows_four_waves_equal_the_c_oracle(c_oracle, K, margin):
-    """the four-wave form of the 16-bit-row kernel (documents below 2^16 tokens: llda_sweep_args.max_doc_tokens) against the C
-    oracle (LabeledLDA.py:106-125), every draw tier -- and against the three-wave form (debug_margin -8) at production margins"""
+@pytest.mark.parametrize("margin", [0, -1, -2, 6])
+@pytest.mark.parametrize("K,quad", [(512, True), (512, False), (1024, None)])
+def test_16_bit_rows_four_waves_equal_the_c_oracle(c_oracle, K, quad, margin):
+    """documents below 2^16 tokens (llda_sweep_args.max_doc_tokens) against the C oracle (LabeledLDA.py:106-125), every draw tier:
+    K = 512 with FOUR documents per wavefront (quad: the image holds every row, the library flags per sweep the rows that fit -- words 0
+    and 3 do not: their sites read the int32 row) and with two (the static flags of llda_pack_rows16), K = 1024 with one -- and, at
+    production margins, against the three-wave form (debug_margin -8)"""
     import torch
     from lda_thesis_amd.sampler import GibbsSampler
     doc_off, word, freq, z, V = _rows16_corpus_short_docs(K, 3 * K + margin)
     labs = np.ones((len(doc_off) - 1, K), dtype=np.uint8)
-    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=9, commit_log=True, rows16=True, doc_base=5)
-    assert s.n_kw16 is not None and 0 < s.max_doc_tokens < 65536
-    flagged = s.row16.cpu().numpy().astype(bool)
-    assert not flagged[0] and not flagged[3] and flagged[1] and flagged[4:].all()
+    s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=9, commit_log=True, rows16=True, doc_base=5, quad=quad)
+    assert s.n_kw16 is not None and 0 < s.max_doc_tokens < 65536 and s.quad == bool(quad)
+    if not s.quad:
+        flagged = s.row16.cpu().numpy().astype(bool)
+        assert not flagged[0] and not flagged[3] and flagged[1] and flagged[4:].all()
     assert int(s.n_kw.max()) > (1 << 16)
     s.debug_margin = margin
     cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
     for i in range(3):
+        wide_now = (s.n_kw.max(dim=1).values > 65535).cpu().numpy()
         s.sweep()
+        if s.quad:                                                       # the flags the sweep just used: exactly the rows that fit
+            np.testing.assert_array_equal(s.row16.cpu().numpy().astype(bool), ~wide_now)
+            assert wide_now[0] and not wide_now[1]
         cs.sweep(1, 9, i, doc_base=5, threads=4)
         np.testing.assert_array_equal(s.z_topics(), cs.z)
         np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
@@ -468,12 +475,13 @@ def test_16_bit_rows_four_waves_equal_the_c_oracle(c_oracle, K, margin):
         np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
     s.check_status()
     if margin == 0:
-        r = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=9, commit_log=True, rows16=True, doc_base=5)
+        r = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=9, commit_log=True, rows16=True, doc_base=5, quad=False)
         r.debug_margin = -8                                              # the three-wave form, production margins
         for i in range(3):
             r.sweep()
         assert torch.equal(r.z, s.z) and torch.equal(r._counts, s._counts) and torch.equal(r.n_dk, s.n_dk)
-        assert torch.equal(r.status[1:3], s.status[1:3])                 # the same sites left tier 0 / reached the exact tier
+        if not s.quad:
+            assert torch.equal(r.status[1:3], s.status[1:3])             # the same sites left tier 0 / reached the exact tier
 
 
 def test_16_bit_rows_four_waves_flag_a_wrong_token_bound():

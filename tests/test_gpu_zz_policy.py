@@ -19,7 +19,10 @@ def test_16_bit_rows_are_chosen_by_document_and_n_kw_size():
             f[0] = 70000                                                  # one document of 70 299 tokens
         s = GibbsSampler(off, w, f, z, 512, V, 0.1, 0.01, labs=None, seed=1)
         assert (s.n_kw16 is not None) == want, (zipf, V, long_doc)
-        assert (s.site_row is not None) == want
+        # K = 512 with every document below 2^16 tokens: four documents per wavefront, flags per word from the library instead of
+        # per-site row starts
+        assert s.quad == (want and not long_doc)
+        assert (s.site_row is not None) == (want and long_doc)
         if want:
             assert (0 < s.max_doc_tokens < 65536) == (not long_doc)
         s.sweep()
