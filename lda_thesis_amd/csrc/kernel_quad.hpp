@@ -25,6 +25,7 @@ namespace {
 // compared directly (98.2 v), chain B against the bounds minus chain A's total (99.2 v) -- inside the 105 v of the 2-document kernel,
 // margin 128 v.  Int32 rows with counts >= 2^24: + 2 v.
 // ---------------------------------------------------------------------------------------------
+constexpr float LLDA_MARGIN0_QUAD = 0x1.ap-18f;   // tier-0 margin of this kernel: 104 * 2^-24 (bound 99.2 v, 101.2 v with int32 counts >= 2^24)
 constexpr int QT = 32;        // slots per quad lane
 constexpr int QNT = 128;      // threads per workgroup: two wavefronts, eight documents
 
@@ -70,33 +71,41 @@ __device__ __noinline__ int quad_cold(const int (*s_ndk)[QNT], const int *s_nk0,
 typedef float q_v2f __attribute__((ext_vector_type(2)));
 typedef float q_v32f __attribute__((ext_vector_type(32)));
 
-// Tier 0 for four documents at once, in two pieces so that the caller can put independent work (the NEXT site's row conversion)
-// between them.  nb = (row minus the site's own count) + beta, pa = the cached factors, both in slot order rho: the pair (2a, 2a+1)
-// holds element a of chain A and of chain B, so ONE packed instruction advances both chains.
-struct QuadScan { float tot, prev; };
-__device__ __forceinline__ QuadScan quad_chains(q_v2f (&Q)[16], const q_v2f (&nb)[16], const q_v2f (&pa)[16], int bp_last)
+// Tier 0 for four documents at once.  xv = the row minus the site's own count (fp32, exact), pa = the cached factors, both in slot
+// order rho: the pair (2a, 2a+1) holds element a of chain A and of chain B, so ONE packed instruction advances both chains.
+// Returns the wavefront's ballot of the lanes that are not sure; zn = the position every lane's document drew.
+__device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa)[16], float u, float margin_rel, float beta,
+                                              int lq, int bp_last, int &zn)
 {
+    const q_v2f b2 = {beta, beta};
+    q_v2f Q[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
-        if (a == 0) Q[0] = nb[0] * pa[0];
-        else Q[a] = __builtin_elementwise_fma(nb[a], pa[a], Q[a - 1]);
+        const q_v2f x2 = {xv[2 * a], xv[2 * a + 1]};
+        const q_v2f nb = x2 + b2;
+        if (a == 0) Q[0] = nb * pa[0];
+        else Q[a] = __builtin_elementwise_fma(nb, pa[a], Q[a - 1]);
     }
     // inclusive scan over the 16 lanes of the document = one DPP row
-    float X = Q[15].x + Q[15].y;
+    const float X0 = Q[15].x + Q[15].y;
+    float X = X0;
     X += dpp_f32<DPP_ROW_SHR + 1>(X);
     X += dpp_f32<DPP_ROW_SHR + 2>(X);
     X += dpp_f32<DPP_ROW_SHR + 4>(X);
     X += dpp_f32<DPP_ROW_SHR + 8>(X);
-    QuadScan r;
-    r.tot = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_last, __float_as_int(X)));              // the row's last lane
-    r.prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), DPP_ROW_SHR + 1, 0xF, 0xF, true));
-    return r;
-}
-// Returns the wavefront's ballot of the lanes that are not sure; zn = the position every lane's document drew.
-__device__ __forceinline__ uint64_t quad_search(const q_v2f (&Q)[16], const QuadScan sc, float u, float margin_rel, int lq, int &zn)
-{
-    const float tot = sc.tot;
-    const float tg = __builtin_fmaf(u, tot, -sc.prev);
+#ifdef QUAD_TOT_BPERMUTE
+    const float tot = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_last, __float_as_int(X)));     // the row's last lane
+#else
+    // the document's total in every lane: four rotate-and-add steps over the lane totals, next to the scan (an LDS round trip for the
+    // scan's last lane costs the wavefront ~100 cycles of waiting).  Another association order than the scan's: within 33 v as well.
+    float tot = X0;
+    tot += dpp_f32<DPP_ROW_ROR + 8>(tot);
+    tot += dpp_f32<DPP_ROW_ROR + 4>(tot);
+    tot += dpp_f32<DPP_ROW_ROR + 2>(tot);
+    tot += dpp_f32<DPP_ROW_ROR + 1>(tot);
+#endif
+    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), DPP_ROW_SHR + 1, 0xF, 0xF, true));
+    const float tg = __builtin_fmaf(u, tot, -prev);
     const float margin = tot * margin_rel;
     const float lo0 = tg - margin, hi0 = tg + margin;
     // chain A or chain B?
@@ -129,23 +138,24 @@ __device__ __forceinline__ uint64_t quad_search(const q_v2f (&Q)[16], const Quad
     const uint64_t unsure = __ballot(!(ub > hi)) | bad_total;
     // the position this lane would name, keyed by its lane; the document's first lane with a slot above lo wins (none: 511, the
     // last slot of the last lane).  Row-wide minimum: four DPP steps, one instruction each (the compiler's form is three)
-    const uint32_t p = (c1 ? 256u : 0u) | (c2 ? 128u : 0u) | (c3 ? 2u : 0u) | (c4 ? 1u : 0u) | (c0 ? 4u : 0u) | ((uint32_t)lq << 3);
-    uint32_t key = c5 ? 0xFFFFu : (((uint32_t)lq << 9) | p);
+    // key = lane << 14 | slot rho << 9 | position: every search outcome sets its bit of the position AND of the slot number
+    const uint32_t p = (c1 ? (256u | 16u << 9) : 0u) | (c2 ? (128u | 8u << 9) : 0u) | (c3 ? (2u | 4u << 9) : 0u) | (c4 ? (1u | 2u << 9) : 0u) |
+                       (c0 ? (4u | 1u << 9) : 0u) | ((uint32_t)lq << 3) | ((uint32_t)lq << 14);
+    uint32_t key = c5 ? 0xFFFFFu : p;                       // (no slot above lo: position 511 = slot 31 of lane 15 wins only if no lane has one)
     asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(key));
-    zn = (int)(key & 511u);
+    zn = (int)(key & 0x3FFFu);                              // slot << 9 | position; the lane is position >> 3 & 15
     return unsure;
 }
 
 // Tier 1 in the quad layout, for the wavefront iterations in which tier 0 is unsure about some document: the decision from
 // unnormalised fp64 prefix sums with the margin 2^-40 of the total (draw_tiers.hpp, cold_tiers_acc: the same test on a different
 // association order -- the bound there, 254 u < 2^-44, grows by the 16 more additions of a 32-slot chain).  All four documents at once;
-// nb = fl32(x + beta32) with x = the row minus the site's own count, a 16-bit count: x = rint(nb - beta32) exactly (both roundings
-// together stay below 2^-7).  Returns the ballot of the lanes that are STILL not sure; zn as quad_search.
-__device__ __forceinline__ uint64_t quad_tier1(const q_v2f (&nb)[16], float beta32, const int (*s_ndk)[QNT], const int *s_nk0, int tid, int lq,
-                                               double u, double alpha, double beta, double vbeta, double margin_rel, int &zn)
+// xv = the row minus the site's own count, exact in fp32.  Returns the ballot of the lanes that are STILL not sure; zn as quad_draw.
+__device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_ndk)[QNT], const int *s_nk0, int tid, int lq, double u,
+                                               double alpha, double beta, double vbeta, double margin_rel, int &zn)
 {
     double W[QT];
     double run = 0.0;
@@ -156,11 +166,11 @@ __device__ __forceinline__ uint64_t quad_tier1(const q_v2f (&nb)[16], float beta
         const int w = s_ndk[rho][tid];
         const int nd = w & 0xffff, nk = s_nk0[(i << 7) | (lq << 3) | (e << 2) | c] + nd - (int)((uint32_t)w >> 16);
         const double den = (double)nk + vbeta;
-        double y = __builtin_amdgcn_rcp(den);
+        // 1 / den from the fp32 reciprocal (1 ulp) and two Newton steps in fp64: within 2^-50, as cold_tiers_acc's
+        double y = (double)__builtin_amdgcn_rcpf((float)den);
         y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
         y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
-        const float xf = __builtin_rintf((e ? nb[a].y : nb[a].x) - beta32);
-        run = run + ((double)nd + alpha) * (((double)xf + beta) * y);
+        run = run + ((double)nd + alpha) * (((double)xv[rho] + beta) * y);
         W[k] = run;
     }
     const double X = group_scan<16>(run, lq);
@@ -178,17 +188,18 @@ __device__ __forceinline__ uint64_t quad_tier1(const q_v2f (&nb)[16], float beta
     const uint64_t unsure = __ballot((cnt_lo != cnt_hi) || !(tot > 0.0) || !(margin < tot));
     // position of chain index cnt_lo: e = k >> 4, i = (k >> 2) & 3, c = k & 3
     const uint32_t k = (uint32_t)cnt_lo;
-    const uint32_t p = (((k >> 2) & 3u) << 7) | ((uint32_t)lq << 3) | (((k >> 4) & 1u) << 2) | (k & 3u);
-    uint32_t key = cnt_lo >= QT ? 0xFFFFu : (((uint32_t)lq << 9) | p);
+    const uint32_t i_ = (k >> 2) & 3u, e_ = (k >> 4) & 1u, c_ = k & 3u;
+    const uint32_t p = (i_ << 7) | ((uint32_t)lq << 3) | (e_ << 2) | c_ | ((8u * i_ + 2u * c_ + e_) << 9) | ((uint32_t)lq << 14);
+    uint32_t key = cnt_lo >= QT ? 0xFFFFFu : p;
     asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(key));
-    zn = (int)(key & 511u);
+    zn = (int)(key & 0x3FFFu);
     return unsure;
 }
 
-struct QuadSite { int v, f, zo, c, zn, lo, so, w; };  // (lo, so) = quad lane and slot rho of zo; w = row flag of the site's word (0: wide)
+struct QuadSite { int v, f, zo, c, zn, lo, so; };     // (lo, so) = quad lane and slot rho of zo
 
 // -DQUAD_PROFILE (tools/quad_phase_profile.py; never in a production build: llda_build_info reports it): wavefront 0 of workgroup 0
 // stamps the shader clock at the phase boundaries of every site and adds the differences up in status[8 + phase]
@@ -290,12 +301,12 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
         };
         // the 16-bit row of word v: chunks (e, j) = slots 8j .. 8j+7 of standard lane 2 lq + e, and the row's flag
         // (32-bit byte offsets from the image: llda_sweep checked V * 1024 < 2^32)
-        int xp[16];
-        auto load_row16 = [&](const int v, int &flag) {
+        int xp[16], fl;
+        auto load_row16 = [&](const int v) {
 #ifdef ABL_NOLOAD
 #pragma unroll
             for (int k = 0; k < 16; ++k) xp[k] = ((v + k) & 7) * 0x10001;      // ablation: no n_kw traffic
-            flag = 1;
+            fl = 1;
             return;
 #endif
             const LLDA_GLOBAL char *q = (const LLDA_GLOBAL char *)P.n_kw16 + (((uint32_t)v << 10) + (uint32_t)lq * 32u);
@@ -305,87 +316,17 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             xp[4] = b.x; xp[5] = b.y; xp[6] = b.z; xp[7] = b.w;
             xp[8] = c.x; xp[9] = c.y; xp[10] = c.z; xp[11] = c.w;
             xp[12] = e.x; xp[13] = e.y; xp[14] = e.z; xp[15] = e.w;
-            flag = *(const LLDA_GLOBAL uint8_t *)((const LLDA_GLOBAL char *)P.row16 + (uint32_t)v);
-        };
-        // xp -> fp32 in slot order (exact: 16-bit counts); the lanes of a document whose row does not fit 16 bits read the int32
-        // row now, without prefetch (an int32 count beyond 2^24 rounds: tier 0 stays inside its margin, section 4.3; tier 1 is skipped)
-        q_v32f xv;
-        auto convert_row = [&](const int v, const int flag) {
-            const uint64_t wide_w = __ballot(flag == 0);
-            if (__builtin_expect(wide_w == 0, 1)) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int e = k >> 3, j = (k >> 2) & 1, m = k & 3;
-                    const int i = 2 * j + (m >> 1), c = 2 * (m & 1);
-                    xv[quad_rho_of(i, e, c)] = (float)((uint32_t)xp[k] & 0xffffu);
-                    xv[quad_rho_of(i, e, c + 1)] = (float)((uint32_t)xp[k] >> 16);
-                }
-            } else {
-                int xi[QT];
-#pragma unroll
-                for (int t = 0; t < QT; ++t) xi[t] = 0;
-                if (flag == 0) {
-                    const LLDA_GLOBAL v4i *q = (const LLDA_GLOBAL v4i *)((const LLDA_GLOBAL int32_t *)P.n_kw + ((uint64_t)(uint32_t)v << 9));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const v4i a = q[i * 32 + 2 * lq], b = q[i * 32 + 2 * lq + 1];
-                        xi[quad_rho_of(i, 0, 0)] = a.x; xi[quad_rho_of(i, 0, 1)] = a.y; xi[quad_rho_of(i, 0, 2)] = a.z; xi[quad_rho_of(i, 0, 3)] = a.w;
-                        xi[quad_rho_of(i, 1, 0)] = b.x; xi[quad_rho_of(i, 1, 1)] = b.y; xi[quad_rho_of(i, 1, 2)] = b.z; xi[quad_rho_of(i, 1, 3)] = b.w;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int e = k >> 3, j = (k >> 2) & 1, m = k & 3;
-                    const int i = 2 * j + (m >> 1), c = 2 * (m & 1);
-                    const int ra_ = quad_rho_of(i, e, c), rb_ = quad_rho_of(i, e, c + 1);
-                    xv[ra_] = flag == 0 ? (float)xi[ra_] : (float)((uint32_t)xp[k] & 0xffffu);
-                    xv[rb_] = flag == 0 ? (float)xi[rb_] : (float)((uint32_t)xp[k] >> 16);
-                }
-            }
-        };
-        // the site's own count leaves the fp32 row through the slot index (uniform in a document): per document ONE indexed
-        // read-modify-write under the document's exec mask
-        auto remove_own = [&](const int so, const float own) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int so_r = __builtin_amdgcn_readlane(so, r * 16);
-                const uint64_t em = 0xFFFFull << (16 * r);
-                // (s_nop 3 behind s_set_gpr_idx_on: without it the v_sub used a STALE index every few thousand sites -- measured,
-                // tools/quad_debug.py: the stray write cleared a live register of a later workgroup; the compiler's own sequences
-                // put no VALU write of the index SGPR this close in front, and the hazard tables list nothing for it)
-                asm volatile("s_mov_b64 exec, %2\n\ts_set_gpr_idx_on %1, gpr_idx(SRC0,DST)\n\ts_nop 3\n\tv_sub_f32_e32 v64, v64, %3\n\t"
-                             "s_nop 0\n\ts_set_gpr_idx_off\n\ts_mov_b64 exec, -1"
-                             : "+{v[64:95]}"(xv) : "s"(so_r), "s"(em), "v"(own));
-            }
-        };
-        const q_v2f b2 = {beta32, beta32};
-        q_v2f nb[16];                                    // (row of the current site minus its own count) + beta, pairs (chain A, chain B)
-        auto make_nb = [&]() {
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                const q_v2f x2 = {xv[2 * a], xv[2 * a + 1]};
-                nb[a] = x2 + b2;
-            }
+            fl = *(const LLDA_GLOBAL uint8_t *)((const LLDA_GLOBAL char *)P.row16 + (uint32_t)v);
         };
 
-        // Software pipeline.  Iteration n decides site n from nb (made during iteration n-1) and meanwhile turns the row of site n+1
-        // -- in flight since the middle of iteration n-1 -- into the next nb: the conversions and the own-count removal fill the
-        // waits of the dependent chain (factors from LDS, chains, lane scan, search, pick, count update).  Scalars run two sites
-        // ahead in three rotating register sets (the loop is unrolled by three), the word ids three sites ahead (wq).
         QuadSite R0, R1, R2;
         load_scalars(R0, off_of(0)); R0.zn = 0;
-        load_scalars(R1, off_of(1)); R1.zn = 0;
-        R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = R2.w = 0;
-        load_row16(R0.v, R0.w);
-        int wq = gload_i32(word_b, off_of(2));           // word of site n+2 at the top of iteration n
+        load_scalars(R1, off_of(1)); R1.zn = 0; R1.lo = R1.so = 0;
+        R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = 0;
+        load_row16(R0.v);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         decode_old(R0);
         if (len > 0 && lq == R0.lo) update(R0.so, R0.zo, -R0.f);      // site 0 leaves its topic (LabeledLDA.py:109-111)
-        convert_row(R0.v, R0.w);
-        load_row16(R1.v, R1.w);                                        // row of site 1
-        remove_own(R0.so, (len > 0 && lq == R0.lo) ? (float)R0.f : 0.0f);
-        make_nb();
-        decode_old(R1);
 
         auto site = [&](const int n, QuadSite &cur, QuadSite &nxt, QuadSite &prv) {
             const bool act = n < len, more = n + 1 < len;
@@ -406,30 +347,67 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 s_u[grp][2 * lq + 1] = (float)(r2 >> 5) * 0x1p-27f;
             }
             const float u32 = s_u[grp][n & 31];
-            // commit of site n-1 (deferred: its stores leave under this site's arithmetic), scalars of site n+2, word of site n+3
-#ifndef ABL_NOCOMMIT
-            if (lq == 0 && n > 0 && act)
-                commit_site_off<true>(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn, prv.c & 0x7fffffff, KP);
-#endif
-            const int w_next = wq;                                       // word of site n+2
-            load_scalars(prv, off_of(n + 2));
-            wq = gload_i32(word_b, off_of(n + 3));
-            // site n: chains and lane scan (the total comes back from LDS while the row of site n+1 is converted)
-            q_v2f Q[16];
-            const QuadScan sc = quad_chains(Q, nb, pa, bp_last);
-            QP_MARK(0);
-            // site n+1: its row (issued in the middle of iteration n-1) -> fp32, own count out; then the row of site n+2 is issued
-            convert_row(nxt.v, nxt.w);
-            load_row16(w_next, prv.w);
-            remove_own(nxt.so, (more && lq == nxt.lo) ? (float)nxt.f : 0.0f);
-            // site n: search and pick
+            __builtin_amdgcn_sched_barrier(0);
+            // the row as fp32 (exact: 16-bit counts; an int32 count beyond 2^24 rounds, section 4.3)
+            q_v32f xv;
+            const uint64_t wide_w = __ballot(fl == 0);
+            if (__builtin_expect(wide_w == 0, 1)) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int e = k >> 3, j = (k >> 2) & 1, m = k & 3;
+                    const int i = 2 * j + (m >> 1), c = 2 * (m & 1);
+                    xv[quad_rho_of(i, e, c)] = (float)((uint32_t)xp[k] & 0xffffu);
+                    xv[quad_rho_of(i, e, c + 1)] = (float)((uint32_t)xp[k] >> 16);
+                }
+            } else {
+                // some document's word has a count beyond 16 bits: its lanes read the int32 row now (no prefetch)
+                int xi[QT];
+#pragma unroll
+                for (int s = 0; s < QT; ++s) xi[s] = 0;
+                if (fl == 0) {
+                    const LLDA_GLOBAL v4i *q = (const LLDA_GLOBAL v4i *)((const LLDA_GLOBAL int32_t *)P.n_kw + ((uint64_t)(uint32_t)cur.v << 9));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const v4i a = q[i * 32 + 2 * lq], b = q[i * 32 + 2 * lq + 1];
+                        xi[quad_rho_of(i, 0, 0)] = a.x; xi[quad_rho_of(i, 0, 1)] = a.y; xi[quad_rho_of(i, 0, 2)] = a.z; xi[quad_rho_of(i, 0, 3)] = a.w;
+                        xi[quad_rho_of(i, 1, 0)] = b.x; xi[quad_rho_of(i, 1, 1)] = b.y; xi[quad_rho_of(i, 1, 2)] = b.z; xi[quad_rho_of(i, 1, 3)] = b.w;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int e = k >> 3, j = (k >> 2) & 1, m = k & 3;
+                    const int i = 2 * j + (m >> 1), c = 2 * (m & 1);
+                    const int ra_ = quad_rho_of(i, e, c), rb_ = quad_rho_of(i, e, c + 1);
+                    xv[ra_] = fl == 0 ? (float)xi[ra_] : (float)((uint32_t)xp[k] & 0xffffu);
+                    xv[rb_] = fl == 0 ? (float)xi[rb_] : (float)((uint32_t)xp[k] >> 16);
+                }
+            }
+            // the site's own count leaves the fp32 row through the slot index (uniform in a document): per document ONE indexed
+            // read-modify-write under the document's exec mask
+            {
+                const float own = (act && lq == cur.lo) ? (float)f : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int so_r = __builtin_amdgcn_readlane(cur.so, r * 16);
+                    const uint64_t em = 0xFFFFull << (16 * r);
+                    // (s_nop 3 behind s_set_gpr_idx_on: without it the v_sub used a STALE index every few thousand sites -- measured, tools/quad_debug.py:
+                    // the stray write cleared a live register of a later workgroup; the compiler's own sequences put no VALU write of the index
+                    // SGPR this close in front, and the hazard tables list nothing for it)
+                    asm volatile("s_mov_b64 exec, %2\n\ts_set_gpr_idx_on %1, gpr_idx(SRC0,DST)\n\ts_nop 3\n\tv_sub_f32_e32 v64, v64, %3\n\t"
+                                 "s_nop 0\n\ts_set_gpr_idx_off\n\ts_mov_b64 exec, -1"
+                                 : "+{v[64:95]}"(xv) : "s"(so_r), "s"(em), "v"(own));
+                }
+            }
+            const int fl_cur = fl;                                     // (flag of THIS site's row: 0 = read as int32)
+            load_row16(nxt.v);                                         // row of site n+1 (clamped)
+            QP_MARK(0);                                                // pa, row, conversion, own count, commit, loads issued
+
             int zn;
-            uint64_t unsure = quad_search(Q, sc, u32, P.margin0_rel, lq, zn) & __ballot(act);
-            QP_MARK(1);
+            uint64_t unsure = quad_draw(xv, pa, u32, P.margin0_rel, beta32, lq, bp_last, zn) & __ballot(act);
+            QP_MARK(1);                                                // chains, scan, search, pick
             if (__builtin_expect(unsure != 0, 0)) {
                 // tier 1 (fp64, margin 2^-40) right here, in this layout, for all four documents; what IT cannot decide (~1e-9 of the
-                // sites) and the documents whose row is wide go to the exact tier out of line, one document at a time, the whole
-                // wavefront playing it in the standard layout
+                // sites) goes to the exact tier out of line, one document at a time, the whole wavefront playing it in the standard layout
                 const int holder = (n >> 1) & 15;
                 const uint32_t ra_l = (n & 1) ? r2 : r0, rb_l = (n & 1) ? r3 : r1;
                 const int bp_h = ((lane & 48) | holder) << 2;
@@ -437,8 +415,9 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 const uint64_t t0_w = unsure;                          // documents tier 0 was unsure about
                 if (lq == 0 && ((t0_w >> (lane & 48)) & 0xFFFFull) && P.status) atomicAdd(P.status + 1, 1);   // statistics
                 int z1;
-                const uint64_t still = ((P.margin_rel < 1.0 ? quad_tier1(nb, beta32, s_ndk, s_nk0, tid, lq, uniform53(ra, rb), P.alpha, P.beta,
-                                                                        P.vbeta, P.margin_rel, z1) : ~0ull) | __ballot(cur.w == 0)) & __ballot(act);
+                // (a document whose row was read as int32 skips tier 1: a count of 2^24 or more is not exact in xv)
+                const uint64_t still = ((P.margin_rel < 1.0 ? quad_tier1(xv, s_ndk, s_nk0, tid, lq, uniform53(ra, rb), P.alpha, P.beta, P.vbeta,
+                                                                        P.margin_rel, z1) : ~0ull) | __ballot(fl_cur == 0)) & __ballot(act);
                 const bool mine0 = ((t0_w >> (lane & 48)) & 0xFFFFull) != 0;
                 zn = mine0 ? z1 : zn;
                 uint32_t rows = 0;
@@ -459,31 +438,45 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                         zc = zo_r;
                         if (lane == 0 && P.status) atomicOr(P.status, 1);   // no topic with positive probability
                     }
-                    zn = (row == r) ? zc : zn;
+                    zn = (row == r) ? (zc | (quad_rho(zc) << 9)) : zn;
                 }
             }
-            cur.zn = zn;
             QP_MARK(2);                                                // (cold tiers)
-            make_nb();                                                 // nb of site n+1 (the cold tiers were the last readers of site n's)
 
-            // add the site back (LabeledLDA.py:121-125) and take the NEXT site out of its topic, in one masked pass; a second pass
-            // for the documents where one lane owns both
+            // add the site back (LabeledLDA.py:121-125) and take the NEXT site out of its topic: ONE read-modify-write per lane, branch
+            // free -- a lane that owns neither rewrites its slot 0 with what is there (the factor is a function of the counts) --, a
+            // second pass (rare) for the documents where one lane owns both.  The commit of this site (z and ONE log word, quad lane 0 of
+            // every document that has the site: exec mask by hand, no divergent region) and the scalar loads of site n+2 are issued in
+            // the shadow of the LDS reads.
             {
-                const int ln = (zn >> 3) & 15, sn = quad_rho(zn);
+                const int zpos = zn & 511, sn = zn >> 9, ln = (zn >> 3) & 15;
+                cur.zn = zpos;
+                decode_old(nxt);
                 const bool own_new = act && lq == ln, own_old = more && lq == nxt.lo;
-                if (own_new || own_old) update(own_new ? sn : nxt.so, own_new ? zn : nxt.zo, own_new ? f : -nxt.f);
+                const int sg = own_new ? sn : own_old ? nxt.so : 0;
+                const int ps = own_new ? zpos : own_old ? nxt.zo : (lq << 3);
+                const int df = own_new ? f : own_old ? -nxt.f : 0;
+                const int w0 = s_ndk[sg][tid], k0 = s_nk0[ps];
+#ifndef ABL_NOCOMMIT
+                {
+                    const uint32_t zoff = opaque_u32(sb + (uint32_t)n * 4u);
+                    const LLDA_GLOBAL uint32_t *lp = (const LLDA_GLOBAL uint32_t *)P.commit_log + (uint32_t)(cur.c & 0x7fffffff);
+                    const uint32_t word = (uint32_t)zo | ((uint32_t)zpos << 16);
+                    const uint64_t cm = __ballot(act) & lq0_w;
+                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dword %1, %2, %3\n\tglobal_store_dword %4, %5, off\n\ts_mov_b64 exec, -1"
+                                 : : "s"(cm), "v"(zoff), "v"(zpos), "s"(z_b), "v"(lp), "v"(word) : "memory");
+                }
+#endif
+                load_scalars(prv, off_of(n + 2));                      // scalars of site n+2 (clamped)
+                const int w = w0 + df;                                  // (0 <= n_dk + df < 2^16: no carry into the upper half)
+                s_ndk[sg][tid] = w;
+                const int nd = w & 0xffff, nk = k0 + nd - (int)((uint32_t)w >> 16);
+                s_pa[sg][tid] = tier0_factor(nd, nk, alpha32, vbeta32);
                 if (__builtin_expect(__ballot(own_new && own_old) != 0, 0)) {
                     if (own_new && own_old) update(nxt.so, nxt.zo, -nxt.f);
                 }
             }
-            decode_old(prv);                                           // (site n+2: its scalars were loaded at the top)
             QP_MARK(3);                                                // count update
-            // the last site of a document is committed right away
-#ifndef ABL_NOCOMMIT
-            if (__builtin_expect((__ballot(act && !more) & lq0_w) != 0, 0))
-                if (lq == 0 && act && !more)
-                    commit_site_off<true>(P, z_b, opaque_u32(sb + (uint32_t)n * 4u), cur.v, cur.f, cur.zo, cur.zn, cur.c & 0x7fffffff, KP);
-#endif
         };
         for (int n = 0;; n += 3) {                                  // (uniform trip count: the longest document of the wavefront)
             site(n, R0, R1, R2);

@@ -638,6 +638,7 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         if (a->n_sites < 1) return LLDA_OK;                              // (documents without sites: nothing to sample)
         P.n_kw16 = a->n_kw16;
         P.row16 = a->row16;
+        if (a->debug_margin == 0) P.margin0_rel = LLDA_MARGIN0_QUAD;     // (this kernel's own bound: kernel_quad.hpp)
         const int64_t per_q = (int64_t)(QNT / 16) * dpg;
         const int64_t qblocks = (a->D + per_q - 1) / per_q;
         if (qblocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
