@@ -6,6 +6,15 @@ namespace {
 
 thread_local int g_last_hip_error = 0;
 
+// -DLLDA_BUDGET_MARKS (tools/site_loop_budget.py; llda_build_info reports it): comment lines in the device assembly at the boundaries
+// of the functional classes of a site, so that every instruction of the site loop can be attributed.  The marks are scheduling barriers:
+// the marked build is for COUNTING, not for timing.
+#ifdef LLDA_BUDGET_MARKS
+#define LLDA_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; @" name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LLDA_MARK(name)
+#endif
+
 #define LLDA_MAX_LIVE 64   // most allowed topics per document the sparse kernel handles
 #define LLDA_NARROW_KP 1024  // longest row of a narrow layout (<= 8 leaves: 64 lanes x 16 slots)
 

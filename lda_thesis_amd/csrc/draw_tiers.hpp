@@ -185,6 +185,7 @@ __device__ __forceinline__ uint64_t draw_fast_dense_f32(const float (&qw)[16], f
     // add whose row mask leaves the other rows alone (the compiler's form is v_mov 0 + v_mov_dpp + v_add: it does not fold a
     // partial row mask into a floating-point add) -- written by hand together with the wait states a DPP source and a v_readlane
     // of a freshly written register need (the hazard recogniser does not look inside inline assembly).
+    LLDA_MARK("lane_scan");
     float X = qw[15];
     X += dpp_f32<DPP_ROW_SHR + 1>(X);
     X += dpp_f32<DPP_ROW_SHR + 2>(X);
@@ -199,9 +200,11 @@ __device__ __forceinline__ uint64_t draw_fast_dense_f32(const float (&qw)[16], f
     const float tot = bcast_last_f32<G>(X, lane);
     // X of the lane below; 0.0 shifted into lane 0 (bound_ctrl: no register to preset)
     const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), DPP_WAVE_SHR1, 0xF, 0xF, true));
+    LLDA_MARK("threshold");
     const float tg = u * tot - (lig ? prev : 0.0f);
     const float margin = tot * margin_rel;
     const float lo = tg - margin, hi = tg + margin;
+    LLDA_MARK("search");
     const bool c5 = qw[15] <= lo;
     float ub = c5 ? __int_as_float(0x7f800000) : qw[15];           // smallest element known to be > lo (count_sorted_f32)
     const bool c1 = qw[7] <= lo;
@@ -226,6 +229,7 @@ __device__ __forceinline__ uint64_t draw_fast_dense_f32(const float (&qw)[16], f
     uint64_t bad_total;
     asm("v_cmp_class_f32_e64 %0, %1, %2" : "=s"(bad_total) : "v"(tot - margin), "v"(0x2FF));
     const uint64_t unsure = __ballot(!(ub > hi)) | bad_total;
+    LLDA_MARK("pick");
     const int p = (c1 ? 8 * G : 0) | (c2 ? 4 * G : 0) | (lig << 2) | (c3 ? 2 : 0) | (c4 ? 1 : 0);
     const uint64_t above = __ballot(!c5);
     if constexpr (G == 64) {

@@ -79,6 +79,7 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
 {
     const q_v2f b2 = {beta, beta};
     q_v2f Q[16];
+    LLDA_MARK("scores");
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
         const q_v2f x2 = {xv[2 * a], xv[2 * a + 1]};
@@ -87,6 +88,7 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
         else Q[a] = __builtin_elementwise_fma(nb, pa[a], Q[a - 1]);
     }
     // inclusive scan over the 16 lanes of the document = one DPP row
+    LLDA_MARK("lane_scan");
     const float X0 = Q[15].x + Q[15].y;
     float X = X0;
     X += dpp_f32<DPP_ROW_SHR + 1>(X);
@@ -105,10 +107,12 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
     tot += dpp_f32<DPP_ROW_ROR + 1>(tot);
 #endif
     const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), DPP_ROW_SHR + 1, 0xF, 0xF, true));
+    LLDA_MARK("threshold");
     const float tg = __builtin_fmaf(u, tot, -prev);
     const float margin = tot * margin_rel;
     const float lo0 = tg - margin, hi0 = tg + margin;
     // chain A or chain B?
+    LLDA_MARK("search");
     const bool c0 = Q[15].x <= lo0;
     const float dA = c0 ? Q[15].x : 0.0f;
     const float lo = lo0 - dA, hi = hi0 - dA;
@@ -139,6 +143,7 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
     // the position this lane would name, keyed by its lane; the document's first lane with a slot above lo wins (none: 511, the
     // last slot of the last lane).  Row-wide minimum: four DPP steps, one instruction each (the compiler's form is three)
     // key = lane << 14 | slot rho << 9 | position: every search outcome sets its bit of the position AND of the slot number
+    LLDA_MARK("pick");
     const uint32_t p = (c1 ? (256u | 16u << 9) : 0u) | (c2 ? (128u | 8u << 9) : 0u) | (c3 ? (2u | 4u << 9) : 0u) | (c4 ? (1u | 2u << 9) : 0u) |
                        (c0 ? (4u | 1u << 9) : 0u) | ((uint32_t)lq << 3) | ((uint32_t)lq << 14);
     uint32_t key = c5 ? 0xFFFFFu : p;                       // (no slot above lo: position 511 = slot 31 of lane 15 wins only if no lane has one)
@@ -332,6 +337,8 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             const bool act = n < len, more = n + 1 < len;
             const int f = cur.f, zo = cur.zo;
             QP_START();
+            LLDA_MARK("site_top");
+            LLDA_MARK("lds_factors");
             q_v2f pa[16];
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
@@ -340,16 +347,20 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             }
             // the random bits of 32 sites at a time (one Philox block per lane serves two sites); their fp32 images -- the top 27
             // bits, within 2^-24 relative + 2^-27 absolute of u -- go through LDS, the bits themselves are only needed by the cold tiers
+            LLDA_MARK("rng");
             if ((n & 31) == 0) {
+                LLDA_MARK("rare_philox");
                 r0 = (uint32_t)(n >> 1) + (uint32_t)lq; r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
                 philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
                 s_u[grp][2 * lq] = (float)(r0 >> 5) * 0x1p-27f;
                 s_u[grp][2 * lq + 1] = (float)(r2 >> 5) * 0x1p-27f;
+                LLDA_MARK("rng");
             }
             const float u32 = s_u[grp][n & 31];
             __builtin_amdgcn_sched_barrier(0);
             // the row as fp32 (exact: 16-bit counts; an int32 count beyond 2^24 rounds, section 4.3)
             q_v32f xv;
+            LLDA_MARK("convert");
             const uint64_t wide_w = __ballot(fl == 0);
             if (__builtin_expect(wide_w == 0, 1)) {
 #pragma unroll
@@ -361,6 +372,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 }
             } else {
                 // some document's word has a count beyond 16 bits: its lanes read the int32 row now (no prefetch)
+                LLDA_MARK("rare_wide_row");
                 int xi[QT];
 #pragma unroll
                 for (int s = 0; s < QT; ++s) xi[s] = 0;
@@ -384,6 +396,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             }
             // the site's own count leaves the fp32 row through the slot index (uniform in a document): per document ONE indexed
             // read-modify-write under the document's exec mask
+            LLDA_MARK("own_removal");
             {
                 const float own = (act && lq == cur.lo) ? (float)f : 0.0f;
 #pragma unroll
@@ -398,6 +411,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                                  : "+{v[64:95]}"(xv) : "s"(so_r), "s"(em), "v"(own));
                 }
             }
+            LLDA_MARK("row_prefetch");
             const int fl_cur = fl;                                     // (flag of THIS site's row: 0 = read as int32)
             load_row16(nxt.v);                                         // row of site n+1 (clamped)
             QP_MARK(0);                                                // pa, row, conversion, own count, commit, loads issued
@@ -405,7 +419,9 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             int zn;
             uint64_t unsure = quad_draw(xv, pa, u32, P.margin0_rel, beta32, lq, bp_last, zn) & __ballot(act);
             QP_MARK(1);                                                // chains, scan, search, pick
+            LLDA_MARK("cold_check");
             if (__builtin_expect(unsure != 0, 0)) {
+                LLDA_MARK("rare_cold");
                 // tier 1 (fp64, margin 2^-40) right here, in this layout, for all four documents; what IT cannot decide (~1e-9 of the
                 // sites) goes to the exact tier out of line, one document at a time, the whole wavefront playing it in the standard layout
                 const int holder = (n >> 1) & 15;
@@ -442,6 +458,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 }
             }
             QP_MARK(2);                                                // (cold tiers)
+            LLDA_MARK("decode");
 
             // add the site back (LabeledLDA.py:121-125) and take the NEXT site out of its topic: ONE read-modify-write per lane, branch
             // free -- a lane that owns neither rewrites its slot 0 with what is there (the factor is a function of the counts) --, a
@@ -456,9 +473,11 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 const int sg = own_new ? sn : own_old ? nxt.so : 0;
                 const int ps = own_new ? zpos : own_old ? nxt.zo : (lq << 3);
                 const int df = own_new ? f : own_old ? -nxt.f : 0;
+                LLDA_MARK("count_update");
                 const int w0 = s_ndk[sg][tid], k0 = s_nk0[ps];
 #ifndef ABL_NOCOMMIT
                 {
+                    LLDA_MARK("commit");
                     const uint32_t zoff = opaque_u32(sb + (uint32_t)n * 4u);
                     const LLDA_GLOBAL uint32_t *lp = (const LLDA_GLOBAL uint32_t *)P.commit_log + (uint32_t)(cur.c & 0x7fffffff);
                     const uint32_t word = (uint32_t)zo | ((uint32_t)zpos << 16);
@@ -467,15 +486,19 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                                  : : "s"(cm), "v"(zoff), "v"(zpos), "s"(z_b), "v"(lp), "v"(word) : "memory");
                 }
 #endif
+                LLDA_MARK("scalars");
                 load_scalars(prv, off_of(n + 2));                      // scalars of site n+2 (clamped)
+                LLDA_MARK("count_update");
                 const int w = w0 + df;                                  // (0 <= n_dk + df < 2^16: no carry into the upper half)
                 s_ndk[sg][tid] = w;
                 const int nd = w & 0xffff, nk = k0 + nd - (int)((uint32_t)w >> 16);
                 s_pa[sg][tid] = tier0_factor(nd, nk, alpha32, vbeta32);
                 if (__builtin_expect(__ballot(own_new && own_old) != 0, 0)) {
+                    LLDA_MARK("rare_second_update");
                     if (own_new && own_old) update(nxt.so, nxt.zo, -nxt.f);
                 }
             }
+            LLDA_MARK("loop");
             QP_MARK(3);                                                // count update
         };
         for (int n = 0;; n += 3) {                                  // (uniform trip count: the longest document of the wavefront)

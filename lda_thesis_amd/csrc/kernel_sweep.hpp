@@ -335,6 +335,8 @@ __global__ void __launch_bounds__(256, W4 ? 4 : (T <= 12 && G >= 16) ? LLDA_WAVE
         // reloaded with the scalars of site n+2)
         auto site = [&](const int n, SiteRegs &cur, SiteRegs &nxt, SiteRegs &prv, int (&xc)[T], int (&xnx)[XM]) {
             const int f = cur.f, zo = cur.zo;
+            LLDA_MARK("site_top");
+            LLDA_MARK("lds_factors");
             // the cached tier-0 factors of the lane, fetched from LDS first thing: nothing below depends on them until
             // the scores, and the kernel is bound by the latency of one wavefront's instruction stream (39 % of the
             // wave cycles sat in s_waitcnt, mostly on LDS: eight waits per site when the reads trickle in pairs)
@@ -343,8 +345,10 @@ __global__ void __launch_bounds__(256, W4 ? 4 : (T <= 12 && G >= 16) ? LLDA_WAVE
             for (int s = 0; s < T; ++s) pa[s] = s_pa[s][tid];
             // ... and so are the site's random bits (a cross-lane pick through LDS for groups wider than 16 lanes)
             uint32_t ra, rb;
+            LLDA_MARK("rng");
             site_random_bits<G>(P, n, n == n0, gdoc, lig, r0, r1, r2, r3, ra, rb);
             __builtin_amdgcn_sched_barrier(0);
+            LLDA_MARK("convert");
             // the fetched row minus the site's own count (n_dk / n_k were updated already)
             int x[T];
             [[maybe_unused]] float xf[R16 ? T : 1];                   // R16: the counts as fp32 (exact: 16-bit rows hold < 2^16)
@@ -369,6 +373,7 @@ __global__ void __launch_bounds__(256, W4 ? 4 : (T <= 12 && G >= 16) ? LLDA_WAVE
                 }
                 typedef float v16f __attribute__((ext_vector_type(16)));
                 v16f xv;
+                LLDA_MARK("own_removal");
 #pragma unroll
                 for (int s = 0; s < T; ++s) xv[s] = xf[s];
                 const float own = (lig == cur.lo) ? (float)f : 0.0f;
@@ -399,11 +404,13 @@ __global__ void __launch_bounds__(256, W4 ? 4 : (T <= 12 && G >= 16) ? LLDA_WAVE
                 onehot_add_to<T>(x, xc, (lig == cur.lo) ? (1u << cur.so) : 0u, f);   // m = -1 at the slot: += (-1) * f
             }
             int (&xl)[T] = *(int (*)[T])(INDEXED && !W4 ? (void *)&xnx : (void *)&xc);     // where the next row goes (W4: one tuple)
+            LLDA_MARK("commit");
 #ifndef ABL_NOCOMMIT
             if (lig == 0 && n > n0)
                 commit_site_off<LOGGED>(P, z_b, opaque_u32(sb + (uint32_t)(n - 1) * 4u), prv.v, prv.f, prv.zo, prv.zn,
                                         R16 ? prv.c & 0x7fffffff : prv.c, KP);
 #endif
+            LLDA_MARK("row_prefetch");
 #ifndef ABL_NOLOAD
             load_word_row(xl, nxt.v, nxt.c);                              // row of site n+1 (clamped)
 #else
@@ -411,6 +418,7 @@ __global__ void __launch_bounds__(256, W4 ? 4 : (T <= 12 && G >= 16) ? LLDA_WAVE
             for (int s = 0; s < T; ++s) xl[s] = (nxt.v + s) & 7;          // ablation: no n_kw traffic
 #endif
             {
+                LLDA_MARK("scalars");
                 const uint32_t o2 = opaque_u32(sb + (uint32_t)(n + 2 < len ? n + 2 : len - 1) * 4u);   // scalars of site n+2 (clamped)
                 load_scalars(prv, o2);
             }
@@ -442,15 +450,19 @@ __global__ void __launch_bounds__(256, W4 ? 4 : (T <= 12 && G >= 16) ? LLDA_WAVE
                 }
             };
             // fp32 image of the uniform: the top 27 bits (within 2^-24 relative + 2^-27 absolute of u)
+            LLDA_MARK("rng");
             const float u32 = (float)(ra >> 5) * 0x1p-27f;
             if constexpr (DENSE && T == 16 && G >= 32) {
                 // tier 0: fp32 (a margin >= 1 switches it off by making every site unsure: no test here).  unsure = the
                 // wavefront's lanes tier 0 is not sure about (uniform)
                 float qf[T];
+                LLDA_MARK("scores");
                 if constexpr (R16) prefix_scores_f32<T, DENSE>(qf, xf, pa, mask, beta32);
                 else prefix_scores_f32<T, DENSE>(qf, x, pa, mask, beta32);
                 const uint64_t unsure = draw_fast_dense_f32<G>(qf, u32, P.margin0_rel, lig, lane, zn);
+                LLDA_MARK("cold_check");
                 if (__builtin_expect(unsure != 0, 0)) {                                  // one scalar branch per site
+                    LLDA_MARK("rare_cold");
                     if (__builtin_amdgcn_inverse_ballot_w64(spread_any<G>(unsure))) cold();   // the whole document group enters
                 }
             } else {
@@ -464,6 +476,7 @@ __global__ void __launch_bounds__(256, W4 ? 4 : (T <= 12 && G >= 16) ? LLDA_WAVE
                 if (__builtin_expect(!decided, 0)) cold();
             }
             cur.zn = zn;
+            LLDA_MARK("decode");
 
             // add the site back (LabeledLDA.py:121-125), and take the NEXT site out of its topic already (its
             // scalars are in registers): the LDS state is final long before the next site's scores read it.
@@ -475,6 +488,7 @@ __global__ void __launch_bounds__(256, W4 ? 4 : (T <= 12 && G >= 16) ? LLDA_WAVE
                 lane_slot_of<G, T>(zn, ln, sn);
                 lane_slot_of<G, T>(nxt.zo, nxt.lo, nxt.so);                  // (kept for the next site's removal from x)
                 const int lo2 = nxt.lo, so2 = nxt.so;
+                LLDA_MARK("count_update");
                 if constexpr (INDEXED) {
                     // The three compares by hand, their lane masks as scalars: the compiler keeps such a mask as a per-lane bool
                     // and, where a ballot of a COMBINATION is wanted, rebuilds it through v_cndmask + v_cmp_ne.  more = the
@@ -496,6 +510,7 @@ __global__ void __launch_bounds__(256, W4 ? 4 : (T <= 12 && G >= 16) ? LLDA_WAVE
                     // (rare blocks behind ONE scalar branch on the ballot: entering and leaving a divergent region costs four
                     // scalar instructions whether or not a lane takes it, and the scalar unit's cycles are not hidden here)
                     if (__builtin_expect(both_w != 0, 0)) {
+                        LLDA_MARK("rare_second_update");
                         if (__builtin_amdgcn_inverse_ballot_w64(both_w)) {
                             if constexpr (W4) count_update_w4(s_ndk, s_nk0, s_pa, so2, nxt.zo, tid, alpha32, vbeta32, -nxt.f);
                             else count_update(s_ndk, s_nkc, s_pa, so2, tid, alpha32, vbeta32, -nxt.f);
@@ -512,6 +527,7 @@ __global__ void __launch_bounds__(256, W4 ? 4 : (T <= 12 && G >= 16) ? LLDA_WAVE
                     }
                 }
             }
+            LLDA_MARK("loop");
 #ifndef ABL_NOCOMMIT
             // the last site of the document is committed right away
             if (__builtin_expect((__ballot(n + 1 == len) & lig0_w) != 0, 0))
