@@ -95,14 +95,41 @@ def algorithmic_bytes(sites, docs, A):
 
 
 # ------------------------------------------------------------------------------------------------ workloads
+class one_device_lock(object):
+    """cross-process mutex (flock on a file named after the rendezvous port) for the ranks of a --one-device run; re-usable"""
+
+    def __init__(self):
+        import tempfile
+        self.path = os.path.join(tempfile.gettempdir(), "llda_bench_%s.lock" % os.environ.get("MASTER_PORT", "0"))
+        self.fh = None
+
+    def __enter__(self):
+        import fcntl
+        self.fh = open(self.path, "w")
+        fcntl.flock(self.fh, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        torch.cuda.synchronize()                     # the section's GPU work is done before the next rank starts its own
+        fcntl.flock(self.fh, fcntl.LOCK_UN)
+        self.fh.close()
+        self.fh = None
+        return False
+
+
 def build_sampler(name, dev, rank, world, dist_on, docs_total=0, docs_per_group=0, force_exchange=False,
-                  overlap=None, rows16=None):
+                  overlap=None, rows16=None, build_lock=None):
     """-> (sampler, info dict).  Inputs are generated on the device."""
     Dt, N, V, K, zs, block, desc = WORKLOADS[name]
     if docs_total:
         Dt = docs_total
     info = dict(desc=desc, K=K, V=V, N=N, live_topics=float(K), docs_total=Dt)
     kw = {} if overlap is None else dict(overlap_ranges=overlap)
+    if build_lock is not None:
+        kw["build_lock"] = build_lock
+    import contextlib
+    locked = build_lock if build_lock is not None else contextlib.nullcontext()
     if rows16 is None and os.environ.get("LLDA_BENCH_ROWS16"):        # ablation: "on" / "off" for every sampler of the run
         rows16 = os.environ["LLDA_BENCH_ROWS16"] == "on"
     if rows16 is not None:
@@ -123,7 +150,8 @@ def build_sampler(name, dev, rank, world, dist_on, docs_total=0, docs_per_group=
         if block is None:
             raise SystemExit("%d documents do not split over %d GPUs" % (Dt, world))
     lo, hi = Dt // world * rank, Dt // world * (rank + 1)
-    doc_off, word, freq, z = synthetic_corpus_blocks(lo, hi, N, V, K, 1234, dev, zipf_s=zs, block=block)
+    with locked:
+        doc_off, word, freq, z = synthetic_corpus_blocks(lo, hi, N, V, K, 1234, dev, zipf_s=zs, block=block)
     Dg = hi - lo
     info["docs_local"] = Dg
     if name in ("synth2_sparse", "synth_wide_sparse", "synth2_sparse_hier"):
@@ -316,7 +344,23 @@ def cpu_strong_leg(sampler, info, labs_rows=None):
                             sampler.beta, sampler.seed, 0, threads=threads)
         dt = time.perf_counter() - t0
         legs.append({"threads": threads, "docs": n, "sites": s1, "seconds": dt, "value": s1 / dt / 1e6})
-    return {"best": max(legs, key=lambda l: l["value"]), "legs": legs, "physical_cores": phys, "logical_cores": logical}
+    out = {"best": max(legs, key=lambda l: l["value"]), "legs": legs, "physical_cores": phys, "logical_cores": logical,
+           "layout": "the reference's: n_k_v (K, V) int64, strided column gather per site (LabeledLDA.py:114)"}
+    if labs_rows is None:
+        # the same sweep on the layout the GPU kernels use (int32, word-major: a site reads ONE contiguous row) -- what a CPU does
+        # when it is given the better layout; dense masks only
+        wm_legs = []
+        for threads in sorted({cap, max(1, cap // 2), max(1, cap // 4)}, reverse=True):
+            n = max(1, n_top * threads // cap)
+            s1 = int(doc_off[n])
+            st = c_oracle.WMState(doc_off[:n + 1], word[:s1], freq[:s1], z[:s1], n_d_k[:n], n_k_v, n_zk, sampler.V, sampler.alpha, sampler.beta)
+            t0 = time.perf_counter()
+            st.sweep(sampler.seed, 0, doc_base=sampler.doc_base, threads=threads)
+            dt = time.perf_counter() - t0
+            wm_legs.append({"threads": threads, "docs": n, "sites": s1, "seconds": dt, "value": s1 / dt / 1e6})
+        out["word_major"] = {"best": max(wm_legs, key=lambda l: l["value"]), "legs": wm_legs,
+                             "layout": "the GPU kernels': n_kw (V, K) int32 word-major, n_d_k / n_k int32 (oracle/llda_oracle.c, llda_oracle_sweep_wm)"}
+    return out
 
 
 def cpu_baseline(sampler, doc_off, word, freq, n_docs_py, n_docs_c, labs=None):
@@ -392,7 +436,7 @@ def cpu_baseline_json(sampler, info, name, value):
         strong = cpu_strong_leg(sampler, info, lab_rows)
     model, logical, phys = host_cpu()
     return {
-        "cpu_model": model, "physical_cores": phys, "c_port_strong": strong,
+        "cpu_model": model, "physical_cores": phys, "c_port_reference_layout": strong,
         "value": base["numpy"]["value"], "unit": "Mtokens/s", "cores": 1, "kind": "port",
         "sample": "first %d docs (%d sites) of the same workload, 1 sweep, numpy per-site loop "
                   "restating LabeledLDA.py:108-125 (oracle/llda_oracle.py sweep_sequential), %.1f s"
@@ -662,10 +706,11 @@ def short_kernel_name(name):
     return m.group(0) if m else name
 
 
-def pmc_inner(dev, workloads):
-    """the process rocprofv3 wraps: PMC_SWEEPS sweeps of each workload, nothing else."""
+def pmc_inner(dev, workloads, docs=0):
+    """the process rocprofv3 wraps: PMC_SWEEPS sweeps of each workload, nothing else.  docs > 0: a corpus of that many documents (the
+    single-process replica of ONE rank's shard of an N > 1 run: the same kernel, the same n_kw, the rank's share of the documents)."""
     for name in workloads:
-        s, info = build_sampler(name, dev, 0, 1, False)
+        s, info = build_sampler(name, dev, 0, 1, False, docs_total=docs)
         for _ in range(PMC_SWEEPS):
             s.sweep()
         torch.cuda.synchronize()
@@ -673,7 +718,7 @@ def pmc_inner(dev, workloads):
         torch.cuda.empty_cache()
 
 
-def pmc_collect(workloads, keep_dir=None, timeout=300):
+def pmc_collect(workloads, keep_dir=None, timeout=300, docs=0, passes=None):
     """Run this script under rocprofv3, one --pmc group per pass, and return
     ({workload: {counter: mean per sweep-kernel launch}}, note).  A pass that fails only loses its own counters."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -686,11 +731,12 @@ def pmc_collect(workloads, keep_dir=None, timeout=300):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     try:
-        for tag, counters in PMC_PASSES:
+        for tag, counters in (passes or PMC_PASSES):
             d = os.path.join(tmp, tag)
             cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "pmc", "--",
                                                                  sys.executable, os.path.join(ROOT, "bench.py"),
-                                                                 "--pmc-inner", ",".join(workloads)]
+                                                                 "--pmc-inner", ",".join(workloads)] + \
+                  (["--docs", str(docs)] if docs else [])
             # own session: on a timeout the whole process group (rocprofv3 AND the python under it) is ended
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                     start_new_session=True)
@@ -892,11 +938,19 @@ def compact_roofline(r):
            "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"), "traffic": r.get("traffic"),
            "traffic_kind": r.get("traffic_kind"), "algorithmic_bytes": r.get("algorithmic_bytes_per_launch"),
            "algorithmic_GBps": r.get("algorithmic_GBps"), "traffic_over_algorithmic": r.get("traffic_over_algorithmic"),
+           # SURVEY 8(d) bytes over time against 8 TB/s: NOT a fraction (rows served on-die never cross HBM; above 1 on configs[3])
+           "algorithmic_frac": (r.get("algorithmic_GBps") or 0.0) / HBM_PEAK_GBS if r.get("algorithmic_GBps") is not None else None,
+           "algorithmic_frac_note": "not a fraction: rows served by L2 / Infinity Cache",
+           "frac_is": "fabric (L2 <-> fabric bytes, Infinity-Cache hits included) / 8 TB/s: an upper bound of the HBM fraction",
            "valu_busy_frac": v.get("valu_busy_frac"), "valu_insts_per_site": v.get("valu_insts_per_site"),
            "waves_per_simd": v.get("waves_per_simd_avg"), "wave_cycles_waiting_frac": v.get("wave_cycles_waiting_frac"),
            "l2_hit_rate": l2.get("hit_rate"), "fabric_read_requests_per_site": l2.get("fabric_read_requests_per_site"),
            "ta_busy_frac": r.get("ta_busy_frac"), "binding_roof": (r.get("binding_roof") or "").split(" ")[0] or None}
-    return {k: _num(x, 5) for k, x in out.items()}
+    he = r.get("hbm_estimate")
+    out = {k: _num(x, 5) for k, x in out.items()}
+    if he:
+        out["hbm_frac_bounds"] = [_num(he["lower_GBps"] / HBM_PEAK_GBS, 4), _num(he["upper_GBps"] / HBM_PEAK_GBS, 4)]
+    return out
 
 
 def compact_cpu(c):
@@ -909,12 +963,18 @@ def compact_cpu(c):
         out["c_port_1thread"] = _num(c["c_port_1thread_Mtokens_s"], 5)
     if c.get("c_port_allcores_Mtokens_s") is not None:
         out["c_port_allcores_small_sample"] = _num(c["c_port_allcores_Mtokens_s"], 5)
-    st = c.get("c_port_strong")
+    st = c.get("c_port_reference_layout")
     if st:
         b = st["best"]
-        out["c_port_strong"] = {"value": _num(b["value"], 5), "threads": b["threads"], "docs": b["docs"],
-                                "seconds": _num(b["seconds"], 4),
-                                "legs": [[l["threads"], _num(l["value"], 4)] for l in st["legs"]]}
+        out["c_port_reference_layout"] = {"value": _num(b["value"], 5), "threads": b["threads"], "docs": b["docs"],
+                                          "seconds": _num(b["seconds"], 4),
+                                          "legs": [[l["threads"], _num(l["value"], 4)] for l in st["legs"]]}
+        wm = st.get("word_major")
+        if wm:
+            b = wm["best"]
+            out["c_port_word_major"] = {"value": _num(b["value"], 5), "threads": b["threads"], "docs": b["docs"],
+                                        "seconds": _num(b["seconds"], 4),
+                                        "legs": [[l["threads"], _num(l["value"], 4)] for l in wm["legs"]]}
     for k in ("train_s", "test_s"):
         if c.get(k) is not None:
             out[k] = _num(c[k], 5)
@@ -924,7 +984,8 @@ def compact_cpu(c):
 def compact_extra(e):
     """{value, unit, ms_per_step, frac, binding_roof} (+ the CPU figures where the workload has them) of one extra workload"""
     out = {"value": _num(e.get("value")), "unit": e.get("unit")}
-    for k in ("ms_per_step", "kernel_ms", "steps", "speedup_vs_cpu_port", "cold_first_call_s", "median_s", "max_s", "n_kw_rows_short"):
+    for k in ("ms_per_step", "kernel_ms", "steps", "speedup_vs_cpu_port", "cold_first_call_s", "median_s", "max_s", "n_kw_rows_short",
+              "Mtokens_s", "tokens_per_site"):
         if e.get(k) is not None:
             out[k] = _num(e[k], 5)
     r = e.get("roofline")
@@ -936,8 +997,8 @@ def compact_extra(e):
         cb = e["cpu_baseline"]
         out["cpu"] = {"value": _num(cb.get("value"), 5), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
                       "scaled_from_sample": "scaled" in str(cb.get("sample", ""))}
-        if cb.get("c_port_strong"):
-            out["cpu"]["c_port_strong"] = _num(cb["c_port_strong"]["best"]["value"], 5)
+        if cb.get("c_port_reference_layout"):
+            out["cpu"]["c_port_reference_layout"] = _num(cb["c_port_reference_layout"]["best"]["value"], 5)
     if e.get("stages_s"):
         out["stages_s"] = {k: _num(x, 4) for k, x in e["stages_s"].items()}
     return out
@@ -950,7 +1011,7 @@ def compact_line(detail, detail_path=None):
     line = {k: _num(detail.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                               "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     line["config"] = {k: _num(cfg.get(k)) for k in ("workload", "docs_total", "docs_per_gpu", "sites_per_doc", "K", "V", "alpha",
-                                                     "beta", "label_mask", "kernel", "n_kw_rows_short", "sites_per_sweep",
+                                                     "beta", "label_mask", "kernel", "n_kw_rows_short", "sites_per_sweep", "tokens_per_site",
                                                      "timed_seconds", "state_checksum_n_k", "state_checksum_n_kw",
                                                      "sweeps_behind_checksum", "build_info", "abi", "library")
                       if cfg.get(k) is not None}
@@ -975,6 +1036,11 @@ def compact_line(detail, detail_path=None):
             line["overlap_probe"]["exposed_ms_per_sweep"] = _num(pr["exchange_ms"].get("exposed_ms_per_sweep"), 5)
     if detail.get("extra"):
         line["extra"] = {k: compact_extra(e) for k, e in detail["extra"].items()}
+        hb = (detail["extra"].get("hbm_bound") or {}).get("roofline") or {}
+        if line["roofline"] is not None and hb.get("frac") is not None:
+            # the one workload of the run whose fabric bytes ARE HBM bytes (n_kw = 1 GB, four times the Infinity Cache, uniform words):
+            # what the sweep kernel achieves against the HBM roof when nothing is served on-die
+            line["roofline"]["hbm_credential"] = {"workload": "hbm_bound", "frac": _num(hb["frac"], 5), "kernel": hb.get("kernel")}
     if len(json.dumps(line)) > LINE_LIMIT and "extra" in line:
         line["extra"] = {k: {"value": e.get("value"), "unit": e.get("unit")} for k, e in line["extra"].items()}
     if len(json.dumps(line)) > LINE_LIMIT:
@@ -996,6 +1062,29 @@ def self_launch(args):
 
 
 _T0 = time.time()
+
+
+def start_watchdog(seconds, rank, world, args):
+    """after `seconds`: every thread's stack on stderr, ONE JSON line with an "error" key on stdout (rank 0), exit code 3 -- a run
+    that cannot finish says so instead of hanging until somebody kills it"""
+    import faulthandler
+    import threading
+
+    def fire():
+        try:
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            if rank == 0:
+                print(json.dumps({"metric": "million tokens resampled/sec (Gibbs sweep)", "value": None, "unit": "Mtokens/s",
+                                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                  "error": "bench.py did not finish within its deadline of %d s (--deadline); every thread's stack is on "
+                                           "stderr of each rank" % seconds}), flush=True)
+        finally:
+            os._exit(3)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def trace(msg):
@@ -1026,6 +1115,9 @@ def main():
     ap.add_argument("--overlap", type=int, default=-1, help="document ranges per sweep for the overlapped exchange")
     ap.add_argument("--docs-per-group", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", help="diagnostic: gloo runs the N > 1 code path without RCCL")
+    ap.add_argument("--deadline", type=int, default=1500,
+                    help="seconds after which a run that is still going prints a one-line JSON with an \"error\" key (rank 0), dumps every "
+                         "thread's stack on stderr and exits with code 3 instead of hanging; collectives time out after the same span")
     ap.add_argument("--one-device", action="store_true",
                     help="diagnostic: every rank uses cuda:0 (functional check of the N > 1 path on a one-GPU box, with gloo)")
     args = ap.parse_args()
@@ -1047,25 +1139,37 @@ def main():
         raise SystemExit("bench.py: %s was built with %s (llda_build_info() = %#x): not the production library, no line is printed"
                          % (_native.LIB_PATH, ", ".join(build_names), build_bits))
     if args.pmc_inner:
-        pmc_inner(dev, args.pmc_inner.split(","))
+        pmc_inner(dev, args.pmc_inner.split(","), docs=args.docs)
         return
+    watchdog = start_watchdog(args.deadline, rank, world, args)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a wedged collective raises after the deadline instead of blocking for ever (RCCL: the watchdog thread of the process group
+        # aborts the communicator; gloo: the wait itself times out)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        pg_timeout = datetime.timedelta(seconds=max(60, args.deadline))
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world, timeout=pg_timeout)
 
     trace("process group ready" if dist is not None else "single process")
     if os.environ.get("LLDA_BENCH_TRACE"):                # where every rank stands if the run is still going after a minute
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ.get("LLDA_BENCH_TRACE_DUMP_S", "60")), repeat=False, file=sys.stderr)
     name = args.workload
+    # --one-device: the ranks share ONE GPU.  Several processes pushing long streams of small kernels and host synchronisations at one
+    # device at the same time (the generator, the sorts and scans of the sampler's construction) are time-sliced by the GPU's scheduler
+    # process by process: the same construction took 1 s, 40 - 70 s, 179 s or more than 150 s from one attempt to the next
+    # (profiles/HISTORY.md, round 5).  There the heavy LOCAL sections of the construction take turns (a file lock; no collective
+    # inside a locked section); the timed sweeps do run concurrently.
+    lock = one_device_lock() if (args.one_device and dist is not None) else None
     sampler, info = build_sampler(name, dev, rank, world, dist is not None, docs_total=args.docs,
                                   docs_per_group=args.docs_per_group, force_exchange=args.force_exchange,
-                                  overlap=None if args.overlap < 0 else args.overlap)
+                                  overlap=None if args.overlap < 0 else args.overlap, build_lock=lock)
     sites_local = sampler.S
     torch.cuda.synchronize()
     trace("sampler built: %d local sites" % sites_local)
@@ -1128,7 +1232,7 @@ def main():
         live = info["live_topics"]
         ms = dt / args.steps * 1e3
         value = total_sites * args.steps / dt / 1e6
-        do_pmc = world == 1 and not args.no_pmc and name in PMC_WORKLOADS
+        do_pmc = not args.no_pmc and name in PMC_WORKLOADS
         extras_on = world == 1 and not args.no_extras and name == "synth2" and not args.docs
         pmc_names = [w for w in PMC_WORKLOADS if w == name or extras_on] if do_pmc else []
         line = {
@@ -1136,7 +1240,7 @@ def main():
             "value": value, "unit": "Mtokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong" if name != "abstracts" else "weak",
-            "vs_baseline": None, "dtype": "f64",
+            "vs_baseline": None, "dtype": "f64-exact (fp32 tier 0 + fp64 tiers: the drawn topic is the fp64 pipeline's)",
             "data": "synthetic" if name != "abstracts" else "tokenised abstracts_data.csv (fixture)",
             "config": {"workload": info["desc"], "docs_total": info["docs_total"], "docs_per_gpu": info["docs_local"],
                        "sites_per_doc": N, "K": K, "V": V, "alpha": ALPHA, "beta": BETA,
@@ -1145,7 +1249,7 @@ def main():
                        "n_kw_rows": rows_description(sampler),
                        "n_kw_rows_short": rows_short(sampler),
                        "build_info": build_bits, "abi": _native.ABI_VERSION, "library": os.path.relpath(_native.LIB_PATH, ROOT),
-                       "sites_per_sweep": total_sites, "timed_seconds": dt,
+                       "sites_per_sweep": total_sites, "tokens_per_site": 1.0 if name != "abstracts" else None, "timed_seconds": dt,
                        "exchange": sampler.exchange_description() if world > 1 else "none (single GPU: the commit log is "
                                    "folded straight into n_kw)",
                        "semantics": "per-document snapshot (bit-exact vs the reference under O3)",
@@ -1168,7 +1272,8 @@ def main():
         extra = {}
         measured = {name: dict(kernel_ms=kavg, sites=sites_local, docs=info["docs_local"], live=live,
                                shared=sampler._counts.numel() * 4)}
-        if world == 1 and not args.no_cpu:
+        if not args.no_cpu:
+            # (N > 1: rank 0 times the port on the first documents of ITS shard while the other ranks wait at the final barrier)
             line["cpu_baseline"], line["speedup_vs_cpu_port"] = cpu_baseline_json(sampler, info, name, value)
         del sampler, info
         torch.cuda.empty_cache()
@@ -1188,6 +1293,9 @@ def main():
                 measured[wname] = dict(kernel_ms=k2, sites=s2.S, docs=i2["docs_local"], live=i2["live_topics"],
                                        shared=s2._counts.numel() * 4)
                 if wname == "abstracts":
+                    # a site of a real corpus carries its word's frequency in the document (1.24 tokens on average here): both rates
+                    tokens_per_site = float(s2.freq.sum(dtype=torch.int64).item()) / max(s2.S, 1)
+                    e["unit"], e["Mtokens_s"], e["tokens_per_site"] = "Msites/s", v2 * tokens_per_site, tokens_per_site
                     e["live_topics_per_doc"] = i2["live_topics"]
                     e["algorithmic_GBps"] = algorithmic_bytes(s2.S, i2["docs_local"], i2["live_topics"]) / (k2 * 1e-3) / 1e9
                     e["note"] = "latency bound (one 48-site document chain per lane group), not bandwidth bound"
@@ -1219,9 +1327,15 @@ def main():
             extra["pipeline_abstracts"] = pipeline_extra(with_cpu=not args.no_cpu)
             extra["cascade_test"] = cascade_test_extra(with_cpu=not args.no_cpu)
         # ---- roofline: HBM-side counters collected in this run (separate rocprofv3 passes) ----
-        pmc, source = ({}, "not collected (N > 1 or --no-pmc)")
-        if pmc_names:
-            pmc, source = pmc_collect(pmc_names, keep_dir=args.pmc_keep or None)
+        pmc, source = ({}, "not collected (--no-pmc)")
+        if pmc_names and world == 1:
+            pmc, source = pmc_collect(pmc_names, keep_dir=args.pmc_keep or None, docs=args.docs)
+        elif pmc_names:
+            # N > 1: the counters of a single-process replica of rank 0's shard on rank 0's GPU (the other ranks idle at the final
+            # barrier): the same kernel and n_kw, 1 / N of the documents -- three passes (fabric bytes and issue), not five
+            pmc, source = pmc_collect(pmc_names, keep_dir=args.pmc_keep or None, docs=measured[name]["docs"],
+                                      passes=[p_ for p_ in PMC_PASSES if p_[0] in ("fetch", "write", "sq")])
+            source = "single-process replica of rank 0's shard (%d documents); " % measured[name]["docs"] + source
         m = measured[name]
         line["roofline"] = roofline_json(m["kernel_ms"], m["sites"], m["docs"], m["live"], pmc.get(name), source,
                                          stored_key=name, shared_bytes=m["shared"])
@@ -1250,6 +1364,7 @@ def main():
         trace("final barrier passed")
         dist.destroy_process_group()
     trace("done")
+    watchdog.cancel()
 
 
 if __name__ == "__main__":

@@ -96,6 +96,9 @@ class GibbsSampler(object):
                sweep by ``llda_pack_rows16_all`` from the counts themselves; a row that does not is read as int32.  Same results.
                None (default) = wherever it applies; False = the two-documents-per-wavefront kernel; LLDA_QUAD=on|off in the
                environment decides for callers that cannot pass the argument.
+    build_lock : a context manager the heavy LOCAL sections of the construction run under (the sorts of the commit log, the count
+               initialisation, the images) -- never a collective.  For several processes that share one device (bench.py --one-device,
+               tests): concurrent constructions are time-sliced by the GPU's scheduler and take seconds to minutes instead of one second.
     image    : sparse label sets (the sparse-label kernel): the kernel gathers its counts from a SATURATING narrow image of n_kw
                (8 or 16 bits per count, refreshed by ``llda_pack_image`` at the start of every sweep) and re-reads an entry that
                shows 255 / 65535 from n_kw itself: a row spans a quarter / half as many cache lines, and the kernel is bound by
@@ -108,9 +111,11 @@ class GibbsSampler(object):
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
                  stream_id=0, doc_base=0, device=None, group=None, sort_docs=True,
                  docs_per_group=0, sharded=True, sparse_labels=True, commit_log=None, exchange_always=False,
-                 overlap_ranges=1, rows16=None, image=None, quad=None):
+                 overlap_ranges=1, rows16=None, image=None, quad=None, build_lock=None):
         _native.lib()                                       # fail loudly when the extension is missing
         _native.require_device()                            # ... or when no GPU is visible: there is no CPU fallback
+        import contextlib
+        locked = build_lock if build_lock is not None else contextlib.nullcontext()
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.K, self.V = int(K), int(V)
         self.alpha, self.beta = float(alpha), float(beta)
@@ -176,7 +181,8 @@ class GibbsSampler(object):
         if self.S >= (1 << 31):
             commit_log = False                      # log positions are int32
         if commit_log and self.S > 0:
-            self._make_commit_log()
+            with locked:
+                self._make_commit_log()
         self._sort_docs = bool(sort_docs)
         self._call_limit = min(self.MAX_CALL_SITES, self.MAX_CALL_SITES_REC) if self.site_rec is not None else self.MAX_CALL_SITES
         self._off_host = self.doc_off.cpu().numpy() if (self.S > self._call_limit or len(self._ranges) > 2) else None
@@ -195,8 +201,9 @@ class GibbsSampler(object):
         self.n_k_delta = self._delta[self.V * KP:]
         self.status = torch.zeros((4,), dtype=torch.int32, device=dev)   # [flags, tier-0 unsure, exact tier, -]
         if counts is None:
-            _native.count_init(self.doc_off, self.word, self.freq, self.z, self.D, self.K,
-                               self.n_dk, self.n_kw, self.n_k)
+            with locked:
+                _native.count_init(self.doc_off, self.word, self.freq, self.z, self.D, self.K,
+                                   self.n_dk, self.n_kw, self.n_k)
             if self.sharded and _dist_active(self.group):
                 import torch.distributed as dist
                 dist.all_reduce(self._counts, group=self.group)
@@ -226,7 +233,8 @@ class GibbsSampler(object):
         self._quad_wanted = quad
         if (rows16 is not False and self.S and self.dense_mask and self.commit_log is not None
                 and _native.rows16_ok(self.K) and self.alpha >= 1e-6 and self.beta >= 1e-6):
-            self._make_rows16(auto=rows16 is None)
+            with locked:
+                self._make_rows16(auto=rows16 is None)
         self.n_kw_img = None
         if image is None and os.environ.get("LLDA_IMAGE") in ("0", "8", "16"):   # for callers behind the LabeledLDA front end
             image = int(os.environ["LLDA_IMAGE"])

@@ -38,6 +38,10 @@ def lib():
         L.llda_oracle_sweep_docs.argtypes = [ctypes.c_int64, P, ctypes.c_int, ctypes.c_int64, P, P, P, P, P, P, P, P,
                                              ctypes.c_double, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint32,
                                              ctypes.c_uint32, ctypes.c_int]
+        L.llda_oracle_sweep_wm.restype = ctypes.c_int
+        L.llda_oracle_sweep_wm.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int64, P, P, P, P, P, P, P,
+                                           ctypes.c_double, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                           ctypes.c_int64, ctypes.c_int]
         L.llda_oracle_pairwise_sum.restype = ctypes.c_double
         L.llda_oracle_pairwise_sum.argtypes = [P, ctypes.c_int64]
         L.llda_oracle_uniform.restype = ctypes.c_double
@@ -101,6 +105,30 @@ class CState(object):
                                      seed, sweep, stream, doc_base, threads)
         if rc != 0:
             raise RuntimeError("llda_oracle_sweep failed: %d" % rc)
+
+
+class WMState(object):
+    """Word-major int32 state for llda_oracle_sweep_wm (dense label mask): n_d_k (D,K) int32, n_kw (V,K) int32, n_k (K,) int32 -- the
+    layout of the GPU kernels; the assignments after a sweep equal CState.sweep(1, ...)'s."""
+
+    def __init__(self, doc_off, word, freq, z, n_d_k, n_k_v, n_zk, V, alpha, beta):
+        self.doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
+        self.word = np.ascontiguousarray(word, dtype=np.int32)
+        self.freq = np.ascontiguousarray(freq, dtype=np.int32)
+        self.z = np.array(z, dtype=np.int32)
+        self.n_d_k = np.array(n_d_k, dtype=np.int32, order="C")
+        self.n_kw = np.ascontiguousarray(np.asarray(n_k_v).T, dtype=np.int32)
+        self.n_k = np.array(n_zk, dtype=np.int32)
+        self.D, self.K = self.n_d_k.shape
+        self.V = int(V)
+        self.alpha, self.beta = float(alpha), float(beta)
+
+    def sweep(self, seed, sweep, stream=0, doc_base=0, threads=1):
+        rc = lib().llda_oracle_sweep_wm(self.D, self.K, self.V, _p(self.doc_off), _p(self.word), _p(self.freq), _p(self.z),
+                                        _p(self.n_d_k), _p(self.n_kw), _p(self.n_k), self.alpha, self.beta, seed, sweep, stream,
+                                        doc_base, threads)
+        if rc != 0:
+            raise RuntimeError("llda_oracle_sweep_wm failed: %d" % rc)
 
 
 def sweep_docs(doc_ids, doc_off, word, freq, z, labs, n_d_k, n_k_v, n_zk, V, alpha, beta, seed, sweep, stream=0,

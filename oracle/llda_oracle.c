@@ -319,3 +319,71 @@ int llda_oracle_sweep_docs(int64_t n_sel, const int64_t *doc_ids, int K, int64_t
     free(ones);
     return err;
 }
+
+/* ---------------- word-major int32 variant (bench.py's strong CPU leg) ----------------
+ * The same per-document snapshot sweep (O3, dense label mask: LocalLDA's case and BASELINE configs[2]/[3]) on the layout the GPU
+ * kernels use: n_kw [V][K] int32 WORD-major -- the reference's strided column n_k_v[:, v] (LabeledLDA.py:114) is one contiguous
+ * row --, n_d_k [D][K] int32, n_k [K] int32.  Same arithmetic, same association order, same keyed draw: the assignments equal
+ * llda_oracle_sweep's (tests/test_oracle_units.py).  Not the reference's layout: reported beside the reference-layout leg. */
+int llda_oracle_sweep_wm(int64_t D, int K, int64_t V,
+                         const int64_t *doc_off, const int32_t *word, const int32_t *freq, int32_t *z,
+                         int32_t *n_d_k, int32_t *n_kw, int32_t *n_k,
+                         double alpha, double beta, uint64_t seed, uint32_t sweep, uint32_t stream,
+                         int64_t doc_base, int threads)
+{
+    layout_t L;
+    if (make_layout(&L, K)) return -1;
+    const int64_t S = doc_off[D];
+    int32_t *z_old = (int32_t *)malloc(sizeof(int32_t) * (size_t)(S ? S : 1));
+    if (!z_old) return -4;
+    memcpy(z_old, z, sizeof(int32_t) * (size_t)S);
+    const double vbeta = (double)V * beta;
+    int err = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        double prob[MAX_KP];
+        int32_t *nk = (int32_t *)malloc(sizeof(int32_t) * (size_t)K);
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t d = 0; d < D; d++) {
+            memcpy(nk, n_k, sizeof(int32_t) * (size_t)K);
+            int32_t *row = n_d_k + d * K;
+            for (int64_t i = doc_off[d]; i < doc_off[d + 1]; i++) {
+                const int32_t *col = n_kw + (int64_t)word[i] * K;
+                const int32_t f = freq[i];
+                const int zo = z[i];
+                row[zo] -= f;
+                nk[zo] -= f;
+                for (int k = 0; k < K; k++) {
+                    const double a = (double)row[k] + alpha;
+                    const double num_b = (double)(col[k] - (k == zo ? f : 0)) + beta;
+                    const double den_b = (double)nk[k] + vbeta;
+                    prob[k] = (1.0 * a) * (num_b / den_b);
+                }
+                const double s = pairwise_sum(prob, K);
+                for (int k = 0; k < K; k++) prob[k] /= s;
+                const double u = keyed_uniform(seed, sweep, stream, (uint32_t)(d + doc_base), (uint32_t)(i - doc_off[d]));
+                const int zn = draw_keyed(&L, prob, u);
+                if (zn < 0) {
+#pragma omp atomic write
+                    err = -3;
+                    break;
+                }
+                z[i] = zn;
+                row[zn] += f;
+                nk[zn] += f;
+            }
+        }
+        free(nk);
+    }
+    for (int64_t i = 0; i < S; i++) {                                 /* the integer deltas (commutative) */
+        const int64_t v = word[i];
+        const int32_t f = freq[i];
+        n_kw[v * K + z_old[i]] -= f;
+        n_kw[v * K + z[i]] += f;
+        n_k[z_old[i]] -= f;
+        n_k[z[i]] += f;
+    }
+    free(z_old);
+    return err;
+}

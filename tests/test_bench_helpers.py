@@ -100,12 +100,16 @@ def _canned_detail(bench, n_gpus=1):
     cpu = {"cpu_model": "AMD EPYC 9575F 64-Core Processor", "physical_cores": 128, "value": 0.0819498709, "unit": "Mtokens/s", "cores": 1,
            "kind": "port", "sample": "first 3000 docs (900000 sites) of the same workload, " + essay, "c_port_1thread_Mtokens_s": 0.33124,
            "c_port_allcores_Mtokens_s": 1.4989, "host_cores": 256, "port_vs_reference": essay,
-           "c_port_strong": {"best": {"threads": 64, "docs": 100000, "sites": 30000000, "seconds": 2.9, "value": 10.3},
-                             "legs": [{"threads": t, "docs": 100000 * t // 64, "sites": 1, "seconds": 3.0, "value": v}
-                                      for t, v in ((64, 10.3), (32, 6.1), (16, 3.2))], "physical_cores": 128, "logical_cores": 256}}
+           "c_port_reference_layout": {"best": {"threads": 64, "docs": 100000, "sites": 30000000, "seconds": 2.9, "value": 10.3},
+                                       "legs": [{"threads": t, "docs": 100000 * t // 64, "sites": 1, "seconds": 3.0, "value": v}
+                                                for t, v in ((64, 10.3), (32, 6.1), (16, 3.2))], "physical_cores": 128, "logical_cores": 256,
+                                       "layout": essay,
+                                       "word_major": {"best": {"threads": 64, "docs": 100000, "sites": 30000000, "seconds": 1.1, "value": 27.5},
+                                                      "legs": [{"threads": t, "docs": 100000 * t // 64, "sites": 1, "seconds": 1.0, "value": v}
+                                                               for t, v in ((64, 27.5), (32, 15.0), (16, 8.0))], "layout": essay}}}
     detail = {"metric": "million tokens resampled/sec (Gibbs sweep)", "value": 6245.746077706536, "unit": "Mtokens/s", "n_gpus": n_gpus,
               "steps": 20, "warmup": 5, "ms_per_step": 48.03269237454515, "higher_is_better": True, "scaling": "strong",
-              "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+              "vs_baseline": None, "dtype": "f64-exact (fp32 tier 0 + fp64 tiers: the drawn topic is the fp64 pipeline's)", "data": "synthetic",
               "config": {"workload": bench.WORKLOADS["synth2"][6], "docs_total": 1000000, "docs_per_gpu": 1000000 // n_gpus,
                          "sites_per_doc": 300, "K": 512, "V": 100000, "alpha": 0.1, "beta": 0.01, "label_mask": "dense",
                          "kernel": "dense", "n_kw_rows": essay, "n_kw_rows_short": "16-bit image + int32 hot rows", "build_info": 0,
@@ -130,7 +134,8 @@ def _canned_detail(bench, n_gpus=1):
                           "ms_per_step": 3.4002120699733496, "timed_seconds": 0.34, "docs": 125000, "sites_per_sweep": 37500000, "K": 512,
                           "V": 100000, "kernel": "sparse", "n_kw_rows": essay, "kernel_ms": 3.31, "note": essay,
                           "roofline": bench.roofline_json(3.31, 37500000, 125000, 8.0, full, essay, shared_bytes=205 * 10 ** 6)}
-        extra["abstracts"]["cpu_baseline"] = dict(cpu, c_port_strong=None)
+        extra["abstracts"]["cpu_baseline"] = dict(cpu, c_port_reference_layout=None)
+        extra["abstracts"].update(unit="Msites/s", Mtokens_s=11028.7 * 1.24, tokens_per_site=1.24)
         extra["abstracts"]["speedup_vs_cpu_port"] = 19876.5
         extra["cascade"] = {"workload": essay, "value": 0.085, "median_s": 0.09, "max_s": 0.18, "unit": "s", "higher_is_better": False,
                             "cold_first_call_s": 1.9, "warm_calls_s": [0.098, 0.085, 0.181, 0.09, 0.09, 0.09], "reference_cpu_note": essay}
@@ -170,8 +175,18 @@ def test_the_printed_line_is_small_parseable_and_numbers_only(bench, n_gpus):
         assert 0 < r["valu_busy_frac"] <= 1.0 and 0 < r["l2_hit_rate"] < 1 and r["binding_roof"] in ("valu_issue", "fabric", "hbm")
         c = back["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] == 1 and c["cpu_model"].startswith("AMD EPYC") and c["value"] > 0
-        assert c["c_port_strong"] == {"value": 10.3, "threads": 64, "docs": 100000, "seconds": 2.9,
-                                      "legs": [[64, 10.3], [32, 6.1], [16, 3.2]]}
+        assert c["c_port_reference_layout"] == {"value": 10.3, "threads": 64, "docs": 100000, "seconds": 2.9,
+                                                "legs": [[64, 10.3], [32, 6.1], [16, 3.2]]}
+        assert c["c_port_word_major"] == {"value": 27.5, "threads": 64, "docs": 100000, "seconds": 1.1,
+                                          "legs": [[64, 27.5], [32, 15.0], [16, 8.0]]}
+        # what the numbers ARE: the SURVEY 8(d) rate over the peak is flagged as no fraction, the HBM fraction is bracketed, the
+        # cache-hostile extra is the kernel's HBM credential, the dtype names both tiers, a real corpus reports sites AND tokens
+        assert r["algorithmic_frac"] == pytest.approx(r["algorithmic_GBps"] / 8000.0, rel=1e-4) and "not a fraction" in r["algorithmic_frac_note"]
+        assert len(r["hbm_frac_bounds"]) == 2 and 0 < r["hbm_frac_bounds"][0] < r["hbm_frac_bounds"][1] <= r["frac"] + 1e-9
+        assert r["hbm_credential"]["workload"] == "hbm_bound" and r["hbm_credential"]["frac"] > 0
+        assert back["dtype"].startswith("f64-exact") and "fp32 tier 0" in back["dtype"]
+        assert back["extra"]["abstracts"]["unit"] == "Msites/s" and back["extra"]["abstracts"]["tokens_per_site"] == 1.24
+        assert back["extra"]["abstracts"]["Mtokens_s"] == pytest.approx(11028.7 * 1.24, rel=1e-4)
         assert set(back["extra"]) == set(detail["extra"])
         for key, e in back["extra"].items():
             assert "value" in e and "unit" in e, key

@@ -73,3 +73,32 @@ def test_draw_frequencies_follow_the_probabilities():
     us = (np.arange(20000) + 0.5) / 20000
     counts = np.bincount([orc.draw_keyed(p, u) for u in us], minlength=K)
     np.testing.assert_allclose(counts / 20000.0, p, atol=2e-4)
+
+
+@pytest.mark.parametrize("K", [12, 130, 512])
+def test_word_major_c_sweep_equals_the_reference_layout_sweep(c_oracle, K):
+    """bench.py's strong CPU leg (llda_oracle_sweep_wm: int32, word-major -- the GPU kernels' layout) leaves the assignments and counts
+    of the reference-layout C oracle (LabeledLDA.py:108-125 restated) under O3, dense label mask, several threads"""
+    rng = np.random.default_rng(K)
+    D, V = 40, 60
+    lens = rng.integers(1, 30, size=D)
+    doc_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    S = int(doc_off[-1])
+    word = np.concatenate([rng.choice(V, size=n, replace=False) for n in lens]).astype(np.int32)
+    freq = rng.integers(1, 5, size=S).astype(np.int32)
+    z = rng.integers(0, K, size=S).astype(np.int32)
+    n_d_k = np.zeros((D, K), dtype=np.int64)
+    n_k_v = np.zeros((K, V), dtype=np.int64)
+    doc = np.repeat(np.arange(D), lens)
+    np.add.at(n_d_k, (doc, z), freq)
+    np.add.at(n_k_v, (z, word), freq)
+    n_zk = n_k_v.sum(axis=1)
+    a = c_oracle.CState(doc_off, word, freq, z, np.ones((D, K), dtype=np.uint8), n_d_k, n_k_v, n_zk, V, 0.1, 0.01)
+    b = c_oracle.WMState(doc_off, word, freq, z, n_d_k, n_k_v, n_zk, V, 0.1, 0.01)
+    for i in range(3):
+        a.sweep(1, 11, i, stream=2, doc_base=5, threads=2)
+        b.sweep(11, i, stream=2, doc_base=5, threads=3)
+        np.testing.assert_array_equal(a.z, b.z)
+        np.testing.assert_array_equal(a.n_d_k, b.n_d_k)
+        np.testing.assert_array_equal(a.n_k_v.T, b.n_kw)
+        np.testing.assert_array_equal(a.n_zk, b.n_k)
