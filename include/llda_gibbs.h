@@ -316,7 +316,7 @@ int llda_pack_rows16_all(const int32_t *n_kw, int64_t V, int32_t K, uint16_t *n_
 
 /* The saturating narrow image of n counts for llda_sweep_args.n_kw_img (ABI 18): img[i] = min(n_kw[i], 255) as uint8_t
  * (bits 8) or min(n_kw[i], 65535) as uint16_t (bits 16); a negative count saturates as well.  n = V*KP, a multiple of 4;
- * n_kw and img 16-byte / 4-byte aligned.  Call it once per sweep, after the counts of the previous sweep were folded in and
+ * n_kw 16-byte aligned, img 4-byte (bits 8) / 8-byte (bits 16) aligned -- llda_sweep asks the same of llda_sweep_args.n_kw_img.  Call it once per sweep, after the counts of the previous sweep were folded in and
  * before the first llda_sweep. */
 int llda_pack_image(const int32_t *n_kw, int64_t n, int32_t bits, void *img, void *stream);
 

@@ -171,8 +171,11 @@ class SubLDA(object):
         return self._upload().ph_rows().cpu().numpy()
 
     def training_iteration(self):
-        """One Gibbs sweep: reference CascadeLDA.py:397-421 (same body as LabeledLDA.py:101-125)."""
-        self._upload().sweep()
+        """One Gibbs sweep: reference CascadeLDA.py:397-421 (same body as LabeledLDA.py:101-125); the status word as in
+        LabeledLDA.training_iteration."""
+        sm = self._upload()
+        sm.sweep()
+        sm.post_status()
 
     def run_training(self, it=120, thinning=15):
         """reference CascadeLDA.py:423-434: snapshot ph when (i+1)/thinning is integral."""

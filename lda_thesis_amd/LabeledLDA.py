@@ -136,20 +136,26 @@ class LabeledLDA(object):
     # and pickling (__getstate__) GATHER the per-rank slices and are therefore COLLECTIVE -- every rank must read
     # them (reading on one rank only, e.g. `if rank == 0: pickle.dump(model)`, blocks).  n_zk, n_k_v, ph_hat and
     # perplexity() are replicated / already reduced and can be read anywhere.
+    # (materialising the state synchronises anyway: the status word is looked at first -- where the reference would have raised
+    # inside the sweep, LabeledLDA.py:117-119, the caller gets the ValueError no later than here)
     @property
     def n_zk(self):
+        self._sampler.check_status()
         return self._sampler.n_zk()
 
     @property
     def n_d_k(self):
+        self._sampler.check_status()
         return _gather_rows(self._sampler.n_d_k())
 
     @property
     def n_k_v(self):
+        self._sampler.check_status()
         return self._sampler.n_k_v()
 
     @property
     def z_dn(self):
+        self._sampler.check_status()
         z = _gather_rows(self._sampler.z_topics())
         return [z[self._doc_off[d]:self._doc_off[d + 1]].copy() for d in range(self.D)]
 
@@ -180,8 +186,11 @@ class LabeledLDA(object):
 
     # ---- training ----
     def training_iteration(self):
-        """One Gibbs sweep over every (document, word) site: reference LabeledLDA.py:101-125."""
+        """One Gibbs sweep over every (document, word) site: reference LabeledLDA.py:101-125.  A site whose probabilities are all
+        zero makes numpy raise at that site (LabeledLDA.py:117-119); here the kernels set a status bit, which a caller that loops this
+        method sees a few sweeps later (an asynchronous copy, no synchronisation) and at the latest when it reads the counts."""
         self._sampler.sweep()
+        self._sampler.post_status()
 
     def run_training(self, iters, thinning):
         """Sweep loop with thinning read-outs and running means: reference LabeledLDA.py:127-153.  phi, theta,

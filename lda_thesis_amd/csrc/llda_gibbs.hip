@@ -434,7 +434,7 @@ static int take_image(const llda_sweep_args *a, KParams &P)
     P.img = nullptr;
     if (!a->n_kw_img && !a->img_bits) return LLDA_OK;
     if (!a->n_kw_img || (a->img_bits != 8 && a->img_bits != 16)) return LLDA_E_BAD_ARG;
-    if (reinterpret_cast<uintptr_t>(a->n_kw_img) & 3) return LLDA_E_BAD_ARG;
+    if (reinterpret_cast<uintptr_t>(a->n_kw_img) & (a->img_bits == 8 ? 3 : 7)) return LLDA_E_BAD_ARG;     // (as llda_pack_image)
     P.img = a->n_kw_img;
     return LLDA_OK;
 }
@@ -490,7 +490,10 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         static_cast<KParams &>(W) = P;
         W.site_rec = nullptr;
         W.live_off = a->live_off; W.live_pos = a->live_pos;
-        if (a->debug_margin < 0) W.margin_rel = 2.0;        // test hook: every site goes through the exact pipeline
+        if (a->debug_margin < 0) {                          // test hook: every site goes through the exact pipeline
+            W.margin_rel = 2.0;
+            W.margin0_rel = 2.0f;                           // (also with -8, which keeps the fp32 tier only for the dense 16-bit-row kernel)
+        }
         fill_wide(L, W.w);
         const int GS = a->live_max <= 8 ? 8 : a->live_max <= 16 ? 16 : a->live_max <= 32 ? 32 : 64;
         int dpg = a->docs_per_group < 1 ? 1 : a->docs_per_group;
@@ -611,7 +614,10 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
 
     if (sparse) {
         P.live_off = a->live_off; P.live_pos = a->live_pos;
-        if (a->debug_margin < 0) P.margin_rel = 2.0;       // test hook: every site goes through the exact pipeline
+        if (a->debug_margin < 0) {                         // test hook: every site goes through the exact pipeline
+            P.margin_rel = 2.0;
+            P.margin0_rel = 2.0f;                          // (also with -8, which keeps the fp32 tier only for the dense 16-bit-row kernel)
+        }
         const dim3 grid((unsigned)blocks), block(256);
         const int rimg = take_image(a, P);
         if (rimg) return rimg;

@@ -6,8 +6,6 @@ macro_auc_roc, n_error, get_f1, binary_yreal) and /root/reference/evaluate_Casca
 cases (the counts are numpy integers as in the reference, so a rate with an empty denominator is
 nan/inf with a RuntimeWarning rather than an exception, and get_f1 skips nan with nanmax).  Pinned by tests/golden/evaluate.npz.
 """
-import re
-
 import numpy as np
 
 
@@ -80,14 +78,15 @@ def n_error(th_hat, y_real_binary, n):
 
 
 def get_f1(tps, fps, tns, fns):
-    """mean over documents of the best F1 over thresholds: evaluate_LabeledLDA.py:85-93."""
-    f1 = []
-    for tp, fp, tn, fn in zip(tps, fps, tns, fns):
-        prec, rec = precision_recall(tp, fp, tn, fn)
-        with np.errstate(invalid='ignore'):
-            raw = [(2 * p * r) / (p + r) for p, r in zip(prec, rec)]
-        f1.append(np.nanmax(raw))
-    return np.mean(f1)
+    """mean over documents of the best F1 over the thresholds of the document: evaluate_LabeledLDA.py:85-93.  One array expression
+    per document; a threshold without positives on either side gives nan (0 / 0 on numpy integers, as there) and is skipped."""
+    best = np.empty(len(tps))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for d, (tp, fp, fn) in enumerate(zip(tps, fps, fns)):
+            tp, fp, fn = np.asarray(tp), np.asarray(fp), np.asarray(fn)
+            prec, rec = tp / (tp + fp), tp / (tp + fn)
+            best[d] = np.nanmax((2 * prec * rec) / (prec + rec))
+    return np.mean(best)
 
 
 def binary_yreal(label_strings, label_dict):
@@ -100,24 +99,38 @@ def binary_yreal(label_strings, label_dict):
     return y_true
 
 
+def _codes_below(code, codes):
+    """the codes that extend ``code`` by exactly one digit, as they occur in ``codes`` (a code can occur inside a longer one: 'C6' is
+    found in 'C6' but not in 'C61', whose next character is a digit as well) -- what evaluate_CascadeLDA.py:113-114 asks its
+    pattern for."""
+    n, out = len(code), []
+    for c in codes:
+        i = c.find(code)
+        while i >= 0:
+            j = i + n
+            if j < len(c) and c[j].isdigit() and (j + 1 == len(c) or not c[j + 1].isdigit()):
+                out.append(c[i:j + 1])
+            i = c.find(code, i + 1)
+    return out
+
+
 def setup_theta(l1p, l2p, l3p, model):
-    """fold the per-level predictions of CascadeLDA.test_down_tree into one (docs, labels) matrix,
-    multiplying every local load by the loads of its ancestors: evaluate_CascadeLDA.py:95-127."""
-    n, k = len(l1p), len(model.labelmap)
-    th_hat = np.zeros((n, k), dtype=float)
-    for d in range(n):
-        levels = dict()
-        for tuplist in l3p[d]:
-            levels.update(tuplist)
-        for tuplist in l2p[d]:
-            levels.update(tuplist)
-        levels.update(l1p[d])
-        lookup = " ".join(list(levels.keys()))
-        for p in [s for (s, _) in l1p[d]]:
-            for c in re.findall(re.compile("(" + p + "[0-9])(?:[^0-9]|$)"), lookup):
-                levels[c] *= levels[p]
-                for f in re.findall(re.compile(c + "[0-9]"), lookup):
-                    levels[f] *= levels[c]
-        labs, probs = zip(*levels.items())
-        th_hat[d, [model.labelmap[x] for x in labs]] = probs
+    """Fold the per-level predictions of CascadeLDA.test_down_tree into one (documents, labels) matrix: a load is local to its
+    parent's sub-problem, so a second-level code is scaled by its first-level code and every third-level code below it by the
+    product (evaluate_CascadeLDA.py:95-127).  Per document ONE table code -> load, filled deepest level first (an upper level
+    overwrites what a lower one said about the same code, as there), then one walk down from the first-level codes."""
+    th_hat = np.zeros((len(l1p), len(model.labelmap)))
+    for d, (first, second, third) in enumerate(zip(l1p, l2p, l3p)):
+        load = {}
+        for group in list(third) + list(second) + [first]:
+            load.update(group)
+        codes = list(load)
+        for top, _ in first:
+            for mid in _codes_below(top, codes):
+                load[mid] *= load[top]
+                for c in codes:                                # every code that holds  mid + one more digit
+                    for i in range(len(c) - len(mid)):
+                        if c.startswith(mid, i) and c[i + len(mid)].isdigit():
+                            load[c[i:i + len(mid) + 1]] *= load[mid]
+        th_hat[d, [model.labelmap[c] for c in codes]] = [load[c] for c in codes]
     return th_hat

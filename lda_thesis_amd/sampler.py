@@ -214,7 +214,8 @@ class GibbsSampler(object):
         # wide layouts, dense or general label masks: work space that lets the sweep keep fp32 factors only in LDS
         # (llda_sweep_args.scratch)
         self._scratch = None
-        if lay.wide and self.live_off is None and self.D > 0:
+        if lay.wide and (self.live_off is None or self._heavy is not None) and self.D > 0:
+            # (sparse label sets: the HEAVY documents of the shard go to the general wide kernel in a launch of their own, _lane_parts)
             nbytes = _native.sweep_scratch_bytes(self.K, max(hi - lo for lo, hi, _ in self._calls))
             if nbytes:
                 self._scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
@@ -270,18 +271,20 @@ class GibbsSampler(object):
         refreshed by llda_pack_image at the start of every sweep.  bits=None picks 8, 16 or no image from the size of the problem
         and the sampled escape rates; the choice only ever changes how fast a sweep runs."""
         n = self.V * self.layout.KP
-        if bits is None:
-            if n * 4 < self.IMAGE_MIN_BYTES or self.S < self.IMAGE_MIN_SITES:
-                return
-            r8, r16 = self._image_escape_rates()
-            bits = 8 if r8 <= self.IMAGE_MAX_ESCAPES else 16 if r16 <= self.IMAGE_MAX_ESCAPES else 0
-            if not bits:
-                return
+        if self.live_max == 0:
+            return                                              # (every document is heavy: no launch of the sparse-label kernel)
         try:
+            if bits is None:
+                if n * 4 < self.IMAGE_MIN_BYTES or self.S < self.IMAGE_MIN_SITES:
+                    return
+                r8, r16 = self._image_escape_rates()
+                bits = 8 if r8 <= self.IMAGE_MAX_ESCAPES else 16 if r16 <= self.IMAGE_MAX_ESCAPES else 0
+                if not bits:
+                    return
             self.n_kw_img = torch.zeros((n,), dtype=torch.uint8 if bits == 8 else torch.int16, device=self.device)
         except torch.cuda.OutOfMemoryError:
             import warnings
-            warnings.warn("GibbsSampler: no room for the %d-bit image of n_kw (%.1f GB); gathering from n_kw itself" % (bits, n * bits / 8e9))
+            warnings.warn("GibbsSampler: no room for the narrow image of n_kw (%.1f GB at 8 bits); gathering from n_kw itself" % (n / 1e9))
             self.n_kw_img = None
 
     ROWS16_MIN_BYTES = 64 << 20      # rows16=None, documents of 2^16 tokens or more (three waves per SIMD): below this n_kw
@@ -510,10 +513,10 @@ class GibbsSampler(object):
         document is in changes nothing (snapshot semantics); ``order`` is kept inside a class."""
         if self.live_off is None or (self.live_max <= 8 and self._heavy is None) or hi <= lo:
             return [(order, hi - lo, self.live_max)]
-        key = (lo, hi, None if order is None else order.data_ptr())
+        key = (lo, hi)
         hit = self._parts_cache.get(key)
-        if hit is not None:
-            return hit
+        if hit is not None and hit[0] is order:              # (the SAME tensor object: an address can be handed out again)
+            return hit[1]
         idx = order.to(torch.int64) if order is not None else torch.arange(hi - lo, device=self.device)
         n = (self.live_off[lo + 1:hi + 1] - self.live_off[lo:hi])[idx]
         heavy = self._heavy[lo:hi][idx] if self._heavy is not None else torch.zeros_like(n, dtype=torch.bool)
@@ -525,9 +528,7 @@ class GibbsSampler(object):
         sel = idx[heavy]
         if sel.numel():
             parts.append((sel.to(torch.int32).contiguous(), int(sel.numel()), 0))
-        if len(self._parts_cache) >= 64:                      # (grows only when a caller keeps replacing doc_order)
-            self._parts_cache.clear()
-        self._parts_cache[key] = parts
+        self._parts_cache[key] = (order, parts)              # (holds the keyed tensor: one entry per call range)
         return parts
 
     def _make_commit_log(self):
@@ -690,9 +691,32 @@ class GibbsSampler(object):
                                                                           self.rows.numel() * 4 / 1e6))
         return "one RCCL int32 SUM all-reduce per sweep of the n_kw / n_k delta buffer, %.1f MB" % (self._delta.numel() * 4 / 1e6)
 
+    STATUS_EVERY = 4     # sweeps between two asynchronous copies of the status word (post_status)
+
+    def post_status(self, every=None):
+        """For callers that loop ``sweep()`` themselves (the reference's ``training_iteration`` API, LabeledLDA.py:101): every
+        ``every`` sweeps an asynchronous copy of the status word is queued behind the sweep, and the copy queued EARLIER is looked at
+        when it has landed -- no synchronisation; a site without a topic of positive probability (numpy raises at that site,
+        LabeledLDA.py:117-119) raises here at most ``every`` + 1 sweeps late instead of only at the next thinning point."""
+        import torch
+        ev = getattr(self, "_status_event", None)
+        if ev is not None and ev.query():
+            self._status_event = None
+            self._raise_for(int(self._status_host[0]))
+        every = self.STATUS_EVERY if every is None else every
+        if self._status_event is None and self.sweeps_done % max(1, every) == 0:
+            if getattr(self, "_status_host", None) is None:
+                self._status_host = torch.zeros((4,), dtype=torch.int32).pin_memory()
+            self._status_host.copy_(self.status[:4], non_blocking=True)
+            self._status_event = torch.cuda.Event()
+            self._status_event.record()
+
     def check_status(self):
         """Raise like the reference would (numpy's multinomial rejects a NaN pvals vector)."""
-        st = int(self.status[0].item())
+        self._raise_for(int(self.status[0].item()))
+
+    @staticmethod
+    def _raise_for(st):
         if st & 1:
             raise ValueError("a site had no topic with positive probability (pvals would be NaN)")
         if st & 4:

@@ -492,3 +492,28 @@ def test_sampler_validates_frequencies_and_word_ids():
     s = GibbsSampler(off, w, np.array([1, (1 << 23) - 1]), z, 2, 3, 0.1, 0.01)
     s.sweep()
     assert int(s.n_k.sum()) == 1 << 23
+
+
+def test_training_iteration_loop_raises_where_the_reference_raises():
+    """alpha = 0 and a document of ONE site: once the site has left its topic every allowed topic of the document has n_dk + alpha = 0, the
+    probabilities are all zero, `prob /= np.sum(prob)` is NaN and numpy's multinomial raises ValueError inside training_iteration
+    (/root/reference/LabeledLDA.py:117-119).  A caller that loops training_iteration() -- never run_training -- gets the ValueError
+    from the status word: a few sweeps late through the asynchronous copy, at the latest when it reads the counts."""
+    from lda_thesis_amd.LabeledLDA import LabeledLDA
+    from lda_thesis_amd.text import Dictionary
+    docs = [["aa", "bb", "cc", "aa"], ["bb"], ["cc", "dd", "aa"]]
+    labs = [["x"], ["y"], ["x", "y"]]
+    np.random.seed(3)
+    m = LabeledLDA(docs, labs, ["x", "y"], Dictionary(docs), 0.0, 0.01, seed=5)
+    with pytest.raises(ValueError, match="positive probability"):
+        for _ in range(64):                               # the copy of the status word is polled without synchronising: it lands
+            m.training_iteration()                        # within a few sweeps
+    m = LabeledLDA(docs, labs, ["x", "y"], Dictionary(docs), 0.0, 0.01, seed=5)
+    m.training_iteration()
+    with pytest.raises(ValueError, match="positive probability"):
+        m.n_d_k                                           # (materialising the counts looks at the status word first)
+    # the same corpus with alpha > 0 is fine
+    m = LabeledLDA(docs, labs, ["x", "y"], Dictionary(docs), 0.1, 0.01, seed=5)
+    for _ in range(8):
+        m.training_iteration()
+    assert m.n_d_k.sum() == 8
