@@ -74,6 +74,10 @@ WORKLOADS = {
                            "synthetic 125k docs x 300 tokens, K=512, sparse label mask with CO-LOCATED labels: root + 7 labels drawn "
                            "from ONE block of 32 consecutive topic ids per document (a label hierarchy whose siblings have "
                            "neighbouring ids: 32 consecutive topics share a 128-byte line of every n_kw row), V=100k"),
+    "synth2_sparse_scr": (125000, 300, 100000, 512, 1.0, 15625,
+                          "the co-located label sets of synth2_sparse_hier with the topic ids SCRAMBLED by a fixed permutation: the same "
+                          "co-occurrence structure, but the caller's label order no longer puts siblings next to each other -- what the "
+                          "sampler's own column order of the narrow image (GibbsSampler(image_order=...)) is for"),
     "synth_wide_sparse": (125000, 300, 100000, 2048, 1.0, 15625,
                           "synthetic 125k docs x 300 tokens, K=2048 (a 'wide' layout), sparse label mask (root + 7 random "
                           "labels per doc), V=100k: Labeled LDA proper with thousands of labels -- the sparse-label kernel "
@@ -154,14 +158,19 @@ def build_sampler(name, dev, rank, world, dist_on, docs_total=0, docs_per_group=
         doc_off, word, freq, z = synthetic_corpus_blocks(lo, hi, N, V, K, 1234, dev, zipf_s=zs, block=block)
     Dg = hi - lo
     info["docs_local"] = Dg
-    if name in ("synth2_sparse", "synth_wide_sparse", "synth2_sparse_hier"):
+    if name in ("synth2_sparse", "synth_wide_sparse", "synth2_sparse_hier", "synth2_sparse_scr"):
         gen = torch.Generator(device=dev)
         gen.manual_seed(99 + rank)
-        if name == "synth2_sparse_hier":
+        if name in ("synth2_sparse_hier", "synth2_sparse_scr"):
             # 7 distinct labels inside one block of 32 consecutive topic ids (block 0 without the root's id 0)
             blk = torch.randint(0, K // 32, (Dg, 1), device=dev, generator=gen)
             inner = torch.argsort(torch.rand((Dg, 31), device=dev, generator=gen), dim=1)[:, :7] + 1     # 7 of 1..31
             lab = torch.sort(blk * 32 + inner, dim=1).values
+            if name == "synth2_sparse_scr":                  # the same sets under a fixed permutation of the ids 1 .. K-1
+                g2 = torch.Generator(device=dev)
+                g2.manual_seed(4242)
+                perm = torch.cat([torch.zeros((1,), dtype=torch.int64, device=dev), torch.randperm(K - 1, device=dev, generator=g2) + 1])
+                lab = torch.sort(perm[lab], dim=1).values
         else:
             # root + 7 distinct random labels per document: sort 7 draws, bump duplicates (still <= K-1)
             lab = torch.sort(torch.randint(1, K - 8, (Dg, 7), device=dev, generator=gen), dim=1).values
@@ -410,7 +419,7 @@ def cpu_baseline_json(sampler, info, name, value):
     Dg = info["docs_local"]
     n_py = n_c = min(Dg, 3000)                         # ~10 s of single-core numpy work at K=512
     labs_h = None
-    if name in ("synth2_sparse", "synth2_sparse_hier"):
+    if name in ("synth2_sparse", "synth2_sparse_hier", "synth2_sparse_scr"):
         labs_h = np.zeros((n_py, K), dtype=np.uint8)
         lh = info["lab"][:n_py].cpu().numpy()
         labs_h[np.repeat(np.arange(lh.shape[0]), 8), lh.reshape(-1)] = 1
@@ -428,7 +437,7 @@ def cpu_baseline_json(sampler, info, name, value):
     strong = None
     if name != "abstracts":                            # (abstracts: the whole corpus already ran on all cores above)
         lab_rows = None
-        if name in ("synth2_sparse", "synth2_sparse_hier"):
+        if name in ("synth2_sparse", "synth2_sparse_hier", "synth2_sparse_scr"):
             n_top = min(Dg, STRONG_CPU_DOCS)
             lab_rows = np.zeros((n_top, K), dtype=np.uint8)
             lh = info["lab"][:n_top].cpu().numpy()
@@ -682,7 +691,7 @@ def cascade_test_extra(with_cpu=True):
 
 # ------------------------------------------------------------------------------------------------ PMC passes
 # every workload whose sweep is ONE kernel launch per sweep, in the order the inner run sweeps them
-PMC_WORKLOADS = ("synth2", "synth1", "synth2_hostile", "synth2_sparse", "synth2_sparse_hier", "synth_wide_sparse", "synth_wide",
+PMC_WORKLOADS = ("synth2", "synth1", "synth2_hostile", "synth2_sparse", "synth2_sparse_hier", "synth2_sparse_scr", "synth_wide_sparse", "synth_wide",
                  "abstracts")
 PMC_SWEEPS = 3                                              # per workload in the inner run (all are measured)
 # one rocprofv3 run per group (kernel trace only, as the guide prescribes).  TCC holds 4 counters per pass
@@ -1280,7 +1289,8 @@ def main():
         if extras_on:
             for key, wname, st, wu in (("synth1", "synth1", 200, 5), ("hbm_bound", "synth2_hostile", 40, 3),
                                        ("sparse_labels", "synth2_sparse", 100, 5),
-                                       ("sparse_labels_colocated", "synth2_sparse_hier", 100, 5), ("abstracts", "abstracts", 3000, 20),
+                                       ("sparse_labels_colocated", "synth2_sparse_hier", 100, 5),
+                                       ("sparse_labels_scrambled", "synth2_sparse_scr", 100, 5), ("abstracts", "abstracts", 3000, 20),
                                        ("wide_k2048", "synth_wide", 20, 2), ("wide_sparse_k2048", "synth_wide_sparse", 50, 3)):
                 s2, i2 = build_sampler(wname, dev, 0, 1, False)
                 torch.cuda.synchronize()
@@ -1310,6 +1320,10 @@ def main():
                     e["note"] = ("the same kernel and arithmetic as sparse_labels; only WHICH labels a document carries differs: "
                                  "siblings with neighbouring topic ids share cache lines (a caller gets this by ordering a "
                                  "hierarchical labelset by code before handing it to LabeledLDA)")
+                if wname == "synth2_sparse_scr":
+                    e["live_topics_per_doc"] = i2["live_topics"]
+                    e["note"] = ("sparse_labels_colocated's label sets under a fixed permutation of the topic ids: the image's own column "
+                                 "order (greedy clustering of the label co-occurrence) puts the siblings back into shared cache lines")
                 if wname == "synth2_sparse":
                     e["live_topics_per_doc"] = i2["live_topics"]
                     e["algorithmic_GBps"] = algorithmic_bytes(s2.S, i2["docs_local"], i2["live_topics"]) / (k2 * 1e-3) / 1e9
@@ -1340,7 +1354,7 @@ def main():
         line["roofline"] = roofline_json(m["kernel_ms"], m["sites"], m["docs"], m["live"], pmc.get(name), source,
                                          stored_key=name, shared_bytes=m["shared"])
         for key, wname in (("synth1", "synth1"), ("hbm_bound", "synth2_hostile"), ("sparse_labels", "synth2_sparse"),
-                           ("sparse_labels_colocated", "synth2_sparse_hier"), ("wide_sparse_k2048", "synth_wide_sparse"), ("wide_k2048", "synth_wide"), ("abstracts", "abstracts")):
+                           ("sparse_labels_colocated", "synth2_sparse_hier"), ("sparse_labels_scrambled", "synth2_sparse_scr"), ("wide_sparse_k2048", "synth_wide_sparse"), ("wide_k2048", "synth_wide"), ("abstracts", "abstracts")):
             if key in extra:
                 m = measured[wname]
                 extra[key]["roofline"] = roofline_json(m["kernel_ms"], m["sites"], m["docs"], m["live"], pmc.get(wname),

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 19
+#define LLDA_ABI_VERSION 20
 #define LLDA_MAX_K 7688          /* every K up to here splits into <= 64 pairwise leaves                       */
 #define LLDA_MAX_KP 8192         /* longest padded row: 64 leaves x 128                                        */
 #define LLDA_MAX_LEAVES 8        /* "narrow" layouts: one lane group of <= 64 lanes x <= 16 slots per document  */
@@ -192,6 +192,11 @@ typedef struct llda_sweep_args {
                                     pick and count update is shared by four sites instead of two.  A site whose row is not flagged
                                     reads the int32 row (no prefetch: meant to be rare).  Bit 31 of csc_pos is ignored.  Results do
                                     not depend on it. */
+    const int32_t *img_col;      /* [dev] [KP] optional (ABI 20), with n_kw_img: the image column that holds the count of every device
+                                    position -- the inverse of the col_src handed to llda_pack_image_cols.  The sparse-label kernel is
+                                    bound by the L2's line fills: an image whose columns are ordered so that topics which are allowed
+                                    TOGETHER sit in one 128-byte line costs a site fewer fills.  NULL: column = position
+                                    (llda_pack_image).  Results do not depend on it. */
 } llda_sweep_args;
 
 /* ---- host-only (no device needed) ---- */
@@ -307,6 +312,10 @@ int llda_apply_rows(const int64_t *row_off, int32_t *rows, int64_t n_rows, int32
  * of status word 0. */
 int llda_pack_rows16(const int32_t *n_kw, const uint8_t *row16, int64_t V, int32_t K, uint16_t *n_kw16, int32_t *status,
                      void *stream);
+
+/* llda_pack_image with the image's columns in an order of the caller's (ABI 20): img[v][c] = min(n_kw[v][col_src[c]], 255 | 65535)
+ * for c < KP; col_src (dev, int32[KP], 16-byte aligned) is a permutation of the device positions.  For llda_sweep_args.n_kw_img + img_col. */
+int llda_pack_image_cols(const int32_t *n_kw, int64_t V, int32_t K, int32_t bits, const int32_t *col_src, void *img, void *stream);
 
 /* The 16-bit image of EVERY row of n_kw plus, per word, whether all counts of its row fit 16 bits in this sweep's n_kw
  * (row16[v] = 1; ABI 19) -- for llda_sweep_args.row16.  K = 512 only (LLDA_E_BAD_K otherwise); n_kw and n_kw16 16-byte aligned.

@@ -16,7 +16,7 @@ MAX_KP = 8192
 MAX_LEAVES = 8          # narrow layouts
 MAX_WIDE_LEAVES = 64
 MAX_ROUNDS = 4
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -55,7 +55,7 @@ class LldaSweepArgs(ctypes.Structure):
                 ("live_off", _c_p), ("live_pos", _c_p), ("scratch", _c_p), ("scratch_bytes", _c_i64),
                 ("live_max", _c_i32), ("max_doc_tokens", _c_i32), ("csc_pos", _c_p), ("commit_log", _c_p),
                 ("n_sites", _c_i64), ("site_rec", _c_p), ("n_kw16", _c_p), ("site_row", _c_p),
-                ("n_kw_img", _c_p), ("img_bits", _c_i32), ("reserved_img", _c_i32), ("row16", _c_p)]
+                ("n_kw_img", _c_p), ("img_bits", _c_i32), ("reserved_img", _c_i32), ("row16", _c_p), ("img_col", _c_p)]
 
 
 class LldaBatchArgs(ctypes.Structure):
@@ -69,7 +69,7 @@ class LldaBatchArgs(ctypes.Structure):
 
 
 EXPORTS = ("llda_abi_version", "llda_build_info", "llda_strerror", "llda_last_hip_error", "llda_struct_size", "llda_layout_init",
-           "llda_sweep_scratch_bytes", "llda_rows16_ok", "llda_pack_rows16", "llda_pack_rows16_all", "llda_pack_image",
+           "llda_sweep_scratch_bytes", "llda_rows16_ok", "llda_pack_rows16", "llda_pack_rows16_all", "llda_pack_image", "llda_pack_image_cols",
 
            "llda_sweep", "llda_sweep_batch", "llda_commit_log", "llda_apply_rows", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
            "llda_readout_phi", "llda_readout_theta", "llda_selftest_div")
@@ -115,6 +115,8 @@ def lib():
     L.llda_pack_rows16.argtypes = [_c_p, _c_p, _c_i64, _c_i32, _c_p, _c_p, _c_p]
     L.llda_pack_rows16_all.restype = ctypes.c_int
     L.llda_pack_rows16_all.argtypes = [_c_p, _c_i64, _c_i32, _c_p, _c_p, _c_p]
+    L.llda_pack_image_cols.restype = ctypes.c_int
+    L.llda_pack_image_cols.argtypes = [_c_p, _c_i64, _c_i32, _c_i32, _c_p, _c_p, _c_p]
     L.llda_pack_image.restype = ctypes.c_int
     L.llda_pack_image.argtypes = [_c_p, _c_i64, _c_i32, _c_p, _c_p]
     L.llda_sweep_batch.restype = ctypes.c_int
@@ -207,7 +209,8 @@ def _launch(ref, fn, what, *args):
 def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
           status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
           dense_mask=False, debug_margin=0, live_off=None, live_pos=None, live_max=0, csc_pos=None, commit_log=None,
-          n_sites=None, site_rec=None, max_doc_tokens=0, scratch=None, n_kw16=None, site_row=None, n_kw_img=None, row16=None):
+          n_sites=None, site_rec=None, max_doc_tokens=0, scratch=None, n_kw16=None, site_row=None, n_kw_img=None, row16=None,
+          img_col=None):
     """llda_sweep on the current torch stream.  All array arguments are torch CUDA tensors.  n_sites = the sites
     the D documents span (default: all of ``word``); scratch = a uint8 tensor of sweep_scratch_bytes(K, D) bytes (wide
     layouts) or None; n_kw16 = the 16-bit image written by pack_rows16 (then csc_pos carries the row flags in bit 31 and site_row the row starts) or None;
@@ -222,7 +225,7 @@ def sweep(*, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta
                       int(stream_id) & 0xFFFFFFFF, int(doc_base), _ptr(live_off), _ptr(live_pos), _ptr(scratch),
                       0 if scratch is None else int(scratch.numel() * scratch.element_size()), int(live_max), int(max_doc_tokens),
                       _ptr(csc_pos), _ptr(commit_log), int(word.numel() if n_sites is None else n_sites), _ptr(site_rec),
-                      _ptr(n_kw16), _ptr(site_row), _ptr(n_kw_img), img_bits, 0, _ptr(row16))
+                      _ptr(n_kw16), _ptr(site_row), _ptr(n_kw_img), img_bits, 0, _ptr(row16), _ptr(img_col))
     _launch(z, lib().llda_sweep, "llda_sweep", ctypes.byref(a))
 
 
@@ -246,6 +249,12 @@ def pack_rows16_all(n_kw, K, n_kw16, row16):
     """llda_pack_rows16_all on the current torch stream: the 16-bit image of EVERY row of n_kw and, in row16 (uint8 [V]), whether
     all counts of the row fit 16 bits."""
     _launch(n_kw, lib().llda_pack_rows16_all, "llda_pack_rows16_all", _ptr(n_kw), int(row16.numel()), int(K), _ptr(n_kw16), _ptr(row16))
+
+
+def pack_image_cols(n_kw, K, col_src, img):
+    """llda_pack_image_cols: the saturating image with its columns in the order col_src (int32 [KP] on the device)."""
+    _launch(n_kw, lib().llda_pack_image_cols, "llda_pack_image_cols", _ptr(n_kw), int(n_kw.shape[0]), int(K), 8 * img.element_size(),
+            _ptr(col_src), _ptr(img))
 
 
 def pack_image(n_kw, img):

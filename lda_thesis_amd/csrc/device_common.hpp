@@ -55,6 +55,7 @@ struct KParams {
     const int32_t *site_row;   // with n_kw16: start of the row of each site's word, 16-byte units from n_kw (read instead of word)
     const void *img;           // sparse-label kernels: optional narrow image of n_kw (llda_pack_image: one byte / 16-bit word per count,
                                // saturating); an entry that reads 255 / 65535 is re-read from n_kw
+    const int32_t *img_col;    // with img: image column of every device position (llda_pack_image_cols); NULL = the position itself
     int w4;                    // with n_kw16: documents hold < 2^16 tokens -- the four-wave form of the kernel may run
     const uint8_t *row16;      // quad kernel (kernel_quad.hpp): per word, 1 = every count of its row fits the 16-bit image this sweep
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];   // 4 bits per leaf: partner leaf

@@ -53,6 +53,37 @@ __global__ void __launch_bounds__(256) llda_pack_image_kernel(const int4 *__rest
     }
 }
 
+// the same with the image's columns in an order of their own: image column c of every row holds the count at position col_src[c].
+// One workgroup per row at a time: the row comes in with 16-byte loads and goes through LDS, where every thread picks the four counts
+// of its four image columns (a 4- or 8-byte store) -- the gathers never leave the CU.
+template <int BITS>
+__global__ void __launch_bounds__(256) llda_pack_image_cols_kernel(const int32_t *__restrict__ n_kw, const int32_t *__restrict__ col_src,
+                                                                   void *__restrict__ out, int64_t V, int KP)
+{
+    constexpr uint32_t SAT = BITS == 8 ? 255u : 65535u;
+    extern __shared__ int s_row[];                       // KP counts
+    const int q4 = KP / 4;
+    for (int64_t v = blockIdx.x; v < V; v += gridDim.x) {
+        const int4 *src = reinterpret_cast<const int4 *>(n_kw + v * KP);
+        for (int i = threadIdx.x; i < q4; i += 256) reinterpret_cast<int4 *>(s_row)[i] = src[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < q4; i += 256) {
+            const int4 cs = reinterpret_cast<const int4 *>(col_src)[i];
+            const uint32_t x = min((uint32_t)s_row[cs.x], SAT), y = min((uint32_t)s_row[cs.y], SAT),
+                           z = min((uint32_t)s_row[cs.z], SAT), w = min((uint32_t)s_row[cs.w], SAT);
+            if constexpr (BITS == 8) {
+                static_cast<uint32_t *>(out)[v * q4 + i] = x | (y << 8) | (z << 16) | (w << 24);
+            } else {
+                uint2 o;
+                o.x = x | (y << 16);
+                o.y = z | (w << 16);
+                static_cast<uint2 *>(out)[v * q4 + i] = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fold of the commit log into word-major counts (llda_commit_log, include/llda_gibbs.h): one wavefront per
 // item (a run of log entries of one word), a histogram of the word's row per wavefront in LDS.  The histogram

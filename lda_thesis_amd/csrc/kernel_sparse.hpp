@@ -286,6 +286,13 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const PT P)
         const int A = (int)(live_off[d + 1] - l0);
         const bool live = valid && len > 0 && lig < A;
         const int pos = live ? Q->live_pos[l0 + lig] : -1;
+        // where the topic's counts sit in a row of the narrow image: the sampler may have reordered the image's columns so that
+        // topics that are allowed together share cache lines (llda_pack_image_cols); the counts themselves keep their order
+        [[maybe_unused]] int ipos = pos;
+        if constexpr (IMG != 0) {
+            const int32_t *ic = Q->img_col;
+            if (ic && live) ipos = ic[pos];
+        }
         int32_t *ndk_p = Q->n_dk + d * KP + (live ? pos : 0);
         int ndk = live ? *ndk_p : 0;
         const int ndk0 = ndk;
@@ -377,7 +384,7 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const PT P)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xn[j] = 0;
                 if (live && nbb > 0) {
-                    const LLDA_GLOBAL IT *col = (const LLDA_GLOBAL IT *)P.img + pos;
+                    const LLDA_GLOBAL IT *col = (const LLDA_GLOBAL IT *)P.img + ipos;
                     xn[0] = col[(int64_t)w0 * KP]; xn[1] = col[(int64_t)w1 * KP]; xn[2] = col[(int64_t)w2 * KP];
                     xn[3] = col[(int64_t)w3 * KP]; xn[4] = col[(int64_t)w4 * KP]; xn[5] = col[(int64_t)w5 * KP];
                     xn[6] = col[(int64_t)w6 * KP]; xn[7] = col[(int64_t)w7 * KP];

@@ -436,6 +436,7 @@ static int take_image(const llda_sweep_args *a, KParams &P)
     if (!a->n_kw_img || (a->img_bits != 8 && a->img_bits != 16)) return LLDA_E_BAD_ARG;
     if (reinterpret_cast<uintptr_t>(a->n_kw_img) & (a->img_bits == 8 ? 3 : 7)) return LLDA_E_BAD_ARG;     // (as llda_pack_image)
     P.img = a->n_kw_img;
+    P.img_col = a->img_col;
     return LLDA_OK;
 }
 
@@ -769,6 +770,25 @@ int llda_pack_rows16(const int32_t *n_kw, const uint8_t *row16, int64_t V, int32
     if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
     hipLaunchKernelGGL(llda_pack_rows16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_kw, row16, n_kw16,
                        V, L.G, status);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LLDA_OK : hip_fail(e);
+}
+
+int llda_pack_image_cols(const int32_t *n_kw, int64_t V, int32_t K, int32_t bits, const int32_t *col_src, void *img, void *stream)
+{
+    if (V < 0 || (bits != 8 && bits != 16)) return LLDA_E_BAD_ARG;
+    int rc;
+    const llda_layout *Lp = layout_of(K, &rc);
+    if (rc) return rc;
+    if (V == 0) return LLDA_OK;
+    if (!n_kw || !img || !col_src || (Lp->KP & 3)) return LLDA_E_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(n_kw) & 15) || (reinterpret_cast<uintptr_t>(img) & (bits == 8 ? 3 : 7))) return LLDA_E_BAD_ARG;
+    if (reinterpret_cast<uintptr_t>(col_src) & 15) return LLDA_E_BAD_ARG;
+    int64_t blocks = V < 256 * 32 ? V : 256 * 32;
+    const dim3 grid((unsigned)blocks), block(256);
+    const size_t lds = (size_t)Lp->KP * sizeof(int);
+    if (bits == 8) hipLaunchKernelGGL(llda_pack_image_cols_kernel<8>, grid, block, lds, (hipStream_t)stream, n_kw, col_src, img, V, Lp->KP);
+    else hipLaunchKernelGGL(llda_pack_image_cols_kernel<16>, grid, block, lds, (hipStream_t)stream, n_kw, col_src, img, V, Lp->KP);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
 }

@@ -96,6 +96,11 @@ class GibbsSampler(object):
                sweep by ``llda_pack_rows16_all`` from the counts themselves; a row that does not is read as int32.  Same results.
                None (default) = wherever it applies; False = the two-documents-per-wavefront kernel; LLDA_QUAD=on|off in the
                environment decides for callers that cannot pass the argument.
+    image_order : the narrow image keeps its columns in an order of its own: topics that are allowed TOGETHER (label co-occurrence over
+               the local documents, weighted by their sites) are packed into the same 128-byte lines by a greedy clustering, so a site's
+               gathers touch fewer lines -- the sparse-label kernel is bound by the L2's line fills.  The counts, the draw order and the
+               results are untouched (``llda_pack_image_cols`` / ``llda_sweep_args.img_col``).  None (default) = taken when it saves at
+               least a tenth of the lines a site touches (``image_lines_per_site`` = (before, after)); True = always; False = never.
     build_lock : a context manager the heavy LOCAL sections of the construction run under (the sorts of the commit log, the count
                initialisation, the images) -- never a collective.  For several processes that share one device (bench.py --one-device,
                tests): concurrent constructions are time-sliced by the GPU's scheduler and take seconds to minutes instead of one second.
@@ -111,7 +116,7 @@ class GibbsSampler(object):
     def __init__(self, doc_off, word, freq, z, K, V, alpha, beta, labs=None, counts=None, seed=0,
                  stream_id=0, doc_base=0, device=None, group=None, sort_docs=True,
                  docs_per_group=0, sharded=True, sparse_labels=True, commit_log=None, exchange_always=False,
-                 overlap_ranges=1, rows16=None, image=None, quad=None, build_lock=None):
+                 overlap_ranges=1, rows16=None, image=None, quad=None, build_lock=None, image_order=None):
         _native.lib()                                       # fail loudly when the extension is missing
         _native.require_device()                            # ... or when no GPU is visible: there is no CPU fallback
         import contextlib
@@ -124,6 +129,7 @@ class GibbsSampler(object):
         self.sharded = bool(sharded)
         self.docs_per_group = int(docs_per_group)
         self.sweeps_done = 0
+        self._status_event = self._status_host = None     # post_status: the asynchronous copy of the status word in flight
         self._parts_cache = {}
         self.debug_margin = 0          # test hook of the two-tier draw (include/llda_gibbs.h)
         self.kernel_events = None      # set to [] to record a (start, end) HIP event pair per sweep kernel
@@ -241,9 +247,14 @@ class GibbsSampler(object):
             image = int(os.environ["LLDA_IMAGE"])
         if image not in (None, 0, 8, 16):
             raise ValueError("image must be None (automatic), 0 (off), 8 or 16")
+        self._img_src = self._img_col = None
         if (image != 0 and self.S and self.live_off is not None and self.alpha >= 1e-6 and self.beta >= 1e-6
                 and self.V * self.beta < 2.0 ** 40):
             self._make_image(image)
+            self.image_lines_per_site = None
+            if self.n_kw_img is not None and image_order is not False:
+                with locked:
+                    self._make_image_order(force=image_order)
 
     IMAGE_MIN_BYTES = 32 << 20       # image=None: below this n_kw (the eight L2s hold it) or below IMAGE_MIN_SITES sites the per-sweep
     IMAGE_MIN_SITES = 1 << 20        # llda_pack_image pass costs more than the line fills it saves
@@ -286,6 +297,67 @@ class GibbsSampler(object):
             import warnings
             warnings.warn("GibbsSampler: no room for the narrow image of n_kw (%.1f GB at 8 bits); gathering from n_kw itself" % (n / 1e9))
             self.n_kw_img = None
+
+    def _make_image_order(self, force=None):
+        """column order of the narrow image: a greedy clustering of the label co-occurrence matrix into lines of 128 bytes.
+        C[p, q] = sum over the local documents that allow both p and q of the document's sites (every site gathers all of its
+        document's topics); a line is seeded with the heaviest position not placed yet and filled with the positions that share the
+        most weight with what the line already holds.  _img_src[c] = position held by image column c, _img_col = its inverse."""
+        dev, KP = self.device, self.layout.KP
+        per_line = 128 // self.n_kw_img.element_size()
+        if KP <= per_line:
+            return                                              # one line per row anyway
+        lens = (self.doc_off[1:] - self.doc_off[:-1]).to(torch.float32)
+        cnt = self.live_off[1:] - self.live_off[:-1]
+        C = torch.zeros((KP, KP), dtype=torch.float64, device=dev)
+        step = max(1, (1 << 26) // KP)
+        for d0 in range(0, self.D, step):
+            d1 = min(self.D, d0 + step)
+            l0, l1 = int(self.live_off[d0]), int(self.live_off[d1])
+            if l1 == l0:
+                continue
+            rows = torch.repeat_interleave(torch.arange(d1 - d0, device=dev), cnt[d0:d1])
+            M = torch.zeros((d1 - d0, KP), dtype=torch.float32, device=dev)
+            M[rows, self.live_pos[l0:l1].to(torch.int64)] = 1.0
+            C += ((M * lens[d0:d1, None]).t() @ M).to(torch.float64)
+        C = C.cpu().numpy()
+        w = C.diagonal().copy()
+        free = w > 0
+        order = []
+        while free.any():
+            seed = int(np.argmax(np.where(free, w, -1.0)))
+            free[seed] = False
+            line, aff = [seed], C[seed].copy()
+            while len(line) < per_line and free.any():
+                cand = np.where(free, aff, -1.0)
+                j = int(np.argmax(cand))
+                if cand[j] <= 0.0:                              # nothing left that is ever allowed together with this line:
+                    j = int(np.argmax(np.where(free, w, -1.0)))  # fill it with the heaviest of the rest rather than leave a hole
+                free[j] = False
+                line.append(j)
+                aff += C[j]
+            order.extend(line)
+        rest = np.setdiff1d(np.arange(KP), np.array(order, dtype=np.int64), assume_unique=False)
+        src = np.concatenate([np.array(order, dtype=np.int64), rest])
+        col = np.empty(KP, dtype=np.int64)
+        col[src] = np.arange(KP)
+        col_t = torch.from_numpy(col).to(dev)
+        # lines a site touches (distinct lines among its document's topics, weighted by the document's sites), before and after: the
+        # order is only taken when it saves at least a tenth of them -- for label sets without structure (or already co-located by the
+        # caller's label order) the plain pack is cheaper and the gathers no better
+        docs = torch.repeat_interleave(torch.arange(self.D, device=dev), cnt)
+        pos = self.live_pos[:int(self.live_off[-1])].to(torch.int64)
+
+        def lines_per_site(column):
+            n_lines = (KP + per_line - 1) // per_line
+            key = torch.unique(docs * n_lines + column // per_line)
+            per_doc = torch.bincount(key // n_lines, minlength=self.D).to(torch.float32)
+            return float((per_doc * lens).sum().item() / max(float(lens.sum().item()), 1.0))
+        self.image_lines_per_site = (lines_per_site(pos), lines_per_site(col_t[pos]))
+        if force is not True and self.image_lines_per_site[1] > 0.9 * self.image_lines_per_site[0]:
+            return
+        self._img_src = torch.from_numpy(src.astype(np.int32)).to(dev)
+        self._img_col = col_t.to(torch.int32)
 
     ROWS16_MIN_BYTES = 64 << 20      # rows16=None, documents of 2^16 tokens or more (three waves per SIMD): below this n_kw
                                      # the L2s serve the int32 rows and the shorter kernel wins
@@ -597,7 +669,9 @@ class GibbsSampler(object):
             _native.pack_rows16_all(self.n_kw, self.K, self.n_kw16, self.row16)
         elif self.n_kw16 is not None:
             _native.pack_rows16(self.n_kw, self.row16, self.K, self.n_kw16, self.status)
-        if self.n_kw_img is not None:
+        if self.n_kw_img is not None and self._img_src is not None:
+            _native.pack_image_cols(self.n_kw, self.K, self._img_src, self.n_kw_img)
+        elif self.n_kw_img is not None:
             _native.pack_image(self.n_kw, self.n_kw_img)
         # decided from values every rank agrees on (a rank with an empty shard logs nothing but must still issue
         # one collective per range)
@@ -628,7 +702,8 @@ class GibbsSampler(object):
                                   live_max=live_max, csc_pos=self.csc_pos, commit_log=self.commit_log,
                                   n_sites=s1 - s0, site_rec=self.site_rec, max_doc_tokens=self.max_doc_tokens,
                                   scratch=self._scratch, n_kw16=self.n_kw16, site_row=self.site_row,
-                                  n_kw_img=self.n_kw_img if sparse else None, row16=self.row16 if self.quad else None)
+                                  n_kw_img=self.n_kw_img if sparse else None, row16=self.row16 if self.quad else None,
+                                  img_col=self._img_col if sparse and self.n_kw_img is not None else None)
             if pipelined:
                 # fold this range's log into ITS exchange rows and start their all-reduce: it runs on the
                 # collective's stream (ordered after the fold) while the next range is sampled on this one
@@ -699,13 +774,13 @@ class GibbsSampler(object):
         when it has landed -- no synchronisation; a site without a topic of positive probability (numpy raises at that site,
         LabeledLDA.py:117-119) raises here at most ``every`` + 1 sweeps late instead of only at the next thinning point."""
         import torch
-        ev = getattr(self, "_status_event", None)
+        ev = self._status_event
         if ev is not None and ev.query():
             self._status_event = None
             self._raise_for(int(self._status_host[0]))
         every = self.STATUS_EVERY if every is None else every
         if self._status_event is None and self.sweeps_done % max(1, every) == 0:
-            if getattr(self, "_status_host", None) is None:
+            if self._status_host is None:
                 self._status_host = torch.zeros((4,), dtype=torch.int32).pin_memory()
             self._status_host.copy_(self.status[:4], non_blocking=True)
             self._status_event = torch.cuda.Event()

@@ -77,6 +77,10 @@ class OracleBackend(object):
         return None
 
     @staticmethod
+    def pack_image_cols(n_kw, K, col_src, img):
+        return None
+
+    @staticmethod
     def pack_rows16(n_kw, row16, K, n_kw16, status):
         return None
 
@@ -108,7 +112,7 @@ class OracleBackend(object):
     def sweep(self, *, doc_off, doc_order, word, freq, z, lab_mask, n_dk, n_kw, n_kw_delta, n_k, n_k_delta,
               status, D, V, K, alpha, beta, seed, sweep, stream_id=0, doc_base=0, docs_per_group=0,
               dense_mask=False, debug_margin=0, live_off=None, live_pos=None, live_max=0, csc_pos=None, commit_log=None, n_sites=None, site_rec=None,
-              max_doc_tokens=0, scratch=None, n_kw16=None, site_row=None, n_kw_img=None, row16=None):
+              max_doc_tokens=0, scratch=None, n_kw16=None, site_row=None, n_kw_img=None, row16=None, img_col=None):
         import torch
         if doc_order is not None and int(D) < int(doc_off.shape[0]) - 1:
             # a launch over a SUBSET of the call's documents (GibbsSampler._lane_parts): the same through views of those documents

@@ -777,6 +777,60 @@ def test_narrow_image_escapes_equal_the_c_oracle(c_oracle, K, image):
     assert torch.equal(img, s.n_kw.reshape(-1).clamp(max=sat))
 
 
+@pytest.mark.parametrize("image", [8, 16])
+@pytest.mark.parametrize("K", [512, 1500])
+def test_narrow_image_column_order_changes_no_result(c_oracle, K, image):
+    """llda_sweep_args.img_col / llda_pack_image_cols: label sets with structure (every document draws its labels from one of a few
+    families whose topic ids are scattered over the row) -- the sampler reorders the image's columns so that a family shares cache
+    lines; the states with the order forced, refused and chosen by the sampler's own rule are the C oracle's (LabeledLDA.py:106-125),
+    every draw tier; and the image is the saturated copy of the counts in that order."""
+    import torch
+    import lda_thesis_amd._native as nat
+    from lda_thesis_amd.sampler import GibbsSampler
+    rng = np.random.default_rng(K + image)
+    D, V, fam = 700, 300, 14
+    ids = rng.permutation(K - 1) + 1
+    families = [ids[i * fam:(i + 1) * fam] for i in range((K - 1) // fam)]
+    lens = rng.integers(1, 40, size=D)
+    doc_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    word = np.concatenate([np.sort(rng.choice(V, size=n, replace=False)) for n in lens]).astype(np.int32)
+    freq = rng.integers(1, 4, size=int(doc_off[-1])).astype(np.int32)
+    labs = np.zeros((D, K), dtype=np.uint8)
+    labs[:, 0] = 1
+    for d in range(D):
+        f = families[int(rng.integers(len(families)))]
+        labs[d, rng.choice(f, size=int(rng.integers(1, 8)), replace=False)] = 1
+    z = np.concatenate([rng.choice(np.nonzero(labs[d])[0], size=lens[d]) for d in range(D)])
+    runs = {}
+    for order in (True, False, None):
+        s = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=labs, seed=31, doc_base=3, image=image, image_order=order)
+        assert s.live_off is not None and s.n_kw_img is not None
+        assert (s._img_src is not None) == (order is not False)          # (None: the rule takes it -- the families are scattered)
+        if order is not False:
+            before, after = s.image_lines_per_site
+            assert after < 0.75 * before
+            src = s._img_src.cpu().numpy()
+            assert sorted(src.tolist()) == list(range(s.layout.KP))
+            np.testing.assert_array_equal(s._img_col.cpu().numpy()[src], np.arange(s.layout.KP))
+        cs = c_oracle.CState(doc_off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
+        for i in range(3):
+            s.debug_margin = (0, 6, -1)[i]
+            s.sweep()
+            cs.sweep(1, 31, i, doc_base=3, threads=4)
+            np.testing.assert_array_equal(s.z_topics(), cs.z)
+            np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+            np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+        s.check_status()
+        runs[order] = (s.z.clone(), s._counts.clone(), s.n_dk.clone())
+        if order is True:
+            sat = 255 if image == 8 else 65535
+            nat.pack_image_cols(s.n_kw, K, s._img_src, s.n_kw_img)
+            img = (s.n_kw_img.to(torch.int32) & (0xff if image == 8 else 0xffff)).view(V, s.layout.KP)
+            assert torch.equal(img, s.n_kw[:, s._img_src.long()].clamp(max=sat))
+    for order in (False, None):
+        assert all(torch.equal(a, b) for a, b in zip(runs[True], runs[order]))
+
+
 def test_sparse_and_dense_kernels_agree_on_a_large_sparse_workload(c_oracle):
     import torch
     from lda_thesis_amd.corpus import synthetic_corpus
