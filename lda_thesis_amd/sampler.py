@@ -94,8 +94,11 @@ class GibbsSampler(object):
     quad     : K = 512 with the 16-bit rows and every document below 2^16 tokens: the kernel that walks FOUR documents per wavefront
                (16 lanes x 32 slots each; csrc/kernel_quad.hpp) on an image of EVERY row -- which rows fit 16 bits is decided per
                sweep by ``llda_pack_rows16_all`` from the counts themselves; a row that does not is read as int32.  Same results.
-               None (default) = wherever it applies; False = the two-documents-per-wavefront kernel; LLDA_QUAD=on|off in the
-               environment decides for callers that cannot pass the argument.
+               None (default) = wherever it applies AND the rows that do not fit 16 bits are rare: at most QUAD_MAX_WIDE_SITES of the
+               sites may read such a row (the quad kernel reads it without prefetch) -- looked at when the sampler is built and every
+               QUAD_CHECK_EVERY sweeps from the library's own flags, without synchronising; beyond that the sampler goes over to the
+               two-document kernel with its int32 rows for good.  True = always; False = the two-documents-per-wavefront kernel;
+               LLDA_QUAD=on|off in the environment decides for callers that cannot pass the argument.
     image_order : the narrow image keeps its columns in an order of its own: topics that are allowed TOGETHER (label co-occurrence over
                the local documents, weighted by their sites) are packed into the same 128-byte lines by a greedy clustering, so a site's
                gathers touch fewer lines -- the sparse-label kernel is bound by the L2's line fills.  The counts, the draw order and the
@@ -130,6 +133,7 @@ class GibbsSampler(object):
         self.docs_per_group = int(docs_per_group)
         self.sweeps_done = 0
         self._status_event = self._status_host = None     # post_status: the asynchronous copy of the status word in flight
+        self._wide_event = self._wide_host = self._word_sites = None    # _quad_policy
         self._parts_cache = {}
         self.debug_margin = 0          # test hook of the two-tier draw (include/llda_gibbs.h)
         self.kernel_events = None      # set to [] to record a (start, end) HIP event pair per sweep kernel
@@ -359,6 +363,29 @@ class GibbsSampler(object):
         self._img_src = torch.from_numpy(src.astype(np.int32)).to(dev)
         self._img_col = col_t.to(torch.int32)
 
+    QUAD_MAX_WIDE_SITES = 0.02       # quad=None: largest share of the sites that may read a row which does not fit the 16-bit image
+    QUAD_CHECK_EVERY = 32            # ... looked at every so many sweeps (asynchronously)
+
+    def _quad_policy(self):
+        """quad=None: the share of the sites whose row the library flagged as wide in THIS sweep's image, computed on the device and
+        copied to the host without synchronising; the copy of an EARLIER sweep is looked at when it has landed.  Counts that
+        concentrate (a frequent word settling in a few topics) take the sampler over to the two-document kernel."""
+        ev = self._wide_event
+        if ev is not None and ev.query():
+            self._wide_event = None
+            if float(self._wide_host[0]) > self.QUAD_MAX_WIDE_SITES * self.S:
+                self.quad = False
+                self.row16 = None
+                self._flag_rows16()                    # the static flags, bit 31 of csc_pos and site_row of the two-document kernel
+                return
+        if self._wide_event is None and self.sweeps_done % self.QUAD_CHECK_EVERY == 0:
+            if self._wide_host is None:
+                self._wide_host = torch.zeros((1,), dtype=torch.float32).pin_memory()
+            share = ((1.0 - self.row16.to(torch.float32)) * self._word_sites).sum().reshape(1)
+            self._wide_host.copy_(share, non_blocking=True)
+            self._wide_event = torch.cuda.Event()
+            self._wide_event.record()
+
     ROWS16_MIN_BYTES = 64 << 20      # rows16=None, documents of 2^16 tokens or more (three waves per SIMD): below this n_kw
                                      # the L2s serve the int32 rows and the shorter kernel wins
     MAX_FREQ = 1 << 23   # v_mad_i32_i24 moves a site's count (include/llda_gibbs.h: freq)
@@ -389,6 +416,12 @@ class GibbsSampler(object):
         if auto and not four_waves and V * KP * 4 < self.ROWS16_MIN_BYTES:
             return
         quad = bool(self._quad_wanted is not False and four_waves and self.layout.G == 32 and self.layout.T == 16 and V < (1 << 22))
+        if quad and self._quad_wanted is None:
+            # sites whose word has a count beyond 16 bits somewhere in its row: rare, or the two-document kernel's prefetched int32 rows
+            wide = (self.n_kw.max(dim=1).values > 65535) | (self.n_kw.min(dim=1).values < 0)
+            self._word_sites = torch.bincount(self.word.to(torch.int64), minlength=V).to(torch.float32)
+            if float((wide.to(torch.float32) * self._word_sites).sum().item()) > self.QUAD_MAX_WIDE_SITES * self.S:
+                quad = False
         if self._quad_wanted and not quad:
             raise ValueError("quad=True: needs K = 512, documents of fewer than 65 536 tokens and a vocabulary below 2^22 words")
         if not quad and not bool(self._rows16_fits().any()):
@@ -475,7 +508,7 @@ class GibbsSampler(object):
         """n_kw[word, topic] += amount for parallel 1-D arrays (host or device); n_k and n_dk are left alone.
         (SubLDA's phantom columns, reference CascadeLDA.py:382-385, are such counts.)"""
         dev = self.device
-        w = torch.as_tensor(np.asarray(words), dtype=torch.int64, device=dev)
+        w = torch.as_tensor(np.ascontiguousarray(words), dtype=torch.int64, device=dev)
         if w.numel() == 0:
             return
         pos = self._topic_pos[torch.as_tensor(np.asarray(topics), dtype=torch.int64, device=dev)]
@@ -667,6 +700,10 @@ class GibbsSampler(object):
         n_ranges = len(self._ranges) - 1
         if self.quad:                                         # this sweep's n_kw: nothing below changes it before the fold
             _native.pack_rows16_all(self.n_kw, self.K, self.n_kw16, self.row16)
+            if self._quad_wanted is None:
+                self._quad_policy()
+        if self.quad:
+            pass
         elif self.n_kw16 is not None:
             _native.pack_rows16(self.n_kw, self.row16, self.K, self.n_kw16, self.status)
         if self.n_kw_img is not None and self._img_src is not None:

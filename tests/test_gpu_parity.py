@@ -484,6 +484,32 @@ def test_16_bit_rows_four_waves_equal_the_c_oracle(c_oracle, K, quad, margin):
             assert torch.equal(r.status[1:3], s.status[1:3])             # the same sites left tier 0 / reached the exact tier
 
 
+def test_quad_kernel_hands_over_when_wide_rows_become_common(monkeypatch):
+    """quad=None: counts that concentrate -- here the most frequent words get an entry beyond 65 535 in the middle of the run -- make more
+    than QUAD_MAX_WIDE_SITES of the sites read a row that does not fit the 16-bit image; the sampler notices from the library's own flags
+    (asynchronously) and goes over to the two-document kernel.  The states equal those of a sampler that ran that kernel all along."""
+    import torch
+    from lda_thesis_amd.sampler import GibbsSampler
+    monkeypatch.setattr(GibbsSampler, "QUAD_CHECK_EVERY", 1)
+    doc_off, word, freq, z, V = _rows16_corpus_short_docs(512, 77)
+    freq = np.minimum(freq, 5).astype(np.int32)                            # (no wide row to begin with)
+    a = GibbsSampler(doc_off, word, freq, z, 512, V, 0.1, 0.01, labs=None, seed=4, commit_log=True)
+    b = GibbsSampler(doc_off, word, freq, z, 512, V, 0.1, 0.01, labs=None, seed=4, commit_log=True, quad=False)
+    assert a.quad and not b.quad and a.site_row is None and b.site_row is not None
+    hot = np.argsort(np.bincount(word, minlength=V))[::-1][:6]
+    for i in range(12):
+        if i == 3:
+            for s in (a, b):
+                s.add_word_topic_counts(hot, np.full(len(hot), 7), np.full(len(hot), 70000))
+        a.sweep()
+        b.sweep()
+        torch.cuda.synchronize()
+        assert torch.equal(a.z, b.z) and torch.equal(a._counts, b._counts) and torch.equal(a.n_dk, b.n_dk), i
+    assert not a.quad and a.site_row is not None                          # handed over (a few sweeps after the counts changed)
+    a.check_status()
+    b.check_status()
+
+
 def test_16_bit_rows_four_waves_flag_a_wrong_token_bound():
     """a max_doc_tokens that is not a bound (a count of n_dk above 65535 under the four-wave form): status bit 2, check_status raises"""
     from lda_thesis_amd.sampler import GibbsSampler
