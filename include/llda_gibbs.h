@@ -121,7 +121,8 @@ typedef struct llda_sweep_args {
                                     LDS copies of the counts whatever max_doc_tokens says, -5 on the fp64 register
                                     kernel without its fp32 tier, -6 the fp32 tier with fp64 factors in LDS even when
                                     scratch is there, -7 with fp32 factors only whenever scratch is there; -8 (with n_kw16)
-                                    production margins on the three-wave form of the 16-bit-row kernel                     */
+                                    production margins on the three-wave form of the 16-bit-row kernel; -9 (with row16) the quad
+                                    kernel with the constant tier-0 margin 104 * 2^-24 of the total instead of its data-dependent one */
     double   alpha, beta;        /* priors (LabeledLDA.py:55-56)                               */
     uint64_t seed;               /* RNG key                                                    */
     uint32_t sweep;              /* RNG counter word 3                                         */

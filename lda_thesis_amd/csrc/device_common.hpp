@@ -42,6 +42,7 @@ struct KParams {
     int32_t xor_tree;       // leaves combine as p^1, p^2, p^4 (balanced recursion, no padded leaves)
     double margin_rel;      // tier-1 decision margin relative to the total score (2^-40; debug: wider / inf)
     float margin0_rel;      // tier-0 (fp32) margin (2^-17; >= 1 disables tier 0)
+    float margin0_data;     // quad kernel: weight of its data-dependent margin (production: 1 with margin0_rel = 0; test hooks: 0)
     float alpha32, beta32, vbeta32;   // the priors rounded to fp32 (tier 0 of the sparse-label kernels)
     // sparse-label path: per document the device positions of its allowed topics, in draw order ((lane, slot) ascending)
     const int64_t *live_off;

@@ -25,7 +25,16 @@ namespace {
 // compared directly (98.2 v), chain B against the bounds minus chain A's total (99.2 v) -- inside the 105 v of the 2-document kernel,
 // margin 128 v.  Int32 rows with counts >= 2^24: + 2 v.
 // ---------------------------------------------------------------------------------------------
-constexpr float LLDA_MARGIN0_QUAD = 0x1.ap-18f;   // tier-0 margin of this kernel: 104 * 2^-24 (bound 99.2 v, 101.2 v with int32 counts >= 2^24)
+constexpr float LLDA_MARGIN0_QUAD = 0x1.ap-18f;   // tier-0 margin of this kernel relative to the total: 104 * 2^-24 (bound 99.2 v, 101.2 v with
+                                                  // int32 counts >= 2^24) -- what the test hooks scale; production uses the sharper form below
+// The data-dependent margin (production).  With v = 2^-24 and true values L (lane total), P (the lanes before), t = u * total, the
+// compared difference  q~[s] - (tg~ -+ m)  is off by at most
+//     28.1 v L  (prefix: 12 v of the terms + 16 roundings)  + 1 v L (chain B against the bounds minus chain A's total)
+//   + 34.2 v t + 0.125 v total  (u~: 2^-27 + v u; total~: 29.1 v + 4 scan steps)  + 1 v t (t = u * total rounded on its own)
+//   + 33.1 v P  + 3 v |tg|  (tg, its bounds, the chain-B bounds: one rounding each; |tg| <= t + P)  + 2 v for int32 counts >= 2^24
+// <= v (31.1 L + 38.2 t + 36.1 P + 0.125 total) -- a third of 104 v * total on average (L ~ total / 16, t ~ P ~ total / 2).  The kernel
+// takes m = v * 1.05 * (32 L~ + 39 t~ + 37 P~ + 0.25 total~) from the computed values (each within 34 v of its true value).
+constexpr float QM_L = 1.05f * 32.0f * 0x1p-24f, QM_T = 1.05f * 39.0f * 0x1p-24f, QM_P = 1.05f * 37.0f * 0x1p-24f, QM_TOT = 1.05f * 0.25f * 0x1p-24f;
 constexpr int QT = 32;        // slots per quad lane
 constexpr int QNT = 128;      // threads per workgroup: two wavefronts, eight documents
 
@@ -74,7 +83,8 @@ typedef float q_v32f __attribute__((ext_vector_type(32)));
 // Tier 0 for four documents at once.  xv = the row minus the site's own count (fp32, exact), pa = the cached factors, both in slot
 // order rho: the pair (2a, 2a+1) holds element a of chain A and of chain B, so ONE packed instruction advances both chains.
 // Returns the wavefront's ballot of the lanes that are not sure; zn = the position every lane's document drew.
-__device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa)[16], float u, float margin_rel, float beta,
+// margin_rel, margin_data: m = total * margin_rel + margin_data * (the data-dependent form): production (0, 1), test hooks (2^-n or 2, 0)
+__device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa)[16], float u, float margin_rel, float margin_data, float beta,
                                               int lq, int bp_last, int &zn)
 {
     const q_v2f b2 = {beta, beta};
@@ -108,8 +118,10 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
 #endif
     const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), DPP_ROW_SHR + 1, 0xF, 0xF, true));
     LLDA_MARK("threshold");
-    const float tg = __builtin_fmaf(u, tot, -prev);
-    const float margin = tot * margin_rel;
+    const float t = u * tot;
+    const float tg = t - prev;
+    const float md = __builtin_fmaf(QM_L, X0, __builtin_fmaf(QM_T, t, __builtin_fmaf(QM_P, prev, QM_TOT * tot)));
+    const float margin = __builtin_fmaf(tot, margin_rel, margin_data * md);
     const float lo0 = tg - margin, hi0 = tg + margin;
     // chain A or chain B?
     LLDA_MARK("search");
@@ -417,7 +429,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             QP_MARK(0);                                                // pa, row, conversion, own count, commit, loads issued
 
             int zn;
-            uint64_t unsure = quad_draw(xv, pa, u32, P.margin0_rel, beta32, lq, bp_last, zn) & __ballot(act);
+            uint64_t unsure = quad_draw(xv, pa, u32, P.margin0_rel, P.margin0_data, beta32, lq, bp_last, zn) & __ballot(act);
             QP_MARK(1);                                                // chains, scan, search, pick
             LLDA_MARK("cold_check");
             if (__builtin_expect(unsure != 0, 0)) {

@@ -645,7 +645,13 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         if (a->n_sites < 1) return LLDA_OK;                              // (documents without sites: nothing to sample)
         P.n_kw16 = a->n_kw16;
         P.row16 = a->row16;
-        if (a->debug_margin == 0) P.margin0_rel = LLDA_MARGIN0_QUAD;     // (this kernel's own bound: kernel_quad.hpp)
+        if (a->debug_margin == 0) {                                       // (this kernel's own, data-dependent bound: kernel_quad.hpp)
+            P.margin0_rel = 0.0f;
+            P.margin0_data = 1.0f;
+        } else if (a->debug_margin == -9) {                               // test hook: the constant margin 104 * 2^-24 of the total
+            P.margin0_rel = LLDA_MARGIN0_QUAD;
+            P.margin_rel = 0x1p-40;
+        }
         const int64_t per_q = (int64_t)(QNT / 16) * dpg;
         const int64_t qblocks = (a->D + per_q - 1) / per_q;
         if (qblocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
