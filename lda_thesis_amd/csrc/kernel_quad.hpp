@@ -35,6 +35,7 @@ constexpr float LLDA_MARGIN0_QUAD = 0x1.ap-18f;   // tier-0 margin of this kerne
 // <= v (31.1 L + 38.2 t + 36.1 P + 0.125 total) -- a third of 104 v * total on average (L ~ total / 16, t ~ P ~ total / 2).  The kernel
 // takes m = v * 1.05 * (32 L~ + 39 t~ + 37 P~ + 0.25 total~) from the computed values (each within 34 v of its true value).
 constexpr float QM_L = 1.05f * 32.0f * 0x1p-24f, QM_T = 1.05f * 39.0f * 0x1p-24f, QM_P = 1.05f * 37.0f * 0x1p-24f, QM_TOT = 1.05f * 0.25f * 0x1p-24f;
+#define QLDS(arr, rho, t) (arr)[(rho) >> 2][t][(rho) & 3]      // the per-document LDS arrays, see the kernel
 constexpr int QT = 32;        // slots per quad lane
 constexpr int QNT = 128;      // threads per workgroup: two wavefronts, eight documents
 
@@ -44,13 +45,13 @@ constexpr int quad_rho_of(int i, int e, int c) { return 8 * i + 2 * c + e; }
 
 // the counts of one document for the cold tiers, which play it in the STANDARD layout (32 lanes x 16 slots)
 struct QuadCounts {
-    const int (*s_ndk)[QNT];
+    const int (*s_ndk)[QNT][4];
     const int *s_nk0;
     int t;         // thread of the workgroup that holds this standard lane's slots
     int e;         // standard lane & 1
     int g;         // standard lane
     bool st;
-    __device__ __forceinline__ int word(int s) const { return s_ndk[8 * (s >> 2) + 2 * (s & 3) + e][t]; }
+    __device__ __forceinline__ int word(int s) const { return QLDS(s_ndk, 8 * (s >> 2) + 2 * (s & 3) + e, t); }
     __device__ __forceinline__ int nd(int s) const { return word(s) & 0xffff; }
     __device__ __forceinline__ int nk(int s) const
     {
@@ -63,7 +64,7 @@ struct QuadCounts {
 
 // One undecided site: both halves of the wavefront play the document in the standard layout (the upper half silently), the row
 // comes from n_kw itself.  tbase = thread of the document's quad lane 0; w, f, zo = word, frequency and old position of the site.
-__device__ __noinline__ int quad_cold(const int (*s_ndk)[QNT], const int *s_nk0, int tbase, int w, int f, int zo, uint32_t ra,
+__device__ __noinline__ int quad_cold(const int (*s_ndk)[QNT][4], const int *s_nk0, int tbase, int w, int f, int zo, uint32_t ra,
                                       uint32_t rb, int lane, const KParams *P)
 {
     const int g = lane & 31;
@@ -171,7 +172,7 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
 // unnormalised fp64 prefix sums with the margin 2^-40 of the total (draw_tiers.hpp, cold_tiers_acc: the same test on a different
 // association order -- the bound there, 254 u < 2^-44, grows by the 16 more additions of a 32-slot chain).  All four documents at once;
 // xv = the row minus the site's own count, exact in fp32.  Returns the ballot of the lanes that are STILL not sure; zn as quad_draw.
-__device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_ndk)[QNT], const int *s_nk0, int tid, int lq, double u,
+__device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_ndk)[QNT][4], const int *s_nk0, int tid, int lq, double u,
                                                double alpha, double beta, double vbeta, double margin_rel, int &zn)
 {
     double W[QT];
@@ -180,7 +181,7 @@ __device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_n
     for (int k = 0; k < QT; ++k) {                       // k = position in the draw order of the lane: chain A, then chain B
         const int e = k >> 4, a = k & 15, i = a >> 2, c = a & 3;
         const int rho = quad_rho_of(i, e, c);
-        const int w = s_ndk[rho][tid];
+        const int w = QLDS(s_ndk, rho, tid);
         const int nd = w & 0xffff, nk = s_nk0[(i << 7) | (lq << 3) | (e << 2) | c] + nd - (int)((uint32_t)w >> 16);
         const double den = (double)nk + vbeta;
         // 1 / den from the fp32 reciprocal (1 ulp) and two Newton steps in fp64: within 2^-50, as cold_tiers_acc's
@@ -236,8 +237,10 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
     constexpr int KP = 512;
     __shared__ int s_nk[KP];                   // workgroup accumulator of the n_k changes
     __shared__ int s_nk0[KP];                  // the sweep-start n_k
-    __shared__ int s_ndk[QT][QNT];             // n_dk | sweep-start n_dk << 16, [rho][thread]
-    __shared__ float s_pa[QT][QNT];            // tier-0 factor fl32((n_dk + alpha) / (n_k + V*beta))
+    // [rho >> 2][thread][rho & 3]: a lane's four consecutive slots are 16 contiguous bytes, 16 bytes apart from lane to lane -- the 32
+    // factors of a lane come with 8 ds_read_b128 (conflict free) instead of 16 two-address reads
+    __shared__ int s_ndk[QT / 4][QNT][4];      // n_dk | sweep-start n_dk << 16
+    __shared__ float s_pa[QT / 4][QNT][4];     // tier-0 factor fl32((n_dk + alpha) / (n_k + V*beta))
     __shared__ float s_u[QNT / 16][32];        // the fp32 uniforms of the next 32 sites of every document
 
     const int tid = threadIdx.x;
@@ -260,10 +263,10 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
     QP_DECL;
 
     auto update = [&](int sg, int pos, int df) {
-        const int w = s_ndk[sg][tid] + df;                           // (0 <= n_dk + df < 2^16: no carry into the upper half)
-        s_ndk[sg][tid] = w;
+        const int w = QLDS(s_ndk, sg, tid) + df;                     // (0 <= n_dk + df < 2^16: no carry into the upper half)
+        QLDS(s_ndk, sg, tid) = w;
         const int nd = w & 0xffff, nk = s_nk0[pos] + nd - (int)((uint32_t)w >> 16);
-        s_pa[sg][tid] = tier0_factor(nd, nk, alpha32, vbeta32);
+        QLDS(s_pa, sg, tid) = tier0_factor(nd, nk, alpha32, vbeta32);
     };
 
     for (int it = 0; it < P.dpg; ++it) {
@@ -294,8 +297,8 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 for (int j = 0; j < 8; ++j) {
                     const int rho = quad_rho_of(i, j >> 2, j & 3);
                     const int k = s_nk0[i * 128 + lq * 8 + j];
-                    s_ndk[rho][tid] = r[j] | (r[j] << 16);
-                    s_pa[rho][tid] = tier0_factor(r[j], k, alpha32, vbeta32);
+                    QLDS(s_ndk, rho, tid) = r[j] | (r[j] << 16);
+                    QLDS(s_pa, rho, tid) = tier0_factor(r[j], k, alpha32, vbeta32);
                     big |= r[j];
                     tokens += (int)((uint32_t)r[j] & 0xffffu);
                 }
@@ -354,8 +357,8 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             q_v2f pa[16];
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
-                pa[a].x = s_pa[2 * a][tid];
-                pa[a].y = s_pa[2 * a + 1][tid];
+                pa[a].x = QLDS(s_pa, 2 * a, tid);
+                pa[a].y = QLDS(s_pa, 2 * a + 1, tid);
             }
             // the random bits of 32 sites at a time (one Philox block per lane serves two sites); their fp32 images -- the top 27
             // bits, within 2^-24 relative + 2^-27 absolute of u -- go through LDS, the bits themselves are only needed by the cold tiers
@@ -486,7 +489,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 const int ps = own_new ? zpos : own_old ? nxt.zo : (lq << 3);
                 const int df = own_new ? f : own_old ? -nxt.f : 0;
                 LLDA_MARK("count_update");
-                const int w0 = s_ndk[sg][tid], k0 = s_nk0[ps];
+                const int w0 = QLDS(s_ndk, sg, tid), k0 = s_nk0[ps];
 #ifndef ABL_NOCOMMIT
                 {
                     LLDA_MARK("commit");
@@ -502,9 +505,9 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 load_scalars(prv, off_of(n + 2));                      // scalars of site n+2 (clamped)
                 LLDA_MARK("count_update");
                 const int w = w0 + df;                                  // (0 <= n_dk + df < 2^16: no carry into the upper half)
-                s_ndk[sg][tid] = w;
+                QLDS(s_ndk, sg, tid) = w;
                 const int nd = w & 0xffff, nk = k0 + nd - (int)((uint32_t)w >> 16);
-                s_pa[sg][tid] = tier0_factor(nd, nk, alpha32, vbeta32);
+                QLDS(s_pa, sg, tid) = tier0_factor(nd, nk, alpha32, vbeta32);
                 if (__builtin_expect(__ballot(own_new && own_old) != 0, 0)) {
                     LLDA_MARK("rare_second_update");
                     if (own_new && own_old) update(nxt.so, nxt.zo, -nxt.f);
@@ -536,7 +539,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 int o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int w = s_ndk[quad_rho_of(i, j >> 2, j & 3)][tid];
+                    const int w = QLDS(s_ndk, quad_rho_of(i, j >> 2, j & 3), tid);
                     o[j] = w & 0xffff;
                     const int dl = o[j] - (int)((uint32_t)w >> 16);
                     if (dl) atomicAdd(&s_nk[i * 128 + lq * 8 + j], dl);
