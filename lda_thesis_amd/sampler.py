@@ -811,6 +811,8 @@ class GibbsSampler(object):
         when it has landed -- no synchronisation; a site without a topic of positive probability (numpy raises at that site,
         LabeledLDA.py:117-119) raises here at most ``every`` + 1 sweeps late instead of only at the next thinning point."""
         import torch
+        if self.device.type != "cuda":                   # (host-logic tests drive this class with CPU tensors and a stand-in backend)
+            return
         ev = self._status_event
         if ev is not None and ev.query():
             self._status_event = None
