@@ -217,7 +217,7 @@ __device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_n
     return unsure;
 }
 
-struct QuadSite { int v, f, zo, c, zn, lo, so; };     // (lo, so) = quad lane and slot rho of zo
+struct QuadSite { int v, f, zo, c, zn, lo, so, w; };  // (lo, so) = quad lane and slot rho of zo; w = flag of the word's row (0: wide)
 
 // -DQUAD_PROFILE (tools/quad_phase_profile.py; never in a production build: llda_build_info reports it): wavefront 0 of workgroup 0
 // stamps the shader clock at the phase boundaries of every site and adds the differences up in status[8 + phase]
@@ -321,12 +321,12 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
         };
         // the 16-bit row of word v: chunks (e, j) = slots 8j .. 8j+7 of standard lane 2 lq + e, and the row's flag
         // (32-bit byte offsets from the image: llda_sweep checked V * 1024 < 2^32)
-        int xp[16], fl;
-        auto load_row16 = [&](const int v) {
+        int xp[16];
+        auto load_row16 = [&](const int v, int &flag) {
 #ifdef ABL_NOLOAD
 #pragma unroll
             for (int k = 0; k < 16; ++k) xp[k] = ((v + k) & 7) * 0x10001;      // ablation: no n_kw traffic
-            fl = 1;
+            flag = 1;
             return;
 #endif
             const LLDA_GLOBAL char *q = (const LLDA_GLOBAL char *)P.n_kw16 + (((uint32_t)v << 10) + (uint32_t)lq * 32u);
@@ -336,17 +336,78 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             xp[4] = b.x; xp[5] = b.y; xp[6] = b.z; xp[7] = b.w;
             xp[8] = c.x; xp[9] = c.y; xp[10] = c.z; xp[11] = c.w;
             xp[12] = e.x; xp[13] = e.y; xp[14] = e.z; xp[15] = e.w;
-            fl = *(const LLDA_GLOBAL uint8_t *)((const LLDA_GLOBAL char *)P.row16 + (uint32_t)v);
+            flag = *(const LLDA_GLOBAL uint8_t *)((const LLDA_GLOBAL char *)P.row16 + (uint32_t)v);
+        };
+        // xp -> fp32 in slot order (exact: 16-bit counts); the lanes of a document whose row does not fit 16 bits read the int32 row
+        // now, without prefetch (an int32 count beyond 2^24 rounds: tier 0 stays inside its margin, section 4.3; tier 1 is skipped)
+        q_v32f xv;
+        auto convert_row = [&](const int v, const int flag) {
+            LLDA_MARK("convert");
+            const uint64_t wide_w = __ballot(flag == 0);
+            if (__builtin_expect(wide_w == 0, 1)) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int e = k >> 3, j = (k >> 2) & 1, m = k & 3;
+                    const int i = 2 * j + (m >> 1), c = 2 * (m & 1);
+                    xv[quad_rho_of(i, e, c)] = (float)((uint32_t)xp[k] & 0xffffu);
+                    xv[quad_rho_of(i, e, c + 1)] = (float)((uint32_t)xp[k] >> 16);
+                }
+            } else {
+                LLDA_MARK("rare_wide_row");
+                int xi[QT];
+#pragma unroll
+                for (int t = 0; t < QT; ++t) xi[t] = 0;
+                if (flag == 0) {
+                    const LLDA_GLOBAL v4i *q = (const LLDA_GLOBAL v4i *)((const LLDA_GLOBAL int32_t *)P.n_kw + ((uint64_t)(uint32_t)v << 9));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const v4i a = q[i * 32 + 2 * lq], b = q[i * 32 + 2 * lq + 1];
+                        xi[quad_rho_of(i, 0, 0)] = a.x; xi[quad_rho_of(i, 0, 1)] = a.y; xi[quad_rho_of(i, 0, 2)] = a.z; xi[quad_rho_of(i, 0, 3)] = a.w;
+                        xi[quad_rho_of(i, 1, 0)] = b.x; xi[quad_rho_of(i, 1, 1)] = b.y; xi[quad_rho_of(i, 1, 2)] = b.z; xi[quad_rho_of(i, 1, 3)] = b.w;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int e = k >> 3, j = (k >> 2) & 1, m = k & 3;
+                    const int i = 2 * j + (m >> 1), c = 2 * (m & 1);
+                    const int ra_ = quad_rho_of(i, e, c), rb_ = quad_rho_of(i, e, c + 1);
+                    xv[ra_] = flag == 0 ? (float)xi[ra_] : (float)((uint32_t)xp[k] & 0xffffu);
+                    xv[rb_] = flag == 0 ? (float)xi[rb_] : (float)((uint32_t)xp[k] >> 16);
+                }
+            }
+        };
+        // the site's own count leaves the fp32 row through the slot index (uniform in a document): per document ONE indexed
+        // read-modify-write under the document's exec mask
+        auto remove_own = [&](const int so, const float own) {
+            LLDA_MARK("own_removal");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int so_r = __builtin_amdgcn_readlane(so, r * 16);
+                const uint64_t em = 0xFFFFull << (16 * r);
+                // (s_nop 3 behind s_set_gpr_idx_on: without it the v_sub used a STALE index every few thousand sites -- measured,
+                // tools/quad_debug.py: the stray write cleared a live register of a later workgroup; the compiler's own sequences
+                // put no VALU write of the index SGPR this close in front, and the hazard tables list nothing for it)
+                asm volatile("s_mov_b64 exec, %2\n\ts_set_gpr_idx_on %1, gpr_idx(SRC0,DST)\n\ts_nop 3\n\tv_sub_f32_e32 v64, v64, %3\n\t"
+                             "s_nop 0\n\ts_set_gpr_idx_off\n\ts_mov_b64 exec, -1"
+                             : "+{v[64:95]}"(xv) : "s"(so_r), "s"(em), "v"(own));
+            }
         };
 
+        // Software pipeline.  At the top of iteration n, xv holds the row of site n as fp32 with the site's own count taken out -- made
+        // during iteration n-1, in the shadow of the LDS reads of its count update, from the row that was issued an iteration earlier
+        // still.  Scalars run two sites ahead in three rotating register sets (the loop is unrolled by three), the word ids three (wq).
         QuadSite R0, R1, R2;
         load_scalars(R0, off_of(0)); R0.zn = 0;
-        load_scalars(R1, off_of(1)); R1.zn = 0; R1.lo = R1.so = 0;
-        R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = 0;
-        load_row16(R0.v);
+        load_scalars(R1, off_of(1)); R1.zn = 0;
+        R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = R2.w = 0;
+        load_row16(R0.v, R0.w);
+        int wq = gload_i32(word_b, off_of(2));           // word of site n+2 at the top of iteration n
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         decode_old(R0);
         if (len > 0 && lq == R0.lo) update(R0.so, R0.zo, -R0.f);      // site 0 leaves its topic (LabeledLDA.py:109-111)
+        convert_row(R0.v, R0.w);
+        load_row16(R1.v, R1.w);                                        // row of site 1
+        remove_own(R0.so, (len > 0 && lq == R0.lo) ? (float)R0.f : 0.0f);
 
         auto site = [&](const int n, QuadSite &cur, QuadSite &nxt, QuadSite &prv) {
             const bool act = n < len, more = n + 1 < len;
@@ -372,65 +433,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 LLDA_MARK("rng");
             }
             const float u32 = s_u[grp][n & 31];
-            __builtin_amdgcn_sched_barrier(0);
-            // the row as fp32 (exact: 16-bit counts; an int32 count beyond 2^24 rounds, section 4.3)
-            q_v32f xv;
-            LLDA_MARK("convert");
-            const uint64_t wide_w = __ballot(fl == 0);
-            if (__builtin_expect(wide_w == 0, 1)) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int e = k >> 3, j = (k >> 2) & 1, m = k & 3;
-                    const int i = 2 * j + (m >> 1), c = 2 * (m & 1);
-                    xv[quad_rho_of(i, e, c)] = (float)((uint32_t)xp[k] & 0xffffu);
-                    xv[quad_rho_of(i, e, c + 1)] = (float)((uint32_t)xp[k] >> 16);
-                }
-            } else {
-                // some document's word has a count beyond 16 bits: its lanes read the int32 row now (no prefetch)
-                LLDA_MARK("rare_wide_row");
-                int xi[QT];
-#pragma unroll
-                for (int s = 0; s < QT; ++s) xi[s] = 0;
-                if (fl == 0) {
-                    const LLDA_GLOBAL v4i *q = (const LLDA_GLOBAL v4i *)((const LLDA_GLOBAL int32_t *)P.n_kw + ((uint64_t)(uint32_t)cur.v << 9));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const v4i a = q[i * 32 + 2 * lq], b = q[i * 32 + 2 * lq + 1];
-                        xi[quad_rho_of(i, 0, 0)] = a.x; xi[quad_rho_of(i, 0, 1)] = a.y; xi[quad_rho_of(i, 0, 2)] = a.z; xi[quad_rho_of(i, 0, 3)] = a.w;
-                        xi[quad_rho_of(i, 1, 0)] = b.x; xi[quad_rho_of(i, 1, 1)] = b.y; xi[quad_rho_of(i, 1, 2)] = b.z; xi[quad_rho_of(i, 1, 3)] = b.w;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int e = k >> 3, j = (k >> 2) & 1, m = k & 3;
-                    const int i = 2 * j + (m >> 1), c = 2 * (m & 1);
-                    const int ra_ = quad_rho_of(i, e, c), rb_ = quad_rho_of(i, e, c + 1);
-                    xv[ra_] = fl == 0 ? (float)xi[ra_] : (float)((uint32_t)xp[k] & 0xffffu);
-                    xv[rb_] = fl == 0 ? (float)xi[rb_] : (float)((uint32_t)xp[k] >> 16);
-                }
-            }
-            // the site's own count leaves the fp32 row through the slot index (uniform in a document): per document ONE indexed
-            // read-modify-write under the document's exec mask
-            LLDA_MARK("own_removal");
-            {
-                const float own = (act && lq == cur.lo) ? (float)f : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int so_r = __builtin_amdgcn_readlane(cur.so, r * 16);
-                    const uint64_t em = 0xFFFFull << (16 * r);
-                    // (s_nop 3 behind s_set_gpr_idx_on: without it the v_sub used a STALE index every few thousand sites -- measured, tools/quad_debug.py:
-                    // the stray write cleared a live register of a later workgroup; the compiler's own sequences put no VALU write of the index
-                    // SGPR this close in front, and the hazard tables list nothing for it)
-                    asm volatile("s_mov_b64 exec, %2\n\ts_set_gpr_idx_on %1, gpr_idx(SRC0,DST)\n\ts_nop 3\n\tv_sub_f32_e32 v64, v64, %3\n\t"
-                                 "s_nop 0\n\ts_set_gpr_idx_off\n\ts_mov_b64 exec, -1"
-                                 : "+{v[64:95]}"(xv) : "s"(so_r), "s"(em), "v"(own));
-                }
-            }
-            LLDA_MARK("row_prefetch");
-            const int fl_cur = fl;                                     // (flag of THIS site's row: 0 = read as int32)
-            load_row16(nxt.v);                                         // row of site n+1 (clamped)
-            QP_MARK(0);                                                // pa, row, conversion, own count, commit, loads issued
-
+            QP_MARK(0);                                                // factors + uniform issued
             int zn;
             uint64_t unsure = quad_draw(xv, pa, u32, P.margin0_rel, P.margin0_data, beta32, lq, bp_last, zn) & __ballot(act);
             QP_MARK(1);                                                // chains, scan, search, pick
@@ -448,7 +451,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 int z1;
                 // (a document whose row was read as int32 skips tier 1: a count of 2^24 or more is not exact in xv)
                 const uint64_t still = ((P.margin_rel < 1.0 ? quad_tier1(xv, s_ndk, s_nk0, tid, lq, uniform53(ra, rb), P.alpha, P.beta, P.vbeta,
-                                                                        P.margin_rel, z1) : ~0ull) | __ballot(fl_cur == 0)) & __ballot(act);
+                                                                        P.margin_rel, z1) : ~0ull) | __ballot(cur.w == 0)) & __ballot(act);
                 const bool mine0 = ((t0_w >> (lane & 48)) & 0xFFFFull) != 0;
                 zn = mine0 ? z1 : zn;
                 uint32_t rows = 0;
@@ -490,6 +493,27 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 const int df = own_new ? f : own_old ? -nxt.f : 0;
                 LLDA_MARK("count_update");
                 const int w0 = QLDS(s_ndk, sg, tid), k0 = s_nk0[ps];
+                LLDA_MARK("scalars");
+                const int w_next = wq;                                 // word of site n+2 (loaded an iteration ago)
+                load_scalars(prv, off_of(n + 2));                      // scalars of site n+2 (clamped)
+                wq = gload_i32(word_b, off_of(n + 3));
+                // site n+1: its row (issued an iteration ago) -> fp32, own count out; then the row of site n+2 is issued
+                convert_row(nxt.v, nxt.w);
+                LLDA_MARK("row_prefetch");
+                load_row16(w_next, prv.w);
+                remove_own(nxt.so, (more && lq == nxt.lo) ? (float)nxt.f : 0.0f);
+                LLDA_MARK("count_update");
+                const int w = w0 + df;                                  // (0 <= n_dk + df < 2^16: no carry into the upper half)
+                QLDS(s_ndk, sg, tid) = w;
+                const int nd = w & 0xffff, nk = k0 + nd - (int)((uint32_t)w >> 16);
+                QLDS(s_pa, sg, tid) = tier0_factor(nd, nk, alpha32, vbeta32);
+                if (__builtin_expect(__ballot(own_new && own_old) != 0, 0)) {
+                    LLDA_MARK("rare_second_update");
+                    if (own_new && own_old) update(nxt.so, nxt.zo, -nxt.f);
+                }
+                // (the stores sit in inline assembly: the compiler's vmcnt bookkeeping does not see them, so whatever it waits for next
+                // also waits for them -- they are issued LAST, a whole iteration in front of the next vector-memory wait; in the middle
+                // of the iteration every wait for the row stalled on two stores that had just been issued: 42.9 instead of 38.x ms)
 #ifndef ABL_NOCOMMIT
                 {
                     LLDA_MARK("commit");
@@ -501,17 +525,6 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                                  : : "s"(cm), "v"(zoff), "v"(zpos), "s"(z_b), "v"(lp), "v"(word) : "memory");
                 }
 #endif
-                LLDA_MARK("scalars");
-                load_scalars(prv, off_of(n + 2));                      // scalars of site n+2 (clamped)
-                LLDA_MARK("count_update");
-                const int w = w0 + df;                                  // (0 <= n_dk + df < 2^16: no carry into the upper half)
-                QLDS(s_ndk, sg, tid) = w;
-                const int nd = w & 0xffff, nk = k0 + nd - (int)((uint32_t)w >> 16);
-                QLDS(s_pa, sg, tid) = tier0_factor(nd, nk, alpha32, vbeta32);
-                if (__builtin_expect(__ballot(own_new && own_old) != 0, 0)) {
-                    LLDA_MARK("rare_second_update");
-                    if (own_new && own_old) update(nxt.so, nxt.zo, -nxt.f);
-                }
             }
             LLDA_MARK("loop");
             QP_MARK(3);                                                // count update
