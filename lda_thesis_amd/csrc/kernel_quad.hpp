@@ -253,7 +253,6 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
     const int lane = tid & 63, lq = tid & 15, row = lane >> 4, grp = tid >> 4;
     const float vbeta32 = (float)P.vbeta, alpha32 = (float)P.alpha, beta32 = (float)P.beta;
     const int bp_last = (lane | 15) << 2;
-    const uint64_t lq0_w = 0x0001000100010001ull;            // quad lane 0 of the four documents
 
     const int64_t site_base = P.doc_off[0];
     const int32_t *word_b = P.word + site_base, *freq_b = P.freq + site_base, *csc_b = P.csc_pos + site_base;
@@ -511,18 +510,19 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                     LLDA_MARK("rare_second_update");
                     if (own_new && own_old) update(nxt.so, nxt.zo, -nxt.f);
                 }
-                // (the stores sit in inline assembly: the compiler's vmcnt bookkeeping does not see them, so whatever it waits for next
-                // also waits for them -- they are issued LAST, a whole iteration in front of the next vector-memory wait; in the middle
-                // of the iteration every wait for the row stalled on two stores that had just been issued: 42.9 instead of 38.x ms)
+                // (the commit comes LAST, a whole iteration in front of the next vector-memory wait: vmcnt counts in order, so a wait for
+                // the row behind two stores that have just been issued waits for the stores as well -- measured with the stores in the
+                // middle of the iteration and hidden from the compiler in inline assembly: 42.9 instead of 36.6 ms)
 #ifndef ABL_NOCOMMIT
                 {
                     LLDA_MARK("commit");
                     const uint32_t zoff = opaque_u32(sb + (uint32_t)n * 4u);
                     const LLDA_GLOBAL uint32_t *lp = (const LLDA_GLOBAL uint32_t *)P.commit_log + (uint32_t)(cur.c & 0x7fffffff);
                     const uint32_t word = (uint32_t)zo | ((uint32_t)zpos << 16);
-                    const uint64_t cm = __ballot(act) & lq0_w;
-                    asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dword %1, %2, %3\n\tglobal_store_dword %4, %5, off\n\ts_mov_b64 exec, -1"
-                                 : : "s"(cm), "v"(zoff), "v"(zpos), "s"(z_b), "v"(lp), "v"(word) : "memory");
+if (lq == 0 && act) {                                // (plain stores: the compiler's vmcnt bookkeeping sees them)
+                        gstore_i32(z_b, zoff, zpos);
+                        *(LLDA_GLOBAL uint32_t *)lp = word;
+                    }
                 }
 #endif
             }
