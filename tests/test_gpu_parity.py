@@ -616,6 +616,41 @@ def test_edge_empty_shard_and_empty_documents(c_oracle):
     _run_vs_c(c_oracle, off, word, freq, labs, rng.integers(0, 24, size=off[-1]), 24, 200)
 
 
+@pytest.mark.parametrize("dpg,permute", [(0, False), (3, True), (1, True)])
+def test_edge_quad_kernel_ragged_empty_documents_and_schedules(c_oracle, dpg, permute):
+    """the four-documents-per-wavefront kernel (K = 512 dense, commit log) on a ragged shard: empty documents between one-site and
+    long ones, wavefronts whose four documents differ in length by two orders of magnitude, a document count that fills neither the
+    last wavefront nor the last workgroup, frequencies above 1, several documents per lane group and a processing order of the
+    caller's -- against the C oracle (LabeledLDA.py:106-125), three sweeps, production margins / mixed tiers / exact tier"""
+    import torch
+    from lda_thesis_amd.sampler import GibbsSampler
+    rng = np.random.default_rng(17 + dpg)
+    K, V = 512, 400
+    lens = np.concatenate([[0, 1, 0, 0, 330, 1, 2, 0, 77, 0, 0, 0, 0, 5], rng.integers(0, 60, size=37)])
+    D = len(lens)
+    assert D % 4 and D % 8
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    word = np.concatenate([np.sort(rng.choice(V, size=n, replace=False)) for n in lens]).astype(np.int32)
+    freq = rng.integers(1, 6, size=int(off[-1])).astype(np.int32)
+    z = rng.integers(0, K, size=int(off[-1]))
+    labs = np.ones((D, K), dtype=np.uint8)
+    s = GibbsSampler(off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=13, doc_base=7, commit_log=True, docs_per_group=dpg,
+                     sort_docs=not permute)
+    assert s.quad and s.commit_log is not None
+    if permute:
+        s.doc_order = torch.from_numpy(rng.permutation(D).astype(np.int32)).cuda()
+    cs = c_oracle.CState(off, word, freq, z, labs, s.n_d_k(), s.n_k_v(), s.n_zk(), V, 0.1, 0.01)
+    for i in range(3):
+        s.debug_margin = (0, 6, -1)[i]
+        s.sweep()
+        cs.sweep(1, 13, i, doc_base=7, threads=4)
+        np.testing.assert_array_equal(s.z_topics(), cs.z)
+        np.testing.assert_array_equal(s.n_d_k(), cs.n_d_k)
+        np.testing.assert_array_equal(s.n_k_v(), cs.n_k_v)
+        np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
+    s.check_status()
+
+
 @pytest.mark.parametrize("K", [1, 2, 8, 9, 1024])
 def test_edge_topic_counts(c_oracle, K):
     rng = np.random.default_rng(K)
