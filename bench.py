@@ -64,6 +64,9 @@ WORKLOADS = {
                "(BASELINE configs[3])"),
     "synth1": (100000, 200, 50000, 128, 1.0, 12500,
                "synthetic 100k docs x 200 tokens, K=128 dense mask, V=50k (BASELINE configs[2])"),
+    "synth_k256": (100000, 200, 50000, 256, 1.0, 12500,
+                   "synthetic 100k docs x 200 tokens, K=256 dense mask, V=50k (tools and tests: the eight-documents-per-wavefront form "
+                   "of the 16-bit-row kernel)"),
     "synth2_hostile": (125000, 300, 500000, 512, 0.0, 15625,
                        "cache-hostile variant of configs[3]: 125k docs x 300 tokens, K=512 dense mask, UNIFORM words over "
                        "V=500k -- n_kw is 1.02 GB, four times the Infinity Cache, every site reads a cold 2 KB row"),
@@ -223,6 +226,11 @@ def checksum_verdict(name, docs_total, sweeps, got):
     return (got == want), "N = 1 digests after %d sweeps (%s): %r" % (sweeps, t.get("source", "stored"), want)
 
 
+def docs_per_wavefront(sampler):
+    """quad kernel (csrc/kernel_quad.hpp): a document is K / 32 lanes x 32 slots"""
+    return {512: "four", 256: "eight", 128: "sixteen"}.get(int(sampler.K), "?")
+
+
 def rows_description(sampler):
     """how the sweep reads n_kw: int32 rows, or the 16-bit image (llda_sweep_args.n_kw16, refreshed inside every timed sweep)
     for the words whose corpus-wide count fits 16 bits"""
@@ -234,8 +242,8 @@ def rows_description(sampler):
     if getattr(sampler, "quad", False):
         fits = float(sampler.row16.float().mean().item())
         return ("16-bit image of EVERY row (llda_pack_rows16_all runs inside every timed sweep and flags the rows whose counts all fit: "
-                "%.2f %% of the words this sweep; the others are read as int32), four documents per wavefront; same results "
-                "(DESIGN.md section 4.1)" % (100.0 * fits))
+                "%.2f %% of the words this sweep; the others are read as int32), %s documents per wavefront; same results "
+                "(DESIGN.md section 4.1)" % (100.0 * fits, docs_per_wavefront(sampler)))
     flagged = sampler.row16[sampler.word.long()].float().mean().item() if sampler.S else 0.0
     return ("16-bit image for the words whose corpus-wide count fits 16 bits (%.1f %% of the words, %.1f %% of this rank's sites; "
             "llda_pack_rows16 runs inside every timed sweep), int32 rows for the others; same results (DESIGN.md section 4.1)" %
@@ -246,7 +254,7 @@ def rows_short(sampler):
     if getattr(sampler, "n_kw_img", None) is not None:
         return "%d-bit saturating image + int32 escapes" % (8 * sampler.n_kw_img.element_size())
     if getattr(sampler, "quad", False):
-        return "16-bit image of every row, four documents per wavefront"
+        return "16-bit image of every row, %s documents per wavefront" % docs_per_wavefront(sampler)
     return "int32" if getattr(sampler, "n_kw16", None) is None else "16-bit image + int32 hot rows"
 
 

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LLDA_ABI_VERSION 20
+#define LLDA_ABI_VERSION 21
 #define LLDA_MAX_K 7688          /* every K up to here splits into <= 64 pairwise leaves                       */
 #define LLDA_MAX_KP 8192         /* longest padded row: 64 leaves x 128                                        */
 #define LLDA_MAX_LEAVES 8        /* "narrow" layouts: one lane group of <= 64 lanes x <= 16 slots per document  */
@@ -187,10 +187,11 @@ typedef struct llda_sweep_args {
     int32_t  reserved_img;       /* 0                                                                         */
     const uint8_t *row16;        /* [dev] [V] optional (ABI 19), with n_kw16 and WITHOUT site_row: the per-word flags llda_pack_rows16_all
                                     wrote for THIS sweep's n_kw (1 = every count of the row fits 16 bits; n_kw16 then holds EVERY
-                                    row).  K = 512 (32 lanes x 16 slots) with dense_mask = 1, the commit log, alpha, beta >= 1e-6 and
-                                    0 < max_doc_tokens < 65 536 (LLDA_E_BAD_ARG otherwise): the kernel that walks FOUR documents per
-                                    wavefront, 16 lanes x 32 slots each (kernel_quad.hpp) -- the per-iteration work of scan, search,
-                                    pick and count update is shared by four sites instead of two.  A site whose row is not flagged
+                                    row).  K with llda_quad_ok (512; ABI 21: 256 and 128 as well), dense_mask = 1, the commit log,
+                                    alpha, beta >= 1e-6, 0 < max_doc_tokens < 65 536 and, for K = 128 and 256, site_rec (LLDA_E_BAD_ARG otherwise): the kernel that
+                                    walks a document with K / 32 lanes x 32 slots (kernel_quad.hpp), FOUR documents per wavefront at
+                                    K = 512, eight at 256, sixteen at 128 -- the per-iteration work of scan, search, pick and count
+                                    update is shared by that many sites.  A site whose row is not flagged
                                     reads the int32 row (no prefetch: meant to be rare).  Bit 31 of csc_pos is ignored.  Results do
                                     not depend on it. */
     const int32_t *img_col;      /* [dev] [KP] optional (ABI 20), with n_kw_img: the image column that holds the count of every device
@@ -231,6 +232,9 @@ int64_t     llda_sweep_scratch_bytes(int32_t K, int64_t D);
 /* 1 when llda_sweep can read 16-bit rows for K topics (narrow layout, 16 slots per lane, 32 or 64 lanes, no padded slot:
  * K = 512 and K = 1024).  Host only. */
 int         llda_rows16_ok(int32_t K);
+/* 1 when llda_sweep takes llda_sweep_args.row16 for K topics (ABI 21; narrow layout, 16 slots per lane, 8, 16 or 32 lanes, no padded
+ * slot: K = 128, 256 and 512).  Host only. */
+int         llda_quad_ok(int32_t K);
 
 /* ---- device entry points (enqueue on `stream`) ---- */
 /* One Gibbs sweep over the shard: LabeledLDA.py:101-125 / CascadeLDA.py:397-421. */
@@ -319,7 +323,7 @@ int llda_pack_rows16(const int32_t *n_kw, const uint8_t *row16, int64_t V, int32
 int llda_pack_image_cols(const int32_t *n_kw, int64_t V, int32_t K, int32_t bits, const int32_t *col_src, void *img, void *stream);
 
 /* The 16-bit image of EVERY row of n_kw plus, per word, whether all counts of its row fit 16 bits in this sweep's n_kw
- * (row16[v] = 1; ABI 19) -- for llda_sweep_args.row16.  K = 512 only (LLDA_E_BAD_K otherwise); n_kw and n_kw16 16-byte aligned.
+ * (row16[v] = 1; ABI 19) -- for llda_sweep_args.row16.  K with llda_quad_ok (LLDA_E_BAD_K otherwise); n_kw and n_kw16 16-byte aligned.
  * Call it once per sweep, after the counts of the previous sweep were folded in and before the first llda_sweep.  The image of an
  * unflagged row holds the low halves of its counts and is never read. */
 int llda_pack_rows16_all(const int32_t *n_kw, int64_t V, int32_t K, uint16_t *n_kw16, uint8_t *row16, void *stream);

@@ -16,7 +16,7 @@ MAX_KP = 8192
 MAX_LEAVES = 8          # narrow layouts
 MAX_WIDE_LEAVES = 64
 MAX_ROUNDS = 4
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _c_i32, _c_i64, _c_u32, _c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 _c_p, _c_d = ctypes.c_void_p, ctypes.c_double
@@ -69,7 +69,7 @@ class LldaBatchArgs(ctypes.Structure):
 
 
 EXPORTS = ("llda_abi_version", "llda_build_info", "llda_strerror", "llda_last_hip_error", "llda_struct_size", "llda_layout_init",
-           "llda_sweep_scratch_bytes", "llda_rows16_ok", "llda_pack_rows16", "llda_pack_rows16_all", "llda_pack_image", "llda_pack_image_cols",
+           "llda_sweep_scratch_bytes", "llda_rows16_ok", "llda_quad_ok", "llda_pack_rows16", "llda_pack_rows16_all", "llda_pack_image", "llda_pack_image_cols",
 
            "llda_sweep", "llda_sweep_batch", "llda_commit_log", "llda_apply_rows", "llda_apply_delta", "llda_count_init", "llda_loglik", "llda_foldin",
            "llda_readout_phi", "llda_readout_theta", "llda_selftest_div")
@@ -111,6 +111,8 @@ def lib():
     L.llda_sweep_scratch_bytes.argtypes = [_c_i32, _c_i64]
     L.llda_rows16_ok.restype = ctypes.c_int
     L.llda_rows16_ok.argtypes = [_c_i32]
+    L.llda_quad_ok.restype = ctypes.c_int
+    L.llda_quad_ok.argtypes = [_c_i32]
     L.llda_pack_rows16.restype = ctypes.c_int
     L.llda_pack_rows16.argtypes = [_c_p, _c_p, _c_i64, _c_i32, _c_p, _c_p, _c_p]
     L.llda_pack_rows16_all.restype = ctypes.c_int
@@ -237,6 +239,11 @@ def sweep_scratch_bytes(K, D):
 def rows16_ok(K):
     """llda_rows16_ok: can llda_sweep read 16-bit rows for K topics?"""
     return bool(lib().llda_rows16_ok(int(K)))
+
+
+def quad_ok(K):
+    """llda_quad_ok: does llda_sweep take the per-sweep row flags (llda_sweep_args.row16: K / 32 lanes x 32 slots per document)?"""
+    return bool(lib().llda_quad_ok(int(K)))
 
 
 def pack_rows16(n_kw, row16, K, n_kw16, status):

@@ -39,11 +39,51 @@ constexpr float QM_L = 1.05f * 32.0f * 0x1p-24f, QM_T = 1.05f * 39.0f * 0x1p-24f
 constexpr int QT = 32;        // slots per quad lane
 constexpr int QNT = 128;      // threads per workgroup: two wavefronts, eight documents
 
+// The same walk for the narrower layouts of 16 slots per lane (llda_layout: T = 16): a document is LPD = 2^LB lanes x 32 slots, 64 / LPD
+// documents per wavefront --
+//     LB = 4   K = 512 (G = 32): 4 documents per wavefront      LB = 3   K = 256 (G = 16): 8      LB = 2   K = 128 (G = 8): 16
+//     device position     pos   = i << (3 + LB) | lq << 3 | e << 2 | c
+// Everything per lane (chains, search, count update, LDS layout) is the same code; the cross-lane steps stay inside the LPD lanes of a
+// document (scan steps masked at the document's first lanes, totals and the minimum by xor butterflies), the random bits come 2 LPD
+// sites at a time, and the site's own count leaves the PACKED 16-bit row by compare-and-subtract (sixteen documents would mean sixteen
+// indexed writes).  The error bound of tier 0 only shrinks (fewer scan steps), the constants below are kept.
+template <int LB>
+struct QuadGeo {
+    static constexpr int LPD = 1 << LB;            // lanes per document
+    static constexpr int G = 2 * LPD;              // lanes of the standard layout (llda_layout.G)
+    static constexpr int KP = 32 * LPD;            // positions
+    static constexpr int IS = 3 + LB;              // shift of the slot chunk i in a position
+    static constexpr int DPW = 64 / LPD;           // documents per wavefront
+    static constexpr uint64_t GM = LPD == 64 ? ~0ull : ((1ull << LPD) - 1);     // the lanes of a document in a ballot, shifted down
+    static constexpr uint32_t KEY_NONE = 0xFC000u | 31u << 9 | (uint32_t)(KP - 1);   // no slot above lo: the last slot of the last lane
+};
+
 // slot number of a device position: rho = 8 i + 2 c + e
-__device__ __forceinline__ int quad_rho(int pos) { return ((pos >> 4) & 0x18) | ((pos & 3) << 1) | ((pos >> 2) & 1); }
+template <int LB>
+__device__ __forceinline__ int quad_rho(int pos) { return ((pos >> LB) & 0x18) | ((pos & 3) << 1) | ((pos >> 2) & 1); }
 constexpr int quad_rho_of(int i, int e, int c) { return 8 * i + 2 * c + e; }
 
-// the counts of one document for the cold tiers, which play it in the STANDARD layout (32 lanes x 16 slots)
+// minimum of a key over the lanes of a document, in every lane: one DPP instruction per step (the compiler's form is three)
+template <int LB>
+__device__ __forceinline__ uint32_t quad_min_key(uint32_t key)
+{
+    if constexpr (LB == 4)
+        asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(key));
+    else if constexpr (LB == 3)
+        asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(key));
+    else
+        asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(key));
+    return key;
+}
+
+// the counts of one document for the cold tiers, which play it in the STANDARD layout (G lanes x 16 slots)
+template <int LB>
 struct QuadCounts {
     const int (*s_ndk)[QNT][4];
     const int *s_nk0;
@@ -56,37 +96,40 @@ struct QuadCounts {
     __device__ __forceinline__ int nk(int s) const
     {
         const int w = word(s);
-        return s_nk0[pos_of<32, 16>(g, s)] + (w & 0xffff) - (int)((uint32_t)w >> 16);
+        return s_nk0[pos_of<QuadGeo<LB>::G, 16>(g, s)] + (w & 0xffff) - (int)((uint32_t)w >> 16);
     }
     __device__ __forceinline__ bool stats() const { return st; }
     __device__ __forceinline__ bool count_unsure() const { return false; }     // (the kernel counted the site before its own tier 1)
 };
 
-// One undecided site: both halves of the wavefront play the document in the standard layout (the upper half silently), the row
+// One undecided site: every G lanes of the wavefront play the document in the standard layout (all but the first G silently), the row
 // comes from n_kw itself.  tbase = thread of the document's quad lane 0; w, f, zo = word, frequency and old position of the site.
+template <int LB>
 __device__ __noinline__ int quad_cold(const int (*s_ndk)[QNT][4], const int *s_nk0, int tbase, int w, int f, int zo, uint32_t ra,
                                       uint32_t rb, int lane, const KParams *P)
 {
-    const int g = lane & 31;
+    constexpr int G = QuadGeo<LB>::G;
+    const int g = lane & (G - 1);
     int x[16];
-    gload_lane_row<32, 16>(P->n_kw, (int64_t)w * 512, g, x);
+    gload_lane_row<G, 16>(P->n_kw, (int64_t)w * QuadGeo<LB>::KP, g, x);
     int lo, so;
-    lane_slot_of<32, 16>(zo, lo, so);
+    lane_slot_of<G, 16>(zo, lo, so);
 #pragma unroll
     for (int s = 0; s < 16; ++s) x[s] -= (g == lo && s == so) ? f : 0;       // the site's own count (LabeledLDA.py:109-111)
-    const QuadCounts dc{s_ndk, s_nk0, tbase + (g >> 1), g & 1, g, lane < 32};
-    return cold_tiers_acc<32, 16, false, true>(dc, x, 0xFFFFu, uniform53(ra, rb), g, lane, P);
+    const QuadCounts<LB> dc{s_ndk, s_nk0, tbase + (g >> 1), g & 1, g, lane < G};
+    return cold_tiers_acc<G, 16, false, true>(dc, x, 0xFFFFu, uniform53(ra, rb), g, lane, P);
 }
 
 typedef float q_v2f __attribute__((ext_vector_type(2)));
 typedef float q_v32f __attribute__((ext_vector_type(32)));
 
-// Tier 0 for four documents at once.  xv = the row minus the site's own count (fp32, exact), pa = the cached factors, both in slot
+// Tier 0 for all documents of the wavefront at once.  xv = the row minus the site's own count (fp32, exact), pa = the cached factors, both in slot
 // order rho: the pair (2a, 2a+1) holds element a of chain A and of chain B, so ONE packed instruction advances both chains.
 // Returns the wavefront's ballot of the lanes that are not sure; zn = the position every lane's document drew.
 // margin_rel, margin_data: m = total * margin_rel + margin_data * (the data-dependent form): production (0, 1), test hooks (2^-n or 2, 0)
+template <int LB>
 __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa)[16], float u, float margin_rel, float margin_data, float beta,
-                                              int lq, int bp_last, int &zn)
+                                              int lq, int &zn)
 {
     const q_v2f b2 = {beta, beta};
     q_v2f Q[16];
@@ -98,26 +141,38 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
         if (a == 0) Q[0] = nb * pa[0];
         else Q[a] = __builtin_elementwise_fma(nb, pa[a], Q[a - 1]);
     }
-    // inclusive scan over the 16 lanes of the document = one DPP row
+    // inclusive scan over the lanes of the document (16 lanes = one DPP row)
     LLDA_MARK("lane_scan");
     const float X0 = Q[15].x + Q[15].y;
     float X = X0;
-    X += dpp_f32<DPP_ROW_SHR + 1>(X);
-    X += dpp_f32<DPP_ROW_SHR + 2>(X);
-    X += dpp_f32<DPP_ROW_SHR + 4>(X);
-    X += dpp_f32<DPP_ROW_SHR + 8>(X);
-#ifdef QUAD_TOT_BPERMUTE
-    const float tot = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_last, __float_as_int(X)));     // the row's last lane
-#else
-    // the document's total in every lane: four rotate-and-add steps over the lane totals, next to the scan (an LDS round trip for the
-    // scan's last lane costs the wavefront ~100 cycles of waiting).  Another association order than the scan's: within 33 v as well.
-    float tot = X0;
-    tot += dpp_f32<DPP_ROW_ROR + 8>(tot);
-    tot += dpp_f32<DPP_ROW_ROR + 4>(tot);
-    tot += dpp_f32<DPP_ROW_ROR + 2>(tot);
-    tot += dpp_f32<DPP_ROW_ROR + 1>(tot);
-#endif
-    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), DPP_ROW_SHR + 1, 0xF, 0xF, true));
+    float tot = X0, prev;
+    if constexpr (LB == 4) {
+        X += dpp_f32<DPP_ROW_SHR + 1>(X);
+        X += dpp_f32<DPP_ROW_SHR + 2>(X);
+        X += dpp_f32<DPP_ROW_SHR + 4>(X);
+        X += dpp_f32<DPP_ROW_SHR + 8>(X);
+        // the document's total in every lane: four rotate-and-add steps over the lane totals, next to the scan (an LDS round trip for
+        // the scan's last lane costs the wavefront ~100 cycles of waiting).  Another association order than the scan's: within 33 v too.
+        tot += dpp_f32<DPP_ROW_ROR + 8>(tot);
+        tot += dpp_f32<DPP_ROW_ROR + 4>(tot);
+        tot += dpp_f32<DPP_ROW_ROR + 2>(tot);
+        tot += dpp_f32<DPP_ROW_ROR + 1>(tot);
+        prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), DPP_ROW_SHR + 1, 0xF, 0xF, true));
+    } else {
+        // several documents share a DPP row: a step adds 1.0 * the shifted value, or 0.0 * it in the first lanes of a document (one
+        // fma with the DPP operand; x * 1.0 is exact, so the sum rounds once, as the plain add)
+        const float m1 = lq >= 1 ? 1.0f : 0.0f, m2 = lq >= 2 ? 1.0f : 0.0f;
+        X = __builtin_fmaf(dpp_f32<DPP_ROW_SHR + 1>(X), m1, X);
+        X = __builtin_fmaf(dpp_f32<DPP_ROW_SHR + 2>(X), m2, X);
+        if constexpr (LB == 3) {
+            const float m4 = lq >= 4 ? 1.0f : 0.0f;
+            X = __builtin_fmaf(dpp_f32<DPP_ROW_SHR + 4>(X), m4, X);
+            tot += dpp_f32<DPP_HALF_MIRROR>(tot);
+        }
+        tot += dpp_f32<DPP_XOR1>(tot);
+        tot += dpp_f32<DPP_XOR2>(tot);
+        prev = dpp_f32<DPP_ROW_SHR + 1>(X) * m1;
+    }
     LLDA_MARK("threshold");
     const float t = u * tot;
     const float tg = t - prev;
@@ -157,14 +212,12 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
     // last slot of the last lane).  Row-wide minimum: four DPP steps, one instruction each (the compiler's form is three)
     // key = lane << 14 | slot rho << 9 | position: every search outcome sets its bit of the position AND of the slot number
     LLDA_MARK("pick");
-    const uint32_t p = (c1 ? (256u | 16u << 9) : 0u) | (c2 ? (128u | 8u << 9) : 0u) | (c3 ? (2u | 4u << 9) : 0u) | (c4 ? (1u | 2u << 9) : 0u) |
+    constexpr uint32_t I1 = 2u << QuadGeo<LB>::IS, I0 = 1u << QuadGeo<LB>::IS;
+    const uint32_t p = (c1 ? (I1 | 16u << 9) : 0u) | (c2 ? (I0 | 8u << 9) : 0u) | (c3 ? (2u | 4u << 9) : 0u) | (c4 ? (1u | 2u << 9) : 0u) |
                        (c0 ? (4u | 1u << 9) : 0u) | ((uint32_t)lq << 3) | ((uint32_t)lq << 14);
-    uint32_t key = c5 ? 0xFFFFFu : p;                       // (no slot above lo: position 511 = slot 31 of lane 15 wins only if no lane has one)
-    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(key));
-    zn = (int)(key & 0x3FFFu);                              // slot << 9 | position; the lane is position >> 3 & 15
+    uint32_t key = c5 ? QuadGeo<LB>::KEY_NONE : p;          // (no slot above lo: the last slot of the last lane wins only if no lane has one)
+    key = quad_min_key<LB>(key);
+    zn = (int)(key & 0x3FFFu);                              // slot << 9 | position; the lane is position >> 3 & (LPD - 1)
     return unsure;
 }
 
@@ -172,6 +225,7 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
 // unnormalised fp64 prefix sums with the margin 2^-40 of the total (draw_tiers.hpp, cold_tiers_acc: the same test on a different
 // association order -- the bound there, 254 u < 2^-44, grows by the 16 more additions of a 32-slot chain).  All four documents at once;
 // xv = the row minus the site's own count, exact in fp32.  Returns the ballot of the lanes that are STILL not sure; zn as quad_draw.
+template <int LB>
 __device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_ndk)[QNT][4], const int *s_nk0, int tid, int lq, double u,
                                                double alpha, double beta, double vbeta, double margin_rel, int &zn)
 {
@@ -182,7 +236,7 @@ __device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_n
         const int e = k >> 4, a = k & 15, i = a >> 2, c = a & 3;
         const int rho = quad_rho_of(i, e, c);
         const int w = QLDS(s_ndk, rho, tid);
-        const int nd = w & 0xffff, nk = s_nk0[(i << 7) | (lq << 3) | (e << 2) | c] + nd - (int)((uint32_t)w >> 16);
+        const int nd = w & 0xffff, nk = s_nk0[(i << QuadGeo<LB>::IS) | (lq << 3) | (e << 2) | c] + nd - (int)((uint32_t)w >> 16);
         const double den = (double)nk + vbeta;
         // 1 / den from the fp32 reciprocal (1 ulp) and two Newton steps in fp64: within 2^-50, as cold_tiers_acc's
         double y = (double)__builtin_amdgcn_rcpf((float)den);
@@ -191,9 +245,11 @@ __device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_n
         run = run + ((double)nd + alpha) * (((double)xv[rho] + beta) * y);
         W[k] = run;
     }
-    const double X = group_scan<16>(run, lq);
-    const double tot = bcast_last<16>(X, tid & 63);
-    const double prev = dpp_f64<DPP_ROW_SHR + 1>(X);                   // (0.0 into the first lane of the row)
+    constexpr int LPD = QuadGeo<LB>::LPD;
+    const double X = group_scan<LPD>(run, lq);
+    const double tot = bcast_last<LPD>(X, tid & 63);
+    double prev = dpp_f64<DPP_ROW_SHR + 1>(X);                         // (0.0 into the first lane of the row)
+    if constexpr (LB < 4) prev = lq ? prev : 0.0;
     const double tg = u * tot - prev;
     const double margin = tot * margin_rel;
     const double lo = tg - margin, hi = tg + margin;
@@ -207,12 +263,9 @@ __device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_n
     // position of chain index cnt_lo: e = k >> 4, i = (k >> 2) & 3, c = k & 3
     const uint32_t k = (uint32_t)cnt_lo;
     const uint32_t i_ = (k >> 2) & 3u, e_ = (k >> 4) & 1u, c_ = k & 3u;
-    const uint32_t p = (i_ << 7) | ((uint32_t)lq << 3) | (e_ << 2) | c_ | ((8u * i_ + 2u * c_ + e_) << 9) | ((uint32_t)lq << 14);
-    uint32_t key = cnt_lo >= QT ? 0xFFFFFu : p;
-    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(key));
+    const uint32_t p = (i_ << QuadGeo<LB>::IS) | ((uint32_t)lq << 3) | (e_ << 2) | c_ | ((8u * i_ + 2u * c_ + e_) << 9) | ((uint32_t)lq << 14);
+    uint32_t key = cnt_lo >= QT ? QuadGeo<LB>::KEY_NONE : p;
+    key = quad_min_key<LB>(key);
     zn = (int)(key & 0x3FFFu);
     return unsure;
 }
@@ -232,16 +285,18 @@ struct QuadSite { int v, f, zo, c, zn, lo, so, w; };  // (lo, so) = quad lane an
 #define QP_MARK(k)
 #endif
 
+template <int LB>
 __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P)
 {
-    constexpr int KP = 512;
+    typedef QuadGeo<LB> Geo;
+    constexpr int KP = Geo::KP, LPD = Geo::LPD, G = Geo::G, IS = Geo::IS;
     __shared__ int s_nk[KP];                   // workgroup accumulator of the n_k changes
     __shared__ int s_nk0[KP];                  // the sweep-start n_k
     // [rho >> 2][thread][rho & 3]: a lane's four consecutive slots are 16 contiguous bytes, 16 bytes apart from lane to lane -- the 32
     // factors of a lane come with 8 ds_read_b128 (conflict free) instead of 16 two-address reads
     __shared__ int s_ndk[QT / 4][QNT][4];      // n_dk | sweep-start n_dk << 16
     __shared__ float s_pa[QT / 4][QNT][4];     // tier-0 factor fl32((n_dk + alpha) / (n_k + V*beta))
-    __shared__ float s_u[QNT / 16][32];        // the fp32 uniforms of the next 32 sites of every document
+    __shared__ float s_u[QNT / LPD][2 * LPD];  // the fp32 uniforms of the next 2 LPD sites of every document
 
     const int tid = threadIdx.x;
     for (int i = tid; i < KP; i += QNT) {
@@ -250,9 +305,9 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
     }
     __syncthreads();
 
-    const int lane = tid & 63, lq = tid & 15, row = lane >> 4, grp = tid >> 4;
+    const int lane = tid & 63, lq = tid & (LPD - 1), row = lane >> LB, grp = tid >> LB;
+    const int gbase = lane & (64 - LPD);                 // first lane of the document
     const float vbeta32 = (float)P.vbeta, alpha32 = (float)P.alpha, beta32 = (float)P.beta;
-    const int bp_last = (lane | 15) << 2;
 
     const int64_t site_base = P.doc_off[0];
     const int32_t *word_b = P.word + site_base, *freq_b = P.freq + site_base, *csc_b = P.csc_pos + site_base;
@@ -269,7 +324,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
     };
 
     for (int it = 0; it < P.dpg; ++it) {
-        const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * (QNT / 16) + grp;
+        const int64_t idx = ((int64_t)blockIdx.x * P.dpg + it) * (QNT / LPD) + grp;
         // a lane group without a document walks a copy of the last one with no sites: every lane of the wavefront stays in the site
         // loop (the cold tiers need all of them) and nothing it computes is stored
         const bool valid = idx < P.D;
@@ -281,8 +336,16 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             len = 0;
             s0 = site_base;
         }
-        const int maxlen = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
-                               max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
+        int maxlen;
+        if constexpr (LB == 4) {
+            maxlen = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
+                         max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
+        } else {
+            int ml = len;
+#pragma unroll
+            for (int m = LPD; m < 64; m <<= 1) ml = max(ml, __shfl_xor(ml, m, 64));
+            maxlen = __builtin_amdgcn_readfirstlane(ml);
+        }
         if (maxlen == 0) continue;                                   // (uniform)
 
         int32_t *ndk_row = P.n_dk + d * KP;
@@ -290,12 +353,12 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             int big = 0, tokens = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const v4i a = ((const v4i *)ndk_row)[i * 32 + 2 * lq], b = ((const v4i *)ndk_row)[i * 32 + 2 * lq + 1];
+                const v4i a = ((const v4i *)ndk_row)[i * G + 2 * lq], b = ((const v4i *)ndk_row)[i * G + 2 * lq + 1];
                 const int r[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int rho = quad_rho_of(i, j >> 2, j & 3);
-                    const int k = s_nk0[i * 128 + lq * 8 + j];
+                    const int k = s_nk0[(i << IS) + lq * 8 + j];
                     QLDS(s_ndk, rho, tid) = r[j] | (r[j] << 16);
                     QLDS(s_pa, rho, tid) = tier0_factor(r[j], k, alpha32, vbeta32);
                     big |= r[j];
@@ -304,7 +367,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             }
             // the packed word holds the counts of a document of at most 65 535 tokens (kernel_sweep.hpp, W4): status bit 2 otherwise
 #pragma unroll
-            for (int m = 1; m < 16; m <<= 1) tokens += __shfl_xor(tokens, m, 16);
+            for (int m = 1; m < LPD; m <<= 1) tokens += __shfl_xor(tokens, m, LPD);
             if (valid && (((uint32_t)big >> 16) || tokens > 65535) && P.status) atomicOr(P.status, 4);
         }
         const uint32_t gdoc = (uint32_t)(d + P.doc_base);
@@ -314,12 +377,21 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
         auto load_scalars = [&](QuadSite &R, const uint32_t o) {
             R.v = gload_i32(word_b, o); R.f = gload_i32(freq_b, o); R.c = gload_i32(csc_b, o); R.zo = gload_i32(z_b, o);
         };
+        // LB < 4 (eight or sixteen documents per wavefront: every scalar load touches that many cache lines, and the vector-memory address
+        // pipeline becomes the bound -- TA busy 0.71 with five scalar loads per site): {word, freq, csc_pos} come as ONE 16-byte record
+        // (llda_sweep_args.site_rec), read THREE sites ahead, so that the row of site n+2 is issued from a record that has landed
+        const int32_t *rec_b = LB < 4 ? P.site_rec + site_base * 4 : nullptr;
+        int pv = 0, pf = 0, pc = 0;                                     // the record in flight
+        auto load_rec = [&](int &v, int &f, int &c, const uint32_t o) {
+            const v4i r = *(const LLDA_GLOBAL v4i *)((const LLDA_GLOBAL char *)rec_b + (o << 2));
+            v = r.x; f = r.y; c = r.z;
+        };
         auto decode_old = [&](QuadSite &R) {
-            R.lo = (R.zo >> 3) & 15;
-            R.so = quad_rho(R.zo);
+            R.lo = (R.zo >> 3) & (LPD - 1);
+            R.so = quad_rho<LB>(R.zo);
         };
         // the 16-bit row of word v: chunks (e, j) = slots 8j .. 8j+7 of standard lane 2 lq + e, and the row's flag
-        // (32-bit byte offsets from the image: llda_sweep checked V * 1024 < 2^32)
+        // (32-bit byte offsets from the image: llda_sweep checked V * 1024 < 2^32; a row is 2 KP bytes, its second half KP bytes on)
         int xp[16];
         auto load_row16 = [&](const int v, int &flag) {
 #ifdef ABL_NOLOAD
@@ -328,9 +400,11 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             flag = 1;
             return;
 #endif
-            const LLDA_GLOBAL char *q = (const LLDA_GLOBAL char *)P.n_kw16 + (((uint32_t)v << 10) + (uint32_t)lq * 32u);
-            const v4i a = *(const LLDA_GLOBAL v4i *)q, b = *(const LLDA_GLOBAL v4i *)(q + 512);
-            const v4i c = *(const LLDA_GLOBAL v4i *)(q + 16), e = *(const LLDA_GLOBAL v4i *)(q + 528);
+            // (the image is piece major: the 16 bytes of lane lq's piece (j, e) sit at (2 j + e) * 16 LPD + 16 lq, so that the lanes of
+            // a document read CONTIGUOUS bytes with every load -- full 64-byte requests instead of half-used ones)
+            const LLDA_GLOBAL char *q = (const LLDA_GLOBAL char *)P.n_kw16 + (((uint32_t)v << (IS + 3)) + (uint32_t)lq * 16u);
+            const v4i a = *(const LLDA_GLOBAL v4i *)q, b = *(const LLDA_GLOBAL v4i *)(q + 32 * LPD);
+            const v4i c = *(const LLDA_GLOBAL v4i *)(q + 16 * LPD), e = *(const LLDA_GLOBAL v4i *)(q + 48 * LPD);
             xp[0] = a.x; xp[1] = a.y; xp[2] = a.z; xp[3] = a.w;
             xp[4] = b.x; xp[5] = b.y; xp[6] = b.z; xp[7] = b.w;
             xp[8] = c.x; xp[9] = c.y; xp[10] = c.z; xp[11] = c.w;
@@ -340,7 +414,8 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
         // xp -> fp32 in slot order (exact: 16-bit counts); the lanes of a document whose row does not fit 16 bits read the int32 row
         // now, without prefetch (an int32 count beyond 2^24 rounds: tier 0 stays inside its margin, section 4.3; tier 1 is skipped)
         q_v32f xv;
-        auto convert_row = [&](const int v, const int flag) {
+        // (LB < 4: the own count has left xp already, remove_own_packed; the lanes that read an int32 row take it out here: so, own)
+        auto convert_row = [&](const int v, const int flag, const int so, const float own) {
             LLDA_MARK("convert");
             const uint64_t wide_w = __ballot(flag == 0);
             if (__builtin_expect(wide_w == 0, 1)) {
@@ -357,10 +432,10 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
 #pragma unroll
                 for (int t = 0; t < QT; ++t) xi[t] = 0;
                 if (flag == 0) {
-                    const LLDA_GLOBAL v4i *q = (const LLDA_GLOBAL v4i *)((const LLDA_GLOBAL int32_t *)P.n_kw + ((uint64_t)(uint32_t)v << 9));
+                    const LLDA_GLOBAL v4i *q = (const LLDA_GLOBAL v4i *)((const LLDA_GLOBAL int32_t *)P.n_kw + ((uint64_t)(uint32_t)v << (IS + 2)));
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const v4i a = q[i * 32 + 2 * lq], b = q[i * 32 + 2 * lq + 1];
+                        const v4i a = q[i * G + 2 * lq], b = q[i * G + 2 * lq + 1];
                         xi[quad_rho_of(i, 0, 0)] = a.x; xi[quad_rho_of(i, 0, 1)] = a.y; xi[quad_rho_of(i, 0, 2)] = a.z; xi[quad_rho_of(i, 0, 3)] = a.w;
                         xi[quad_rho_of(i, 1, 0)] = b.x; xi[quad_rho_of(i, 1, 1)] = b.y; xi[quad_rho_of(i, 1, 2)] = b.z; xi[quad_rho_of(i, 1, 3)] = b.w;
                     }
@@ -373,11 +448,16 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                     xv[ra_] = flag == 0 ? (float)xi[ra_] : (float)((uint32_t)xp[k] & 0xffffu);
                     xv[rb_] = flag == 0 ? (float)xi[rb_] : (float)((uint32_t)xp[k] >> 16);
                 }
+                if constexpr (LB < 4) {
+#pragma unroll
+                    for (int r = 0; r < QT; ++r) xv[r] -= (flag == 0 && so == r) ? own : 0.0f;
+                }
             }
         };
         // the site's own count leaves the fp32 row through the slot index (uniform in a document): per document ONE indexed
         // read-modify-write under the document's exec mask
         auto remove_own = [&](const int so, const float own) {
+            if constexpr (LB == 4) {
             LLDA_MARK("own_removal");
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -390,21 +470,43 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                              "s_nop 0\n\ts_set_gpr_idx_off\n\ts_mov_b64 exec, -1"
                              : "+{v[64:95]}"(xv) : "s"(so_r), "s"(em), "v"(own));
             }
+            }
+        };
+        // LB < 4 (eight or sixteen documents per wavefront): the own count leaves the packed 16-bit row, one compare and one
+        // conditional subtract per register -- slot rho = 8 i + 2 c' + e sits in xp[e << 3 | (i >> 1) << 2 | (i & 1) << 1 | c' >> 1],
+        // half c' & 1 (convert_row).  own = 0 in the lanes that do not hold the slot.  (A row that does not fit 16 bits: see convert_row.)
+        auto remove_own_packed = [&](const int so, const int own) {
+            if constexpr (LB < 4) {
+                LLDA_MARK("own_removal");
+                const int kk = ((so & 1) << 3) | ((so >> 4) << 2) | (((so >> 3) & 1) << 1) | ((so >> 2) & 1);
+                const int dd = own << (((so >> 1) & 1) << 4);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) xp[k] -= (kk == k) ? dd : 0;
+            }
         };
 
         // Software pipeline.  At the top of iteration n, xv holds the row of site n as fp32 with the site's own count taken out -- made
         // during iteration n-1, in the shadow of the LDS reads of its count update, from the row that was issued an iteration earlier
         // still.  Scalars run two sites ahead in three rotating register sets (the loop is unrolled by three), the word ids three (wq).
         QuadSite R0, R1, R2;
-        load_scalars(R0, off_of(0)); R0.zn = 0;
-        load_scalars(R1, off_of(1)); R1.zn = 0;
+        int wq = 0;                                      // (LB == 4) word of site n+2 at the top of iteration n
+        if constexpr (LB < 4) {
+            load_rec(R0.v, R0.f, R0.c, off_of(0)); R0.zo = gload_i32(z_b, off_of(0));
+            load_rec(R1.v, R1.f, R1.c, off_of(1)); R1.zo = gload_i32(z_b, off_of(1));
+            load_rec(pv, pf, pc, off_of(2));
+        } else {
+            load_scalars(R0, off_of(0));
+            load_scalars(R1, off_of(1));
+            wq = gload_i32(word_b, off_of(2));
+        }
+        R0.zn = R1.zn = 0;
         R2.v = R2.f = R2.zo = R2.c = R2.zn = R2.lo = R2.so = R2.w = 0;
         load_row16(R0.v, R0.w);
-        int wq = gload_i32(word_b, off_of(2));           // word of site n+2 at the top of iteration n
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         decode_old(R0);
         if (len > 0 && lq == R0.lo) update(R0.so, R0.zo, -R0.f);      // site 0 leaves its topic (LabeledLDA.py:109-111)
-        convert_row(R0.v, R0.w);
+        remove_own_packed(R0.so, (len > 0 && lq == R0.lo) ? R0.f : 0);
+        convert_row(R0.v, R0.w, R0.so, (len > 0 && lq == R0.lo) ? (float)R0.f : 0.0f);
         load_row16(R1.v, R1.w);                                        // row of site 1
         remove_own(R0.so, (len > 0 && lq == R0.lo) ? (float)R0.f : 0.0f);
 
@@ -423,7 +525,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             // the random bits of 32 sites at a time (one Philox block per lane serves two sites); their fp32 images -- the top 27
             // bits, within 2^-24 relative + 2^-27 absolute of u -- go through LDS, the bits themselves are only needed by the cold tiers
             LLDA_MARK("rng");
-            if ((n & 31) == 0) {
+            if ((n & (2 * LPD - 1)) == 0) {
                 LLDA_MARK("rare_philox");
                 r0 = (uint32_t)(n >> 1) + (uint32_t)lq; r1 = gdoc; r2 = P.stream_id; r3 = P.sweep;
                 philox4x32_10(r0, r1, r2, r3, P.key0, P.key1);
@@ -431,39 +533,39 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 s_u[grp][2 * lq + 1] = (float)(r2 >> 5) * 0x1p-27f;
                 LLDA_MARK("rng");
             }
-            const float u32 = s_u[grp][n & 31];
+            const float u32 = s_u[grp][n & (2 * LPD - 1)];
             QP_MARK(0);                                                // factors + uniform issued
             int zn;
-            uint64_t unsure = quad_draw(xv, pa, u32, P.margin0_rel, P.margin0_data, beta32, lq, bp_last, zn) & __ballot(act);
+            uint64_t unsure = quad_draw<LB>(xv, pa, u32, P.margin0_rel, P.margin0_data, beta32, lq, zn) & __ballot(act);
             QP_MARK(1);                                                // chains, scan, search, pick
             LLDA_MARK("cold_check");
             if (__builtin_expect(unsure != 0, 0)) {
                 LLDA_MARK("rare_cold");
                 // tier 1 (fp64, margin 2^-40) right here, in this layout, for all four documents; what IT cannot decide (~1e-9 of the
                 // sites) goes to the exact tier out of line, one document at a time, the whole wavefront playing it in the standard layout
-                const int holder = (n >> 1) & 15;
+                const int holder = (n >> 1) & (LPD - 1);
                 const uint32_t ra_l = (n & 1) ? r2 : r0, rb_l = (n & 1) ? r3 : r1;
-                const int bp_h = ((lane & 48) | holder) << 2;
+                const int bp_h = (gbase | holder) << 2;
                 const uint32_t ra = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_h, (int)ra_l), rb = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_h, (int)rb_l);
                 const uint64_t t0_w = unsure;                          // documents tier 0 was unsure about
-                if (lq == 0 && ((t0_w >> (lane & 48)) & 0xFFFFull) && P.status) atomicAdd(P.status + 1, 1);   // statistics
+                if (lq == 0 && ((t0_w >> gbase) & Geo::GM) && P.status) atomicAdd(P.status + 1, 1);   // statistics
                 int z1;
                 // (a document whose row was read as int32 skips tier 1: a count of 2^24 or more is not exact in xv)
-                const uint64_t still = ((P.margin_rel < 1.0 ? quad_tier1(xv, s_ndk, s_nk0, tid, lq, uniform53(ra, rb), P.alpha, P.beta, P.vbeta,
+                const uint64_t still = ((P.margin_rel < 1.0 ? quad_tier1<LB>(xv, s_ndk, s_nk0, tid, lq, uniform53(ra, rb), P.alpha, P.beta, P.vbeta,
                                                                         P.margin_rel, z1) : ~0ull) | __ballot(cur.w == 0)) & __ballot(act);
-                const bool mine0 = ((t0_w >> (lane & 48)) & 0xFFFFull) != 0;
+                const bool mine0 = ((t0_w >> gbase) & Geo::GM) != 0;
                 zn = mine0 ? z1 : zn;
                 uint32_t rows = 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    rows |= (((t0_w >> (16 * r)) & 0xFFFFull) && ((still >> (16 * r)) & 0xFFFFull)) ? (1u << r) : 0u;
+                for (int r = 0; r < Geo::DPW; ++r)
+                    rows |= (((t0_w >> (LPD * r)) & Geo::GM) && ((still >> (LPD * r)) & Geo::GM)) ? (1u << r) : 0u;
                 rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows);
                 while (__builtin_expect(rows != 0, 0)) {
                     const int r = __builtin_ctz(rows);
                     rows &= rows - 1;
-                    const int src = r * 16;
+                    const int src = r * LPD;
                     const int zo_r = __builtin_amdgcn_readlane(zo, src);
-                    int zc = quad_cold(s_ndk, s_nk0, (tid & 64) + src, __builtin_amdgcn_readlane(cur.v, src),
+                    int zc = quad_cold<LB>(s_ndk, s_nk0, (tid & 64) + src, __builtin_amdgcn_readlane(cur.v, src),
                                        __builtin_amdgcn_readlane(f, src), zo_r, (uint32_t)__builtin_amdgcn_readlane((int)ra, src),
                                        (uint32_t)__builtin_amdgcn_readlane((int)rb, src), lane,
                                        (const KParams *)__builtin_amdgcn_kernarg_segment_ptr());
@@ -471,7 +573,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                         zc = zo_r;
                         if (lane == 0 && P.status) atomicOr(P.status, 1);   // no topic with positive probability
                     }
-                    zn = (row == r) ? (zc | (quad_rho(zc) << 9)) : zn;
+                    zn = (row == r) ? (zc | (quad_rho<LB>(zc) << 9)) : zn;
                 }
             }
             QP_MARK(2);                                                // (cold tiers)
@@ -483,7 +585,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             // every document that has the site: exec mask by hand, no divergent region) and the scalar loads of site n+2 are issued in
             // the shadow of the LDS reads.
             {
-                const int zpos = zn & 511, sn = zn >> 9, ln = (zn >> 3) & 15;
+                const int zpos = zn & 511, sn = zn >> 9, ln = (zn >> 3) & (LPD - 1);
                 cur.zn = zpos;
                 decode_old(nxt);
                 const bool own_new = act && lq == ln, own_old = more && lq == nxt.lo;
@@ -493,11 +595,19 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 LLDA_MARK("count_update");
                 const int w0 = QLDS(s_ndk, sg, tid), k0 = s_nk0[ps];
                 LLDA_MARK("scalars");
-                const int w_next = wq;                                 // word of site n+2 (loaded an iteration ago)
-                load_scalars(prv, off_of(n + 2));                      // scalars of site n+2 (clamped)
-                wq = gload_i32(word_b, off_of(n + 3));
+                int w_next;                                            // word of site n+2 (loaded an iteration ago)
+                if constexpr (LB < 4) {
+                    prv.v = w_next = pv; prv.f = pf; prv.c = pc;       // the record of site n+2
+                    prv.zo = gload_i32(z_b, off_of(n + 2));
+                    load_rec(pv, pf, pc, off_of(n + 3));
+                } else {
+                    w_next = wq;
+                    load_scalars(prv, off_of(n + 2));                  // scalars of site n+2 (clamped)
+                    wq = gload_i32(word_b, off_of(n + 3));
+                }
                 // site n+1: its row (issued an iteration ago) -> fp32, own count out; then the row of site n+2 is issued
-                convert_row(nxt.v, nxt.w);
+                remove_own_packed(nxt.so, (more && lq == nxt.lo) ? nxt.f : 0);
+                convert_row(nxt.v, nxt.w, nxt.so, (more && lq == nxt.lo) ? (float)nxt.f : 0.0f);
                 LLDA_MARK("row_prefetch");
                 load_row16(w_next, prv.w);
                 remove_own(nxt.so, (more && lq == nxt.lo) ? (float)nxt.f : 0.0f);
@@ -555,11 +665,11 @@ if (lq == 0 && act) {                                // (plain stores: the compi
                     const int w = QLDS(s_ndk, quad_rho_of(i, j >> 2, j & 3), tid);
                     o[j] = w & 0xffff;
                     const int dl = o[j] - (int)((uint32_t)w >> 16);
-                    if (dl) atomicAdd(&s_nk[i * 128 + lq * 8 + j], dl);
+                    if (dl) atomicAdd(&s_nk[(i << IS) + lq * 8 + j], dl);
                 }
                 v4i a = {o[0], o[1], o[2], o[3]}, b = {o[4], o[5], o[6], o[7]};
-                ((v4i *)ndk_row)[i * 32 + 2 * lq] = a;
-                ((v4i *)ndk_row)[i * 32 + 2 * lq + 1] = b;
+                ((v4i *)ndk_row)[i * G + 2 * lq] = a;
+                ((v4i *)ndk_row)[i * G + 2 * lq + 1] = b;
             }
         }
     }
@@ -572,28 +682,31 @@ if (lq == 0 && act) {                                // (plain stores: the compi
 }
 
 // ---------------------------------------------------------------------------------------------
-// llda_pack_rows16_all: the 16-bit image of EVERY row of n_kw (32-lane layouts: one wavefront per row, the packing of
-// llda_pack_rows16) and, per row, whether all of its counts fit 16 bits THIS sweep (row16[v] = 1) -- a row that does not is read
-// from n_kw itself by the sweep.
+// llda_pack_rows16_all: the 16-bit image of EVERY row of n_kw (layouts of 16 slots per lane, G = 8, 16, 32 lanes: 2 G threads per row;
+// the 16-byte pieces of llda_pack_rows16 -- slots 8 j .. 8 j + 7 of standard lane g -- in the order the quad kernel reads them: piece
+// (j, g & 1) of quad lane g >> 1 at 16-byte unit (2 j + (g & 1)) * G / 2 + (g >> 1)) and, per row, whether all of its counts fit 16 bits THIS sweep (row16[v] = 1) -- a row that does
+// not is read from n_kw itself by the sweep.
 // ---------------------------------------------------------------------------------------------
+template <int G>
 __global__ void __launch_bounds__(256) llda_pack_rows16_all_kernel(const int32_t *__restrict__ n_kw, uint16_t *__restrict__ out,
                                                                    uint8_t *__restrict__ row16, int64_t V)
 {
-    constexpr int G = 32;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t w = t >> 6;                                        // (a wavefront never straddles two rows)
+    const int64_t w = t / (2 * G);                                   // (a wavefront holds whole rows)
     if (w >= V) return;
-    const int c = (int)(t & 63), j = c >> 5, g = c & 31;
+    const int c = (int)(t & (2 * G - 1)), j = c / G, g = c & (G - 1);
     const int4 *src = reinterpret_cast<const int4 *>(n_kw + w * (int64_t)(G * 16));
     const int4 a = src[(2 * j) * G + g], b = src[(2 * j + 1) * G + g];
     const int m = a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w;
-    const bool wide = __ballot((unsigned)m > 0xffffu) != 0;          // (a negative count is "wide" too)
+    const uint64_t bal = __ballot((unsigned)m > 0xffffu);            // (a negative count is "wide" too)
+    const int first = (int)(threadIdx.x & 63) & ~(2 * G - 1);        // the row's first lane
+    const bool wide = G == 32 ? bal != 0 : ((bal >> first) & ((1ull << (2 * G % 64)) - 1)) != 0;
     uint4 o;
     o.x = ((uint32_t)a.x & 0xffffu) | ((uint32_t)a.y << 16);
     o.y = ((uint32_t)a.z & 0xffffu) | ((uint32_t)a.w << 16);
     o.z = ((uint32_t)b.x & 0xffffu) | ((uint32_t)b.y << 16);
     o.w = ((uint32_t)b.z & 0xffffu) | ((uint32_t)b.w << 16);
-    reinterpret_cast<uint4 *>(out + w * (int64_t)(G * 16))[j * G + g] = o;
+    reinterpret_cast<uint4 *>(out + w * (int64_t)(G * 16))[(2 * j + (g & 1)) * (G / 2) + (g >> 1)] = o;      // piece major (load_row16)
     if (c == 0) row16[w] = wide ? 0 : 1;
 }
 

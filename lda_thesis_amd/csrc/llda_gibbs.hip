@@ -635,13 +635,14 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
     }
     if (a->n_kw_img || a->img_bits) return LLDA_E_BAD_ARG;         // the narrow image belongs to the sparse-label kernels
     if (a->row16) {
-        // four documents per wavefront (kernel_quad.hpp): K = 512 dense with the commit log, every row in the 16-bit image, flags per
-        // word from llda_pack_rows16_all, documents below 2^16 tokens
+        // four / eight / sixteen documents per wavefront (kernel_quad.hpp): K = 512 / 256 / 128 dense with the commit log, every row in
+        // the 16-bit image, flags per word from llda_pack_rows16_all, documents below 2^16 tokens
         if (!a->n_kw16 || a->site_row) return LLDA_E_BAD_ARG;
-        if (!(fast && dense && logged && L.T == 16 && L.G == 32)) return LLDA_E_BAD_ARG;
+        if (!(fast && dense && logged && llda_quad_ok(a->K))) return LLDA_E_BAD_ARG;
         if (!(a->max_doc_tokens > 0 && a->max_doc_tokens < 65536)) return LLDA_E_BAD_ARG;
         if ((reinterpret_cast<uintptr_t>(a->n_kw16) | reinterpret_cast<uintptr_t>(a->n_kw)) & 15) return LLDA_E_BAD_ARG;
         if (a->V >= (1LL << 22)) return LLDA_E_BAD_ARG;                  // (the image is addressed with 32-bit byte offsets)
+        if (L.G <= 16 && !P.site_rec) return LLDA_E_BAD_ARG;             // (8 / 16 documents per wavefront read 16-byte site records)
         if (a->n_sites < 1) return LLDA_OK;                              // (documents without sites: nothing to sample)
         P.n_kw16 = a->n_kw16;
         P.row16 = a->row16;
@@ -652,10 +653,12 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
             P.margin0_rel = LLDA_MARGIN0_QUAD;
             P.margin_rel = 0x1p-40;
         }
-        const int64_t per_q = (int64_t)(QNT / 16) * dpg;
+        const int64_t per_q = (int64_t)(2 * QNT / L.G) * dpg;             // (a document is G / 2 lanes)
         const int64_t qblocks = (a->D + per_q - 1) / per_q;
         if (qblocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
-        hipLaunchKernelGGL(llda_sweep_quad_kernel, dim3((unsigned)qblocks), dim3(QNT), 0, st, P);
+        if (L.G == 32) hipLaunchKernelGGL(llda_sweep_quad_kernel<4>, dim3((unsigned)qblocks), dim3(QNT), 0, st, P);
+        else if (L.G == 16) hipLaunchKernelGGL(llda_sweep_quad_kernel<3>, dim3((unsigned)qblocks), dim3(QNT), 0, st, P);
+        else hipLaunchKernelGGL(llda_sweep_quad_kernel<2>, dim3((unsigned)qblocks), dim3(QNT), 0, st, P);
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? LLDA_OK : hip_fail(e);
     }
@@ -763,6 +766,13 @@ int llda_rows16_ok(int32_t K)
     return !rc && !Lp->wide && Lp->T == 16 && Lp->G >= 32 && Lp->K == Lp->KP ? 1 : 0;
 }
 
+int llda_quad_ok(int32_t K)
+{
+    int rc;
+    const llda_layout *Lp = layout_of(K, &rc);
+    return !rc && !Lp->wide && Lp->T == 16 && (Lp->G == 8 || Lp->G == 16 || Lp->G == 32) && Lp->K == Lp->KP ? 1 : 0;
+}
+
 int llda_pack_rows16(const int32_t *n_kw, const uint8_t *row16, int64_t V, int32_t K, uint16_t *n_kw16, int32_t *status,
                      void *stream)
 {
@@ -805,13 +815,17 @@ int llda_pack_rows16_all(const int32_t *n_kw, int64_t V, int32_t K, uint16_t *n_
     int rc;
     const llda_layout *Lp = layout_of(K, &rc);
     if (rc) return rc;
-    if (!llda_rows16_ok(K) || Lp->G != 32) return LLDA_E_BAD_K;
+    if (!llda_quad_ok(K)) return LLDA_E_BAD_K;
     if (V == 0) return LLDA_OK;
     if (!n_kw || !row16 || !n_kw16) return LLDA_E_BAD_ARG;
     if ((reinterpret_cast<uintptr_t>(n_kw16) | reinterpret_cast<uintptr_t>(n_kw)) & 15) return LLDA_E_BAD_ARG;
-    const int64_t blocks = (V * 64 + 255) / 256;
+    const int64_t blocks = (V * 2 * Lp->G + 255) / 256;
     if (blocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
-    hipLaunchKernelGGL(llda_pack_rows16_all_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_kw, n_kw16, row16, V);
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (Lp->G == 32) hipLaunchKernelGGL(llda_pack_rows16_all_kernel<32>, grid, block, 0, st, n_kw, n_kw16, row16, V);
+    else if (Lp->G == 16) hipLaunchKernelGGL(llda_pack_rows16_all_kernel<16>, grid, block, 0, st, n_kw, n_kw16, row16, V);
+    else hipLaunchKernelGGL(llda_pack_rows16_all_kernel<8>, grid, block, 0, st, n_kw, n_kw16, row16, V);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? LLDA_OK : hip_fail(e);
 }

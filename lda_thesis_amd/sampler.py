@@ -243,7 +243,8 @@ class GibbsSampler(object):
             quad = os.environ["LLDA_QUAD"] == "on"
         self._quad_wanted = quad
         if (rows16 is not False and self.S and self.dense_mask and self.commit_log is not None
-                and _native.rows16_ok(self.K) and self.alpha >= 1e-6 and self.beta >= 1e-6):
+                and (_native.rows16_ok(self.K) or (quad is not False and _native.quad_ok(self.K)))
+                and self.alpha >= 1e-6 and self.beta >= 1e-6):
             with locked:
                 self._make_rows16(auto=rows16 is None)
         self.n_kw_img = None
@@ -376,7 +377,10 @@ class GibbsSampler(object):
             if float(self._wide_host[0]) > self.QUAD_MAX_WIDE_SITES * self.S:
                 self.quad = False
                 self.row16 = None
-                self._flag_rows16()                    # the static flags, bit 31 of csc_pos and site_row of the two-document kernel
+                if _native.rows16_ok(self.K):
+                    self._flag_rows16()                # the static flags, bit 31 of csc_pos and site_row of the two-document kernel
+                else:
+                    self.n_kw16 = None                 # (K = 128, 256: the int32 rows of the general kernel; the image stays allocated)
                 return
         if self._wide_event is None and self.sweeps_done % self.QUAD_CHECK_EVERY == 0:
             if self._wide_host is None:
@@ -415,7 +419,8 @@ class GibbsSampler(object):
         four_waves = 0 < tokens_max < 65536
         if auto and not four_waves and V * KP * 4 < self.ROWS16_MIN_BYTES:
             return
-        quad = bool(self._quad_wanted is not False and four_waves and self.layout.G == 32 and self.layout.T == 16 and V < (1 << 22))
+        quad = bool(self._quad_wanted is not False and four_waves and _native.quad_ok(self.K) and V < (1 << 22))
+        two_doc = _native.rows16_ok(self.K)       # the kernel with static flags (bit 31 of csc_pos, site_row): K = 512, 1024
         if quad and self._quad_wanted is None:
             # sites whose word has a count beyond 16 bits somewhere in its row: rare, or the two-document kernel's prefetched int32 rows
             wide = (self.n_kw.max(dim=1).values > 65535) | (self.n_kw.min(dim=1).values < 0)
@@ -423,8 +428,8 @@ class GibbsSampler(object):
             if float((wide.to(torch.float32) * self._word_sites).sum().item()) > self.QUAD_MAX_WIDE_SITES * self.S:
                 quad = False
         if self._quad_wanted and not quad:
-            raise ValueError("quad=True: needs K = 512, documents of fewer than 65 536 tokens and a vocabulary below 2^22 words")
-        if not quad and not bool(self._rows16_fits().any()):
+            raise ValueError("quad=True: needs K = 128, 256 or 512, documents of fewer than 65 536 tokens and a vocabulary below 2^22 words")
+        if not quad and not (two_doc and bool(self._rows16_fits().any())):
             return
         n32 = (V + 1) * KP
         try:

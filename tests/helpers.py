@@ -71,6 +71,10 @@ class OracleBackend(object):
     def rows16_ok(K):
         return False
 
+    @staticmethod
+    def quad_ok(K):
+        return False
+
     # the images of n_kw change no result: the stand-in reads the counts themselves (LLDA_IMAGE / LLDA_ROWS16 set in the environment)
     @staticmethod
     def pack_image(n_kw, img):

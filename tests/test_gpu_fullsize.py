@@ -21,7 +21,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = {"synth1": (100_000, 200, 50_000, 128), "synth2_shard": (125_000, 300, 100_000, 512),
+CONFIGS = {"synth1": (100_000, 200, 50_000, 128), "synth_k256": (100_000, 200, 50_000, 256), "synth2_shard": (125_000, 300, 100_000, 512),
            "wide_k2048": (20_000, 100, 20_000, 2048)}      # (a wide layout: bench.py's extra.wide_k2048)
 
 
@@ -132,15 +132,16 @@ def test_full_size_properties(name):
     assert torch.equal(torch.cat([h.n_dk for h in halves]), s.n_dk)
 
 
-@pytest.mark.parametrize("name,n_docs", [("synth1", 3000), ("synth2_shard", 2000), ("synth2_1M", 2000), ("wide_k2048", 600)])
+@pytest.mark.parametrize("name,n_docs", [("synth1", 3000), ("synth_k256", 2500), ("synth2_shard", 2000), ("synth2_1M", 2000), ("wide_k2048", 600)])
 def test_full_size_sampled_documents_vs_c_oracle(c_oracle, name, n_docs):
     """the oracle at full size, by sampling (see the module docstring): two sweeps, a fresh sample each."""
     doc_off, word, freq, z, K, V = corpus(name)
     s = make(doc_off, word, freq, z, K, V)
     del z
     assert s.commit_log is not None and s.debug_margin == 0     # production path: tiers + word-major commit log
-    if K == 512:
-        assert s.n_kw16 is not None and s.quad                   # ... on the kernel bench.py times
+    if K in (128, 256, 512):
+        assert s.n_kw16 is not None and s.quad                   # ... on the kernel bench.py times (K = 512: 4 documents per wavefront,
+                                                                 # 256: 8, 128: 16)
     rng = np.random.default_rng(2024)
     for _ in range(2):
         sweep_and_check_sample(s, c_oracle, n_docs, rng)
@@ -148,7 +149,7 @@ def test_full_size_sampled_documents_vs_c_oracle(c_oracle, name, n_docs):
     check_conservation(s)
 
 
-@pytest.mark.parametrize("name", ["synth1", "synth2_shard", "synth2_1M"])
+@pytest.mark.parametrize("name", ["synth1", "synth_k256", "synth2_shard", "synth2_1M"])
 def test_full_size_production_margins_vs_no_fp32_tier(name):
     """every site of the full-size sweep: the production tiers (fp32 decision first) pick the topic the fp64 tiers
     pick with the fp32 tier switched off (debug_margin = -2), two sweeps.  synth2_1M is the workload bench.py times, on the
@@ -157,7 +158,7 @@ def test_full_size_production_margins_vs_no_fp32_tier(name):
     a = make(doc_off, word, freq, z, K, V)
     b = make(doc_off, word, freq, z, K, V)
     del z
-    if K == 512:
+    if K in (128, 256, 512):
         assert a.n_kw16 is not None and a.quad and b.quad
     b.debug_margin = -2
     for _ in range(2):
@@ -221,19 +222,20 @@ def test_full_size_sparse_labels_sampled_documents_vs_c_oracle(c_oracle, docs, n
     assert 0 < int(st[1]) < s.S // 100                     # the fp32 tier handed a few sites to the fp64 decision
 
 
-@pytest.mark.parametrize("docs", [31_250])
-def test_quad_kernel_equals_the_two_document_kernel_in_every_tier_mode(docs):
+@pytest.mark.parametrize("docs,N,V,K", [(31_250, 300, 100_000, 512), (50_000, 200, 50_000, 256), (50_000, 200, 50_000, 128)])
+def test_quad_kernel_equals_the_two_document_kernel_in_every_tier_mode(docs, N, V, K):
     """K = 512: four documents per wavefront (csrc/kernel_quad.hpp) against the two-document 16-bit-row kernel on a slice of configs[3]
     large enough for every CU to run several workgroups at once -- the full integer state after each of two sweeps, with production
-    margins, without the fp32 tier, with margins 2^-6 and with every site through the exact tier (9.4 million sites each).
+    margins, without the fp32 tier, with margins 2^-6 and with every site through the exact tier (9.4 million sites each).  K = 256 and
+    128 (configs[2]): eight and sixteen documents per wavefront against the general kernel on int32 rows.
     (A stale register index in the quad kernel's own-count removal showed only beyond the first workgroup of a CU and only once enough
     registers were live for the stray write to land in one: tools/quad_debug.py.)"""
     from lda_thesis_amd.corpus import synthetic_corpus_blocks
-    doc_off, word, freq, z = synthetic_corpus_blocks(0, docs, 300, 100_000, 512, 1234, "cuda", block=15625)
+    doc_off, word, freq, z = synthetic_corpus_blocks(0, docs, N, V, K, 1234, "cuda", block=docs // 2)
     ref = None
     for quad, margin in ((False, 0), (True, 0), (True, -2), (True, 6), (True, -1)):
-        s = make(doc_off, word, freq, z, 512, 100_000, quad=quad)
-        assert s.quad == quad and s.n_kw16 is not None
+        s = make(doc_off, word, freq, z, K, V, quad=quad)
+        assert s.quad == quad and (s.n_kw16 is not None) == (quad or K == 512)
         s.debug_margin = margin
         states = []
         for _ in range(2):

@@ -444,12 +444,13 @@ def _rows16_corpus_short_docs(K, seed):
 
 
 @pytest.mark.parametrize("margin", [0, -1, -2, 6])
-@pytest.mark.parametrize("K,quad", [(512, True), (512, False), (1024, None)])
+@pytest.mark.parametrize("K,quad", [(512, True), (512, False), (1024, None), (256, True), (128, True)])
 def test_16_bit_rows_four_waves_equal_the_c_oracle(c_oracle, K, quad, margin):
     """documents below 2^16 tokens (llda_sweep_args.max_doc_tokens) against the C oracle (LabeledLDA.py:106-125), every draw tier:
     K = 512 with FOUR documents per wavefront (quad: the image holds every row, the library flags per sweep the rows that fit -- words 0
     and 3 do not: their sites read the int32 row) and with two (the static flags of llda_pack_rows16), K = 1024 with one -- and, at
-    production margins, against the three-wave form (debug_margin -8)"""
+    production margins, against the three-wave form (debug_margin -8).  K = 256 and 128: the quad kernel with eight and sixteen
+    documents per wavefront (packed own-count removal, 16-byte site records) -- at production margins against the general kernel."""
     import torch
     from lda_thesis_amd.sampler import GibbsSampler
     doc_off, word, freq, z, V = _rows16_corpus_short_docs(K, 3 * K + margin)
@@ -475,8 +476,9 @@ def test_16_bit_rows_four_waves_equal_the_c_oracle(c_oracle, K, quad, margin):
         np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
     s.check_status()
     if margin == 0:
-        r = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=9, commit_log=True, rows16=True, doc_base=5, quad=False)
-        r.debug_margin = -8                                              # the three-wave form, production margins
+        r = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=9, commit_log=True, rows16=K >= 512, doc_base=5, quad=False)
+        assert (r.n_kw16 is not None) == (K >= 512)
+        r.debug_margin = -8 if K >= 512 else 0                           # the three-wave form, production margins (K < 512: int32 rows)
         for i in range(3):
             r.sweep()
         assert torch.equal(r.z, s.z) and torch.equal(r._counts, s._counts) and torch.equal(r.n_dk, s.n_dk)
@@ -484,18 +486,20 @@ def test_16_bit_rows_four_waves_equal_the_c_oracle(c_oracle, K, quad, margin):
             assert torch.equal(r.status[1:3], s.status[1:3])             # the same sites left tier 0 / reached the exact tier
 
 
-def test_quad_kernel_hands_over_when_wide_rows_become_common(monkeypatch):
+@pytest.mark.parametrize("K", [512, 128])
+def test_quad_kernel_hands_over_when_wide_rows_become_common(monkeypatch, K):
     """quad=None: counts that concentrate -- here the most frequent words get an entry beyond 65 535 in the middle of the run -- make more
     than QUAD_MAX_WIDE_SITES of the sites read a row that does not fit the 16-bit image; the sampler notices from the library's own flags
-    (asynchronously) and goes over to the two-document kernel.  The states equal those of a sampler that ran that kernel all along."""
+    (asynchronously) and goes over to the two-document kernel (K = 128: to the general kernel on int32 rows).  The states equal those
+    of a sampler that ran that kernel all along."""
     import torch
     from lda_thesis_amd.sampler import GibbsSampler
     monkeypatch.setattr(GibbsSampler, "QUAD_CHECK_EVERY", 1)
-    doc_off, word, freq, z, V = _rows16_corpus_short_docs(512, 77)
+    doc_off, word, freq, z, V = _rows16_corpus_short_docs(K, 77)
     freq = np.minimum(freq, 5).astype(np.int32)                            # (no wide row to begin with)
-    a = GibbsSampler(doc_off, word, freq, z, 512, V, 0.1, 0.01, labs=None, seed=4, commit_log=True)
-    b = GibbsSampler(doc_off, word, freq, z, 512, V, 0.1, 0.01, labs=None, seed=4, commit_log=True, quad=False)
-    assert a.quad and not b.quad and a.site_row is None and b.site_row is not None
+    a = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=4, commit_log=True)
+    b = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=4, commit_log=True, quad=False)
+    assert a.quad and not b.quad and a.site_row is None and (b.site_row is not None) == (K == 512)
     hot = np.argsort(np.bincount(word, minlength=V))[::-1][:6]
     for i in range(12):
         if i == 3:
@@ -505,7 +509,8 @@ def test_quad_kernel_hands_over_when_wide_rows_become_common(monkeypatch):
         b.sweep()
         torch.cuda.synchronize()
         assert torch.equal(a.z, b.z) and torch.equal(a._counts, b._counts) and torch.equal(a.n_dk, b.n_dk), i
-    assert not a.quad and a.site_row is not None                          # handed over (a few sweeps after the counts changed)
+    assert not a.quad and (a.site_row is not None) == (K == 512)          # handed over (a few sweeps after the counts changed)
+    assert (a.n_kw16 is not None) == (K == 512)
     a.check_status()
     b.check_status()
 
@@ -617,18 +622,19 @@ def test_edge_empty_shard_and_empty_documents(c_oracle):
 
 
 @pytest.mark.parametrize("dpg,permute", [(0, False), (3, True), (1, True)])
-def test_edge_quad_kernel_ragged_empty_documents_and_schedules(c_oracle, dpg, permute):
-    """the four-documents-per-wavefront kernel (K = 512 dense, commit log) on a ragged shard: empty documents between one-site and
-    long ones, wavefronts whose four documents differ in length by two orders of magnitude, a document count that fills neither the
+@pytest.mark.parametrize("K", [512, 256, 128])
+def test_edge_quad_kernel_ragged_empty_documents_and_schedules(c_oracle, dpg, permute, K):
+    """the four-documents-per-wavefront kernel (K = 512 dense, commit log; K = 256 / 128: eight / sixteen) on a ragged shard: empty
+    documents between one-site and long ones, wavefronts whose documents differ in length by two orders of magnitude, a document count that fills neither the
     last wavefront nor the last workgroup, frequencies above 1, several documents per lane group and a processing order of the
     caller's -- against the C oracle (LabeledLDA.py:106-125), three sweeps, production margins / mixed tiers / exact tier"""
     import torch
     from lda_thesis_amd.sampler import GibbsSampler
     rng = np.random.default_rng(17 + dpg)
-    K, V = 512, 400
+    V = 400
     lens = np.concatenate([[0, 1, 0, 0, 330, 1, 2, 0, 77, 0, 0, 0, 0, 5], rng.integers(0, 60, size=37)])
     D = len(lens)
-    assert D % 4 and D % 8
+    assert D % 4 and D % 8 and D % 16 and D % 32
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     word = np.concatenate([np.sort(rng.choice(V, size=n, replace=False)) for n in lens]).astype(np.int32)
     freq = rng.integers(1, 6, size=int(off[-1])).astype(np.int32)

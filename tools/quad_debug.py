@@ -1,14 +1,17 @@
-"""debug aid: the quad kernel (csrc/kernel_quad.hpp) against the two-document kernel on a slice of configs[3], every draw-tier mode:
-full integer state after each of two sweeps.  python tools/quad_debug.py [documents]"""
+"""debug aid: the quad kernel (csrc/kernel_quad.hpp) against the kernel the sampler takes without it (K = 512: two documents per
+wavefront on 16-bit rows; K = 128, 256: the general kernel on int32 rows) on a slice of a bench workload, every draw-tier mode: full
+integer state after each of two sweeps.  python tools/quad_debug.py [documents [workload]]     (synth2 | synth1 | synth_k256)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 dev = torch.device("cuda", 0)
 docs = int(sys.argv[1]) if len(sys.argv) > 1 else 31250
+wl = sys.argv[2] if len(sys.argv) > 2 else "synth2"
 ref, ok = None, True
 for quad, margin in ((False, 0), (True, 0), (True, -2), (True, 6), (True, -1)):
     os.environ["LLDA_QUAD"] = "on" if quad else "off"
-    s, info = bench.build_sampler("synth2", dev, 0, 1, False, docs_total=docs)
+    s, info = bench.build_sampler(wl, dev, 0, 1, False, docs_total=docs)
+    assert s.quad == quad, (s.quad, quad)
     s.debug_margin = margin
     states = []
     for i in range(2):

@@ -1,6 +1,6 @@
 """Where a wavefront of the quad kernel (csrc/kernel_quad.hpp) spends its time: a -DQUAD_PROFILE build stamps the shader clock at the
 phase boundaries of every site in wavefront 0 of workgroup 0 and adds the differences up in status[8 + phase].
-    hipcc ... -DQUAD_PROFILE -o tools/bin/libllda_qprof.so;  LLDA_GIBBS_LIB=$PWD/tools/bin/libllda_qprof.so python tools/quad_phase_profile.py"""
+    hipcc ... -DQUAD_PROFILE -o tools/bin/libllda_qprof.so;  LLDA_GIBBS_LIB=$PWD/tools/bin/libllda_qprof.so python tools/quad_phase_profile.py [documents [workload]]"""
 
 
 def main():
@@ -9,7 +9,8 @@ def main():
     import torch
     import bench
     dev = torch.device("cuda", 0)
-    s, info = bench.build_sampler("synth2", dev, 0, 1, False, docs_total=int(sys.argv[1]) if len(sys.argv) > 1 else 125000)
+    s, info = bench.build_sampler(sys.argv[2] if len(sys.argv) > 2 else "synth2", dev, 0, 1, False,
+                                  docs_total=int(sys.argv[1]) if len(sys.argv) > 1 else 125000)
     assert s.quad
     s.status = torch.zeros((64,), dtype=torch.int32, device=dev)
     for _ in range(3):
