@@ -285,7 +285,8 @@ struct QuadSite { int v, f, zo, c, zn, lo, so, w; };  // (lo, so) = quad lane an
 #define QP_MARK(k)
 #endif
 
-template <int LB>
+// REC: {word, freq, csc_pos} of a site come as one 16-byte record (llda_sweep_args.site_rec; always for LB < 4)
+template <int LB, bool REC = (LB < 4)>
 __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P)
 {
     typedef QuadGeo<LB> Geo;
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
         // LB < 4 (eight or sixteen documents per wavefront: every scalar load touches that many cache lines, and the vector-memory address
         // pipeline becomes the bound -- TA busy 0.71 with five scalar loads per site): {word, freq, csc_pos} come as ONE 16-byte record
         // (llda_sweep_args.site_rec), read THREE sites ahead, so that the row of site n+2 is issued from a record that has landed
-        const int32_t *rec_b = LB < 4 ? P.site_rec + site_base * 4 : nullptr;
+        const int32_t *rec_b = REC ? P.site_rec + site_base * 4 : nullptr;
         int pv = 0, pf = 0, pc = 0;                                     // the record in flight
         auto load_rec = [&](int &v, int &f, int &c, const uint32_t o) {
             const v4i r = *(const LLDA_GLOBAL v4i *)((const LLDA_GLOBAL char *)rec_b + (o << 2));
@@ -489,8 +490,8 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
         // during iteration n-1, in the shadow of the LDS reads of its count update, from the row that was issued an iteration earlier
         // still.  Scalars run two sites ahead in three rotating register sets (the loop is unrolled by three), the word ids three (wq).
         QuadSite R0, R1, R2;
-        int wq = 0;                                      // (LB == 4) word of site n+2 at the top of iteration n
-        if constexpr (LB < 4) {
+        int wq = 0;                                      // (!REC) word of site n+2 at the top of iteration n
+        if constexpr (REC) {
             load_rec(R0.v, R0.f, R0.c, off_of(0)); R0.zo = gload_i32(z_b, off_of(0));
             load_rec(R1.v, R1.f, R1.c, off_of(1)); R1.zo = gload_i32(z_b, off_of(1));
             load_rec(pv, pf, pc, off_of(2));
@@ -596,7 +597,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 const int w0 = QLDS(s_ndk, sg, tid), k0 = s_nk0[ps];
                 LLDA_MARK("scalars");
                 int w_next;                                            // word of site n+2 (loaded an iteration ago)
-                if constexpr (LB < 4) {
+                if constexpr (REC) {
                     prv.v = w_next = pv; prv.f = pf; prv.c = pc;       // the record of site n+2
                     prv.zo = gload_i32(z_b, off_of(n + 2));
                     load_rec(pv, pf, pc, off_of(n + 3));

@@ -656,7 +656,9 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         const int64_t per_q = (int64_t)(2 * QNT / L.G) * dpg;             // (a document is G / 2 lanes)
         const int64_t qblocks = (a->D + per_q - 1) / per_q;
         if (qblocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
-        if (L.G == 32) hipLaunchKernelGGL(llda_sweep_quad_kernel<4>, dim3((unsigned)qblocks), dim3(QNT), 0, st, P);
+        // (K = 512 with the site records measured SLOWER: 5.19 vs 4.84 ms on 125 000 documents -- four documents per wavefront are not
+        // bound by the address pipeline, and the records are 4 more bytes per site)
+        if (L.G == 32) hipLaunchKernelGGL((llda_sweep_quad_kernel<4>), dim3((unsigned)qblocks), dim3(QNT), 0, st, P);
         else if (L.G == 16) hipLaunchKernelGGL(llda_sweep_quad_kernel<3>, dim3((unsigned)qblocks), dim3(QNT), 0, st, P);
         else hipLaunchKernelGGL(llda_sweep_quad_kernel<2>, dim3((unsigned)qblocks), dim3(QNT), 0, st, P);
         const hipError_t e = hipGetLastError();
