@@ -23,6 +23,7 @@ run default --gpus 1 --steps 20 --warmup 5
 run sparse --workload synth2_sparse --steps 50 --warmup 5
 run scrambled --workload synth2_sparse_scr --steps 50 --warmup 5
 run abstracts --workload abstracts --steps 500 --warmup 20
+run synth1 --workload synth1 --steps 200 --warmup 5
 # the same lines WITH the counter passes, raw per-dispatch counter rows kept
 timeout 600 python bench.py --workload synth2_sparse --steps 50 --warmup 5 --no-cpu --pmc-keep $OUT/pmc_sparse --detail-out $OUT/sparse_detail.json > $OUT/sparse_line.json 2> $OUT/sparse.err
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-extras --pmc-keep $OUT/pmc_default --detail-out $OUT/default_detail.json > $OUT/default_line.json 2> $OUT/default.err
