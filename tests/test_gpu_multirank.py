@@ -94,6 +94,17 @@ def _digest(t):
 
 
 def _slice_worker(rank, world, port, overlap, rows16, q):
+    _run_slice(rank, world, port, overlap, rows16, q, SLICE_DOCS, SLICE_N, SLICE_V, SLICE_K, SLICE_BLOCK)
+
+
+K128 = dict(docs=40000, N=200, V=50000, K=128, block=5000)      # a slice of BASELINE configs[2]
+
+
+def _k128_worker(rank, world, port, overlap, q):
+    _run_slice(rank, world, port, overlap, None, q, K128["docs"], K128["N"], K128["V"], K128["K"], K128["block"])
+
+
+def _run_slice(rank, world, port, overlap, rows16, q, SLICE_DOCS, SLICE_N, SLICE_V, SLICE_K, SLICE_BLOCK):
     from lda_thesis_amd.corpus import synthetic_corpus_blocks
     from lda_thesis_amd.sampler import GibbsSampler
     if world > 1:
@@ -107,7 +118,7 @@ def _slice_worker(rank, world, port, overlap, rows16, q):
                                                      block=SLICE_BLOCK)
     s = GibbsSampler(doc_off, word, freq, z, SLICE_K, SLICE_V, 0.1, 0.01, labs=None, seed=42, doc_base=lo, device=dev,
                      overlap_ranges=overlap, rows16=rows16)
-    facts = dict(rows=s.rows is not None, logged=s.commit_log is not None, rows16=s.n_kw16 is not None,
+    facts = dict(rows=s.rows is not None, logged=s.commit_log is not None, rows16=s.n_kw16 is not None, quad=bool(s.quad),
                  pair_rows=int((s.row_off[:-1] < 0).sum()) if s.row_off is not None else -1,
                  collectives=len(s._rows_list) if s._rows_list is not None else 0)
     for _ in range(SLICE_SWEEPS):
@@ -154,6 +165,19 @@ def test_configs3_slice_sharded_over_ranks_equals_the_one_rank_run(one_rank_slic
         assert facts["collectives"] == overlap and facts["rows16"] == rows16
     got = sorted(b for _, _, blocks, _, _ in res for b in blocks)
     assert got == sorted(blocks1), "z / n_dk of the shards differ from the one-rank run"
+
+
+def test_configs2_slice_on_the_sixteen_document_kernel_sharded_over_two_ranks():
+    """K = 128 (a 40 000-document slice of BASELINE configs[2]): llda_sweep_quad_kernel<2> -- sixteen documents per wavefront, 16-byte
+    site records, the 16-bit image of every rank's n_kw replica repacked each sweep -- under the exchange: both ranks' [n_kw | n_k] and
+    the shards' z / n_dk equal the one-process run (which folds its log straight into n_kw)."""
+    (rank, counts1, blocks1, facts1, tokens1), = _spawn(1, _k128_worker, (1,))
+    assert facts1["quad"] and facts1["rows16"] and facts1["logged"] and tokens1 == K128["docs"] * K128["N"]
+    res = _spawn(2, _k128_worker, (2,), timeout=900)
+    for rank, counts, blocks, facts, tokens in res:
+        assert counts == counts1, "rank %d: [n_kw | n_k] differs from the one-rank run" % rank
+        assert facts["quad"] and facts["rows"] and facts["logged"] and facts["collectives"] == 2 and tokens == tokens1
+    assert sorted(b for _, _, blocks, _, _ in res for b in blocks) == sorted(blocks1)
 
 
 # ---- the same slice with SPARSE label sets (root + 7 labels per document): the sparse-label kernel, with and without its narrow image
