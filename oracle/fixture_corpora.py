@@ -40,6 +40,10 @@ TINY = [
     # i.e. the 16-bit rows at four waves per SIMD the bench's headline runs on, against the reference itself
     ("k512dense",  30, 150,  511, 511,    (10, 60),  0.1, 0.01, 2),
     ("k1024dense", 12, 100, 1023, 1023,   (10, 40),  0.1, 0.01, 2),
+    # ... and the narrower forms of the same kernel: K = 256 / 128 with eight / sixteen documents per wavefront (D is no multiple of
+    # either: the last wavefront and the last workgroup are partly empty)
+    ("k256dense",  45, 150,  255, 255,    (10, 60),  0.1, 0.01, 2),
+    ("k128dense",  70, 150,  127, 127,    (10, 60),  0.1, 0.01, 2),
     # wide layouts (more than 8 pairwise leaves: 64-lane tiers of one wavefront)
     ("k1031",    10, 100, 1030, 400,      (10, 40),  0.1, 0.01, 2),    # 9 leaves -> 2 tiers x 16 slots, tail 7
     ("k1100",    10, 100, 1099,  30,      (10, 40),  0.1, 0.01, 2),    # 16 leaves, 12 slots per lane, tail 4, sparse labels
@@ -48,7 +52,7 @@ TINY = [
 ]
 
 
-ALL_LABELS = ("k512dense", "k1024dense")      # fixtures whose documents carry the whole label set
+ALL_LABELS = ("k512dense", "k1024dense", "k256dense", "k128dense")      # fixtures whose documents carry the whole label set
 
 
 def all_labels(name, docs, labs, labelset):

@@ -61,6 +61,25 @@ def test_headline_kernels_match_reference_o3(name):
             assert bool(s.row16.all()) and s.site_row is None           # (the library's flags: every row of the fixture fits)
 
 
+@pytest.mark.parametrize("name", ["tiny_k256dense", "tiny_k128dense"])
+def test_narrow_quad_kernels_match_reference_o3(name):
+    """K = 256 / 128, every label in every document, commit log: llda_sweep_quad_kernel<3> / <2> -- eight / sixteen documents per
+    wavefront, 16-byte site records, own count out of the packed row -- against the reference's own O3 sweeps, in every tier mode; and
+    the general kernel (quad False) on the same fixture"""
+    g = load_golden(name)
+    for margin, quad in ((0, None), (6, True), (-2, True), (-1, True), (0, False)):
+        s = make_sampler(g, commit_log=True, quad=quad)
+        assert s.dense_mask and s.commit_log is not None and s.site_rec is not None
+        assert s.quad == (quad is not False) and (s.n_kw16 is not None) == s.quad
+        s.debug_margin = margin
+        for i in range(int(g["sweeps"])):
+            s.sweep()
+            assert_state_equal(g, "o3_s%d" % (i + 1), s.n_k_v(), s.n_d_k(), s.n_zk(), s.z_topics(), name)
+        s.check_status()
+        if s.quad:
+            assert bool(s.row16.all()) and s.site_row is None and 0 < s.max_doc_tokens < 65536
+
+
 @pytest.mark.parametrize("name", [n for n in TINY if int(n.split("k")[-1].rstrip("dense")) > 1024])
 def test_wide_layout_kernels_agree_with_reference(c_oracle, name):
     """wide layouts (more than 8 pairwise leaves): the LDS-only tiered kernel (debug_margin -3; production runs the one that
