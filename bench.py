@@ -16,6 +16,8 @@ With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its o
 
 At N = 1 the same JSON line also carries (key "extra"):
   * "synth1"          BASELINE configs[2] (100k docs x 200 sites, K = 128): the roofline case BASELINE names;
+  * "dense_k256"      the same corpus shape at K = 256 (the eight-documents-per-wavefront form of the 16-bit-row kernel; K = 128
+                      runs sixteen, K = 512 four);
   * "hbm_bound"       a cache-hostile variant (uniform words, V = 500 000: n_kw = 1 GB > the 256 MB Infinity Cache)
                       that shows the genuinely HBM-bound regime of the same kernel;
   * "abstracts"       Labeled LDA on the tokenised abstracts_data.csv fixture (configs[0]/[1]) with its own
@@ -699,7 +701,7 @@ def cascade_test_extra(with_cpu=True):
 
 # ------------------------------------------------------------------------------------------------ PMC passes
 # every workload whose sweep is ONE kernel launch per sweep, in the order the inner run sweeps them
-PMC_WORKLOADS = ("synth2", "synth1", "synth2_hostile", "synth2_sparse", "synth2_sparse_hier", "synth2_sparse_scr", "synth_wide_sparse", "synth_wide",
+PMC_WORKLOADS = ("synth2", "synth1", "synth_k256", "synth2_hostile", "synth2_sparse", "synth2_sparse_hier", "synth2_sparse_scr", "synth_wide_sparse", "synth_wide",
                  "abstracts")
 PMC_SWEEPS = 3                                              # per workload in the inner run (all are measured)
 # one rocprofv3 run per group (kernel trace only, as the guide prescribes).  TCC holds 4 counters per pass
@@ -1295,7 +1297,7 @@ def main():
         del sampler, info
         torch.cuda.empty_cache()
         if extras_on:
-            for key, wname, st, wu in (("synth1", "synth1", 200, 5), ("hbm_bound", "synth2_hostile", 40, 3),
+            for key, wname, st, wu in (("synth1", "synth1", 200, 5), ("dense_k256", "synth_k256", 100, 5), ("hbm_bound", "synth2_hostile", 40, 3),
                                        ("sparse_labels", "synth2_sparse", 100, 5),
                                        ("sparse_labels_colocated", "synth2_sparse_hier", 100, 5),
                                        ("sparse_labels_scrambled", "synth2_sparse_scr", 100, 5), ("abstracts", "abstracts", 3000, 20),
@@ -1361,7 +1363,7 @@ def main():
         m = measured[name]
         line["roofline"] = roofline_json(m["kernel_ms"], m["sites"], m["docs"], m["live"], pmc.get(name), source,
                                          stored_key=name, shared_bytes=m["shared"])
-        for key, wname in (("synth1", "synth1"), ("hbm_bound", "synth2_hostile"), ("sparse_labels", "synth2_sparse"),
+        for key, wname in (("synth1", "synth1"), ("dense_k256", "synth_k256"), ("hbm_bound", "synth2_hostile"), ("sparse_labels", "synth2_sparse"),
                            ("sparse_labels_colocated", "synth2_sparse_hier"), ("sparse_labels_scrambled", "synth2_sparse_scr"), ("wide_sparse_k2048", "synth_wide_sparse"), ("wide_k2048", "synth_wide"), ("abstracts", "abstracts")):
             if key in extra:
                 m = measured[wname]
