@@ -151,7 +151,8 @@ def test_commit_paths_agree(name, commit, monkeypatch):
     s.check_status()
 
 
-@pytest.mark.parametrize("name", ["tiny_k40", "tiny_k130", "tiny_k392", "tiny_k512", "sublda"])
+@pytest.mark.parametrize("name", ["tiny_k40", "tiny_k130", "tiny_k392", "tiny_k512", "sublda", "tiny_k512dense", "tiny_k256dense",
+                                  "tiny_k128dense"])          # (the dense ones with the commit log: the quad kernel, 4 / 8 / 16 documents per wavefront)
 def test_shard_split_into_several_calls(name, monkeypatch):
     """llda_sweep addresses the sites of one call with 32-bit offsets from its first document, so a shard that
     spans 2^30 sites is walked in several calls over document ranges; here the limit is lowered to 150 sites."""
@@ -160,6 +161,7 @@ def test_shard_split_into_several_calls(name, monkeypatch):
     monkeypatch.setattr(GibbsSampler, "MAX_CALL_SITES", 150)
     for commit in (False, True):
         s = make_sampler(g, commit_log=commit)
+        assert s.quad == (commit and name.endswith("dense"))
         assert len(s._calls) > 2 and s._calls[0][0] == 0 and s._calls[-1][1] == s.D
         assert all(a[1] == b[0] for a, b in zip(s._calls, s._calls[1:]))
         for i in range(int(g["sweeps"])):
