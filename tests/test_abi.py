@@ -76,6 +76,15 @@ def test_layout_init_rejects_bad_k(K):
     assert _native.lib().llda_layout_init(K, ctypes.byref(out)) == -1        # LLDA_E_BAD_K
 
 
+def test_which_k_take_the_16_bit_rows():
+    """host-only predicates: llda_rows16_ok (static flags: 16 slots per lane, 32 or 64 lanes, no padded slot) and llda_quad_ok (per-sweep
+    flags, K / 32 lanes x 32 slots per document: 8, 16 or 32 lanes)"""
+    from lda_thesis_amd import _native
+    assert [K for K in (64, 100, 128, 200, 256, 392, 512, 777, 1024, 1031, 2048) if _native.rows16_ok(K)] == [512, 1024]
+    assert [K for K in (64, 100, 128, 200, 256, 392, 512, 777, 1024, 1031, 2048) if _native.quad_ok(K)] == [128, 256, 512]
+    assert not _native.quad_ok(0) and not _native.quad_ok(10 ** 6)
+
+
 def test_device_entry_points_validate_arguments():
     from lda_thesis_amd import _native
     L = _native.lib()
