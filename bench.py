@@ -69,6 +69,10 @@ WORKLOADS = {
     "synth_k256": (100000, 200, 50000, 256, 1.0, 12500,
                    "synthetic 100k docs x 200 tokens, K=256 dense mask, V=50k (tools and tests: the eight-documents-per-wavefront form "
                    "of the 16-bit-row kernel)"),
+    "synth_k100": (100000, 200, 50000, 100, 1.0, 12500,
+                   "synthetic 100k docs x 200 tokens, K=100 dense mask, V=50k (tools: a layout with positions that hold no topic, KP = 128)"),
+    "synth_k400": (100000, 300, 100000, 400, 1.0, 12500,
+                   "synthetic 100k docs x 300 tokens, K=400 dense mask, V=100k (tools: four unequal leaves, KP = 512)"),
     "synth2_hostile": (125000, 300, 500000, 512, 0.0, 15625,
                        "cache-hostile variant of configs[3]: 125k docs x 300 tokens, K=512 dense mask, UNIFORM words over "
                        "V=500k -- n_kw is 1.02 GB, four times the Infinity Cache, every site reads a cold 2 KB row"),
@@ -230,7 +234,7 @@ def checksum_verdict(name, docs_total, sweeps, got):
 
 def docs_per_wavefront(sampler):
     """quad kernel (csrc/kernel_quad.hpp): a document is K / 32 lanes x 32 slots"""
-    return {512: "four", 256: "eight", 128: "sixteen"}.get(int(sampler.K), "?")
+    return {32: "four", 16: "eight", 8: "sixteen"}.get(int(sampler.layout.G), "?")
 
 
 def rows_description(sampler):

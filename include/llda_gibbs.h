@@ -187,7 +187,7 @@ typedef struct llda_sweep_args {
     int32_t  reserved_img;       /* 0                                                                         */
     const uint8_t *row16;        /* [dev] [V] optional (ABI 19), with n_kw16 and WITHOUT site_row: the per-word flags llda_pack_rows16_all
                                     wrote for THIS sweep's n_kw (1 = every count of the row fits 16 bits; n_kw16 then holds EVERY
-                                    row).  K with llda_quad_ok (512; ABI 21: 256 and 128 as well), dense_mask = 1, the commit log,
+                                    row).  K with llda_quad_ok (512; ABI 21: the layouts of 16 slots per lane with 8, 16 or 32 lanes), dense_mask = 1, the commit log,
                                     alpha, beta >= 1e-6, 0 < max_doc_tokens < 65 536 and, for K = 128 and 256, site_rec (LLDA_E_BAD_ARG otherwise): the kernel that
                                     walks a document with K / 32 lanes x 32 slots (kernel_quad.hpp), FOUR documents per wavefront at
                                     K = 512, eight at 256, sixteen at 128 -- the per-iteration work of scan, search, pick and count
@@ -232,8 +232,11 @@ int64_t     llda_sweep_scratch_bytes(int32_t K, int64_t D);
 /* 1 when llda_sweep can read 16-bit rows for K topics (narrow layout, 16 slots per lane, 32 or 64 lanes, no padded slot:
  * K = 512 and K = 1024).  Host only. */
 int         llda_rows16_ok(int32_t K);
-/* 1 when llda_sweep takes llda_sweep_args.row16 for K topics (ABI 21; narrow layout, 16 slots per lane, 8, 16 or 32 lanes, no padded
- * slot: K = 128, 256 and 512).  Host only. */
+/* 1 when llda_sweep takes llda_sweep_args.row16 for K topics (ABI 21; narrow layout of 16 slots per lane whose 8, 16 or 32 lanes all
+ * belong to a leaf of numpy's pairwise sum: K = 97 .. 128 (one leaf), 185 .. 248 without 192 and 256 (two), 361 .. 488 without 368,
+ * 376, 384 and 496, 504, 512 (four) -- K = 100, 120, 200, 240, 400, 480 as well as 128, 256, 512; not 250 (three leaves in a four-leaf
+ * layout) or 500 (five leaves).  Positions without a topic
+ * keep the factor 0, the exact tier sums in numpy's order for K.  Host only. */
 int         llda_quad_ok(int32_t K);
 
 /* ---- device entry points (enqueue on `stream`) ---- */

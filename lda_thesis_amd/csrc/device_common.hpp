@@ -59,6 +59,7 @@ struct KParams {
     const int32_t *img_col;    // with img: image column of every device position (llda_pack_image_cols); NULL = the position itself
     int w4;                    // with n_kw16: documents hold < 2^16 tokens -- the four-wave form of the kernel may run
     const uint8_t *row16;      // quad kernel (kernel_quad.hpp): per word, 1 = every count of its row fits the 16-bit image this sweep
+    int quad_pad;              // quad kernel: K < KP (positions without a topic: their factors are 0, the cold tiers take the masked form)
     uint32_t rounds_pk[LLDA_MAX_ROUNDS];   // 4 bits per leaf: partner leaf
 };
 

@@ -104,9 +104,9 @@ struct QuadCounts {
 
 // One undecided site: every G lanes of the wavefront play the document in the standard layout (all but the first G silently), the row
 // comes from n_kw itself.  tbase = thread of the document's quad lane 0; w, f, zo = word, frequency and old position of the site.
-template <int LB>
+template <int LB, bool PAD>
 __device__ __noinline__ int quad_cold(const int (*s_ndk)[QNT][4], const int *s_nk0, int tbase, int w, int f, int zo, uint32_t ra,
-                                      uint32_t rb, int lane, const KParams *P)
+                                      uint32_t rb, int lane, int64_t d, const KParams *P)
 {
     constexpr int G = QuadGeo<LB>::G;
     const int g = lane & (G - 1);
@@ -117,7 +117,9 @@ __device__ __noinline__ int quad_cold(const int (*s_ndk)[QNT][4], const int *s_n
 #pragma unroll
     for (int s = 0; s < 16; ++s) x[s] -= (g == lo && s == so) ? f : 0;       // the site's own count (LabeledLDA.py:109-111)
     const QuadCounts<LB> dc{s_ndk, s_nk0, tbase + (g >> 1), g & 1, g, lane < G};
-    return cold_tiers_acc<G, 16, false, true>(dc, x, 0xFFFFu, uniform53(ra, rb), g, lane, P);
+    // K < KP (positions without a topic, a last leaf with a tail, leaves of unequal length): the masked form with numpy's tail
+    if constexpr (PAD) return cold_tiers_acc<G, 16, true, false>(dc, x, P->lab_mask[d * G + g], uniform53(ra, rb), g, lane, P);
+    else return cold_tiers_acc<G, 16, false, true>(dc, x, 0xFFFFu, uniform53(ra, rb), g, lane, P);
 }
 
 typedef float q_v2f __attribute__((ext_vector_type(2)));
@@ -227,7 +229,7 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
 // xv = the row minus the site's own count, exact in fp32.  Returns the ballot of the lanes that are STILL not sure; zn as quad_draw.
 template <int LB>
 __device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_ndk)[QNT][4], const int *s_nk0, int tid, int lq, double u,
-                                               double alpha, double beta, double vbeta, double margin_rel, int &zn)
+                                               double alpha, double beta, double vbeta, double margin_rel, uint32_t vm, int &zn)
 {
     double W[QT];
     double run = 0.0;
@@ -242,7 +244,8 @@ __device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_n
         double y = (double)__builtin_amdgcn_rcpf((float)den);
         y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
         y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
-        run = run + ((double)nd + alpha) * (((double)xv[rho] + beta) * y);
+        const double ws = ((double)nd + alpha) * (((double)xv[rho] + beta) * y);
+        run = run + (((vm >> k) & 1u) ? ws : 0.0);                // (vm: bit 16 e + a = this position holds a topic)
         W[k] = run;
     }
     constexpr int LPD = QuadGeo<LB>::LPD;
@@ -286,7 +289,8 @@ struct QuadSite { int v, f, zo, c, zn, lo, so, w; };  // (lo, so) = quad lane an
 #endif
 
 // REC: {word, freq, csc_pos} of a site come as one 16-byte record (llda_sweep_args.site_rec; always for LB < 4)
-template <int LB, bool REC = (LB < 4)>
+// PAD: K < KP -- positions without a topic (the K == KP instantiations stay what they were: the validity word is a constant there)
+template <int LB, bool REC = (LB < 4), bool PAD = false>
 __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P)
 {
     typedef QuadGeo<LB> Geo;
@@ -350,6 +354,9 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
         if (maxlen == 0) continue;                                   // (uniform)
 
         int32_t *ndk_row = P.n_dk + d * KP;
+        // the positions of this lane that hold a topic (bit 16 e + slot: the masks of the standard lanes 2 lq and 2 lq + 1; all ones
+        // when K == KP): a position without one keeps the factor 0 -- it is never drawn, and nothing ever updates it
+        const uint32_t vm = PAD ? (uint32_t)P.lab_mask[d * G + 2 * lq] | (uint32_t)P.lab_mask[d * G + 2 * lq + 1] << 16 : ~0u;
         {
             int big = 0, tokens = 0;
 #pragma unroll
@@ -361,7 +368,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                     const int rho = quad_rho_of(i, j >> 2, j & 3);
                     const int k = s_nk0[(i << IS) + lq * 8 + j];
                     QLDS(s_ndk, rho, tid) = r[j] | (r[j] << 16);
-                    QLDS(s_pa, rho, tid) = tier0_factor(r[j], k, alpha32, vbeta32);
+                    QLDS(s_pa, rho, tid) = ((vm >> (16 * (j >> 2) + 4 * i + (j & 3))) & 1u) ? tier0_factor(r[j], k, alpha32, vbeta32) : 0.0f;
                     big |= r[j];
                     tokens += (int)((uint32_t)r[j] & 0xffffu);
                 }
@@ -553,7 +560,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 int z1;
                 // (a document whose row was read as int32 skips tier 1: a count of 2^24 or more is not exact in xv)
                 const uint64_t still = ((P.margin_rel < 1.0 ? quad_tier1<LB>(xv, s_ndk, s_nk0, tid, lq, uniform53(ra, rb), P.alpha, P.beta, P.vbeta,
-                                                                        P.margin_rel, z1) : ~0ull) | __ballot(cur.w == 0)) & __ballot(act);
+                                                                        P.margin_rel, vm, z1) : ~0ull) | __ballot(cur.w == 0)) & __ballot(act);
                 const bool mine0 = ((t0_w >> gbase) & Geo::GM) != 0;
                 zn = mine0 ? z1 : zn;
                 uint32_t rows = 0;
@@ -566,9 +573,10 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                     rows &= rows - 1;
                     const int src = r * LPD;
                     const int zo_r = __builtin_amdgcn_readlane(zo, src);
-                    int zc = quad_cold<LB>(s_ndk, s_nk0, (tid & 64) + src, __builtin_amdgcn_readlane(cur.v, src),
+                    int zc = quad_cold<LB, PAD>(s_ndk, s_nk0, (tid & 64) + src, __builtin_amdgcn_readlane(cur.v, src),
                                        __builtin_amdgcn_readlane(f, src), zo_r, (uint32_t)__builtin_amdgcn_readlane((int)ra, src),
                                        (uint32_t)__builtin_amdgcn_readlane((int)rb, src), lane,
+                                       (int64_t)__builtin_amdgcn_readlane((int)d, src),          // (llda_sweep: D < 2^31)
                                        (const KParams *)__builtin_amdgcn_kernarg_segment_ptr());
                     if (__builtin_expect(zc < 0, 0)) {
                         zc = zo_r;

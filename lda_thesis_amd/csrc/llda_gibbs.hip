@@ -638,7 +638,10 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         // four / eight / sixteen documents per wavefront (kernel_quad.hpp): K = 512 / 256 / 128 dense with the commit log, every row in
         // the 16-bit image, flags per word from llda_pack_rows16_all, documents below 2^16 tokens
         if (!a->n_kw16 || a->site_row) return LLDA_E_BAD_ARG;
-        if (!(fast && dense && logged && llda_quad_ok(a->K))) return LLDA_E_BAD_ARG;
+        if (!(fast && a->dense_mask != 0 && logged && llda_quad_ok(a->K))) return LLDA_E_BAD_ARG;
+        if (a->D >= (1LL << 31)) return LLDA_E_BAD_ARG;
+        P.quad_pad = L.K != L.KP;
+        if (P.quad_pad && !P.lab_mask) return LLDA_E_BAD_ARG;
         if (!(a->max_doc_tokens > 0 && a->max_doc_tokens < 65536)) return LLDA_E_BAD_ARG;
         if ((reinterpret_cast<uintptr_t>(a->n_kw16) | reinterpret_cast<uintptr_t>(a->n_kw)) & 15) return LLDA_E_BAD_ARG;
         if (a->V >= (1LL << 22)) return LLDA_E_BAD_ARG;                  // (the image is addressed with 32-bit byte offsets)
@@ -658,9 +661,16 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         if (qblocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
         // (K = 512 with the site records measured SLOWER: 5.19 vs 4.84 ms on 125 000 documents -- four documents per wavefront are not
         // bound by the address pipeline, and the records are 4 more bytes per site)
-        if (L.G == 32) hipLaunchKernelGGL((llda_sweep_quad_kernel<4>), dim3((unsigned)qblocks), dim3(QNT), 0, st, P);
-        else if (L.G == 16) hipLaunchKernelGGL(llda_sweep_quad_kernel<3>, dim3((unsigned)qblocks), dim3(QNT), 0, st, P);
-        else hipLaunchKernelGGL(llda_sweep_quad_kernel<2>, dim3((unsigned)qblocks), dim3(QNT), 0, st, P);
+        const dim3 qgrid((unsigned)qblocks), qblock(QNT);
+        if (!P.quad_pad) {
+            if (L.G == 32) hipLaunchKernelGGL((llda_sweep_quad_kernel<4>), qgrid, qblock, 0, st, P);
+            else if (L.G == 16) hipLaunchKernelGGL((llda_sweep_quad_kernel<3>), qgrid, qblock, 0, st, P);
+            else hipLaunchKernelGGL((llda_sweep_quad_kernel<2>), qgrid, qblock, 0, st, P);
+        } else {                                                          // K < KP: positions without a topic
+            if (L.G == 32) hipLaunchKernelGGL((llda_sweep_quad_kernel<4, false, true>), qgrid, qblock, 0, st, P);
+            else if (L.G == 16) hipLaunchKernelGGL((llda_sweep_quad_kernel<3, true, true>), qgrid, qblock, 0, st, P);
+            else hipLaunchKernelGGL((llda_sweep_quad_kernel<2, true, true>), qgrid, qblock, 0, st, P);
+        }
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? LLDA_OK : hip_fail(e);
     }
@@ -772,7 +782,9 @@ int llda_quad_ok(int32_t K)
 {
     int rc;
     const llda_layout *Lp = layout_of(K, &rc);
-    return !rc && !Lp->wide && Lp->T == 16 && (Lp->G == 8 || Lp->G == 16 || Lp->G == 32) && Lp->K == Lp->KP ? 1 : 0;
+    // (every lane group holds a leaf: the branch-free count update rewrites slot 0 of the lanes that own neither topic of a site
+    // with the factor of ITS counts, which must then be a position with a topic -- K = 250, three leaves in a four-leaf layout, is out)
+    return !rc && !Lp->wide && Lp->T == 16 && (Lp->G == 8 || Lp->G == 16 || Lp->G == 32) && Lp->n_leaves * 8 == Lp->G ? 1 : 0;
 }
 
 int llda_pack_rows16(const int32_t *n_kw, const uint8_t *row16, int64_t V, int32_t K, uint16_t *n_kw16, int32_t *status,

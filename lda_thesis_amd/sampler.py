@@ -91,8 +91,10 @@ class GibbsSampler(object):
                the counts plus 4 bytes per site; with rows16=None a shard that has no room for it sweeps with int32 rows
                (with a warning) and the environment variable LLDA_ROWS16=on|off decides for callers that cannot pass the
                argument.
-    quad     : K = 512 with the 16-bit rows and every document below 2^16 tokens: the kernel that walks FOUR documents per wavefront
-               (16 lanes x 32 slots each; csrc/kernel_quad.hpp) on an image of EVERY row -- which rows fit 16 bits is decided per
+    quad     : K = 512 (and every K whose layout has 16 slots per lane in 8, 16 or 32 lanes that all hold topics: 97 .. 128, most of
+               185 .. 256 and 361 .. 512 -- ``_native.quad_ok``) with the 16-bit rows and every document below 2^16 tokens: the kernel
+               that walks FOUR documents per wavefront (16 lanes x 32 slots each; eight / sixteen documents for the 16- / 8-lane layouts;
+               csrc/kernel_quad.hpp) on an image of EVERY row -- which rows fit 16 bits is decided per
                sweep by ``llda_pack_rows16_all`` from the counts themselves; a row that does not is read as int32.  Same results.
                None (default) = wherever it applies AND the rows that do not fit 16 bits are rare: at most QUAD_MAX_WIDE_SITES of the
                sites may read such a row (the quad kernel reads it without prefetch) -- looked at when the sampler is built and every
@@ -428,7 +430,8 @@ class GibbsSampler(object):
             if float((wide.to(torch.float32) * self._word_sites).sum().item()) > self.QUAD_MAX_WIDE_SITES * self.S:
                 quad = False
         if self._quad_wanted and not quad:
-            raise ValueError("quad=True: needs K = 128, 256 or 512, documents of fewer than 65 536 tokens and a vocabulary below 2^22 words")
+            raise ValueError("quad=True: needs a K with llda_quad_ok (16 slots per lane in 8, 16 or 32 lanes: K = 100, 128, 200, 256, 400, 512 ...), "
+                             "documents of fewer than 65 536 tokens and a vocabulary below 2^22 words")
         if not quad and not (two_doc and bool(self._rows16_fits().any())):
             return
         n32 = (V + 1) * KP

@@ -44,6 +44,12 @@ TINY = [
     # either: the last wavefront and the last workgroup are partly empty)
     ("k256dense",  45, 150,  255, 255,    (10, 60),  0.1, 0.01, 2),
     ("k128dense",  70, 150,  127, 127,    (10, 60),  0.1, 0.01, 2),
+    # ... with positions that hold no topic (K < KP): one leaf of 100 (tail 4), two leaves 96 + 104, four leaves 96 + 104 + 96 + 104;
+    # k250dense (three leaves 120 + 64 + 66 in a four-leaf layout, an unbalanced tree with a tail) stays on the general kernel
+    ("k100dense",  70, 150,   99,  99,    (10, 60),  0.1, 0.01, 2),
+    ("k200dense",  45, 150,  199, 199,    (10, 60),  0.1, 0.01, 2),
+    ("k250dense",  30, 150,  249, 249,    (10, 60),  0.1, 0.01, 2),
+    ("k400dense",  30, 150,  399, 399,    (10, 60),  0.1, 0.01, 2),
     # wide layouts (more than 8 pairwise leaves: 64-lane tiers of one wavefront)
     ("k1031",    10, 100, 1030, 400,      (10, 40),  0.1, 0.01, 2),    # 9 leaves -> 2 tiers x 16 slots, tail 7
     ("k1100",    10, 100, 1099,  30,      (10, 40),  0.1, 0.01, 2),    # 16 leaves, 12 slots per lane, tail 4, sparse labels
@@ -52,7 +58,7 @@ TINY = [
 ]
 
 
-ALL_LABELS = ("k512dense", "k1024dense", "k256dense", "k128dense")      # fixtures whose documents carry the whole label set
+ALL_LABELS = ("k512dense", "k1024dense", "k256dense", "k128dense", "k100dense", "k200dense", "k250dense", "k400dense")      # fixtures whose documents carry the whole label set
 
 
 def all_labels(name, docs, labs, labelset):

@@ -78,10 +78,12 @@ def test_layout_init_rejects_bad_k(K):
 
 def test_which_k_take_the_16_bit_rows():
     """host-only predicates: llda_rows16_ok (static flags: 16 slots per lane, 32 or 64 lanes, no padded slot) and llda_quad_ok (per-sweep
-    flags, K / 32 lanes x 32 slots per document: 8, 16 or 32 lanes)"""
+    flags, KP / 32 lanes x 32 slots per document: 8, 16 or 32 lanes, each lane group a leaf)"""
     from lda_thesis_amd import _native
     assert [K for K in (64, 100, 128, 200, 256, 392, 512, 777, 1024, 1031, 2048) if _native.rows16_ok(K)] == [512, 1024]
-    assert [K for K in (64, 100, 128, 200, 256, 392, 512, 777, 1024, 1031, 2048) if _native.quad_ok(K)] == [128, 256, 512]
+    # (K < KP is fine as long as every lane group holds a leaf of numpy's pairwise sum: 250 = 120 + 64 + 66 and 500 = five leaves are out)
+    assert [K for K in (64, 96, 97, 100, 128, 129, 192, 200, 248, 250, 256, 257, 392, 400, 480, 500, 512, 777, 1024, 1031, 2048)
+            if _native.quad_ok(K)] == [97, 100, 128, 200, 248, 256, 392, 400, 480, 512]
     assert not _native.quad_ok(0) and not _native.quad_ok(10 ** 6)
 
 

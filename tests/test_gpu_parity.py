@@ -61,15 +61,17 @@ def test_headline_kernels_match_reference_o3(name):
             assert bool(s.row16.all()) and s.site_row is None           # (the library's flags: every row of the fixture fits)
 
 
-@pytest.mark.parametrize("name", ["tiny_k256dense", "tiny_k128dense"])
+@pytest.mark.parametrize("name", ["tiny_k256dense", "tiny_k128dense", "tiny_k100dense", "tiny_k200dense", "tiny_k400dense"])
 def test_narrow_quad_kernels_match_reference_o3(name):
     """K = 256 / 128, every label in every document, commit log: llda_sweep_quad_kernel<3> / <2> -- eight / sixteen documents per
     wavefront, 16-byte site records, own count out of the packed row -- against the reference's own O3 sweeps, in every tier mode; and
-    the general kernel (quad False) on the same fixture"""
+    the general kernel (quad False) on the same fixture.  K = 100, 200, 250, 400: the same kernels on layouts with positions that hold no
+    topic (K < KP: one leaf with a tail, two unequal leaves, four unequal leaves) --
+    the exact tier (margin -1: every site) sums in numpy's order for K."""
     g = load_golden(name)
     for margin, quad in ((0, None), (6, True), (-2, True), (-1, True), (0, False)):
         s = make_sampler(g, commit_log=True, quad=quad)
-        assert s.dense_mask and s.commit_log is not None and s.site_rec is not None
+        assert s.dense_mask and s.commit_log is not None and (s.site_rec is not None) == (s.layout.G <= 16)
         assert s.quad == (quad is not False) and (s.n_kw16 is not None) == s.quad
         s.debug_margin = margin
         for i in range(int(g["sweeps"])):
@@ -152,7 +154,7 @@ def test_commit_paths_agree(name, commit, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["tiny_k40", "tiny_k130", "tiny_k392", "tiny_k512", "sublda", "tiny_k512dense", "tiny_k256dense",
-                                  "tiny_k128dense"])          # (the dense ones with the commit log: the quad kernel, 4 / 8 / 16 documents per wavefront)
+                                  "tiny_k128dense", "tiny_k100dense"])          # (the dense ones with the commit log: the quad kernel, 4 / 8 / 16 documents per wavefront)
 def test_shard_split_into_several_calls(name, monkeypatch):
     """llda_sweep addresses the sites of one call with 32-bit offsets from its first document, so a shard that
     spans 2^30 sites is walked in several calls over document ranges; here the limit is lowered to 150 sites."""
@@ -465,7 +467,7 @@ def _rows16_corpus_short_docs(K, seed):
 
 
 @pytest.mark.parametrize("margin", [0, -1, -2, 6])
-@pytest.mark.parametrize("K,quad", [(512, True), (512, False), (1024, None), (256, True), (128, True)])
+@pytest.mark.parametrize("K,quad", [(512, True), (512, False), (1024, None), (256, True), (128, True), (100, True), (400, True)])
 def test_16_bit_rows_four_waves_equal_the_c_oracle(c_oracle, K, quad, margin):
     """documents below 2^16 tokens (llda_sweep_args.max_doc_tokens) against the C oracle (LabeledLDA.py:106-125), every draw tier:
     K = 512 with FOUR documents per wavefront (quad: the image holds every row, the library flags per sweep the rows that fit -- words 0
@@ -497,9 +499,10 @@ def test_16_bit_rows_four_waves_equal_the_c_oracle(c_oracle, K, quad, margin):
         np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
     s.check_status()
     if margin == 0:
-        r = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=9, commit_log=True, rows16=K >= 512, doc_base=5, quad=False)
-        assert (r.n_kw16 is not None) == (K >= 512)
-        r.debug_margin = -8 if K >= 512 else 0                           # the three-wave form, production margins (K < 512: int32 rows)
+        two_doc = K in (512, 1024)
+        r = GibbsSampler(doc_off, word, freq, z, K, V, 0.1, 0.01, labs=None, seed=9, commit_log=True, rows16=two_doc, doc_base=5, quad=False)
+        assert (r.n_kw16 is not None) == two_doc
+        r.debug_margin = -8 if two_doc else 0                           # the three-wave form, production margins (K < 512: int32 rows)
         for i in range(3):
             r.sweep()
         assert torch.equal(r.z, s.z) and torch.equal(r._counts, s._counts) and torch.equal(r.n_dk, s.n_dk)
@@ -643,7 +646,7 @@ def test_edge_empty_shard_and_empty_documents(c_oracle):
 
 
 @pytest.mark.parametrize("dpg,permute", [(0, False), (3, True), (1, True)])
-@pytest.mark.parametrize("K", [512, 256, 128])
+@pytest.mark.parametrize("K", [512, 256, 128, 100, 400])
 def test_edge_quad_kernel_ragged_empty_documents_and_schedules(c_oracle, dpg, permute, K):
     """the four-documents-per-wavefront kernel (K = 512 dense, commit log; K = 256 / 128: eight / sixteen) on a ragged shard: empty
     documents between one-site and long ones, wavefronts whose documents differ in length by two orders of magnitude, a document count that fills neither the
