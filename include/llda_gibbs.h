@@ -122,7 +122,9 @@ typedef struct llda_sweep_args {
                                     kernel without its fp32 tier, -6 the fp32 tier with fp64 factors in LDS even when
                                     scratch is there, -7 with fp32 factors only whenever scratch is there; -8 (with n_kw16)
                                     production margins on the three-wave form of the 16-bit-row kernel; -9 (with row16) the quad
-                                    kernel with the constant tier-0 margin 104 * 2^-24 of the total instead of its data-dependent one */
+                                    kernel with the constant tier-0 margin 104 * 2^-24 of the total instead of its data-dependent one;
+                                    -10 ... -18 (with row16) the data-dependent margin scaled by 1 / 1.05 (the derived error bound itself),
+                                    1/2, 1/4 ... 1/256: tests/neartie.py measures how much of the margin the worst planted tie needs */
     double   alpha, beta;        /* priors (LabeledLDA.py:55-56)                               */
     uint64_t seed;               /* RNG key                                                    */
     uint32_t sweep;              /* RNG counter word 3                                         */

@@ -655,6 +655,10 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
         } else if (a->debug_margin == -9) {                               // test hook: the constant margin 104 * 2^-24 of the total
             P.margin0_rel = LLDA_MARGIN0_QUAD;
             P.margin_rel = 0x1p-40;
+        } else if (a->debug_margin <= -10 && a->debug_margin >= -18) {    // test hooks: the data-dependent margin SCALED DOWN -- by 1 / 1.05
+            P.margin0_rel = 0.0f;                                         // (the derived bound itself), 1/2, 1/4 ... 1/256: how much of the
+            P.margin0_data = a->debug_margin == -10 ? 1.0f / 1.05f : ldexpf(1.0f, a->debug_margin + 10);   // margin the worst site needs
+            P.margin_rel = 0x1p-40;
         }
         const int64_t per_q = (int64_t)(2 * QNT / L.G) * dpg;             // (a document is G / 2 lanes)
         const int64_t qblocks = (a->D + per_q - 1) / per_q;

@@ -32,9 +32,29 @@ def _gap(cum, t):
     return float(np.min(np.abs(cum - t)) / cum[-1])
 
 
+PLACES = ("lane0", "lastlane", "seam", "last")
+
+
 def make_neartie_state(K, D, dense, seed, rng, max_sites=4, safe=2.0 ** -14, tuned=2.0 ** -24, alpha=0.1, beta=0.01,
-                       stream=0, doc_base=0, label_count=None):
-    """-> dict(doc_off, word, freq, z, labs, n_d_k, n_k_v, n_zk, V, n_tuned, tuned_gap_max, safe_gap_min)."""
+                       stream=0, doc_base=0, label_count=None, xcap=2e8, xlog=11.5, nd_big=2000, place=None, wide_every=0,
+                       rounds=6):
+    """-> dict(doc_off, word, freq, z, labs, n_d_k, n_k_v, n_zk, V, n_tuned, tuned_gap_max, safe_gap_min, ...).
+
+    xcap, xlog : every entry of n_k_v stays below xcap (65 000: the whole state fits the 16-bit image of the quad kernels), the random
+                 columns are exp(uniform(0, xlog)); nd_big: range of the large entries of n_d_k (documents below 2^16 tokens: 600).
+    place      : None = the boundary the keyed uniform happens to select; one of PLACES, or "mix" (documents take PLACES in turn) =
+                 the column is shaped so that the tuned boundary is where the quad kernel's tier 0 has the least room
+                 (csrc/kernel_quad.hpp: a document is G / 2 quad lanes, each walking standard lanes 2 lq (chain A) and 2 lq + 1 (B)):
+                 "lane0"    a slot of quad lane 0 -- no lanes before it, the data-dependent margin is at its smallest;
+                 "lastlane" a slot of the last quad lane -- the scan's longest sum in front of it;
+                 "seam"     the last slot of a standard lane -- chain A's total against chain B's first element, or the lane total;
+                 "last"     the last but one position with a topic -- everything behind the boundary is ONE slot (the key "no slot
+                            above the threshold" names it).
+                 -> place_of[D] (index into PLACES, -1 = not placed: the uniform did not allow it) and tuned_pos[D] (draw-order
+                 position of the boundary).
+    wide_every : n > 0 = in every n-th document the tuned site's word has counts beyond 65 535 (one of them beyond 2^24): the quad
+                 kernel reads such a row as int32, without tier 1 (xcap does not apply to those entries).
+    """
     lay = orc.layout(K)
     lens = rng.integers(1, max_sites + 1, size=D)
     doc_off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
@@ -59,13 +79,18 @@ def make_neartie_state(K, D, dense, seed, rng, max_sites=4, safe=2.0 ** -14, tun
     n_k_v = np.zeros((K, V), dtype=np.int64)
     slot_of = lay.topic_slot                                 # topic -> device position
     n_tuned, tuned_gap_max, safe_gap_min = 0, 0.0, 1.0
+    place_of = np.full(D, -1, dtype=np.int64)
+    tuned_pos = np.full(D, -1, dtype=np.int64)
+    tuned_gap = np.zeros(D)
+    tuned_terms = np.zeros((D, 4))                           # (lane total, u * total, lanes before, total) of the tuned site, quad lanes
+    wide_docs = np.zeros(D, dtype=bool)
     for d in range(D):
         allowed = np.flatnonzero(labs[d])
         lab = labs[d].astype(np.float64)
         s0, L = int(doc_off[d]), int(lens[d])
         zo = rng.choice(allowed, size=L)
         z[s0:s0 + L] = zo
-        nd = np.where(rng.random(K) < 0.1, rng.integers(0, 2000, size=K), rng.integers(0, 20, size=K)) * labs[d]
+        nd = np.where(rng.random(K) < 0.1, rng.integers(0, nd_big, size=K), rng.integers(0, 20, size=K)) * labs[d]
         np.add.at(nd, zo, freq[s0:s0 + L])
         n_d_k[d] = nd
         nd = nd.astype(np.float64)
@@ -76,15 +101,31 @@ def make_neartie_state(K, D, dense, seed, rng, max_sites=4, safe=2.0 ** -14, tun
             nd[zo[n]] -= f
             nk[zo[n]] -= f
             last = n == L - 1
-            for _attempt in range(200):
-                x = np.floor(np.exp(rng.uniform(0.0, 11.5, size=K)))          # 1 .. 1e5, heavy tailed
+            want = -1
+            if last and place is not None:
+                want = d % len(PLACES) if place == "mix" else PLACES.index(place)
+            wide = bool(last and wide_every and d % wide_every == 0)
+            for _attempt in range(400):
+                x = np.minimum(np.floor(np.exp(rng.uniform(0.0, xlog, size=K))), xcap - 8)      # 1 .. 1e5, heavy tailed
                 x[rng.random(K) < 0.3] = 0.0
+                frozen = None
+                if wide:                                     # counts the 16-bit image cannot hold; the tuner leaves them alone
+                    frozen = rng.choice(allowed, size=min(3, len(allowed)), replace=False)
+                    x[frozen] = np.floor(np.exp(rng.uniform(np.log(7e4), np.log(4e5), size=len(frozen))))
+                    x[frozen[0]] = float(rng.integers(1 << 24, 1 << 25))
+                placed = False
                 if last:
-                    ok = _tune(lay, lab, nd, nk, x, u, alpha, beta, vbeta, allowed, slot_of, tuned)
+                    if want >= 0 and _attempt < 300:
+                        placed = _place(lay, lab, nd, nk, x, u, alpha, beta, vbeta, slot_of, PLACES[want], rng, xcap, frozen)
+                        if not placed:
+                            continue
+                    ok = _tune(lay, lab, nd, nk, x, u, alpha, beta, vbeta, allowed, slot_of, tuned, xcap, frozen, rounds)
                     if not ok:
                         continue
                 wp, cum = _site_scores(lay, lab, nd, nk, x, alpha, beta, vbeta)
                 gap = _gap(cum, u * cum[-1])
+                if last and placed and not _is_place(lay, int(np.argmin(np.abs(cum - u * cum[-1]))), PLACES[want]):
+                    continue                                 # (the tuner moved the boundary somewhere else)
                 if last or gap > safe:
                     break
             else:
@@ -92,6 +133,15 @@ def make_neartie_state(K, D, dense, seed, rng, max_sites=4, safe=2.0 ** -14, tun
             if last:
                 n_tuned += 1
                 tuned_gap_max = max(tuned_gap_max, gap)
+                tuned_gap[d] = gap
+                b = int(np.argmin(np.abs(cum - u * cum[-1])))
+                tuned_pos[d] = b
+                place_of[d] = want if placed else -1
+                wide_docs[d] = wide
+                if lay.G >= 2:                                # the terms of the quad kernel's data-dependent margin
+                    ql = b // (2 * lay.T)
+                    lane_tot = wp.reshape(lay.G // 2, 2 * lay.T).sum(axis=1)
+                    tuned_terms[d] = (lane_tot[ql], u * cum[-1], lane_tot[:ql].sum(), cum[-1])
             else:
                 safe_gap_min = min(safe_gap_min, gap)
             col = x.astype(np.int64)
@@ -102,15 +152,94 @@ def make_neartie_state(K, D, dense, seed, rng, max_sites=4, safe=2.0 ** -14, tun
             nd[zn] += f
             nk[zn] += f
     return dict(doc_off=doc_off, word=word, freq=freq, z=z, labs=labs, n_d_k=n_d_k, n_k_v=n_k_v, n_zk=n_zk, V=V,
-                alpha=alpha, beta=beta, n_tuned=n_tuned, tuned_gap_max=tuned_gap_max, safe_gap_min=safe_gap_min)
+                alpha=alpha, beta=beta, n_tuned=n_tuned, tuned_gap_max=tuned_gap_max, safe_gap_min=safe_gap_min,
+                place_of=place_of, tuned_pos=tuned_pos, tuned_gap=tuned_gap, tuned_terms=tuned_terms, wide_docs=wide_docs)
 
 
-def _tune(lay, lab, nd, nk, x, u, alpha, beta, vbeta, allowed, slot_of, target):
+def _is_place(lay, b, kind):
+    """is draw-order position b (lane * T + slot) a boundary of the wanted kind?"""
+    T, G = lay.T, lay.G
+    valid = np.flatnonzero(lay.slot_topic >= 0)
+    g = b // T
+    if kind == "lane0":
+        return g < 2
+    if kind == "lastlane":
+        return g >= G - 2 and b != valid[-1]
+    if kind == "seam":
+        nxt = valid[np.searchsorted(valid, b, side="right")] if b != valid[-1] else -1
+        return nxt >= 0 and nxt // T != g                    # the next position with a topic is in another standard lane
+    return b == valid[-2]
+
+
+def _place(lay, lab, nd, nk, x, u, alpha, beta, vbeta, slot_of, kind, rng, xcap, frozen):
+    """shape the column x (in place) so that the first prefix sum above u * total is a boundary of the wanted kind, with the threshold
+    in the upper tenth of that (wide) slot: the entries before / behind it are scaled down until the prefix share matches u."""
+    T, G, KP = lay.T, lay.G, lay.KP
+    valid = np.flatnonzero((lay.slot_topic >= 0) & (lab[np.maximum(lay.slot_topic, 0)] > 0))
+    cand = np.array([b for b in valid if _is_place(lay, int(b), kind)])
+    if len(cand) == 0:
+        return False
+    b = int(rng.choice(cand))
+    jb = int(lay.slot_topic[b])
+    hold = set() if frozen is None else set(int(j) for j in frozen)
+    if jb in hold:
+        return False
+    cap = min(xcap, 1e5)
+    x[jb] = np.floor(rng.uniform(0.3, 0.9) * cap)            # a wide slot: room for the tuner behind the threshold
+    theta = 0.1
+    if kind == "last":
+        # everything behind the boundary is ONE slot: make that one wide, and the boundary's slot as wide as the uniform allows
+        # (0.9 Wb < u (Wb + B0), or no scaling of what lies before can bring the threshold into the slot)
+        jl = int(lay.slot_topic[valid[-1]])
+        if jl in hold:
+            return False
+        x[jl] = np.floor(rng.uniform(0.5, 0.95) * cap)
+        if u < 0.85:
+            c = lab * (nd + alpha) / (nk + vbeta)
+            room = 0.5 * u * c[jl] * (x[jl] + beta) / (0.9 - u)
+            x[jb] = min(x[jb], np.floor(room / c[jb] - beta))
+            if x[jb] < 1:
+                return False
+    pos = np.asarray(slot_of)                                # topic -> draw-order position
+    keep = np.zeros(len(x), dtype=bool)
+    keep[jb] = True
+    keep[list(hold)] = True
+    for _ in range(4):
+        wp, cum = _site_scores(lay, lab, nd, nk, x, alpha, beta, vbeta)
+        Wb, A0 = wp[b], cum[b] - wp[b]
+        B0 = cum[-1] - cum[b]
+        # A0 sA + Wb (1 - theta) = u (A0 sA + Wb + B0 sB)
+        sA, sB = 1.0, 1.0
+        if B0 > 0:
+            sB = ((A0 + Wb * (1 - theta)) / u - A0 - Wb) / B0
+        if sB > 1.0 or B0 <= 0:
+            sB = 1.0
+            if A0 <= 0:
+                return False
+            sA = (u * (Wb + B0) - Wb * (1 - theta)) / (A0 * (1 - u))
+        if not (0.0 < sA <= 1.0 and 0.0 < sB <= 1.0):
+            return False
+        if sA < 1.0:
+            m = (pos < b) & ~keep
+            x[m] = np.floor(x[m] * sA)
+        if sB < 1.0:
+            m = (pos > b) & ~keep
+            x[m] = np.floor(x[m] * sB)
+        wp, cum = _site_scores(lay, lab, nd, nk, x, alpha, beta, vbeta)
+        t = u * cum[-1]
+        if int(np.searchsorted(cum, t, side="right")) == b and (cum[b] - t) < 0.5 * wp[b]:
+            return True
+    return False
+
+
+def _tune(lay, lab, nd, nk, x, u, alpha, beta, vbeta, allowed, slot_of, target, xcap=2e8, frozen=None, rounds=6):
     """nudge entries of the column x (in place, whole counts, >= 0) until u * total is within `target` of a prefix
     sum.  Raising x[j] by one raises the score of topic j by c_j = (nd_j + alpha) / (nk_j + V beta): a topic behind
     the boundary moves only the threshold (by u c_j), a topic before it moves the boundary too."""
     c = lab * (nd + alpha) / (nk + vbeta)
-    for _round in range(6):
+    if frozen is not None:
+        allowed = np.setdiff1d(allowed, frozen)
+    for _round in range(rounds):
         wp, cum = _site_scores(lay, lab, nd, nk, x, alpha, beta, vbeta)
         t = u * cum[-1]
         b = int(np.searchsorted(cum, t, side="right"))       # first boundary above t
@@ -124,7 +253,7 @@ def _tune(lay, lab, nd, nk, x, u, alpha, beta, vbeta, allowed, slot_of, target):
         best = None
         for j in behind:                                     # x[j] += k lowers E by k u c_j
             k = np.floor(E / (u * c[j]))
-            if k >= 1 and x[j] + k < 2e8:
+            if k >= 1 and x[j] + k < xcap:
                 r = E - k * u * c[j]
                 if best is None or r < best[0]:
                     best = (r, j, k)

@@ -1035,6 +1035,67 @@ def test_adversarial_near_ties_for_the_fp32_tier(c_oracle, K, dense):
             assert int(runs[m][4][1]) == st["n_tuned"]
 
 
+def quad_neartie_state(K, D, wide_every=0, seed=4242):
+    """tests/neartie.py for the quad kernels (csrc/kernel_quad.hpp): every count fits the 16-bit image (wide_every = n: every n-th
+    document's tuned word has counts beyond 65 535 and one beyond 2^24 -- the int32 read without tier 1), documents below 2^16 tokens,
+    and the tuned boundary where tier 0's data-dependent margin has the least room: quad lane 0, the last quad lane, the seam
+    between chain A and chain B / between two lanes, the last but one position.  Thresholds within 2^-28 of the boundary: the
+    margin exceeds the derived error bound by at least 0.125 * 2^-24 of the total, so a tie this close MUST be called undecidable."""
+    import neartie
+    return neartie.make_neartie_state(K, D, True, seed=seed, rng=np.random.default_rng(K + 7 * wide_every), doc_base=7, xcap=65000, xlog=11.0,
+                                      nd_big=600, place="mix", wide_every=wide_every, tuned=2.0 ** -28, rounds=10)
+
+
+@pytest.mark.parametrize("K,D,wide_every", [(512, 500, 0), (512, 300, 5), (256, 500, 0), (128, 700, 0), (128, 300, 5), (100, 600, 0), (400, 400, 0),
+                                             (400, 200, 5)])
+def test_adversarial_near_ties_for_the_quad_tier0(c_oracle, K, D, wide_every):
+    """The kernel bench.py times (llda_sweep_quad_kernel, csrc/kernel_quad.hpp) decides 99.8 % of its sites in fp32 with a DATA-DEPENDENT
+    margin m = 1.05 v (32 L + 39 t + 37 P + 0.25 total) derived by hand against the bound v (31.1 L + 38.2 t + 36.1 P + 0.125 total):
+    here every document's last site has its keyed threshold within 2^-28 of a prefix-sum boundary -- in quad lane 0 (P = 0: the margin
+    at its smallest), in the last lane, at the chain A / chain B seam, in front of the last slot, a quarter of the documents each --
+    and all other sites are at least 2^-14.5 away.  Tier 0 must hand over EVERY tuned site and no other: with the production margin,
+    with the margin scaled down to the derived bound itself (debug_margin -10) and with the constant margin (-9); the sweep must
+    leave what the exact pipeline (-1) and the C oracle leave (/root/reference/LabeledLDA.py:113-119).  K = 100, 400: positions
+    without a topic (PAD); wide_every: rows the 16-bit image cannot hold (int32 read, + 2 v, no tier 1)."""
+    from lda_thesis_amd.sampler import GibbsSampler
+    st = quad_neartie_state(K, D, wide_every)
+    assert st["tuned_gap_max"] < 2.0 ** -27.5 and st["safe_gap_min"] > 2.0 ** -14.5
+    assert int(st["n_d_k"].sum(axis=1).max()) < 65536
+    last_word = st["word"][st["doc_off"][1:] - 1]
+    assert int(st["n_k_v"][:, np.setdiff1d(np.arange(st["V"]), last_word[st["wide_docs"]])].max()) <= 65535
+    placed = np.bincount(st["place_of"][st["place_of"] >= 0], minlength=4)
+    assert (placed >= D // 16).all(), placed                 # every kind of boundary is there (each is wanted by a quarter of the documents)
+    counts = dict(n_d_k=st["n_d_k"], n_k_v=st["n_k_v"], n_zk=st["n_zk"])
+    runs = {}
+    for margin in (0, -10, -9, -1):
+        s = GibbsSampler(st["doc_off"], st["word"], st["freq"], st["z"], K, st["V"], st["alpha"], st["beta"],
+                         counts=counts, seed=4242, doc_base=7, commit_log=True, rows16=True, quad=True)
+        assert s.quad and s.row16 is not None
+        s.debug_margin = margin
+        s.sweep()
+        s.check_status()
+        if wide_every:
+            assert int((s.row16 == 0).sum()) == int(st["wide_docs"].sum())       # exactly the planted rows are read as int32
+        else:
+            assert int((s.row16 == 0).sum()) == 0
+        runs[margin] = (s.z_topics(), s.n_d_k(), s.n_k_v(), s.n_zk(), s.status.cpu().numpy())
+    cs = c_oracle.CState(st["doc_off"], st["word"], st["freq"], st["z"], st["labs"], st["n_d_k"], st["n_k_v"],
+                         st["n_zk"], st["V"], st["alpha"], st["beta"])
+    cs.sweep(1, 4242, 0, doc_base=7, threads=4)
+    for margin, (z, ndk, nkv, nzk, _) in runs.items():
+        np.testing.assert_array_equal(z, cs.z, err_msg="debug_margin %d" % margin)
+        np.testing.assert_array_equal(ndk, cs.n_d_k)
+        np.testing.assert_array_equal(nkv, cs.n_k_v)
+        np.testing.assert_array_equal(nzk, cs.n_zk)
+    # tier 0 gave up on every tuned site and on no other
+    for margin in (0, -10, -9):
+        assert int(runs[margin][4][1]) == st["n_tuned"], (margin, int(runs[margin][4][1]), st["n_tuned"])
+    # ... and the fp64 decision behind it (margin 2^-40: in the quad layout, or -- int32 rows -- in the standard layout out of line)
+    # settled most of them (the tuner stops below 2^-28 and often lands far below: a few per cent are within 2^-40, the exact tier's)
+    assert int(runs[0][4][2]) <= max(2, st["n_tuned"] // 10)
+    assert int(runs[-1][4][2]) == int(st["doc_off"][-1])          # debug_margin -1: every site through the exact pipeline
+
+
 @pytest.mark.parametrize("K,labels,image", [(40, 7, 0), (392, 7, 0), (512, 7, 8), (512, 20, 16), (777, 40, 0), (1031, 7, 0), (2048, 7, 8)])
 def test_adversarial_near_ties_for_the_sparse_fp32_tier(c_oracle, K, labels, image):
     """the same for the sparse-label kernel's tier 0 (kernel_sparse.hpp: fp32 scores of the allowed topics, margin 2^-17, bound
