@@ -302,11 +302,18 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
     __shared__ int s_ndk[QT / 4][QNT][4];      // n_dk | sweep-start n_dk << 16
     __shared__ float s_pa[QT / 4][QNT][4];     // tier-0 factor fl32((n_dk + alpha) / (n_k + V*beta))
     __shared__ float s_u[QNT / LPD][2 * LPD];  // the fp32 uniforms of the next 2 LPD sites of every document
+    __shared__ int s_hot[QT][16];              // row rho: -1 (or -65536: the upper half) in the packed register that holds slot rho, else 0
 
     const int tid = threadIdx.x;
     for (int i = tid; i < KP; i += QNT) {
         s_nk[i] = 0;
         s_nk0[i] = P.n_k[i];
+    }
+    for (int i = tid; i < QT * 16; i += QNT) {
+        // slot rho = 8 i + 2 c' + e sits in xp[e << 3 | (i >> 1) << 2 | (i & 1) << 1 | c' >> 1], half c' & 1 (convert_row)
+        const int so = i >> 4, k = i & 15;
+        const int kk = ((so & 1) << 3) | ((so >> 4) << 2) | (((so >> 3) & 1) << 1) | ((so >> 2) & 1);
+        s_hot[so][k] = k == kk ? -(1 << (((so >> 1) & 1) << 4)) : 0;
     }
     __syncthreads();
 
@@ -422,7 +429,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
         // xp -> fp32 in slot order (exact: 16-bit counts); the lanes of a document whose row does not fit 16 bits read the int32 row
         // now, without prefetch (an int32 count beyond 2^24 rounds: tier 0 stays inside its margin, section 4.3; tier 1 is skipped)
         q_v32f xv;
-        // (LB < 4: the own count has left xp already, remove_own_packed; the lanes that read an int32 row take it out here: so, own)
+        // (the own count has left xp already, remove_own_packed; the lanes that read an int32 row take it out here: so, own)
         auto convert_row = [&](const int v, const int flag, const int so, const float own) {
             LLDA_MARK("convert");
             const uint64_t wide_w = __ballot(flag == 0);
@@ -456,40 +463,24 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                     xv[ra_] = flag == 0 ? (float)xi[ra_] : (float)((uint32_t)xp[k] & 0xffffu);
                     xv[rb_] = flag == 0 ? (float)xi[rb_] : (float)((uint32_t)xp[k] >> 16);
                 }
-                if constexpr (LB < 4) {
 #pragma unroll
-                    for (int r = 0; r < QT; ++r) xv[r] -= (flag == 0 && so == r) ? own : 0.0f;
-                }
+                for (int r = 0; r < QT; ++r) xv[r] -= (flag == 0 && so == r) ? own : 0.0f;
             }
         };
-        // the site's own count leaves the fp32 row through the slot index (uniform in a document): per document ONE indexed
-        // read-modify-write under the document's exec mask
-        auto remove_own = [&](const int so, const float own) {
-            if constexpr (LB == 4) {
-            LLDA_MARK("own_removal");
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int so_r = __builtin_amdgcn_readlane(so, r * 16);
-                const uint64_t em = 0xFFFFull << (16 * r);
-                // (s_nop 3 behind s_set_gpr_idx_on: without it the v_sub used a STALE index every few thousand sites -- measured,
-                // tools/quad_debug.py: the stray write cleared a live register of a later workgroup; the compiler's own sequences
-                // put no VALU write of the index SGPR this close in front, and the hazard tables list nothing for it)
-                asm volatile("s_mov_b64 exec, %2\n\ts_set_gpr_idx_on %1, gpr_idx(SRC0,DST)\n\ts_nop 3\n\tv_sub_f32_e32 v64, v64, %3\n\t"
-                             "s_nop 0\n\ts_set_gpr_idx_off\n\ts_mov_b64 exec, -1"
-                             : "+{v[64:95]}"(xv) : "s"(so_r), "s"(em), "v"(own));
-            }
-            }
-        };
-        // LB < 4 (eight or sixteen documents per wavefront): the own count leaves the packed 16-bit row, one compare and one
-        // conditional subtract per register -- slot rho = 8 i + 2 c' + e sits in xp[e << 3 | (i >> 1) << 2 | (i & 1) << 1 | c' >> 1],
-        // half c' & 1 (convert_row).  own = 0 in the lanes that do not hold the slot.  (A row that does not fit 16 bits: see convert_row.)
+        // The site's own count leaves the PACKED 16-bit row: the slot number so is uniform in a document, and row so of s_hot holds -1 or
+        // -65536 in the one register of the sixteen that carries the slot -- four LDS reads (the same address in every lane of a
+        // document: broadcasts) and sixteen multiply-adds, for all documents of the wavefront at once.  own = 0 in the lanes that do
+        // not hold the slot.  (Round 5 took it out of the fp32 row with a register-indexed subtract per document -- s_set_gpr_idx_on
+        // under a hand-set exec mask on pinned registers, correct only behind an s_nop found by experiment; the narrower geometries
+        // paid sixteen compare-select-subtract triples.  A row that does not fit 16 bits: see convert_row.)
         auto remove_own_packed = [&](const int so, const int own) {
-            if constexpr (LB < 4) {
-                LLDA_MARK("own_removal");
-                const int kk = ((so & 1) << 3) | ((so >> 4) << 2) | (((so >> 3) & 1) << 1) | ((so >> 2) & 1);
-                const int dd = own << (((so >> 1) & 1) << 4);
+            LLDA_MARK("own_removal");
+            const v4i *hot = (const v4i *)&s_hot[so][0];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) xp[k] -= (kk == k) ? dd : 0;
+            for (int j = 0; j < 4; ++j) {
+                const v4i h = hot[j];
+                xp[4 * j] += __mul24(h.x, own); xp[4 * j + 1] += __mul24(h.y, own);
+                xp[4 * j + 2] += __mul24(h.z, own); xp[4 * j + 3] += __mul24(h.w, own);
             }
         };
 
@@ -516,7 +507,6 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
         remove_own_packed(R0.so, (len > 0 && lq == R0.lo) ? R0.f : 0);
         convert_row(R0.v, R0.w, R0.so, (len > 0 && lq == R0.lo) ? (float)R0.f : 0.0f);
         load_row16(R1.v, R1.w);                                        // row of site 1
-        remove_own(R0.so, (len > 0 && lq == R0.lo) ? (float)R0.f : 0.0f);
 
         auto site = [&](const int n, QuadSite &cur, QuadSite &nxt, QuadSite &prv) {
             const bool act = n < len, more = n + 1 < len;
@@ -619,7 +609,6 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 convert_row(nxt.v, nxt.w, nxt.so, (more && lq == nxt.lo) ? (float)nxt.f : 0.0f);
                 LLDA_MARK("row_prefetch");
                 load_row16(w_next, prv.w);
-                remove_own(nxt.so, (more && lq == nxt.lo) ? (float)nxt.f : 0.0f);
                 LLDA_MARK("count_update");
                 const int w = w0 + df;                                  // (0 <= n_dk + df < 2^16: no carry into the upper half)
                 QLDS(s_ndk, sg, tid) = w;

@@ -1,5 +1,8 @@
 set -u
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r06a
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "quad_tier0" > gpurun_out/r06a/neartie_quad.log 2>&1; echo "rc=$?"; tail -5 gpurun_out/r06a/neartie_quad.log
-timeout 1200 python tools/quad_margin_headroom.py > gpurun_out/r06a/headroom.md 2> gpurun_out/r06a/headroom.err; echo "rc=$?"; cat gpurun_out/r06a/headroom.md; tail -3 gpurun_out/r06a/headroom.err
+mkdir -p gpurun_out/r06b
+{
+bash tools/ab_lib.sh synth2 synth1 synth_k256
+} > gpurun_out/r06b/ab_hot.txt 2>&1
+cat gpurun_out/r06b/ab_hot.txt | grep -v amdgpu.ids
+timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "quad or headline or narrow" > gpurun_out/r06b/quad_tests.log 2>&1; echo "rc=$?"; tail -3 gpurun_out/r06b/quad_tests.log
