@@ -98,30 +98,37 @@ class LabeledLDA(object):
         self.vocab = list(dicti.values())
         self.w_to_v = dicti.token2id
         self.v_to_w = dicti.id2token
-        self.labs = np.array([self.set_label(lab) for lab in labs])
-        self.doc_tups = [dicti.doc2bow(x) for x in docs]
+        # labs[d] = set_label(labs[d]) for every document at once (reference LabeledLDA.py:63,94-99: root + the document's labels;
+        # an unknown label is a KeyError there too)
         self.D = len(docs)
+        lab_len = np.fromiter(map(len, labs), dtype=np.int64, count=len(labs))
+        lab_col = np.fromiter((self.labelmap[x] for lab in labs for x in lab), dtype=np.int64, count=int(lab_len.sum()))
+        self.labs = np.zeros((len(labs), self.K))
+        self.labs[:, 0] = 1.0
+        self.labs[np.repeat(np.arange(len(labs)), lab_len), lab_col] = 1.0
+        self.doc_tups = [dicti.doc2bow(x) for x in docs]
         self.V = len(self.vocab)
         self._ph_hat = HostOrDevice(np.zeros((self.K, self.V), dtype=float))
         self._th_hat = HostOrDevice(np.zeros((self.D, self.K), dtype=float))
         self.cur_perplx = []
 
-        # initial assignments: one np.random.choice per document over its allowed topics
-        # (same calls, same order as reference LabeledLDA.py:80-88 => same stream under np.random.seed)
-        self.docs, self.freqs, z0 = [], [], []
-        for doc, lab in zip(self.doc_tups, self.labs):
-            if not doc:
-                raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
-            ids, freqs = zip(*doc)
-            self.docs.append(list(ids))
-            self.freqs.append(list(freqs))
-            z0.append(np.random.choice(self.K, size=len(doc), p=lab / lab.sum()))
+        doc_off, word, freq = csr_from_doc_tups(self.doc_tups)
+        self._doc_off = doc_off
+        lens = np.diff(doc_off)
+        if len(lens) and int(lens.min()) == 0:
+            raise ValueError("not enough values to unpack: a document has no in-vocabulary word")
+        word_l, freq_l, off_l = word.tolist(), freq.tolist(), doc_off.tolist()
+        self.docs = [word_l[a:b] for a, b in zip(off_l[:-1], off_l[1:])]
+        self.freqs = [freq_l[a:b] for a, b in zip(off_l[:-1], off_l[1:])]
+        # Initial assignments.  The reference draws np.random.choice(K, size=len(doc), p=lab / lab.sum()) per document
+        # (LabeledLDA.py:80-88); numpy's legacy choice is cdf = p.cumsum(); cdf /= cdf[-1]; cdf.searchsorted(random_sample(n), 'right'),
+        # so ONE random_sample of all sites in document order consumes the global stream identically and the searchsorted becomes a
+        # lookup in the cdf table of the document's label-set size (ensemble.draw_initial_topics, checked against np.random.choice
+        # itself in tests/test_host_logic.py) -- the same z under np.random.seed, without 4 171 python-level calls.
+        z0 = self._initial_topics(lens)
         if seed is None:
             seed = int(np.random.randint(0, 2 ** 31 - 1))
         self.seed = seed
-        doc_off, word, freq = csr_from_doc_tups(self.doc_tups)
-        self._doc_off = doc_off
-        z0 = np.concatenate(z0) if z0 else np.zeros(0, np.int64)
         # with torch.distributed initialised the documents are sharded over the ranks by site count
         # (every rank builds the same model object from the same data; it keeps only its slice on the GPU)
         self._bounds = shard_documents(doc_off, _world_size())
@@ -176,6 +183,19 @@ class LabeledLDA(object):
     @th_hat.setter
     def th_hat(self, value):
         self._th_hat.set(value)
+
+    def _initial_topics(self, lens):
+        from .ensemble import draw_initial_topics
+        if int(lens.sum()) == 0:
+            return np.zeros(0, np.int64)
+        n_allowed = self.labs.sum(axis=1).astype(np.int64)
+        rows, cols = np.nonzero(self.labs)                       # row major: a document's allowed topics ascending
+        first = np.zeros(self.D + 1, dtype=np.int64)
+        np.cumsum(n_allowed, out=first[1:])
+        allowed = np.full((self.D, int(n_allowed.max()) if self.D else 1), -1, dtype=np.int64)
+        allowed[rows, np.arange(rows.shape[0]) - first[rows]] = cols
+        u = np.random.random_sample(int(lens.sum()))
+        return draw_initial_topics(allowed, n_allowed, np.repeat(np.arange(self.D), lens), u)
 
     def set_label(self, label):
         vec = np.zeros(len(self.labelmap))

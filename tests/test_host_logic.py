@@ -184,6 +184,29 @@ def test_vectorised_choice_equals_numpy_choice():
         assert after_got == after_want
 
 
+def test_labeledlda_initial_topics_equal_the_reference_loop():
+    """LabeledLDA._initial_topics (one random_sample block + table lookups) == the reference's per-document
+    np.random.choice(K, size=len(doc), p=lab / lab.sum()) (/root/reference/LabeledLDA.py:80-88): same topics, same stream position."""
+    from lda_thesis_amd.LabeledLDA import LabeledLDA
+    rng = np.random.default_rng(5)
+    for K, most in ((392, 8), (40, 39), (3, 2)):
+        D = 500
+        labs = np.zeros((D, K))
+        labs[:, 0] = 1.0
+        for d in range(D):
+            labs[d, rng.choice(K - 1, size=int(rng.integers(0, most + 1)), replace=False) + 1] = 1.0
+        lens = rng.integers(1, 60, size=D)
+        np.random.seed(K)
+        want = np.concatenate([np.random.choice(K, size=n, p=lab / lab.sum()) for lab, n in zip(labs, lens)])
+        after_want = np.random.randint(0, 2 ** 31 - 1)
+        m = object.__new__(LabeledLDA)
+        m.labs, m.D, m.K = labs, D, K
+        np.random.seed(K)
+        got = m._initial_topics(lens)
+        assert np.random.randint(0, 2 ** 31 - 1) == after_want
+        np.testing.assert_array_equal(got, want)
+
+
 def test_plan_subproblems_equals_the_list_based_enumeration():
     """CascadeLDA.plan_subproblems (index arrays for the batched ensemble) describes exactly the sub-problems
     enumerate_subproblems + SubLDA.__init__ build (reference CascadeLDA.py:113-127, 135-184, 347-392), and the
