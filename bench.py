@@ -273,6 +273,22 @@ def time_sweeps(sampler, steps, warmup, dist=None, dev=None, events=True):
     sweeps (sampler.sweeps_done says so; whatever is computed from its state afterwards is a state that many sweeps old)."""
     for _ in range(warmup):
         sampler.sweep()
+    # the collector stays out of the timed region: a generation-2 pass over the heap the earlier workloads of this process left
+    # behind (token lists, the numpy ports' states) takes 10 - 20 ms -- a millisecond per step of a 20-step, 48 ms measurement
+    # (extra.wide_k2048 was 2.43 ms per step in six runs and 3.0 - 3.4 in four; a fresh process always shows 2.43 - 2.45:
+    # tools/wide_step_probe.py, profiles/r06_wide_k2048_bimodal.md)
+    import gc
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()
+    try:
+        return _time_sweeps(sampler, steps, dist, dev, events)
+    finally:
+        if gc_was:
+            gc.enable()
+
+
+def _time_sweeps(sampler, steps, dist, dev, events):
     if not events:
         if dist is not None:
             raise ValueError("time_sweeps(events=False) is a single-process measurement")
@@ -1336,7 +1352,7 @@ def main():
                                        ("sparse_labels", "synth2_sparse", 100, 5),
                                        ("sparse_labels_colocated", "synth2_sparse_hier", 100, 5),
                                        ("sparse_labels_scrambled", "synth2_sparse_scr", 100, 5), ("abstracts", "abstracts", 3000, 20),
-                                       ("wide_k2048", "synth_wide", 20, 2), ("wide_sparse_k2048", "synth_wide_sparse", 50, 3)):
+                                       ("wide_k2048", "synth_wide", 100, 5), ("wide_sparse_k2048", "synth_wide_sparse", 100, 5)):
                 s2, i2 = build_sampler(wname, dev, 0, 1, False)
                 torch.cuda.synchronize()
                 dt2, k2 = time_sweeps(s2, st, wu, events=wname != "abstracts")

@@ -324,7 +324,10 @@ int llda_pack_rows16(const int32_t *n_kw, const uint8_t *row16, int64_t V, int32
                      void *stream);
 
 /* llda_pack_image with the image's columns in an order of the caller's (ABI 20): img[v][c] = min(n_kw[v][col_src[c]], 255 | 65535)
- * for c < KP; col_src (dev, int32[KP], 16-byte aligned) is a permutation of the device positions.  For llda_sweep_args.n_kw_img + img_col. */
+ * for c < KP; col_src (dev, int32[KP], 16-byte aligned) is a permutation of the device positions.  For llda_sweep_args.n_kw_img + img_col.
+ * PRECONDITION, not checked on the host (the table lives on the device): col_src is a permutation of 0 .. KP-1 and img_col its inverse.
+ * An entry outside 0 .. KP-1 is clamped to KP-1 by the kernels (no out-of-bounds access), a table that is not a permutation gives an
+ * image that is not a copy of n_kw: the sweep's results are then undefined (no status bit reports it). */
 int llda_pack_image_cols(const int32_t *n_kw, int64_t V, int32_t K, int32_t bits, const int32_t *col_src, void *img, void *stream);
 
 /* The 16-bit image of EVERY row of n_kw plus, per word, whether all counts of its row fit 16 bits in this sweep's n_kw

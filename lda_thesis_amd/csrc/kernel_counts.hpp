@@ -68,9 +68,12 @@ __global__ void __launch_bounds__(256) llda_pack_image_cols_kernel(const int32_t
         for (int i = threadIdx.x; i < q4; i += 256) reinterpret_cast<int4 *>(s_row)[i] = src[i];
         __syncthreads();
         for (int i = threadIdx.x; i < q4; i += 256) {
+            // (col_src is the caller's: an entry outside 0 .. KP-1 reads position KP-1 instead of someone else's LDS -- the image is
+            // then not the one the caller meant, but nothing out of bounds is touched; include/llda_gibbs.h states the precondition)
             const int4 cs = reinterpret_cast<const int4 *>(col_src)[i];
-            const uint32_t x = min((uint32_t)s_row[cs.x], SAT), y = min((uint32_t)s_row[cs.y], SAT),
-                           z = min((uint32_t)s_row[cs.z], SAT), w = min((uint32_t)s_row[cs.w], SAT);
+            const uint32_t last = (uint32_t)KP - 1u;
+            const uint32_t x = min((uint32_t)s_row[min((uint32_t)cs.x, last)], SAT), y = min((uint32_t)s_row[min((uint32_t)cs.y, last)], SAT),
+                           z = min((uint32_t)s_row[min((uint32_t)cs.z, last)], SAT), w = min((uint32_t)s_row[min((uint32_t)cs.w, last)], SAT);
             if constexpr (BITS == 8) {
                 static_cast<uint32_t *>(out)[v * q4 + i] = x | (y << 8) | (z << 16) | (w << 24);
             } else {

@@ -129,7 +129,10 @@ typedef float q_v32f __attribute__((ext_vector_type(32)));
 // order rho: the pair (2a, 2a+1) holds element a of chain A and of chain B, so ONE packed instruction advances both chains.
 // Returns the wavefront's ballot of the lanes that are not sure; zn = the position every lane's document drew.
 // margin_rel, margin_data: m = total * margin_rel + margin_data * (the data-dependent form): production (0, 1), test hooks (2^-n or 2, 0)
-template <int LB>
+// PAD (K < KP): "no slot above lo in any lane" names position KP - 1, which holds no topic there -- the margin makes that outcome
+// impossible for a sure site (the last lane's last TOPIC has the total as its prefix), but a test hook or a later change of the margin
+// must not be able to write a topic-less position: the document is reported as not sure, and the exact tier's masked fallback decides.
+template <int LB, bool PAD = false>
 __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa)[16], float u, float margin_rel, float margin_data, float beta,
                                               int lq, int &zn)
 {
@@ -209,7 +212,7 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
     // guards on the total in one class test (draw_fast_dense_f32): tot - margin is a positive normal number
     uint64_t bad_total;
     asm("v_cmp_class_f32_e64 %0, %1, %2" : "=s"(bad_total) : "v"(tot - margin), "v"(0x2FF));
-    const uint64_t unsure = __ballot(!(ub > hi)) | bad_total;
+    uint64_t unsure = __ballot(!(ub > hi)) | bad_total;
     // the position this lane would name, keyed by its lane; the document's first lane with a slot above lo wins (none: 511, the
     // last slot of the last lane).  Row-wide minimum: four DPP steps, one instruction each (the compiler's form is three)
     // key = lane << 14 | slot rho << 9 | position: every search outcome sets its bit of the position AND of the slot number
@@ -220,6 +223,7 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
     uint32_t key = c5 ? QuadGeo<LB>::KEY_NONE : p;          // (no slot above lo: the last slot of the last lane wins only if no lane has one)
     key = quad_min_key<LB>(key);
     zn = (int)(key & 0x3FFFu);                              // slot << 9 | position; the lane is position >> 3 & (LPD - 1)
+    if constexpr (PAD) unsure |= __ballot(key == QuadGeo<LB>::KEY_NONE);
     return unsure;
 }
 
@@ -227,7 +231,7 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
 // unnormalised fp64 prefix sums with the margin 2^-40 of the total (draw_tiers.hpp, cold_tiers_acc: the same test on a different
 // association order -- the bound there, 254 u < 2^-44, grows by the 16 more additions of a 32-slot chain).  All four documents at once;
 // xv = the row minus the site's own count, exact in fp32.  Returns the ballot of the lanes that are STILL not sure; zn as quad_draw.
-template <int LB>
+template <int LB, bool PAD = false>
 __device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_ndk)[QNT][4], const int *s_nk0, int tid, int lq, double u,
                                                double alpha, double beta, double vbeta, double margin_rel, uint32_t vm, int &zn)
 {
@@ -262,7 +266,7 @@ __device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_n
         cnt_lo += (W[k] <= lo) ? 1 : 0;
         cnt_hi += (W[k] <= hi) ? 1 : 0;
     }
-    const uint64_t unsure = __ballot((cnt_lo != cnt_hi) || !(tot > 0.0) || !(margin < tot));
+    uint64_t unsure = __ballot((cnt_lo != cnt_hi) || !(tot > 0.0) || !(margin < tot));
     // position of chain index cnt_lo: e = k >> 4, i = (k >> 2) & 3, c = k & 3
     const uint32_t k = (uint32_t)cnt_lo;
     const uint32_t i_ = (k >> 2) & 3u, e_ = (k >> 4) & 1u, c_ = k & 3u;
@@ -270,6 +274,7 @@ __device__ __forceinline__ uint64_t quad_tier1(const q_v32f &xv, const int (*s_n
     uint32_t key = cnt_lo >= QT ? QuadGeo<LB>::KEY_NONE : p;
     key = quad_min_key<LB>(key);
     zn = (int)(key & 0x3FFFu);
+    if constexpr (PAD) unsure |= __ballot(key == QuadGeo<LB>::KEY_NONE);       // (see quad_draw)
     return unsure;
 }
 
@@ -534,7 +539,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             const float u32 = s_u[grp][n & (2 * LPD - 1)];
             QP_MARK(0);                                                // factors + uniform issued
             int zn;
-            uint64_t unsure = quad_draw<LB>(xv, pa, u32, P.margin0_rel, P.margin0_data, beta32, lq, zn) & __ballot(act);
+            uint64_t unsure = quad_draw<LB, PAD>(xv, pa, u32, P.margin0_rel, P.margin0_data, beta32, lq, zn) & __ballot(act);
             QP_MARK(1);                                                // chains, scan, search, pick
             LLDA_MARK("cold_check");
             if (__builtin_expect(unsure != 0, 0)) {
@@ -549,7 +554,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 if (lq == 0 && ((t0_w >> gbase) & Geo::GM) && P.status) atomicAdd(P.status + 1, 1);   // statistics
                 int z1;
                 // (a document whose row was read as int32 skips tier 1: a count of 2^24 or more is not exact in xv)
-                const uint64_t still = ((P.margin_rel < 1.0 ? quad_tier1<LB>(xv, s_ndk, s_nk0, tid, lq, uniform53(ra, rb), P.alpha, P.beta, P.vbeta,
+                const uint64_t still = ((P.margin_rel < 1.0 ? quad_tier1<LB, PAD>(xv, s_ndk, s_nk0, tid, lq, uniform53(ra, rb), P.alpha, P.beta, P.vbeta,
                                                                         P.margin_rel, vm, z1) : ~0ull) | __ballot(cur.w == 0)) & __ballot(act);
                 const bool mine0 = ((t0_w >> gbase) & Geo::GM) != 0;
                 zn = mine0 ? z1 : zn;

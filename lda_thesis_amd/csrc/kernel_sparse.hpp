@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) llda_sweep_sparse_kernel(const PT P)
         [[maybe_unused]] int ipos = pos;
         if constexpr (IMG != 0) {
             const int32_t *ic = Q->img_col;
-            if (ic && live) ipos = ic[pos];
+            if (ic && live) ipos = (int)min((uint32_t)ic[pos], (uint32_t)KP - 1u);      // (a caller's table: never outside the image row)
         }
         int32_t *ndk_p = Q->n_dk + d * KP + (live ? pos : 0);
         int ndk = live ? *ndk_p : 0;

@@ -206,7 +206,10 @@ class GibbsSampler(object):
         # n_kw and n_k (and their delta buffers) are two views of ONE allocation each, so that the per-sweep
         # exchange is a single all-reduce and the fold a single launch
         self._counts = torch.zeros(((self.V + 1) * KP,), dtype=torch.int32, device=dev)
-        self._delta = torch.zeros(((self.V + 1) * KP,), dtype=torch.int32, device=dev)
+        # (FLAG_TAIL more words behind every buffer that is all-reduced: the status flags of all ranks travel with the deltas, _stage_flags)
+        self._delta_full = torch.zeros(((self.V + 1) * KP + self.FLAG_TAIL,), dtype=torch.int32, device=dev)
+        self._delta = self._delta_full[:(self.V + 1) * KP]
+        self._gflags = self._flag_bits_t = None     # the flags every rank agrees on, once a sweep has exchanged them
         self.n_kw = self._counts[:self.V * KP].view(self.V, KP)
         self.n_k = self._counts[self.V * KP:]
         self.n_kw_delta = self._delta[:self.V * KP].view(self.V, KP)
@@ -255,10 +258,10 @@ class GibbsSampler(object):
         if image not in (None, 0, 8, 16):
             raise ValueError("image must be None (automatic), 0 (off), 8 or 16")
         self._img_src = self._img_col = None
+        self.image_lines_per_site = None
         if (image != 0 and self.S and self.live_off is not None and self.alpha >= 1e-6 and self.beta >= 1e-6
                 and self.V * self.beta < 2.0 ** 40):
             self._make_image(image)
-            self.image_lines_per_site = None
             if self.n_kw_img is not None and image_order is not False:
                 with locked:
                     self._make_image_order(force=image_order)
@@ -371,10 +374,17 @@ class GibbsSampler(object):
 
     def _quad_policy(self):
         """quad=None: the share of the sites whose row the library flagged as wide in THIS sweep's image, computed on the device and
-        copied to the host without synchronising; the copy of an EARLIER sweep is looked at when it has landed.  Counts that
-        concentrate (a frequent word settling in a few topics) take the sampler over to the two-document kernel."""
+        copied to the host asynchronously every QUAD_CHECK_EVERY sweeps; the copy is looked at -- after waiting for its event, which
+        has long fired -- exactly QUAD_CHECK_EVERY sweeps later, so WHICH sweep hands over is a function of the counts and not of
+        how fast the host runs (every run of the same corpus takes the same kernels; ranks decide on their own shard's share).
+        Counts that concentrate (a frequent word settling in a few topics) take the sampler over to the two-document kernel.
+        After a hand-over at K = 128 / 256 the 16-bit image stays allocated inside [n_kw | n_k | n_kw16] (half of n_kw again,
+        unused from then on) along with site_rec and max_doc_tokens: the counts are never moved under a running sampler."""
+        if self.sweeps_done % self.QUAD_CHECK_EVERY:
+            return
         ev = self._wide_event
-        if ev is not None and ev.query():
+        if ev is not None:
+            ev.synchronize()
             self._wide_event = None
             if float(self._wide_host[0]) > self.QUAD_MAX_WIDE_SITES * self.S:
                 self.quad = False
@@ -384,13 +394,12 @@ class GibbsSampler(object):
                 else:
                     self.n_kw16 = None                 # (K = 128, 256: the int32 rows of the general kernel; the image stays allocated)
                 return
-        if self._wide_event is None and self.sweeps_done % self.QUAD_CHECK_EVERY == 0:
-            if self._wide_host is None:
-                self._wide_host = torch.zeros((1,), dtype=torch.float32).pin_memory()
-            share = ((1.0 - self.row16.to(torch.float32)) * self._word_sites).sum().reshape(1)
-            self._wide_host.copy_(share, non_blocking=True)
-            self._wide_event = torch.cuda.Event()
-            self._wide_event.record()
+        if self._wide_host is None:
+            self._wide_host = torch.zeros((1,), dtype=torch.float32).pin_memory()
+        share = ((1.0 - self.row16.to(torch.float32)) * self._word_sites).sum().reshape(1)
+        self._wide_host.copy_(share, non_blocking=True)
+        self._wide_event = torch.cuda.Event()
+        self._wide_event.record()
 
     ROWS16_MIN_BYTES = 64 << 20      # rows16=None, documents of 2^16 tokens or more (three waves per SIMD): below this n_kw
                                      # the L2s serve the int32 rows and the shorter kernel wins
@@ -504,13 +513,15 @@ class GibbsSampler(object):
         self.row_off = torch.where(torch.cat([pairs, torch.tensor([False], device=dev)]), ~off, off).contiguous()
         total = int(off[-1].item()) + KP
         # one buffer per overlap range (normally one): the rows of range i travel while range i+1 is sampled
-        self._rows_list = [torch.zeros((total,), dtype=torch.int32, device=dev) for _ in range(len(self._ranges) - 1)]
+        self._rows_full_list = [torch.zeros((total + self.FLAG_TAIL,), dtype=torch.int32, device=dev) for _ in range(len(self._ranges) - 1)]
+        self._rows_list = [f[:total] for f in self._rows_full_list]
         self.rows = self._rows_list[0]
         # the sweep kernels add the n_k changes straight into row V; the int32 delta buffer is not needed
         self._nk_delta_list = [r[total - KP:] for r in self._rows_list]
         self.n_k_delta = self._nk_delta_list[0]
         self.n_kw_delta = None
         self._delta = self.rows
+        self._delta_full = self._rows_full_list[0]
 
     def add_word_topic_counts(self, words, topics, amounts):
         """n_kw[word, topic] += amount for parallel 1-D arrays (host or device); n_k and n_dk are left alone.
@@ -758,7 +769,10 @@ class GibbsSampler(object):
                                        self.commit_log, self.freq_csc, self.K, self._rows_list[r],
                                        row_off=self.row_off)
                 if have_group:
-                    works.append(dist.all_reduce(self._rows_list[r], group=self.group, async_op=True))
+                    last = r == n_ranges - 1                  # (the flags of every range's kernels are there once the last one is queued)
+                    if last:
+                        self._stage_flags(self._rows_full_list[r])
+                    works.append(dist.all_reduce(self._rows_full_list[r] if last else self._rows_list[r], group=self.group, async_op=True))
         if ev is not None:
             ev[1].record()
             self.kernel_events.append(ev)
@@ -771,6 +785,8 @@ class GibbsSampler(object):
                 _native.apply_delta(self._counts, self._delta)
         elif pipelined:
             self._timed(lambda: [w.wait() for w in works])
+            if have_group:
+                self._take_flags(self._rows_full_list[-1])
             for r in range(n_ranges):
                 _native.apply_rows(self.row_off, self._rows_list[r], self.K, self._counts)
         elif self.rows is not None:
@@ -780,14 +796,18 @@ class GibbsSampler(object):
                 _native.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
                                    self.freq_csc, self.K, self.rows, row_off=self.row_off)
             if have_group:
-                self._timed(lambda: dist.all_reduce(self.rows, group=self.group))
+                self._stage_flags(self._rows_full_list[0])
+                self._timed(lambda: dist.all_reduce(self._rows_full_list[0], group=self.group))
+                self._take_flags(self._rows_full_list[0])
             _native.apply_rows(self.row_off, self.rows, self.K, self._counts)
         else:
             if logged:
                 _native.commit_log(self.item_begin, self.item_len, self.item_word, self.commit_log,
                                    self.freq_csc, self.K, self.n_kw_delta)
             if have_group:
-                self._timed(lambda: dist.all_reduce(self._delta, group=self.group))   # RCCL over xGMI: SUM int32, one collective
+                self._stage_flags(self._delta_full)
+                self._timed(lambda: dist.all_reduce(self._delta_full, group=self.group))   # RCCL over xGMI: SUM int32, one collective
+                self._take_flags(self._delta_full)
             _native.apply_delta(self._counts, self._delta)
         self.sweeps_done += 1
 
@@ -812,6 +832,30 @@ class GibbsSampler(object):
         return "one RCCL int32 SUM all-reduce per sweep of the n_kw / n_k delta buffer, %.1f MB" % (self._delta.numel() * 4 / 1e6)
 
     STATUS_EVERY = 4     # sweeps between two asynchronous copies of the status word (post_status)
+    FLAG_TAIL = 2        # words behind an exchanged buffer: how many ranks have status bit 0 / bit 2 set
+    _FLAG_BITS = (1, 4)
+
+    # The status word is written by the kernels of ONE rank; a rank that raised on its own flags while the others went on into the
+    # next collective would leave them waiting for the process-group timeout.  So the two flags that raise travel with the deltas
+    # (SUM of 0 / 1 per rank in the tail of the exchanged buffer: no collective of their own), and check_status / post_status look at
+    # the SUMMED flags: every rank sees the same word after the same sweep and raises, or does not, together.
+    def _stage_flags(self, full):
+        if self._flag_bits_t is None:
+            self._flag_bits_t = torch.tensor(self._FLAG_BITS, dtype=torch.int32, device=full.device)
+        full[-self.FLAG_TAIL:] = ((self.status[:1] & self._flag_bits_t) != 0).to(torch.int32)
+
+    def _take_flags(self, full):
+        if self._gflags is None:
+            self._gflags = torch.zeros((self.FLAG_TAIL,), dtype=torch.int32, device=full.device)
+        self._gflags.copy_(full[-self.FLAG_TAIL:])
+        full[-self.FLAG_TAIL:].zero_()
+
+    def _status_word(self):
+        """one-element device tensor: the status flags -- after an exchange, those of ALL ranks (identical everywhere)."""
+        if self._gflags is None:
+            return self.status[:1]
+        g = (self._gflags > 0).to(torch.int32)
+        return (g[:1] * 1 + g[1:2] * 4) | (self.status[:1] & 2)
 
     def post_status(self, every=None):
         """For callers that loop ``sweep()`` themselves (the reference's ``training_iteration`` API, LabeledLDA.py:101): every
@@ -829,13 +873,13 @@ class GibbsSampler(object):
         if self._status_event is None and self.sweeps_done % max(1, every) == 0:
             if self._status_host is None:
                 self._status_host = torch.zeros((4,), dtype=torch.int32).pin_memory()
-            self._status_host.copy_(self.status[:4], non_blocking=True)
+            self._status_host[:1].copy_(self._status_word(), non_blocking=True)
             self._status_event = torch.cuda.Event()
             self._status_event.record()
 
     def check_status(self):
         """Raise like the reference would (numpy's multinomial rejects a NaN pvals vector)."""
-        self._raise_for(int(self.status[0].item()))
+        self._raise_for(int(self._status_word().item()))
 
     @staticmethod
     def _raise_for(st):

@@ -279,3 +279,50 @@ def test_dropin_labeledlda_shards_documents_over_ranks():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _flag_worker(rank, world, port, q):
+    """a status flag raised on ONE rank (a site without a topic of positive probability, LabeledLDA.py:117-119) reaches check_status
+    of EVERY rank after the next sweep's exchange: all ranks raise together instead of one raising and the others waiting in the
+    next collective."""
+    dev = _setup(rank, world, port, False)
+    from lda_thesis_amd.sampler import GibbsSampler, shard_documents
+    g = load_golden("tiny_k40")
+    off = g["doc_off"]
+    b = shard_documents(off, world)
+    lo, hi = b[rank], b[rank + 1]
+    s0, s1 = int(off[lo]), int(off[hi])
+    res = []
+    for commit in (True, False):                 # exchange rows / the int32 delta buffer
+        s = GibbsSampler(off[lo:hi + 1] - off[lo], g["word"][s0:s1], g["freq"][s0:s1], g["init_z"][s0:s1], int(g["K"]), int(g["V"]),
+                         float(g["alpha"]), float(g["beta"]), labs=g["labs"][lo:hi], seed=int(g["seed"]), doc_base=lo, device=dev,
+                         commit_log=commit)
+        s.sweep()
+        s.check_status()                         # nothing flagged: nobody raises
+        if rank == 1:
+            s.status[0] |= 1                     # ... what the kernel sets
+        s.sweep()
+        try:
+            s.check_status()
+            res.append("no error")
+        except ValueError:
+            res.append("ValueError")
+        ok = np.array_equal(s.n_k_v(), g["o3_s2_n_k_v"])        # the flag words did not leak into the counts
+        res.append(bool(ok))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_status_flags_travel_with_the_deltas():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flag_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == ["ValueError", True, "ValueError", True], res

@@ -252,3 +252,24 @@ def test_quad_kernel_equals_the_two_document_kernel_in_every_tier_mode(docs, N, 
         for (a, b) in zip(ref, states):
             assert all(torch.equal(x, y) for x, y in zip(a, b)), (quad, margin)
         del s
+
+
+def test_exchange_rows_of_configs3_are_what_design_section_7_prices():
+    """DESIGN.md section 7 prices the per-sweep all-reduce of BASELINE configs[3] at 103.5 MB: one int32 SUM over the exchange rows of
+    the whole 1 M-document corpus -- int16 pairs for every word whose frequency mass over ALL ranks is at most 32 767 (98 920 of the
+    100 000 words), int32 for the hot ones, plus the n_k row.  The mass is a property of the corpus, so the size is the same on
+    every rank of any N; here on one rank with the exchange forced on (/root/reference/LabeledLDA.py:109-111,123-125 are the updates
+    that travel)."""
+    doc_off, word, freq, z, K, V = corpus("synth2_1M")
+    s = make(doc_off, word, freq, z, K, V, exchange_always=True, commit_log=True)
+    del z
+    assert s.rows is not None and s.quad
+    pairs = int((s.row_off[:-1] < 0).sum())
+    assert pairs == 98_920
+    assert s.rows.numel() * 4 == (pairs * 256 + (V - pairs) * 512 + 512) * 4 == 103_507_968
+    # ... against the 204.8 MB of the plain int32 delta buffer (SURVEY section 8e)
+    assert (V + 1) * 512 * 4 == 204_802_048
+    s.sweep()                                              # and the path runs: log -> rows -> counts, rows cleared
+    s.check_status()
+    assert int(s.rows.abs().sum()) == 0
+    check_conservation(s)
