@@ -219,6 +219,7 @@ int         llda_abi_version(void);
 #define LLDA_BUILD_ABL_EXTRA_LDS      0x100   /* -DABL_EXTRA_LDS_BYTES=n  unused dynamic LDS (occupancy ablation)          */
 #define LLDA_BUILD_QUAD_PROFILE       0x200   /* -DQUAD_PROFILE           shader-clock stamps in the quad kernel (status[8..]) */
 #define LLDA_BUILD_BUDGET_MARKS       0x400   /* -DLLDA_BUDGET_MARKS      class marks in the assembly of the site loops (counting only) */
+#define LLDA_BUILD_QUAD_PRIO          0x800   /* -DLLDA_QUAD_PRIO=tdb     issue priorities of the quad kernels' phases (experiments)    */
 int         llda_build_info(void);
 const char *llda_strerror(int code);
 int         llda_last_hip_error(void);

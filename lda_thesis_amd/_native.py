@@ -155,7 +155,7 @@ def lib():
 
 
 BUILD_SWITCHES = ("LLDA_MARGIN0", "LLDA_WAVES", "LLDA_MARGIN0_WIDE", "ABL_NOLOAD", "ABL_NOCOMMIT", "ABL_WIDE_NOROW",
-                  "ABL_WIDE_NOADDLOAD", "ABL_NOFMA", "ABL_EXTRA_LDS_BYTES", "QUAD_PROFILE", "LLDA_BUDGET_MARKS")      # bit i of llda_build_info()
+                  "ABL_WIDE_NOADDLOAD", "ABL_NOFMA", "ABL_EXTRA_LDS_BYTES", "QUAD_PROFILE", "LLDA_BUDGET_MARKS", "LLDA_QUAD_PRIO")      # bit i of llda_build_info()
 
 
 def build_info():

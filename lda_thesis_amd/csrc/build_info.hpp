@@ -59,5 +59,10 @@
 #else
 #define LLDA_INFO_BUDGET_MARKS 0
 #endif
-#define LLDA_BUILD_INFO_BITS (LLDA_INFO_QUAD_PROFILE | LLDA_INFO_BUDGET_MARKS | LLDA_INFO_MARGIN0 | LLDA_INFO_WAVES | LLDA_INFO_MARGIN0_WIDE | LLDA_INFO_NOLOAD | LLDA_INFO_NOCOMMIT | \
+#ifdef LLDA_QUAD_PRIO
+#define LLDA_INFO_QUAD_PRIO LLDA_BUILD_QUAD_PRIO
+#else
+#define LLDA_INFO_QUAD_PRIO 0
+#endif
+#define LLDA_BUILD_INFO_BITS (LLDA_INFO_QUAD_PRIO | LLDA_INFO_QUAD_PROFILE | LLDA_INFO_BUDGET_MARKS | LLDA_INFO_MARGIN0 | LLDA_INFO_WAVES | LLDA_INFO_MARGIN0_WIDE | LLDA_INFO_NOLOAD | LLDA_INFO_NOCOMMIT | \
                               LLDA_INFO_WIDE_NOROW | LLDA_INFO_WIDE_NOADDLOAD | LLDA_INFO_NOFMA | LLDA_INFO_EXTRA_LDS)

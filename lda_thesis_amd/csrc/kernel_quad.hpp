@@ -37,6 +37,19 @@ constexpr float LLDA_MARGIN0_QUAD = 0x1.ap-18f;   // tier-0 margin of this kerne
 constexpr float QM_L = 1.05f * 32.0f * 0x1p-24f, QM_T = 1.05f * 39.0f * 0x1p-24f, QM_P = 1.05f * 37.0f * 0x1p-24f, QM_TOT = 1.05f * 0.25f * 0x1p-24f;
 #define QLDS(arr, rho, t) (arr)[(rho) >> 2][t][(rho) & 3]      // the per-document LDS arrays, see the kernel
 constexpr int QT = 32;        // slots per quad lane
+// Issue priority by phase of an iteration (s_setprio; round 6).  The two wavefronts of a SIMD run the same code on documents of the same
+// length: left alone they drift into the SAME phase and compete for the vector unit in the bulk phases while both wait in the dependent
+// ones.  A wavefront raises its priority for the independent bulk of an iteration -- from the scalar loads / LDS reads of the count
+// update through the next site's own-count removal, conversion and row prefetch, the update's arithmetic and the commit (QP_BULK), and
+// for the factor reads and the chains of the next site (QP_TOP) -- and drops it for the dependent decision (lane scan, threshold,
+// search, key minimum, cold tiers, decode: QP_DEC): the wavefront in its bulk gets the issue slots, the other one's dependent chain
+// fills the gaps, and the two stay in antiphase.  configs[3]: 9.39 -> 8.66 ms per 250 000 documents (- 7.7 %), K = 256 - 1.5 %, K = 128
+// - 0.4 %; placements measured: profiles/r06_site_loop_budget.md.  -DLLDA_QUAD_PRIO=tdb (three digits) overrides (llda_build_info bit).
+#ifdef LLDA_QUAD_PRIO
+constexpr int QP_TOP = (LLDA_QUAD_PRIO) / 100 % 10, QP_DEC = (LLDA_QUAD_PRIO) / 10 % 10, QP_BULK = (LLDA_QUAD_PRIO) % 10;
+#else
+constexpr int QP_TOP = 3, QP_DEC = 0, QP_BULK = 2;
+#endif
 constexpr int QNT = 128;      // threads per workgroup: two wavefronts, eight documents
 
 // The same walk for the narrower layouts of 16 slots per lane (llda_layout: T = 16): a document is LPD = 2^LB lanes x 32 slots, 64 / LPD
@@ -148,6 +161,7 @@ __device__ __forceinline__ uint64_t quad_draw(const q_v32f &xv, const q_v2f (&pa
     }
     // inclusive scan over the lanes of the document (16 lanes = one DPP row)
     LLDA_MARK("lane_scan");
+    __builtin_amdgcn_s_setprio(QP_DEC);
     const float X0 = Q[15].x + Q[15].y;
     float X = X0;
     float tot = X0, prev;
@@ -519,6 +533,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
             QP_START();
             LLDA_MARK("site_top");
             LLDA_MARK("lds_factors");
+            __builtin_amdgcn_s_setprio(QP_TOP);
             q_v2f pa[16];
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
@@ -599,6 +614,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 LLDA_MARK("count_update");
                 const int w0 = QLDS(s_ndk, sg, tid), k0 = s_nk0[ps];
                 LLDA_MARK("scalars");
+                __builtin_amdgcn_s_setprio(QP_BULK);
                 int w_next;                                            // word of site n+2 (loaded an iteration ago)
                 if constexpr (REC) {
                     prv.v = w_next = pv; prv.f = pf; prv.c = pc;       // the record of site n+2

@@ -175,8 +175,8 @@ def test_build_info_reports_every_ablation_switch(tmp_path):
     assert bits() == 0
     want = {"-DLLDA_MARGIN0=0x1p-16f": 0x001, "-DLLDA_WAVES=2": 0x002, "-DLLDA_MARGIN0_WIDE=0.1f": 0x004, "-DABL_NOLOAD": 0x008,
             "-DABL_NOCOMMIT": 0x010, "-DABL_WIDE_NOROW": 0x020, "-DABL_WIDE_NOADDLOAD": 0x040, "-DABL_NOFMA": 0x080,
-            "-DABL_EXTRA_LDS_BYTES=20000": 0x100, "-DQUAD_PROFILE": 0x200, "-DLLDA_BUDGET_MARKS": 0x400}
+            "-DABL_EXTRA_LDS_BYTES=20000": 0x100, "-DQUAD_PROFILE": 0x200, "-DLLDA_BUDGET_MARKS": 0x400, "-DLLDA_QUAD_PRIO=202": 0x800}
     for d, b in want.items():
         assert bits(d) == b, d
-    assert bits(*want) == 0x7ff
+    assert bits(*want) == 0xfff
     assert [n for i, n in enumerate(_native.BUILD_SWITCHES)] == [d[2:].split("=")[0] for d in want]
