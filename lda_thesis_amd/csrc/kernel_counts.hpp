@@ -138,26 +138,45 @@ __global__ void __launch_bounds__(256) llda_commit_log_kernel(const CParams P)
     int32_t *row = P.target + (pairs ? ~ro : ro);
     const int sh = pairs ? 1 : 0, n_words = KP >> sh;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    for (int j = lane; j < len; j += 64) {
-        const uint32_t e = P.log[b + j];
+    // the entries of an item are read FOUR per lane and load (16-byte loads behind a head of at most three entries that brings the
+    // address to 16 bytes): a quarter of the load instructions and four times the bytes in flight per wavefront -- the fold streams
+    // 2.4 GB per sweep of configs[3] and was bound by the latency of its 4-byte loads: 0.81 -> 0.56 ms (profiles/r06_site_loop_budget.md section 5)
+    const uint32_t *lg = P.log + b;
+    const int32_t *fq = P.freq + b;
+    // (the head from the ADDRESSES: a caller's arrays need only be 4-byte aligned; log and freq misaligned differently: one entry per load)
+    const unsigned mis_l = (unsigned)(reinterpret_cast<uintptr_t>(lg) & 15), mis_f = (unsigned)(reinterpret_cast<uintptr_t>(fq) & 15);
+    const bool vec = mis_l == mis_f && len >= 256;       // (short items -- the words of a sparse-label corpus -- gain nothing from the head / tail split)
+    const int head = vec ? min(len, (int)(((16u - mis_l) & 15u) >> 2)) : 0, n4 = vec ? (len - head) >> 2 : 0, tail0 = head + 4 * n4;
+    auto count1 = [&](uint32_t e, int f) {
         const int zo = (int)(e & 0xFFFFu), zn = (int)(e >> 16);
         if (zo != zn) {
-            const uint32_t f = (uint32_t)P.freq[b + j];
-            atomicAdd(&hist[zo >> sh], -(int)(f << ((zo & sh) * 16)));
-            atomicAdd(&hist[zn >> sh], (int)(f << ((zn & sh) * 16)));
+            atomicAdd(&hist[zo >> sh], -(int)((uint32_t)f << ((zo & sh) * 16)));
+            atomicAdd(&hist[zn >> sh], (int)((uint32_t)f << ((zn & sh) * 16)));
         }
+    };
+    if (lane < head) count1(lg[lane], fq[lane]);
+    for (int g = lane; g < n4; g += 64) {
+        const uint4 e = *reinterpret_cast<const uint4 *>(lg + head + 4 * g);
+        const int4 f = *reinterpret_cast<const int4 *>(fq + head + 4 * g);
+        count1(e.x, f.x); count1(e.y, f.y); count1(e.z, f.z); count1(e.w, f.w);
     }
+    for (int j = tail0 + lane; j < len; j += 64) count1(lg[j], fq[j]);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (len <= n_words) {
-        for (int j = lane; j < len; j += 64) {
-            const uint32_t e = P.log[b + j];
+        auto flush1 = [&](uint32_t e) {
             const int zo = (int)(e & 0xFFFFu), zn = (int)(e >> 16);
             if (zo != zn) {
                 const int a = atomicExch(&hist[zo >> sh], 0), c = atomicExch(&hist[zn >> sh], 0);
                 if (a) add_count(row + (zo >> sh), a, shared_row);
                 if (c) add_count(row + (zn >> sh), c, shared_row);
             }
+        };
+        if (lane < head) flush1(lg[lane]);
+        for (int g = lane; g < n4; g += 64) {
+            const uint4 e = *reinterpret_cast<const uint4 *>(lg + head + 4 * g);
+            flush1(e.x); flush1(e.y); flush1(e.z); flush1(e.w);
         }
+        for (int j = tail0 + lane; j < len; j += 64) flush1(lg[j]);
     } else {
         for (int p = lane; p < n_words; p += 64) {
             const int a = hist[p];
