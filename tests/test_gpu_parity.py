@@ -1179,3 +1179,31 @@ def test_sparse_documents_are_split_by_the_lanes_they_need(c_oracle, K, image, h
         np.testing.assert_array_equal(s.n_zk(), cs.n_zk)
         assert torch.equal(one.z, s.z) and torch.equal(one._counts, s._counts) and torch.equal(one.n_dk, s.n_dk)
     s.check_status()
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_pack_image_cols_clamps_a_bad_column_table(bits):
+    """include/llda_gibbs.h: col_src is the caller's table and a PRECONDITION (a permutation of the positions); an entry outside
+    0 .. KP-1 must not read someone else's LDS -- the kernel clamps it to KP-1.  A valid table gives the permuted
+    saturating image, a table with wild entries gives the image of the clamped table, and nothing faults."""
+    import torch
+    from lda_thesis_amd import _native as nat
+    K, V = 512, 300
+    KP = nat.layout_init(K)["KP"]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n_kw = torch.randint(0, 70000, (V, KP), dtype=torch.int32, device="cuda", generator=g)
+    sat = 255 if bits == 8 else 65535
+    img = torch.zeros((V * KP,), dtype=torch.uint8 if bits == 8 else torch.int16, device="cuda")
+    perm = torch.randperm(KP, device="cuda", generator=g).to(torch.int32)
+    nat.pack_image_cols(n_kw, K, perm, img)
+    want = n_kw[:, perm.to(torch.int64)].clamp(max=sat)
+    got = img.view(V, KP).to(torch.int32) & sat
+    assert torch.equal(got, want)
+    bad = perm.clone()
+    bad[::7] = torch.tensor([KP, 10 ** 6, -1, -(2 ** 31), 2 ** 31 - 1], dtype=torch.int32, device="cuda").repeat(KP)[:bad[::7].numel()]
+    nat.pack_image_cols(n_kw, K, bad, img)
+    torch.cuda.synchronize()
+    clamped = bad.to(torch.int64)
+    clamped = torch.where((clamped < 0) | (clamped > KP - 1), torch.full_like(clamped, KP - 1), clamped)
+    got = img.view(V, KP).to(torch.int32) & sat
+    assert torch.equal(got, n_kw[:, clamped].clamp(max=sat))
