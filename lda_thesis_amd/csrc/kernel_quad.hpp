@@ -34,6 +34,10 @@ constexpr float LLDA_MARGIN0_QUAD = 0x1.ap-18f;   // tier-0 margin of this kerne
 //   + 33.1 v P  + 3 v |tg|  (tg, its bounds, the chain-B bounds: one rounding each; |tg| <= t + P)  + 2 v for int32 counts >= 2^24
 // <= v (31.1 L + 38.2 t + 36.1 P + 0.125 total) -- a third of 104 v * total on average (L ~ total / 16, t ~ P ~ total / 2).  The kernel
 // takes m = v * 1.05 * (32 L~ + 39 t~ + 37 P~ + 0.25 total~) from the computed values (each within 34 v of its true value).
+// Checked, not only derived: oracle/quad_tier0_model.c replays this arithmetic in fp32 next to 80-bit arithmetic and
+// tests/test_quad_tier0_model.py asserts the sub-bounds and the bound position by position (worst compared difference: 0.48 of m);
+// tests/test_gpu_parity.py::test_adversarial_near_ties_for_the_quad_tier0 plants thresholds within 2^-28 of a prefix boundary where m is
+// smallest, and tools/quad_margin_headroom.py scales m down until planted ties are missed (first at 1/8: profiles/r06_quad_margin_headroom.md).
 constexpr float QM_L = 1.05f * 32.0f * 0x1p-24f, QM_T = 1.05f * 39.0f * 0x1p-24f, QM_P = 1.05f * 37.0f * 0x1p-24f, QM_TOT = 1.05f * 0.25f * 0x1p-24f;
 #define QLDS(arr, rho, t) (arr)[(rho) >> 2][t][(rho) & 3]      // the per-document LDS arrays, see the kernel
 constexpr int QT = 32;        // slots per quad lane
