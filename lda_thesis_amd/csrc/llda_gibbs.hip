@@ -54,7 +54,6 @@
 #include "exact_generic.hpp"
 #include "kernel_sweep.hpp"
 #include "kernel_quad.hpp"
-#include "kernel_oct.hpp"
 #include "kernel_sparse.hpp"
 #include "kernel_batch.hpp"
 #include "kernel_readout.hpp"
@@ -660,21 +659,6 @@ int llda_sweep(const llda_sweep_args *a, void *stream)
             P.margin0_rel = 0.0f;                                         // (the derived bound itself), 1/2, 1/4 ... 1/256: how much of the
             P.margin0_data = a->debug_margin == -10 ? 1.0f / 1.05f : ldexpf(1.0f, a->debug_margin + 10);   // margin the worst site needs
             P.margin_rel = 0x1p-40;
-        }
-#ifndef LLDA_OCT
-#define LLDA_OCT 0                                                        // (-DLLDA_OCT=1: K <= 128 on llda_sweep_oct_kernel -- measured SLOWER,
-#endif                                                                    // profiles/r06_quad_k128.md; this commit is the record of the experiment)
-        if (LLDA_OCT && L.G == 8) {
-            // eight lanes per document (K = 97 .. 128): eight documents per wavefront at four wavefronts per SIMD (kernel_oct.hpp), on the
-            // same image, flags and site records
-            const int64_t per_o = (int64_t)(ONT / OG) * dpg;
-            const int64_t oblocks = (a->D + per_o - 1) / per_o;
-            if (oblocks > 0x7fffffffLL) return LLDA_E_BAD_ARG;
-            const dim3 ogrid((unsigned)oblocks), oblock(ONT);
-            if (!P.quad_pad) hipLaunchKernelGGL((llda_sweep_oct_kernel<false>), ogrid, oblock, 0, st, P);
-            else hipLaunchKernelGGL((llda_sweep_oct_kernel<true>), ogrid, oblock, 0, st, P);
-            const hipError_t e = hipGetLastError();
-            return e == hipSuccess ? LLDA_OK : hip_fail(e);
         }
         const int64_t per_q = (int64_t)(2 * QNT / L.G) * dpg;             // (a document is G / 2 lanes)
         const int64_t qblocks = (a->D + per_q - 1) / per_q;
