@@ -817,6 +817,9 @@ llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel, double *scr
             // ---- tier 0: fp32 prefix values, lane totals, scan ----
             int zn = -1;
             bool decided = false;
+            // (issue priority by phase, as the quad kernels': the chains' vector work wins the arbitration against the other wavefronts'
+            // one-lane count updates -- 2.381 -> 2.336 ms per sweep at K = 2 048, profiles/r06_site_loop_budget.md section 2)
+            __builtin_amdgcn_s_setprio(2);
             if (margin0_rel < 1.0f) {
                 float q[NT][T], Y[NT];
 #pragma unroll
@@ -928,6 +931,7 @@ llda_sweep_wide_f32_kernel(const WParams P, const float margin0_rel, double *scr
                 }
               }
             }
+            __builtin_amdgcn_s_setprio(0);
             if (lane == 0) {
 #ifdef ABL_WIDE_NOADDLOAD                                        // ablation (tools/abl_wide.py): no start-value loads behind the draw
                 const int nd0_z = 0, nk0_z = 1000;
