@@ -617,6 +617,7 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                 const int df = own_new ? f : own_old ? -nxt.f : 0;
                 LLDA_MARK("count_update");
                 const int w0 = QLDS(s_ndk, sg, tid), k0 = s_nk0[ps];
+                QP_MARK(3);                                            // decode, the update's LDS reads issued
                 LLDA_MARK("scalars");
                 __builtin_amdgcn_s_setprio(QP_BULK);
                 int w_next;                                            // word of site n+2 (loaded an iteration ago)
@@ -629,9 +630,11 @@ __global__ void __launch_bounds__(QNT, 2) llda_sweep_quad_kernel(const KParams P
                     load_scalars(prv, off_of(n + 2));                  // scalars of site n+2 (clamped)
                     wq = gload_i32(word_b, off_of(n + 3));
                 }
+                QP_MARK(4);                                            // scalar / record loads of the sites ahead issued
                 // site n+1: its row (issued an iteration ago) -> fp32, own count out; then the row of site n+2 is issued
                 remove_own_packed(nxt.so, (more && lq == nxt.lo) ? nxt.f : 0);
                 convert_row(nxt.v, nxt.w, nxt.so, (more && lq == nxt.lo) ? (float)nxt.f : 0.0f);
+                QP_MARK(5);                                            // next row converted (this is where the wait for it sits)
                 LLDA_MARK("row_prefetch");
                 load_row16(w_next, prv.w);
                 LLDA_MARK("count_update");
@@ -660,7 +663,7 @@ if (lq == 0 && act) {                                // (plain stores: the compi
 #endif
             }
             LLDA_MARK("loop");
-            QP_MARK(3);                                                // count update
+            QP_MARK(6);                                                // row prefetch, count update written, commit
         };
         for (int n = 0;; n += 3) {                                  // (uniform trip count: the longest document of the wavefront)
             site(n, R0, R1, R2);

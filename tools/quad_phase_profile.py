@@ -23,11 +23,12 @@ def main():
     torch.cuda.synchronize()
     st = s.status.cpu().numpy()
     sites = int(st[16])
-    names = ["front (pa reads, row -> fp32, own count, commit, loads issued)", "chains + scan + search + pick", "cold tiers",
-             "count update (LDS)", "-", "-", "-", "-"]
+    names = ["front (factor reads issued, uniform)", "chains + scan + search + pick", "cold tiers",
+             "decode + the update's LDS reads issued", "records / z of the sites ahead issued", "own count out + next row -> fp32 (waits for the row)",
+             "row prefetch issued, update written, commit", "-"]
     tot = float(st[8:16].sum())
     print("wave iterations stamped: %d; clock ticks per iteration: %.1f (s_memtime ticks)" % (sites, tot / max(sites, 1)))
-    for k in range(4):
+    for k in range(7):
         print("  phase %d %-70s %8.2f ticks per iteration  %5.1f %%" % (k, names[k], st[8 + k] / max(sites, 1), 100.0 * st[8 + k] / max(tot, 1)))
 
 
